@@ -1,0 +1,133 @@
+/* mobocmf_hip.h -- C-ABI of the MI355X (gfx950) MFDGP hot path.
+ *
+ * Drop-in boundary for the variational multi-fidelity deep-GP layer + ELBO of fernandezdaniel/MOBOCMF.
+ * The reference has no FFI of its own (it is pure Python on GPyTorch); these entry points replace the
+ * arithmetic that the reference reaches through the following call sites (paths under /root/reference):
+ *
+ *   mobocmf_layer_forward / _backward   mobocmf/layers/mfdgp_hidden_layer.py:232-243 (prior over cat[Z,X]),
+ *                                       :286 -> gpytorch UnwhitenedVariationalStrategy.forward (Gram, Cholesky,
+ *                                       triangular solves, predictive moments) and kl_divergence(); backward =
+ *                                       what torch autograd does for blackbox_mfdgp_fitter.py:168
+ *   mobocmf_propagate_forward/_backward mobocmf/layers/mfdgp_hidden_layer.py:263-274 (hidden-sample propagation)
+ *   mobocmf_elbo_data_forward/_backward mobocmf/mlls/variational_elbo_mf.py:31-35 + GaussianLikelihood.expected_log_prob
+ *   mobocmf_acq_moments_forward/_backward  mobocmf/models/mfdgp.py:258-260 (moments over the S samples)
+ *   mobocmf_jes_forward                 mobocmf/acquisition_functions/JESMOC_MFDGP.py:52
+ *   mobocmf_predictive_covariance       eval branch of the variational strategy: K_nn - K_nm K_mm^-1 K_mn + C^T C
+ *                                       (the full covariance GPyTorch materialises in .eval(), JESMOC_MFDGP.py:42)
+ *   mobocmf_adam_step                   torch.optim.Adam.step at blackbox_mfdgp_fitter.py:169
+ *
+ * Conventions: all pointers are DEVICE pointers to row-major float64 unless stated; sizes are explicit;
+ * every function enqueues work on `stream` and returns immediately (no allocation, no free, no host sync,
+ * no global mutable state -> re-entrant, one process per GPU).  Return value: MOBOCMF_OK or an error
+ * code; a non-positive-definite K_mm is reported through the device word `info` (0 = OK, k>0 = pivot k
+ * failed), mirroring LAPACK potrf / torch.linalg.cholesky_ex, so the caller may retry with more jitter
+ * (gpytorch psd_safe_cholesky semantics) without a sync on the fast path.
+ */
+#ifndef MOBOCMF_HIP_H
+#define MOBOCMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mobocmf_stream_t; /* hipStream_t */
+
+enum {
+    MOBOCMF_OK = 0,
+    MOBOCMF_BAD_ARG = 1,
+    MOBOCMF_WORKSPACE_TOO_SMALL = 2,
+    MOBOCMF_HIP_ERROR = 3,
+    MOBOCMF_NOT_PD = 4, /* only returned by mobocmf_check_info (host-side, synchronising) */
+    MOBOCMF_BAD_ARCH = 5
+};
+
+/* One variational GP layer.
+ * kind 0 (first layer):  k = alpha * RBF_ard(x, x')                              hyp = [alpha, ls[0..d)]
+ * kind 1 (layer >= 1):   k = a1*RBF(x,x';ls1) * (nu*f*f' + af*RBF(f,f';lsf)) + a2*RBF(x,x';ls2)
+ *                        hyp = [a1, af, nu, a2, lsf, ls1[0..d), ls2[0..d)]
+ * The data matrix X~ = [x[n / xdiv], f[n]] is never materialised: row n of the layer input uses row n/xdiv of
+ * `x` (S-fold sample replication, mfdgp.py:248 / SURVEY F7) and f[n] (kind 1 only).  Inducing inputs Z~ = [Zx, zf].
+ */
+typedef struct {
+    int32_t kind;    /* 0 | 1 */
+    int32_t d;       /* columns of x and Zx, 1..32 */
+    int32_t M;       /* inducing points */
+    int32_t xdiv;    /* >= 1 */
+    int64_t Np;      /* rows through the layer (N'), Np % xdiv == 0 */
+    int32_t branch;  /* 0: training branch (clamp(k_nn - q, 0)); 1: eval branch (no clamp) */
+    int32_t want_dx; /* backward also returns d/dx (acquisition optimisation) */
+    double jitter;   /* added to diag(K_mm); gpytorch variational_cholesky_jitter = 1e-6 */
+    double min_var;  /* MultivariateNormal.variance clamp; gpytorch min_variance = 1e-10 */
+} mobocmf_layer_desc;
+
+int mobocmf_version(void);
+/* 1 if the current HIP device is gfx950. */
+int mobocmf_device_arch_ok(void);
+
+/* Bytes of the `saved` buffer (forward -> backward state: L, L^-1, U, K_mn, A, C, ...) and of the scratch
+ * buffer (dead after each call). */
+int mobocmf_layer_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes);
+
+/* mean[Np], var[Np] (clamped at min_var), kl[1] = KL(q(u) || p(u)), info[1]. */
+int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                          const double* zf, const double* hyp, const double* m, const double* L_S /* M x M, ld M */,
+                          double* mean, double* var, double* kl, int32_t* info, void* saved, size_t saved_bytes,
+                          void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+
+/* Gradients of  sum(g_mean*mean) + sum(g_var*var) + g_kl[0]*kl.
+ * Outputs (overwritten): g_f[Np] (kind 1), g_zf[M] (kind 1), g_hyp[hyp_len], g_m[M], g_LS[M x M] (lower),
+ * g_x[(Np/xdiv) x d] (only if want_dx).  g_kl is a device scalar. */
+int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                           const double* zf, const double* hyp, const double* m, const double* L_S,
+                           const double* g_mean, const double* g_var, const double* g_kl, double* g_f, double* g_zf,
+                           double* g_hyp, double* g_m, double* g_LS, double* g_x, void* saved, size_t saved_bytes,
+                           void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+
+/* cov[Np x Np] = K_nn - A^T A + C^T C from the state a forward call left in `saved` (eval branch, full
+ * predictive covariance; MFMA contraction).  Np must be <= 16384. */
+int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f,
+                                  const double* hyp, double* cov, int64_t ldcov, void* saved, size_t saved_bytes,
+                                  void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+
+/* f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n],  n < n_out  (mfdgp_hidden_layer.py:263-274). */
+int mobocmf_propagate_forward(const double* mean, const double* var, const double* eps, double* f_out, int64_t n_out,
+                              int32_t div, mobocmf_stream_t stream);
+/* g_mean[n_out/div], g_var[n_out/div] from g_f[n_out]. */
+int mobocmf_propagate_backward(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
+                               int64_t n_out, int32_t div, mobocmf_stream_t stream);
+
+/* out[0] = (1/div) * sum_{n : fid[n/div] == level} -0.5 * (((y[n/div]-mean[n])^2 + var[n]) / tau + log tau + log 2pi)
+ * tau is a device scalar.  n < n_rows. */
+int mobocmf_elbo_data_forward(const double* mean, const double* var, const double* y, const double* fid,
+                              const double* tau, double level, int64_t n_rows, int32_t div, double* out,
+                              void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+/* g_mean[n_rows], g_var[n_rows], g_tau[1] scaled by the device scalar g_out. */
+int mobocmf_elbo_data_backward(const double* mean, const double* var, const double* y, const double* fid,
+                               const double* tau, double level, int64_t n_rows, int32_t div, const double* g_out,
+                               double* g_mean, double* g_var, double* g_tau, void* scratch, size_t scratch_bytes,
+                               mobocmf_stream_t stream);
+
+/* mus[t] = mean_s mu~[t*S+s];  vars[t] = mean_s(var~ + mu~^2) - mus^2   (mfdgp.py:258-260). */
+int mobocmf_acq_moments_forward(const double* mu_t, const double* var_t, double* mus, double* vars, int64_t T,
+                                int32_t S, mobocmf_stream_t stream);
+int mobocmf_acq_moments_backward(const double* mu_t, const double* g_mus, const double* g_vars, double* g_mu_t,
+                                 double* g_var_t, int64_t T, int32_t S, mobocmf_stream_t stream);
+/* acq[t] = 0.5 * max(log v_uncond[t] - log v_cond[t], 0)   (JESMOC_MFDGP.py:52). */
+int mobocmf_jes_forward(const double* v_uncond, const double* v_cond, double* acq, int64_t T, mobocmf_stream_t stream);
+
+/* Fused Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad) of one flat parameter
+ * segment; `step` is the 1-based step count.  mask (may be NULL) = 0 freezes an element. */
+int mobocmf_adam_step(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, const double* mask,
+                      int64_t n, double lr, double beta1, double beta2, double eps, int64_t step,
+                      mobocmf_stream_t stream);
+
+/* Host-side, synchronising: copies the device word and returns MOBOCMF_OK or MOBOCMF_NOT_PD (pivot in *pivot). */
+int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBOCMF_HIP_H */

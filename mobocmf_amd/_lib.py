@@ -1,0 +1,90 @@
+"""ctypes binding of the C-ABI in include/mobocmf_hip.h (libmobocmf_hip.so, built by csrc/build.sh).
+
+The product path has NO CPU fallback: if the shared library is missing or the device is not a
+gfx950, every compute entry point raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmobocmf_hip.so")
+
+OK, BAD_ARG, WORKSPACE_TOO_SMALL, HIP_ERROR, NOT_PD, BAD_ARCH = range(6)
+_ERR = {1: "MOBOCMF_BAD_ARG", 2: "MOBOCMF_WORKSPACE_TOO_SMALL", 3: "MOBOCMF_HIP_ERROR", 4: "MOBOCMF_NOT_PD",
+        5: "MOBOCMF_BAD_ARCH"}
+
+
+class LayerDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("d", ctypes.c_int32), ("M", ctypes.c_int32), ("xdiv", ctypes.c_int32),
+                ("Np", ctypes.c_int64), ("branch", ctypes.c_int32), ("want_dx", ctypes.c_int32),
+                ("jitter", ctypes.c_double), ("min_var", ctypes.c_double)]
+
+
+class MobocmfError(RuntimeError):
+    pass
+
+
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I32 = ctypes.c_int32
+_D = ctypes.c_double
+_SZ = ctypes.c_size_t
+
+# name -> argtypes   (every symbol include/mobocmf_hip.h declares)
+SYMBOLS = {
+    "mobocmf_version": [],
+    "mobocmf_device_arch_ok": [],
+    "mobocmf_layer_workspace_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
+    "mobocmf_layer_forward": [ctypes.POINTER(LayerDesc)] + [_P] * 11 + [_P, _SZ, _P, _SZ, _P],
+    "mobocmf_layer_backward": [ctypes.POINTER(LayerDesc)] + [_P] * 16 + [_P, _SZ, _P, _SZ, _P],
+    "mobocmf_predictive_covariance": [ctypes.POINTER(LayerDesc), _P, _P, _P, _P, _I64, _P, _SZ, _P, _SZ, _P],
+    "mobocmf_propagate_forward": [_P, _P, _P, _P, _I64, _I32, _P],
+    "mobocmf_propagate_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
+    "mobocmf_elbo_data_forward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _SZ, _P],
+    "mobocmf_elbo_data_backward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _P, _P, _P, _SZ, _P],
+    "mobocmf_acq_moments_forward": [_P, _P, _P, _P, _I64, _I32, _P],
+    "mobocmf_acq_moments_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
+    "mobocmf_jes_forward": [_P, _P, _P, _I64, _P],
+    "mobocmf_adam_step": [_P, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P],
+    "mobocmf_check_info": [_P, ctypes.POINTER(_I32), _P],
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MobocmfError(f"HIP extension missing: {LIB_PATH} (run mobocmf_amd/csrc/build.sh or "
+                               "__graft_entry__.build()); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != OK:
+        raise MobocmfError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+_arch_checked = False
+
+
+def require_device():
+    """Fail loudly unless a gfx950 device is current."""
+    global _arch_checked
+    lib = load()
+    if not _arch_checked:
+        import torch
+        if not torch.cuda.is_available():
+            raise MobocmfError("mobocmf_amd needs an MI355X (gfx950) device: no GPU visible, and there is no CPU fallback")
+        if not lib.mobocmf_device_arch_ok():
+            raise MobocmfError("mobocmf_amd kernels are built for gfx950 only")
+        _arch_checked = True
+    return lib

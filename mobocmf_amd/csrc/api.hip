@@ -1,0 +1,410 @@
+// C-ABI orchestration of one variational MFDGP layer (forward, backward, predictive covariance).
+// See include/mobocmf_hip.h for the contract and DESIGN.md for the algebra.  Every function only
+// enqueues kernels on the caller's stream; all memory is caller-provided (saved / scratch).
+#include "common.h"
+
+// ---- kernels / launchers defined in the other translation units
+int launch_gram_fwd(const GramArgs& g, hipStream_t s);
+int launch_gram_bwd(const GramArgs& g, bool want_dx, hipStream_t s);
+void gram_grid(const GramArgs& g, dim3* grid);
+int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* out, int64_t len, double scale,
+                        int accumulate, hipStream_t s);
+int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, int32_t* info, hipStream_t s);
+int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, hipStream_t s);
+int launch_pad_tril(const double* src, int64_t lds, int M, double* dst, int Mp, hipStream_t s);
+int launch_pad_vec(const double* src, int64_t n, double* dst, int64_t np, hipStream_t s);
+int launch_transpose(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
+int launch_gemv_rows(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double scale,
+                     int accumulate, hipStream_t s);
+int launch_gemv_long(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double* part,
+                     hipStream_t s);
+int launch_kl(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* kl,
+              hipStream_t s);
+int launch_moments_finish(const double* qpart, const double* mupart, const double* rpart, int nrb, int64_t Np, int64_t N,
+                          const double* knn, int branch, double min_var, double* q, double* r, double* varraw,
+                          double* mean, double* var, hipStream_t s);
+int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
+                            const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
+                            double* gv, double* gv2, double* cgv, hipStream_t s);
+int launch_add_kl_terms(double* dU, const double* U, double* da, const double* a, const double* gkl, int Mp, hipStream_t s);
+int launch_rank1_add(double* X, const double* u, const double* v, int Mp, hipStream_t s);
+int launch_dl_from_t2(const double* T2, const double* L, const double* gkl, int M, int Mp, double* dL, hipStream_t s);
+int launch_phi(const double* T3, int Mp, double* P, hipStream_t s);
+int launch_symmetrize(const double* S, int Mp, double* G, hipStream_t s);
+int launch_gls_out(const double* X, const double* LSp, const double* gkl, int M, int Mp, double* gLS, hipStream_t s);
+int launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
+int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s);
+
+#define TRY(x)              \
+    do {                    \
+        int _rc = (x);      \
+        if (_rc) return _rc; \
+    } while (0)
+
+namespace {
+
+struct Bump {
+    char* base;
+    size_t off, cap;
+    bool ok;
+    Bump(void* p, size_t c) : base((char*)p), off(0), cap(c), ok(true) {}
+    double* take(int64_t n) {
+        size_t bytes = ((size_t)n * sizeof(double) + 255) & ~(size_t)255;
+        if (off + bytes > cap) { ok = false; off += bytes; return nullptr; }
+        double* r = (double*)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+struct Dims {
+    int M, Mp, nrb, H;
+    int64_t N, Np, nbase;
+    int splitk;
+    dim3 ggrid_mn, ggrid_mm;
+};
+
+bool valid_desc(const mobocmf_layer_desc* d) {
+    return d && (d->kind == 0 || d->kind == 1) && d->d >= 1 && d->d <= 32 && d->M >= 1 && d->xdiv >= 1 &&
+           d->xdiv <= 48 && d->Np >= 1 && d->Np % d->xdiv == 0 && (d->branch == 0 || d->branch == 1);
+}
+
+Dims dims_of(const mobocmf_layer_desc* d) {
+    Dims D;
+    D.M = d->M;
+    D.Mp = (int)round_up(d->M, TILE);
+    D.nrb = D.Mp / TILE;
+    D.N = d->Np;
+    D.Np = round_up(d->Np, TILE);
+    D.nbase = d->Np / d->xdiv;
+    D.H = hyp_len(d->kind, d->d);
+    int ntl = D.nrb * (D.nrb + 1) / 2;
+    int64_t ksteps = D.Np / 16;
+    int sk = (1024 + ntl - 1) / ntl;
+    if (sk > ksteps / 8) sk = (int)(ksteps / 8);
+    if (sk > 128) sk = 128;
+    if (sk < 1) sk = 1;
+    D.splitk = sk;
+    GramArgs g = {};
+    g.xdiv = d->xdiv;
+    g.Np = D.Np;
+    g.Mp = D.Mp;
+    gram_grid(g, &D.ggrid_mn);
+    g.xdiv = 1;
+    g.Np = D.Mp;
+    gram_grid(g, &D.ggrid_mm);
+    return D;
+}
+
+struct Saved {
+    double *L, *Linv, *LinvT, *U, *UT, *LSp, *a, *mp, *K, *A, *C, *knn, *q, *r, *varraw;
+};
+
+bool carve_saved(Bump& b, const Dims& D, Saved& S) {
+    int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
+    S.L = b.take(mm); S.Linv = b.take(mm); S.LinvT = b.take(mm); S.U = b.take(mm); S.UT = b.take(mm); S.LSp = b.take(mm);
+    S.a = b.take(D.Mp); S.mp = b.take(D.Mp);
+    S.K = b.take(mn); S.A = b.take(mn); S.C = b.take(mn);
+    S.knn = b.take(D.Np); S.q = b.take(D.Np); S.r = b.take(D.Np); S.varraw = b.take(D.Np);
+    return b.ok;
+}
+
+struct ScratchF {
+    double *Dinv, *T, *qpart, *mupart, *rpart;
+};
+bool carve_scratch_fwd(Bump& b, const Dims& D, ScratchF& S) {
+    S.Dinv = b.take((int64_t)(D.Mp / NB) * NB * NB);
+    S.T = b.take((int64_t)D.Mp * D.Mp);
+    S.qpart = b.take((int64_t)D.nrb * D.Np);
+    S.mupart = b.take((int64_t)D.nrb * D.Np);
+    S.rpart = b.take((int64_t)D.nrb * D.Np);
+    return b.ok;
+}
+
+struct ScratchB {
+    double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *W[8], *da, *gpart, *hyp_part, *df_part, *dzf_part, *dx_part,
+        *hyp_part2, *df_part2, *dzf_part2, *gzf_tmp;
+};
+bool carve_scratch_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, ScratchB& S) {
+    int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
+    S.gmu = b.take(D.Np); S.gv = b.take(D.Np); S.gv2 = b.take(D.Np); S.cgv = b.take(D.Np);
+    S.dA = b.take(mn); S.dK = b.take(mn);
+    S.slabs = b.take((int64_t)D.splitk * mm);
+    for (int i = 0; i < 8; ++i) S.W[i] = b.take(mm);
+    S.da = b.take(D.Mp);
+    S.gpart = b.take((int64_t)D.Mp * 16);
+    S.hyp_part = b.take((int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H);
+    S.hyp_part2 = b.take((int64_t)D.ggrid_mm.x * D.ggrid_mm.y * D.H);
+    S.df_part = S.dzf_part = S.df_part2 = S.dzf_part2 = S.gzf_tmp = nullptr;
+    if (d->kind == 1) {
+        S.df_part = b.take((int64_t)D.ggrid_mn.y * D.Np);
+        S.dzf_part = b.take((int64_t)D.ggrid_mn.x * D.Mp);
+        S.df_part2 = b.take((int64_t)D.ggrid_mm.y * D.Mp);
+        S.dzf_part2 = b.take((int64_t)D.ggrid_mm.x * D.Mp);
+        S.gzf_tmp = b.take(D.Mp);
+    }
+    S.dx_part = d->want_dx ? b.take((int64_t)D.ggrid_mn.y * D.nbase * d->d) : nullptr;
+    return b.ok;
+}
+
+GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int Mr, int64_t Nc,
+                   int64_t Kd, int tri, double alpha) {
+    GemmArgs g = {};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.Mr = Mr; g.Nc = Nc; g.Kd = Kd; g.tri = tri; g.alpha = alpha;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mobocmf_version(void) { return 100; }
+
+int mobocmf_device_arch_ok(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    const char* a = p.gcnArchName;
+    return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}
+
+int mobocmf_layer_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes) {
+    if (!valid_desc(desc) || !saved_bytes || !scratch_bytes) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc);
+    Bump bs(nullptr, ~(size_t)0 >> 1);
+    Saved S;
+    carve_saved(bs, D, S);
+    *saved_bytes = bs.off;
+    Bump bf(nullptr, ~(size_t)0 >> 1), bb(nullptr, ~(size_t)0 >> 1);
+    ScratchF F;
+    ScratchB B;
+    carve_scratch_fwd(bf, D, F);
+    carve_scratch_bwd(bb, D, desc, B);
+    // predictive covariance scratch: A^T, C^T (Np x Mp) + padded cov (Np x Np), only sized for Np <= 16384
+    size_t cov = 0;
+    if (D.Np <= 16384) cov = (size_t)(2 * D.Np * D.Mp + D.Np * D.Np) * sizeof(double) + 1024;
+    size_t m = bf.off > bb.off ? bf.off : bb.off;
+    *scratch_bytes = m > cov ? m : cov;
+    return MOBOCMF_OK;
+}
+
+int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                          const double* zf, const double* hyp, const double* m, const double* L_S, double* mean,
+                          double* var, double* kl, int32_t* info, void* saved, size_t saved_bytes, void* scratch,
+                          size_t scratch_bytes, mobocmf_stream_t stream) {
+    if (!valid_desc(desc) || !x || !Zx || !hyp || !m || !L_S || !mean || !var || !kl || !info || !saved || !scratch)
+        return MOBOCMF_BAD_ARG;
+    if (desc->kind == 1 && (!f || !zf)) return MOBOCMF_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    Dims D = dims_of(desc);
+    Bump bs(saved, saved_bytes), bf(scratch, scratch_bytes);
+    Saved S;
+    ScratchF F;
+    if (!carve_saved(bs, D, S) || !carve_scratch_fwd(bf, D, F)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    const int Mp = D.Mp;
+    const int64_t Np = D.Np, mm = (int64_t)Mp * Mp;
+
+    // K_mm + jitter -> L (in place Cholesky)
+    GramArgs g = {};
+    g.kind = desc->kind; g.d = desc->d; g.xdiv = 1; g.zdiv = 1;
+    g.x = Zx; g.f = zf; g.nbase = D.M; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp;
+    g.K = S.L; g.ldk = Mp; g.Mp = Mp; g.Np = Mp; g.knn = nullptr; g.jitter = desc->jitter; g.is_kmm = 1;
+    TRY(launch_gram_fwd(g, s));
+    TRY(launch_potrf(S.L, Mp, Mp, F.Dinv, info, s));
+    HIP_TRY(hipMemsetAsync(S.Linv, 0, mm * sizeof(double), s));
+    TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, s));
+    TRY(launch_transpose(S.Linv, Mp, S.LinvT, Mp, Mp, Mp, s));
+    TRY(launch_pad_tril(L_S, D.M, D.M, S.LSp, Mp, s));
+    TRY(launch_pad_vec(m, D.M, S.mp, Mp, s));
+    // U = L^-1 L_S (lower x lower), a = L^-1 m
+    HIP_TRY(hipMemsetAsync(S.U, 0, mm * sizeof(double), s));
+    {
+        GemmArgs ga = gemm_args(S.Linv, Mp, S.LSp, Mp, S.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
+        ga.lower_out = 1;
+        TRY(launch_gemm(ga, false, 1, s));
+    }
+    TRY(launch_transpose(S.U, Mp, S.UT, Mp, Mp, Mp, s));
+    TRY(launch_gemv_rows(S.Linv, Mp, S.mp, S.a, Mp, Mp, 1.0, 0, s));
+    TRY(launch_kl(S.L, S.LSp, S.U, S.a, D.M, Mp, kl, s));
+
+    // K_mn, k_nn
+    g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
+    g.K = S.K; g.ldk = Np; g.Np = Np; g.knn = S.knn; g.is_kmm = 0;
+    TRY(launch_gram_fwd(g, s));
+    // A = L^-1 K_mn  (+ q, mean partials);  C = U^T A (+ r partials)
+    {
+        GemmArgs ga = gemm_args(S.Linv, Mp, S.K, Np, S.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
+        ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = S.a;
+        TRY(launch_gemm(ga, false, 1, s));
+        GemmArgs gc = gemm_args(S.UT, Mp, S.A, Np, S.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
+        gc.epi = EPI_COLSTATS; gc.colsq_part = F.rpart; gc.coldot_part = nullptr; gc.avec = S.a;
+        TRY(launch_gemm(gc, false, 1, s));
+    }
+    TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, D.nrb, Np, D.N, S.knn, desc->branch, desc->min_var, S.q, S.r,
+                              S.varraw, mean, var, s));
+    return MOBOCMF_OK;
+}
+
+int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                           const double* zf, const double* hyp, const double* m, const double* L_S,
+                           const double* g_mean, const double* g_var, const double* g_kl, double* g_f, double* g_zf,
+                           double* g_hyp, double* g_m, double* g_LS, double* g_x, void* saved, size_t saved_bytes,
+                           void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
+    if (!valid_desc(desc) || !x || !Zx || !hyp || !m || !L_S || !g_hyp || !g_m || !g_LS || !saved || !scratch)
+        return MOBOCMF_BAD_ARG;
+    if (desc->kind == 1 && (!f || !zf || !g_f || !g_zf)) return MOBOCMF_BAD_ARG;
+    if (desc->want_dx && !g_x) return MOBOCMF_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    Dims D = dims_of(desc);
+    Bump bs(saved, saved_bytes), bb(scratch, scratch_bytes);
+    Saved S;
+    ScratchB B;
+    if (!carve_saved(bs, D, S) || !carve_scratch_bwd(bb, D, desc, B)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    const int Mp = D.Mp;
+    const int64_t Np = D.Np, mm = (int64_t)Mp * Mp;
+    double *dU = B.W[0], *dLinv = B.W[1], *T1 = B.W[2], *T2 = B.W[3], *dL = B.W[4], *LT = B.W[5], *T4 = B.W[6],
+           *Gm = B.W[7];
+
+    TRY(launch_moments_bwd_prep(g_mean, g_var, S.knn, S.q, S.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
+                                B.gv2, B.cgv, s));
+    // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
+    {
+        GemmArgs ga = gemm_args(S.U, Mp, S.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
+        ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = S.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = S.A;
+        TRY(launch_gemm(ga, false, 1, s));
+    }
+    // dU = tril(A diag(2 gv) C^T)      (split-K over N')
+    {
+        GemmArgs ga = gemm_args(S.A, Np, S.C, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
+        ga.bscale = B.gv2; ga.lower_out = 1; ga.slab_stride = mm;
+        TRY(launch_gemm(ga, true, D.splitk, s));
+        TRY(launch_reduce_slabs(B.slabs, mm, D.splitk, dU, Mp, Mp, 1.0, 1, 0, s));
+    }
+    // da = A gmu
+    TRY(launch_gemv_long(S.A, Np, B.gmu, B.da, Mp, Np, B.gpart, s));
+    // dK = L^-T dA
+    {
+        GemmArgs ga = gemm_args(S.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
+        TRY(launch_gemm(ga, false, 1, s));
+    }
+    // dLinv = tril(dA K^T)
+    {
+        GemmArgs ga = gemm_args(B.dA, Np, S.K, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
+        ga.lower_out = 1; ga.slab_stride = mm;
+        TRY(launch_gemm(ga, true, D.splitk, s));
+        TRY(launch_reduce_slabs(B.slabs, mm, D.splitk, dLinv, Mp, Mp, 1.0, 1, 0, s));
+    }
+    // Gram backward of K_mn and k_nn
+    GramArgs g = {};
+    g.kind = desc->kind; g.d = desc->d; g.xdiv = desc->xdiv; g.zdiv = 1;
+    g.x = x; g.f = f; g.nbase = D.nbase; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp;
+    g.ldk = Np; g.Mp = Mp; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
+    g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
+    TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
+    TRY(launch_sum_partials(B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, g_hyp, D.H, 1.0, 0, s));
+    if (desc->kind == 1) {
+        TRY(launch_sum_partials(B.df_part, D.ggrid_mn.y, Np, g_f, D.N, 1.0, 0, s));
+        TRY(launch_sum_partials(B.dzf_part, D.ggrid_mn.x, Mp, g_zf, D.M, 1.0, 0, s));
+    }
+    if (desc->want_dx)
+        TRY(launch_sum_partials(B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, g_x, D.nbase * desc->d, 1.0, 0, s));
+
+    // ---- M x M chain
+    TRY(launch_add_kl_terms(dU, S.U, B.da, S.a, g_kl, Mp, s));
+    // dLinv += dU_tot L_S^T + da m^T  (then exact lower triangle)
+    {
+        GemmArgs ga = gemm_args(dU, Mp, S.LSp, Mp, dLinv, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);
+        ga.lower_out = 1; ga.accumulate = 1;
+        TRY(launch_gemm(ga, true, 1, s));
+    }
+    TRY(launch_rank1_add(dLinv, B.da, S.mp, Mp, s));
+    TRY(launch_tril_inplace(dLinv, Mp, Mp, s));
+    // g_m = L^-T da
+    TRY(launch_gemv_rows(S.LinvT, Mp, B.da, g_m, D.M, Mp, 1.0, 0, s));
+    // g_LS = tril(L^-T dU_tot) - gkl diag(1/LS_ii)
+    {
+        GemmArgs ga = gemm_args(S.LinvT, Mp, dU, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        ga.lower_out = 1;
+        TRY(launch_gemm(ga, false, 1, s));
+        TRY(launch_gls_out(T1, S.LSp, g_kl, D.M, Mp, g_LS, s));
+    }
+    // dL = -tril(L^-T dLinv L^-T) + gkl diag(1/L_ii)
+    {
+        GemmArgs ga = gemm_args(S.LinvT, Mp, dLinv, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        TRY(launch_gemm(ga, false, 1, s));
+        GemmArgs gb = gemm_args(T1, Mp, S.LinvT, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_B, 1.0);
+        gb.lower_out = 1;
+        TRY(launch_gemm(gb, false, 1, s));
+        TRY(launch_dl_from_t2(T2, S.L, g_kl, D.M, Mp, dL, s));
+    }
+    // Cholesky backward: dKmm = sym(L^-T Phi(L^T dL) L^-1)
+    {
+        TRY(launch_transpose(S.L, Mp, LT, Mp, Mp, Mp, s));
+        GemmArgs ga = gemm_args(LT, Mp, dL, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        TRY(launch_gemm(ga, false, 1, s));
+        TRY(launch_phi(T2, Mp, T1, s));
+        GemmArgs gb = gemm_args(S.LinvT, Mp, T1, Mp, T4, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        TRY(launch_gemm(gb, false, 1, s));
+        GemmArgs gc = gemm_args(T4, Mp, S.Linv, Mp, T2, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);
+        TRY(launch_gemm(gc, false, 1, s));
+        TRY(launch_symmetrize(T2, Mp, Gm, s));
+    }
+    // Gram backward of K_mm (both arguments are Z~)
+    g.xdiv = 1; g.x = Zx; g.f = zf; g.nbase = D.M; g.ldk = Mp; g.Np = Mp; g.G = Gm; g.gknn = nullptr;
+    g.hyp_part = B.hyp_part2; g.df_part = B.df_part2; g.dzf_part = B.dzf_part2; g.dx_part = nullptr;
+    TRY(launch_gram_bwd(g, false, s));
+    TRY(launch_sum_partials(B.hyp_part2, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, D.H, g_hyp, D.H, 1.0, 1, s));
+    if (desc->kind == 1) {
+        TRY(launch_sum_partials(B.df_part2, D.ggrid_mm.y, Mp, g_zf, D.M, 1.0, 1, s));
+        TRY(launch_sum_partials(B.dzf_part2, D.ggrid_mm.x, Mp, g_zf, D.M, 1.0, 1, s));
+    }
+    return MOBOCMF_OK;
+}
+
+int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* hyp,
+                                  double* cov, int64_t ldcov, void* saved, size_t saved_bytes, void* scratch,
+                                  size_t scratch_bytes, mobocmf_stream_t stream) {
+    if (!valid_desc(desc) || !x || !hyp || !cov || !saved || !scratch || ldcov < desc->Np) return MOBOCMF_BAD_ARG;
+    if (desc->kind == 1 && !f) return MOBOCMF_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    Dims D = dims_of(desc);
+    if (D.Np > 16384) return MOBOCMF_BAD_ARG;
+    Bump bs(saved, saved_bytes), bc(scratch, scratch_bytes);
+    Saved S;
+    if (!carve_saved(bs, D, S)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    const int Mp = D.Mp;
+    const int64_t Np = D.Np;
+    double* AT = bc.take(Np * Mp);
+    double* CT = bc.take(Np * Mp);
+    double* Cv = bc.take(Np * Np);
+    if (!bc.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    // K_nn: Gram with the data rows on both sides
+    GramArgs g = {};
+    g.kind = desc->kind; g.d = desc->d; g.xdiv = desc->xdiv; g.zdiv = desc->xdiv;
+    g.x = x; g.f = f; g.nbase = D.nbase; g.Zx = x; g.zf = f; g.M = (int)D.N; g.hyp = hyp;
+    g.K = Cv; g.ldk = Np; g.Mp = (int)Np; g.Np = Np; g.knn = nullptr; g.jitter = 0.0; g.is_kmm = 0;
+    TRY(launch_gram_fwd(g, s));
+    TRY(launch_transpose(S.A, Np, AT, Mp, Mp, Np, s));
+    TRY(launch_transpose(S.C, Np, CT, Mp, Mp, Np, s));
+    GemmArgs ga = gemm_args(AT, Mp, S.A, Np, Cv, Np, (int)Np, Np, Mp, TRI_NONE, -1.0);
+    ga.accumulate = 1;
+    TRY(launch_gemm(ga, false, 1, s));
+    GemmArgs gc = gemm_args(CT, Mp, S.C, Np, Cv, Np, (int)Np, Np, Mp, TRI_NONE, 1.0);
+    gc.accumulate = 1;
+    TRY(launch_gemm(gc, false, 1, s));
+    TRY(launch_copy_block(Cv, Np, cov, ldcov, D.N, D.N, s));
+    return MOBOCMF_OK;
+}
+
+int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream) {
+    int32_t h = 0;
+    if (hipMemcpyAsync(&h, info, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+        return MOBOCMF_HIP_ERROR;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MOBOCMF_HIP_ERROR;
+    if (pivot) *pivot = h;
+    return h == 0 ? MOBOCMF_OK : MOBOCMF_NOT_PD;
+}
+
+}  // extern "C"

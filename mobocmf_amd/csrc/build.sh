@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds libmobocmf_hip.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+objs=""
+for f in gemm_f64 chol gram elementwise api; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/mobocmf_hip.h -nt $f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o $f.o &
+  fi
+  objs="$objs $f.o"
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libmobocmf_hip.so $objs
+echo "built $(pwd)/libmobocmf_hip.so"

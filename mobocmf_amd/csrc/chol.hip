@@ -1,0 +1,267 @@
+// Blocked in-place Cholesky of K_mm and triangular inverse, gfx950.
+//
+// Right-looking, panel width NB = 64 = one wavefront.  The 64x64 diagonal block is factorised by ONE
+// wavefront with the block held row-per-lane in registers; column broadcasts (pivot, L_kj) are
+// wavefront cross-lane reads (v_readlane), no LDS and no barriers.  The same wavefront-shuffle scheme
+// solves the 64-row panel blocks below the diagonal (X L_jj^T = A_ij) and inverts L_jj (kept for the
+// blocked triangular inverse).  The trailing update A22 -= L21 L21^T runs on the f64 MFMA.
+// Reference behaviour replaced: gpytorch psd_safe_cholesky(K_mm) -> torch.linalg.cholesky_ex.
+#include "common.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double bcast(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c].  Returns the first
+// failed pivot (1-based) or 0.
+__device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane) {
+    int fail = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double ajj = bcast(a[j], j);
+        if (!(ajj > 0.0) && fail == 0) fail = j + 1;
+        double d = sqrt(ajj);
+        double lij = a[j] / d;          // lanes >= j: L[lane][j]  (lane j: d)
+        a[j] = lij;
+#pragma unroll
+        for (int k = j + 1; k < NB; ++k) a[k] -= lij * bcast(lij, k);   // valid for lanes >= k
+    }
+    return fail;
+}
+
+// x[] = row `lane` of L^-1 given L rows in a[] (both lower triangular)
+__device__ __forceinline__ void trinv64_rows(const double (&a)[NB], double (&x)[NB], int lane) {
+#pragma unroll
+    for (int k = NB - 1; k >= 0; --k) {
+        double s = (lane == k) ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = k + 1; t < NB; ++t) s -= x[t] * bcast(a[k], t);
+        x[k] = s / bcast(a[k], k);
+    }
+}
+
+// row `lane` of B <- B L^-T  (forward substitution along the row)
+__device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[NB]) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        double s = b[k];
+#pragma unroll
+        for (int t = 0; t < k; ++t) s -= b[t] * bcast(a[t], k);
+        b[k] = s / bcast(a[k], k);
+    }
+}
+
+// grid.x = number of 64-row blocks at/below the diagonal of panel jb; block = 64 threads (1 wavefront)
+__global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, int32_t* info) {
+    const int lane = threadIdx.x;
+    const int bi = blockIdx.x;
+    const int64_t j0 = (int64_t)jb * NB;
+    double a[NB];
+    const double* drow = A + (j0 + lane) * ld + j0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = drow[c];
+    int fail = chol64_rows(a, lane);
+    if (bi == 0) {
+        double* wrow = A + (j0 + lane) * ld + j0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
+        if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
+        double x[NB];
+        trinv64_rows(a, x, lane);
+        double* irow = Dinv + (int64_t)jb * NB * NB + lane * NB;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) irow[c] = (c <= lane) ? x[c] : 0.0;
+    } else {
+        double b[NB];
+        double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) b[c] = prow[c];
+        trsm64_rows(a, b);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) prow[c] = b[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------- 64x64x64 MFMA product
+#define LD64 66
+// acc (2x2 MFMA tiles of the wavefront's 32x32 quadrant) += As[i][k] * (BT ? Bs[j][k] : Bs[k][j])
+template <bool BT>
+__device__ __forceinline__ void mm64(const double* As, const double* Bs, v4f64 (&acc)[2][2], int wr, int wc, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        double af[2], bf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) af[t] = As[(wr * 32 + t * 16 + li) * LD64 + ks * 4 + lk];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            bf[t] = BT ? Bs[(wc * 32 + t * 16 + li) * LD64 + ks * 4 + lk] : Bs[(ks * 4 + lk) * LD64 + wc * 32 + t * 16 + li];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void load64(double* dst, const double* src, int64_t ld, int tid) {
+    // 64x64 block, 256 threads: thread -> (row = tid/4 (+0), 16 contiguous doubles)
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dst[r * LD64 + c0 + c] = src[(int64_t)r * ld + c0 + c];
+}
+
+// trailing update of panel jb: A[ti][tj] -= P_ti * P_tj^T for 64-blocks ti >= tj > jb (P = panel columns)
+__global__ __launch_bounds__(256) void syrk64_update_kernel(double* A, int64_t ld, int jb) {
+    const int ti = jb + 1 + blockIdx.x, tj = jb + 1 + blockIdx.y;
+    if (tj > ti) return;
+    __shared__ double Pi[NB * LD64], Pj[NB * LD64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int64_t j0 = (int64_t)jb * NB;
+    load64(Pi, A + (int64_t)ti * NB * ld + j0, ld, tid);
+    load64(Pj, A + (int64_t)tj * NB * ld + j0, ld, tid);
+    __syncthreads();
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0, 0, 0, 0};
+    mm64<true>(Pi, Pj, acc, wr, wc, lane);
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t row = (int64_t)ti * NB + wr * 32 + i * 16 + lk + 4 * r;
+                int64_t col = (int64_t)tj * NB + wc * 32 + j * 16 + li;
+                A[row * ld + col] -= acc[i][j][r];
+            }
+}
+
+// zero the strict upper triangle
+__global__ void tril_inplace_kernel(double* A, int64_t ld, int n) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * n) return;
+    int i = (int)(idx / n), j = (int)(idx % n);
+    if (j > i) A[(int64_t)i * ld + j] = 0.0;
+}
+
+int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s) {
+    int64_t n2 = (int64_t)n * n;
+    hipLaunchKernelGGL(tril_inplace_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, A, ld, n);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, int32_t* info, hipStream_t s) {
+    const int nblk = Mp / NB;
+    HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), s));
+    for (int jb = 0; jb < nblk; ++jb) {
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk - jb), dim3(64), 0, s, A, ld, jb, Dinv, info);
+        int nt = nblk - jb - 1;
+        if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, ld, jb);
+    }
+    int64_t n2 = (int64_t)Mp * Mp;
+    hipLaunchKernelGGL(tril_inplace_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, A, ld, Mp);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+// ---------------------------------------------------------------------------------- triangular inverse
+// level 0: the 128x128 diagonal blocks of L^-1 from the 64x64 inverses:  [[D0,0],[-D1 L10 D0, D1]]
+__global__ __launch_bounds__(256) void trtri_level0_kernel(const double* L, int64_t ld, const double* Dinv, double* Linv,
+                                                           int64_t ldi) {
+    const int b = blockIdx.x;
+    __shared__ double S0[NB * LD64], S1[NB * LD64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const double* D0 = Dinv + (int64_t)(2 * b) * NB * NB;
+    const double* D1 = Dinv + (int64_t)(2 * b + 1) * NB * NB;
+    const int64_t o = (int64_t)b * 128;
+    load64(S0, L + (o + 64) * ld + o, ld, tid);   // L10
+    load64(S1, D0, NB, tid);
+    __syncthreads();
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0, 0, 0, 0};
+    mm64<false>(S0, S1, acc, wr, wc, lane);   // T = L10 * D0
+    __syncthreads();
+    // T -> S0 ; D1 -> S1 ; also write D0 / D1 / zero block to Linv
+    {
+        const int r = tid >> 2, c0 = (tid & 3) * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            Linv[(o + r) * ldi + o + c0 + c] = S1[r * LD64 + c0 + c];
+            Linv[(o + r) * ldi + o + 64 + c0 + c] = 0.0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S0[(wr * 32 + i * 16 + lk + 4 * r) * LD64 + wc * 32 + j * 16 + li] = acc[i][j][r];
+    load64(S1, D1, NB, tid);
+    __syncthreads();
+    {
+        const int r = tid >> 2, c0 = (tid & 3) * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Linv[(o + 64 + r) * ldi + o + 64 + c0 + c] = S1[r * LD64 + c0 + c];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0, 0, 0, 0};
+    mm64<false>(S1, S0, acc, wr, wc, lane);   // D1 * T
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Linv[(o + 64 + wr * 32 + i * 16 + lk + 4 * r) * ldi + o + wc * 32 + j * 16 + li] = -acc[i][j][r];
+}
+
+// Linv (Mp x Mp, pre-zeroed above the block diagonal by the caller) = L^-1.  T = scratch Mp x Mp.
+int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, hipStream_t s) {
+    const int nb = Mp / TILE;
+    hipLaunchKernelGGL(trtri_level0_kernel, dim3(nb), dim3(256), 0, s, L, ld, Dinv, Linv, (int64_t)Mp);
+    for (int i = 1; i < nb; ++i) {
+        // T[128 x i*128] = L[i, 0:i] * Linv[0:i, 0:i]       (B lower triangular)
+        GemmArgs g = {};
+        g.A = L + (int64_t)i * TILE * ld;
+        g.lda = ld;
+        g.B = Linv;
+        g.ldb = Mp;
+        g.C = T;
+        g.ldc = Mp;
+        g.Mr = TILE;
+        g.Nc = (int64_t)i * TILE;
+        g.Kd = (int64_t)i * TILE;
+        g.tri = TRI_LOWER_B;
+        g.alpha = 1.0;
+        int rc = launch_gemm(g, false, 1, s);
+        if (rc) return rc;
+        // Linv[i, 0:i] = -Linv[i,i] * T
+        GemmArgs h = {};
+        h.A = Linv + (int64_t)i * TILE * Mp + (int64_t)i * TILE;
+        h.lda = Mp;
+        h.B = T;
+        h.ldb = Mp;
+        h.C = Linv + (int64_t)i * TILE * Mp;
+        h.ldc = Mp;
+        h.Mr = TILE;
+        h.Nc = (int64_t)i * TILE;
+        h.Kd = TILE;
+        h.alpha = -1.0;
+        rc = launch_gemm(h, false, 1, s);
+        if (rc) return rc;
+    }
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}

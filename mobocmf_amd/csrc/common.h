@@ -1,0 +1,88 @@
+// Shared declarations for the gfx950 MFDGP kernels (internal; the public C-ABI is include/mobocmf_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mobocmf_hip.h"
+
+#define TILE 128   // every internal matrix is zero-padded to multiples of TILE in both dimensions
+#define NB 64      // Cholesky / triangular-inverse panel width (one wavefront = one 64x64 diagonal block)
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return MOBOCMF_HIP_ERROR; \
+    } while (0)
+
+// ------------------------------------------------------------------ GEMM (gemm_f64.hip)
+// bit mask: which k range of a tile is structurally non-zero (A is Mr x Kd, logical B is Kd x Nc)
+enum { TRI_NONE = 0, TRI_LOWER_A = 1, TRI_UPPER_A = 2, TRI_LOWER_B = 4, TRI_UPPER_B = 8 };
+enum { EPI_STORE = 0, EPI_COLSTATS = 1, EPI_DA = 2 };
+
+struct GemmArgs {
+    const double* A;   // [Mr x Kd] row-major, lda
+    const double* B;   // B_T ? [Nc x Kd] : [Kd x Nc]
+    double* C;         // [Mr x Nc]
+    int64_t lda, ldb, ldc;
+    int Mr;            // rows (multiple of TILE)
+    int64_t Nc;        // cols (multiple of TILE)
+    int64_t Kd;        // contraction length (multiple of 16)
+    int tri;           // TRI_*: restricts the k range per row block (A triangular, square A: Kd == Mr)
+    int lower_out;     // 1: skip tiles strictly above the diagonal (square outputs)
+    double alpha;
+    int accumulate;    // 1: C += alpha*A*B  (else C = ...)
+    // split-K: gridDim.z slices of the contraction, slice z writes C + z*slab_stride (reduced by reduce_slabs)
+    int64_t slab_stride;
+    // batching (only without split-K): blockIdx.z selects the batch
+    int64_t strideA, strideB, strideC;
+    int batched;
+    // operand scaling: B[k][n] *= bscale[n] (B_T=0)  /  B_T: B[j][k] *= bscale[k]
+    const double* bscale;
+    // epilogues
+    int epi;
+    double* colsq_part;    // EPI_COLSTATS: [Mr/TILE][Nc] partial column sums of C^2
+    double* coldot_part;   // EPI_COLSTATS: [Mr/TILE][Nc] partial column sums of avec[i]*C[i][n]   (may be null)
+    const double* avec;    // EPI_COLSTATS / EPI_DA: length Mr
+    const double* gmu;     // EPI_DA: length Nc
+    const double* cgv;     // EPI_DA: length Nc
+    const double* Aaux;    // EPI_DA: [Mr x Nc], ld = ldc
+};
+
+int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s);
+// out[i][j] = scale * sum_z slabs[z][i][j]  (lower_only: zero above the diagonal), Mr x Mr
+int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, double* out, int64_t ld, int Mr,
+                        double scale, int lower_only, int accumulate, hipStream_t s);
+
+// ------------------------------------------------------------------ Gram (gram.hip)
+struct GramArgs {
+    int kind, d, xdiv, zdiv;
+    const double* x;      // [nbase x d]
+    const double* f;      // [nbase*xdiv] (kind 1)
+    int64_t nbase;
+    const double* Zx;     // [M/zdiv x d]   row side
+    const double* zf;     // [M] (kind 1)
+    int M;
+    const double* hyp;
+    double* K;            // [Mp x Np]
+    int64_t ldk;
+    int Mp;
+    int64_t Np;
+    double* knn;          // [Np] or null
+    double jitter;
+    int is_kmm;           // add jitter on the diagonal, identity on the padded diagonal
+    // backward
+    const double* G;      // dL/dK [Mp x Np], ld = ldk
+    const double* gknn;   // [Np] or null
+    double* hyp_part;     // [gridDim.y*gridDim.x][H]
+    double* df_part;      // [gridDim.y][Np]        (kind 1)
+    double* dzf_part;     // [gridDim.x][Mp]        (kind 1)
+    double* dx_part;      // [gridDim.y][nbase*d]   (want_dx)
+};
+
+// ------------------------------------------------------------------ hyper-parameter packing
+// kind 0: [alpha, ls[0..d)]                                   (1 + d doubles)
+// kind 1: [a1, af, nu, a2, lsf, ls1[0..d), ls2[0..d)]         (5 + 2d doubles)
+static inline int hyp_len(int kind, int d) { return kind == 0 ? 1 + d : 5 + 2 * d; }
+#define MAX_D 64

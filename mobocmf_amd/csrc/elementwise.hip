@@ -1,0 +1,501 @@
+// Small / memory-bound kernels of the MFDGP path (gfx950): padding, transposes, M x M glue of the
+// Cholesky backward chain, predictive-moment finish, KL, sample propagation, ELBO data term,
+// acquisition moments, fused Adam.  All HBM-bound: coalesced, one pass, reductions by wavefront shuffles.
+#include "common.h"
+
+#define LOG_2PI 1.8378770664093454835606594728112
+
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// block-wide sum (blockDim.x = 256), result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    return t;
+}
+
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR)
+
+// ------------------------------------------------------------------ M x M helpers
+// dst (Mp x Mp) = tril(src (M x M, ld lds)) zero padded
+__global__ void pad_tril_kernel(const double* src, int64_t lds, int M, double* dst, int Mp) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    dst[idx] = (i < M && j <= i) ? src[(int64_t)i * lds + j] : 0.0;
+}
+int launch_pad_tril(const double* src, int64_t lds, int M, double* dst, int Mp, hipStream_t s) {
+    hipLaunchKernelGGL(pad_tril_kernel, GRID1((int64_t)Mp * Mp), 0, s, src, lds, M, dst, Mp);
+    return CHECK_LAUNCH();
+}
+
+__global__ void pad_vec_kernel(const double* src, int64_t n, double* dst, int64_t np) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) dst[i] = (src && i < n) ? src[i] : 0.0;
+}
+int launch_pad_vec(const double* src, int64_t n, double* dst, int64_t np, hipStream_t s) {
+    hipLaunchKernelGGL(pad_vec_kernel, GRID1(np), 0, s, src, n, dst, np);
+    return CHECK_LAUNCH();
+}
+
+// out[c][r] = in[r][c]   (rows x cols -> cols x rows), 32x32 LDS tiles
+__global__ void transpose_kernel(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols) {
+    __shared__ double t[32][33];
+    int64_t c = (int64_t)blockIdx.x * 32 + threadIdx.x, r0 = (int64_t)blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += 8)
+        if (r0 + k < rows && c < cols) t[k][threadIdx.x] = in[(r0 + k) * ldi + c];
+    __syncthreads();
+    int64_t r = r0 + threadIdx.x, c0 = (int64_t)blockIdx.x * 32;
+    for (int k = threadIdx.y; k < 32; k += 8)
+        if (c0 + k < cols && r < rows) out[(c0 + k) * ldo + r] = t[threadIdx.x][k];
+}
+int launch_transpose(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s) {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, ldi, out, ldo, rows, cols);
+    return CHECK_LAUNCH();
+}
+
+// out[i] = sum_j Mat[i][j] * vec[j]   (one wavefront per row), optional accumulate
+__global__ void gemv_rows_kernel(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols,
+                                 double scale, int accumulate) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const double* p = Mat + (int64_t)row * ld;
+    double s = 0.0;
+    for (int64_t j = lane; j < cols; j += 64) s += p[j] * vec[j];
+    s = wave_sum(s) * scale;
+    if (lane == 0) out[row] = accumulate ? out[row] + s : s;
+}
+int launch_gemv_rows(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double scale,
+                     int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, Mat, ld, vec, out, rows, cols, scale,
+                       accumulate);
+    return CHECK_LAUNCH();
+}
+
+// long-row gemv: out[row] = sum_n Mat[row][n] * vec[n], one block per (row, chunk) + partials
+__global__ void gemv_long_kernel(const double* Mat, int64_t ld, const double* vec, double* part, int64_t cols,
+                                 int nchunk) {
+    __shared__ double sh[4];
+    int row = blockIdx.y, ch = blockIdx.x;
+    int64_t per = (cols + nchunk - 1) / nchunk, b = ch * per, e = b + per < cols ? b + per : cols;
+    const double* p = Mat + (int64_t)row * ld;
+    double s = 0.0;
+    for (int64_t j = b + threadIdx.x; j < e; j += 256) s += p[j] * vec[j];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[(int64_t)row * nchunk + ch] = s;
+}
+__global__ void gemv_long_finish_kernel(const double* part, int nchunk, double* out, int rows) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += part[(int64_t)r * nchunk + c];
+    out[r] = s;
+}
+int launch_gemv_long(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double* part,
+                     hipStream_t s) {
+    int nchunk = (int)((cols + 8191) / 8192);
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 16) nchunk = 16;
+    hipLaunchKernelGGL(gemv_long_kernel, dim3(nchunk, rows), dim3(256), 0, s, Mat, ld, vec, part, cols, nchunk);
+    hipLaunchKernelGGL(gemv_long_finish_kernel, GRID1(rows), 0, s, part, nchunk, out, rows);
+    return CHECK_LAUNCH();
+}
+
+// KL = 0.5 * (2 sum log L_ii - sum log LS_ii^2 + |U|_F^2 + |a|^2 - M)      (SURVEY A.4), single block
+__global__ void kl_kernel(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp,
+                          double* kl) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256) {
+        double l = L[(int64_t)i * Mp + i], ls = LSp[(int64_t)i * Mp + i];
+        s += 2.0 * log(l) - log(ls * ls) + a[i] * a[i];
+    }
+    for (int64_t e = threadIdx.x; e < (int64_t)M * M; e += 256) {
+        int i = (int)(e / M), j = (int)(e % M);
+        if (j <= i) { double u = U[(int64_t)i * Mp + j]; s += u * u; }
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) kl[0] = 0.5 * (s - (double)M);
+}
+int launch_kl(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* kl,
+              hipStream_t s) {
+    hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(256), 0, s, L, LSp, U, a, M, Mp, kl);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ predictive moments
+// q = sum_rb qpart, mean = sum_rb mupart, r = sum_rb rpart; var_raw = (branch ? knn - q : max(knn - q, 0)) + r
+__global__ void moments_finish_kernel(const double* qpart, const double* mupart, const double* rpart, int nrb,
+                                      int64_t Np, int64_t N, const double* knn, int branch, double min_var, double* q,
+                                      double* r, double* varraw, double* mean, double* var) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Np) return;
+    double qs = 0, ms = 0, rs = 0;
+    for (int b = 0; b < nrb; ++b) {
+        qs += qpart[(int64_t)b * Np + n];
+        ms += mupart[(int64_t)b * Np + n];
+        rs += rpart[(int64_t)b * Np + n];
+    }
+    double sres = knn[n] - qs;
+    if (!branch && sres < 0.0) sres = 0.0;
+    double v = sres + rs;
+    q[n] = qs;
+    r[n] = rs;
+    varraw[n] = v;
+    if (n < N) {
+        mean[n] = ms;
+        var[n] = v < min_var ? min_var : v;
+    }
+}
+int launch_moments_finish(const double* qpart, const double* mupart, const double* rpart, int nrb, int64_t Np, int64_t N,
+                          const double* knn, int branch, double min_var, double* q, double* r, double* varraw,
+                          double* mean, double* var, hipStream_t s) {
+    hipLaunchKernelGGL(moments_finish_kernel, GRID1(Np), 0, s, qpart, mupart, rpart, nrb, Np, N, knn, branch, min_var, q,
+                       r, varraw, mean, var);
+    return CHECK_LAUNCH();
+}
+
+// backward prep: gmu (padded), gv = g_var * [varraw > min_var], gv2 = 2*gv, cgv = gv * [branch || knn - q > 0]
+__global__ void moments_bwd_prep_kernel(const double* g_mean, const double* g_var, const double* knn, const double* q,
+                                        const double* varraw, int branch, double min_var, int64_t N, int64_t Np,
+                                        double* gmu, double* gv, double* gv2, double* cgv) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Np) return;
+    double gm = 0.0, g = 0.0, c = 0.0;
+    if (n < N) {
+        gm = g_mean ? g_mean[n] : 0.0;
+        g = (g_var && varraw[n] > min_var) ? g_var[n] : 0.0;   // clamp_min passes gradient only above the floor
+        c = (branch || knn[n] - q[n] > 0.0) ? g : 0.0;
+    }
+    gmu[n] = gm;
+    gv[n] = g;
+    gv2[n] = 2.0 * g;
+    cgv[n] = c;
+}
+int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
+                            const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
+                            double* gv, double* gv2, double* cgv, hipStream_t s) {
+    hipLaunchKernelGGL(moments_bwd_prep_kernel, GRID1(Np), 0, s, g_mean, g_var, knn, q, varraw, branch, min_var, N, Np,
+                       gmu, gv, gv2, cgv);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ Cholesky-chain backward glue (Mp x Mp)
+// dU_tot = dU + gkl*U ;  da_tot = da + gkl*a        (in place on dU, da)
+__global__ void add_kl_terms_kernel(double* dU, const double* U, double* da, const double* a, const double* gkl, int Mp) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double g = gkl ? gkl[0] : 0.0;
+    if (idx < (int64_t)Mp * Mp) dU[idx] += g * U[idx];
+    if (idx < Mp) da[idx] += g * a[idx];
+}
+int launch_add_kl_terms(double* dU, const double* U, double* da, const double* a, const double* gkl, int Mp, hipStream_t s) {
+    hipLaunchKernelGGL(add_kl_terms_kernel, GRID1((int64_t)Mp * Mp), 0, s, dU, U, da, a, gkl, Mp);
+    return CHECK_LAUNCH();
+}
+
+// X[i][j] += da[i] * m[j]   (rank-1, lower part is what matters)
+__global__ void rank1_add_kernel(double* X, const double* u, const double* v, int Mp) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    X[idx] += u[i] * v[j];
+}
+int launch_rank1_add(double* X, const double* u, const double* v, int Mp, hipStream_t s) {
+    hipLaunchKernelGGL(rank1_add_kernel, GRID1((int64_t)Mp * Mp), 0, s, X, u, v, Mp);
+    return CHECK_LAUNCH();
+}
+
+// dL = -tril(T2) + gkl * diag(1/L_ii)  (rows/cols < M only; zero elsewhere)
+__global__ void dl_from_t2_kernel(const double* T2, const double* L, const double* gkl, int M, int Mp, double* dL) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    double v = 0.0;
+    if (i < M && j <= i) {
+        v = -T2[idx];
+        if (i == j && gkl) v += gkl[0] / L[idx];
+    }
+    dL[idx] = v;
+}
+int launch_dl_from_t2(const double* T2, const double* L, const double* gkl, int M, int Mp, double* dL, hipStream_t s) {
+    hipLaunchKernelGGL(dl_from_t2_kernel, GRID1((int64_t)Mp * Mp), 0, s, T2, L, gkl, M, Mp, dL);
+    return CHECK_LAUNCH();
+}
+
+// P = Phi(T3): lower triangle with halved diagonal
+__global__ void phi_kernel(const double* T3, int Mp, double* P) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    P[idx] = j < i ? T3[idx] : (j == i ? 0.5 * T3[idx] : 0.0);
+}
+int launch_phi(const double* T3, int Mp, double* P, hipStream_t s) {
+    hipLaunchKernelGGL(phi_kernel, GRID1((int64_t)Mp * Mp), 0, s, T3, Mp, P);
+    return CHECK_LAUNCH();
+}
+
+// G = (S + S^T)/2
+__global__ void symmetrize_kernel(const double* S, int Mp, double* G) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    G[idx] = 0.5 * (S[idx] + S[(int64_t)j * Mp + i]);
+}
+int launch_symmetrize(const double* S, int Mp, double* G, hipStream_t s) {
+    hipLaunchKernelGGL(symmetrize_kernel, GRID1((int64_t)Mp * Mp), 0, s, S, Mp, G);
+    return CHECK_LAUNCH();
+}
+
+// g_LS (M x M, ld M) = tril(X (Mp x Mp)) - gkl * diag(1/LS_ii)
+__global__ void gls_out_kernel(const double* X, const double* LSp, const double* gkl, int M, int Mp, double* gLS) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * M) return;
+    int i = (int)(idx / M), j = (int)(idx % M);
+    double v = 0.0;
+    if (j <= i) {
+        v = X[(int64_t)i * Mp + j];
+        if (i == j && gkl) v -= gkl[0] / LSp[(int64_t)i * Mp + i];
+    }
+    gLS[idx] = v;
+}
+int launch_gls_out(const double* X, const double* LSp, const double* gkl, int M, int Mp, double* gLS, hipStream_t s) {
+    hipLaunchKernelGGL(gls_out_kernel, GRID1((int64_t)M * M), 0, s, X, LSp, gkl, M, Mp, gLS);
+    return CHECK_LAUNCH();
+}
+
+__global__ void copy_block_kernel(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    int64_t i = idx / cols, j = idx % cols;
+    dst[i * ldd + j] = src[i * lds + j];
+}
+int launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s) {
+    hipLaunchKernelGGL(copy_block_kernel, GRID1(rows * cols), 0, s, src, lds, dst, ldd, rows, cols);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ public elementwise entry points
+__global__ void propagate_fwd_kernel(const double* mean, const double* var, const double* eps, double* f, int64_t n,
+                                     int div) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t b = i / div;
+    f[i] = mean[b] + sqrt(var[b]) * eps[i];
+}
+__global__ void propagate_bwd_kernel(const double* var, const double* eps, const double* gf, double* gmean, double* gvar,
+                                     int64_t nbase, int div) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbase) return;
+    double sm = 0.0, sv = 0.0;
+    for (int s = 0; s < div; ++s) {
+        double g = gf[b * div + s];
+        sm += g;
+        sv += g * eps[b * div + s];
+    }
+    gmean[b] = sm;
+    gvar[b] = sv * 0.5 / sqrt(var[b]);
+}
+
+__device__ __forceinline__ double elp_term(double y, double mu, double v, double tau, double ltau) {
+    double dlt = y - mu;
+    return -0.5 * ((dlt * dlt + v) / tau + ltau + LOG_2PI);
+}
+__global__ void elbo_fwd_kernel(const double* mean, const double* var, const double* y, const double* fid,
+                                const double* tau_p, double level, int64_t n, int div, double* part) {
+    __shared__ double sh[4];
+    const double tau = tau_p[0], ltau = log(tau);
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t b = i / div;
+        if (fid[b] == level) s += elp_term(y[b], mean[i], var[i], tau, ltau);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void final_sum_kernel(const double* part, int np, double scale, double* out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+__global__ void elbo_bwd_kernel(const double* mean, const double* var, const double* y, const double* fid,
+                                const double* tau_p, double level, int64_t n, int div, const double* gout, double* gmean,
+                                double* gvar, double* part) {
+    __shared__ double sh[4];
+    const double tau = tau_p[0];
+    const double g = gout[0] / div;
+    double st = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t b = i / div;
+        double gm = 0.0, gvv = 0.0;
+        if (fid[b] == level) {
+            double dlt = y[b] - mean[i];
+            gm = g * dlt / tau;
+            gvv = -0.5 * g / tau;
+            st += 0.5 * ((dlt * dlt + var[i]) / (tau * tau) - 1.0 / tau);
+        }
+        gmean[i] = gm;
+        gvar[i] = gvv;
+    }
+    st = block_sum(st, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = st;
+}
+__global__ void final_sum_scaled_kernel(const double* part, int np, const double* gout, double scale, double* out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = s * scale * gout[0];
+}
+
+__global__ void acq_fwd_kernel(const double* mu_t, const double* var_t, double* mus, double* vars, int64_t T, int S) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double sm = 0.0, s2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+        double m = mu_t[t * S + s];
+        sm += m;
+        s2 += var_t[t * S + s] + m * m;
+    }
+    sm /= S;
+    s2 /= S;
+    mus[t] = sm;
+    vars[t] = s2 - sm * sm;
+}
+__global__ void acq_bwd_kernel(const double* mu_t, const double* gmus, const double* gvars, double* gmu_t,
+                               double* gvar_t, int64_t T, int S) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double sm = 0.0;
+    for (int s = 0; s < S; ++s) sm += mu_t[t * S + s];
+    sm /= S;
+    const double gm = gmus ? gmus[t] : 0.0, gvv = gvars ? gvars[t] : 0.0;
+    for (int s = 0; s < S; ++s) {
+        double m = mu_t[t * S + s];
+        gmu_t[t * S + s] = gm / S + gvv * (2.0 * m / S - 2.0 * sm / S);
+        gvar_t[t * S + s] = gvv / S;
+    }
+}
+__global__ void jes_kernel(const double* vu, const double* vc, double* acq, int64_t T) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double v = log(vu[t]) - log(vc[t]);
+    acq[t] = 0.5 * (v > 0.0 ? v : 0.0);
+}
+__global__ void adam_kernel(double* p, const double* g, double* m, double* v, const double* mask, int64_t n, double lr,
+                            double b1, double b2, double eps, double bc1, double bc2_sqrt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (mask && mask[i] == 0.0) return;
+    double gi = g[i];
+    double mi = b1 * m[i] + (1.0 - b1) * gi;
+    double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    // torch.optim.Adam: p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+    p[i] -= (lr / bc1) * mi / (sqrt(vi) / bc2_sqrt + eps);
+}
+
+extern "C" {
+
+int mobocmf_propagate_forward(const double* mean, const double* var, const double* eps, double* f_out, int64_t n_out,
+                              int32_t div, mobocmf_stream_t stream) {
+    if (n_out < 0 || div < 1) return MOBOCMF_BAD_ARG;
+    if (n_out == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(propagate_fwd_kernel, GRID1(n_out), 0, (hipStream_t)stream, mean, var, eps, f_out, n_out, div);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_propagate_backward(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
+                               int64_t n_out, int32_t div, mobocmf_stream_t stream) {
+    if (n_out < 0 || div < 1 || n_out % div) return MOBOCMF_BAD_ARG;
+    if (n_out == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(propagate_bwd_kernel, GRID1(n_out / div), 0, (hipStream_t)stream, var, eps, g_f, g_mean, g_var,
+                       n_out / div, div);
+    return CHECK_LAUNCH();
+}
+
+#define ELBO_BLOCKS 512
+int mobocmf_elbo_data_forward(const double* mean, const double* var, const double* y, const double* fid,
+                              const double* tau, double level, int64_t n_rows, int32_t div, double* out, void* scratch,
+                              size_t scratch_bytes, mobocmf_stream_t stream) {
+    if (n_rows < 0 || div < 1) return MOBOCMF_BAD_ARG;
+    if (scratch_bytes < ELBO_BLOCKS * sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    int nb = (int)((n_rows + 255) / 256);
+    nb = nb < 1 ? 1 : (nb > ELBO_BLOCKS ? ELBO_BLOCKS : nb);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(nb), dim3(256), 0, s, mean, var, y, fid, tau, level, n_rows, div,
+                       (double*)scratch);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, nb, 1.0 / div, out);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_elbo_data_backward(const double* mean, const double* var, const double* y, const double* fid,
+                               const double* tau, double level, int64_t n_rows, int32_t div, const double* g_out,
+                               double* g_mean, double* g_var, double* g_tau, void* scratch, size_t scratch_bytes,
+                               mobocmf_stream_t stream) {
+    if (n_rows < 0 || div < 1) return MOBOCMF_BAD_ARG;
+    if (scratch_bytes < ELBO_BLOCKS * sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    int nb = (int)((n_rows + 255) / 256);
+    nb = nb < 1 ? 1 : (nb > ELBO_BLOCKS ? ELBO_BLOCKS : nb);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(elbo_bwd_kernel, dim3(nb), dim3(256), 0, s, mean, var, y, fid, tau, level, n_rows, div, g_out,
+                       g_mean, g_var, (double*)scratch);
+    hipLaunchKernelGGL(final_sum_scaled_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, nb, g_out, 1.0 / div,
+                       g_tau);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_acq_moments_forward(const double* mu_t, const double* var_t, double* mus, double* vars, int64_t T, int32_t S,
+                                mobocmf_stream_t stream) {
+    if (T < 0 || S < 1) return MOBOCMF_BAD_ARG;
+    if (T == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(acq_fwd_kernel, GRID1(T), 0, (hipStream_t)stream, mu_t, var_t, mus, vars, T, S);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_acq_moments_backward(const double* mu_t, const double* g_mus, const double* g_vars, double* g_mu_t,
+                                 double* g_var_t, int64_t T, int32_t S, mobocmf_stream_t stream) {
+    if (T < 0 || S < 1) return MOBOCMF_BAD_ARG;
+    if (T == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(acq_bwd_kernel, GRID1(T), 0, (hipStream_t)stream, mu_t, g_mus, g_vars, g_mu_t, g_var_t, T, S);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_jes_forward(const double* v_uncond, const double* v_cond, double* acq, int64_t T, mobocmf_stream_t stream) {
+    if (T < 0) return MOBOCMF_BAD_ARG;
+    if (T == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(jes_kernel, GRID1(T), 0, (hipStream_t)stream, v_uncond, v_cond, acq, T);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_adam_step(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, const double* mask,
+                      int64_t n, double lr, double beta1, double beta2, double eps, int64_t step,
+                      mobocmf_stream_t stream) {
+    if (n < 0 || step < 1) return MOBOCMF_BAD_ARG;
+    if (n == 0) return MOBOCMF_OK;
+    double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, GRID1(n), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, mask, n, lr, beta1,
+                       beta2, eps, bc1, sqrt(bc2));
+    return CHECK_LAUNCH();
+}
+
+}  // extern "C"

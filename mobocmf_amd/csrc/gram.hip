@@ -1,0 +1,361 @@
+// Gram matrices of the MFDGP kernels and their backward, gfx950.
+//
+//   kind 0:  k = alpha * exp(-1/2 sum_k ((x_k - z_k)/ls_k)^2)                       (mfdgp_hidden_layer.py:43-47)
+//   kind 1:  k = a1 E1(x,z) (nu f f' + af Ef(f,f')) + a2 E2(x,z)                     (mfdgp_hidden_layer.py:68-88,115)
+//
+// Output K is [Mp x Np] row-major: row m = inducing input m, column n = data row n (coalesced along n).
+// One thread owns one BASE data row n0 (x row) and walks its xdiv sample replicas n = n0*xdiv + s, so the
+// x-only factors E1, E2 (2 of the 3 exponentials) are evaluated once per (m, n0) and shared by the S samples.
+// The inducing rows of the tile (32 x (d+1) doubles + inverse lengthscales) sit in LDS and are read as
+// wave-wide broadcasts; the thread's x row lives in registers.
+#include "common.h"
+
+#define GT 128   // threads per block = base rows per block
+#define GM 32    // inducing rows per block
+
+
+template <int KIND, int DB>
+__global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
+    __shared__ double zs[GM][DB];
+    __shared__ double zfs[GM];
+    __shared__ double il1[DB], il2[DB];
+    const int d = g.d;
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * GM;
+    const double* hyp = g.hyp;
+    double a1, af = 0, nu = 0, a2 = 0, ilf = 0;
+    if (KIND == 0) {
+        a1 = hyp[0];
+        if (tid < d) il1[tid] = 1.0 / hyp[1 + tid];
+    } else {
+        a1 = hyp[0]; af = hyp[1]; nu = hyp[2]; a2 = hyp[3]; ilf = 1.0 / hyp[4];
+        if (tid < d) { il1[tid] = 1.0 / hyp[5 + tid]; il2[tid] = 1.0 / hyp[5 + d + tid]; }
+    }
+    for (int e = tid; e < GM * d; e += GT) {
+        int mm = e / d, k = e % d;
+        int m = m0 + mm;
+        zs[mm][k] = (m < g.M) ? g.Zx[(int64_t)(m / g.zdiv) * d + k] : 0.0;
+    }
+    if (KIND == 1 && tid < GM) zfs[tid] = (m0 + tid < g.M) ? g.zf[m0 + tid] : 0.0;
+    __syncthreads();
+
+    const int64_t n0 = (int64_t)blockIdx.x * GT + tid;
+    const int xdiv = g.xdiv;
+    const int64_t c0 = n0 * xdiv;
+    if (c0 >= g.Np) return;
+    const bool real = n0 < g.nbase;
+    double xr[DB];
+#pragma unroll
+    for (int k = 0; k < DB; ++k) xr[k] = (real && k < d) ? g.x[n0 * d + k] : 0.0;
+
+    if (g.knn && blockIdx.y == 0) {
+        for (int s = 0; s < xdiv; ++s) {
+            int64_t n = c0 + s;
+            if (n >= g.Np) break;
+            double v = 0.0;
+            if (real) {
+                if (KIND == 0) v = a1;
+                else { double fn = g.f[n]; v = a1 * (nu * fn * fn + af) + a2; }
+            }
+            g.knn[n] = v;
+        }
+    }
+    for (int mm = 0; mm < GM; ++mm) {
+        const int m = m0 + mm;
+        double* krow = g.K + (int64_t)m * g.ldk;
+        if (!real || m >= g.M) {
+            for (int s = 0; s < xdiv; ++s) {
+                int64_t n = c0 + s;
+                if (n >= g.Np) break;
+                krow[n] = (g.is_kmm && n == m) ? 1.0 : 0.0;
+            }
+            continue;
+        }
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DB; ++k) {
+            if (k < d) {
+                double df = xr[k] - zs[mm][k];
+                double t1 = df * il1[k];
+                d1 += t1 * t1;
+                if (KIND == 1) { double t2 = df * il2[k]; d2 += t2 * t2; }
+            }
+        }
+        const double E1 = exp(-0.5 * d1);
+        if (KIND == 0) {
+            double v = a1 * E1;
+            if (g.is_kmm && c0 == m) v += g.jitter;
+            krow[c0] = v;   // kind 0 layers always have xdiv == 1 for Kmm; general loop below for replicas
+            for (int s = 1; s < xdiv; ++s) krow[c0 + s] = a1 * E1;
+        } else {
+            const double E2 = exp(-0.5 * d2);
+            const double zfm = zfs[mm];
+            const double c1 = a1 * E1, c2 = a2 * E2;
+            for (int s = 0; s < xdiv; ++s) {
+                const int64_t n = c0 + s;
+                const double fn = g.f[n];
+                const double fd = (fn - zfm) * ilf;
+                const double Ef = exp(-0.5 * fd * fd);
+                double v = c1 * (nu * fn * zfm + af * Ef) + c2;
+                if (g.is_kmm && n == m) v += g.jitter;
+                krow[n] = v;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// Backward: consumes G = dL/dK (and gknn) and produces per-block partial sums (deterministic two-stage
+// reduction, no float atomics across workgroups).
+template <int KIND, int DB, bool WANT_DX>
+__global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
+    __shared__ double zs[GM][DB];
+    __shared__ double zfs[GM];
+    __shared__ double il1[DB], il2[DB];
+    __shared__ double dzf_s[GM];
+    __shared__ double red[2][8 + 2 * DB];
+    extern __shared__ double dfs[];   // [xdiv][GT] per-thread private df accumulators (kind 1)
+    const int d = g.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * GM;
+    const double* hyp = g.hyp;
+    double a1, af = 0, nu = 0, a2 = 0, ilf = 0;
+    if (KIND == 0) {
+        a1 = hyp[0];
+        if (tid < d) il1[tid] = 1.0 / hyp[1 + tid];
+    } else {
+        a1 = hyp[0]; af = hyp[1]; nu = hyp[2]; a2 = hyp[3]; ilf = 1.0 / hyp[4];
+        if (tid < d) { il1[tid] = 1.0 / hyp[5 + tid]; il2[tid] = 1.0 / hyp[5 + d + tid]; }
+    }
+    for (int e = tid; e < GM * d; e += GT) {
+        int mm = e / d, k = e % d;
+        int m = m0 + mm;
+        zs[mm][k] = (m < g.M) ? g.Zx[(int64_t)(m / g.zdiv) * d + k] : 0.0;
+    }
+    if (tid < GM) {
+        dzf_s[tid] = 0.0;
+        if (KIND == 1) zfs[tid] = (m0 + tid < g.M) ? g.zf[m0 + tid] : 0.0;
+    }
+    __syncthreads();
+
+    const int64_t n0 = (int64_t)blockIdx.x * GT + tid;
+    const int xdiv = g.xdiv;
+    const int64_t c0 = n0 * xdiv;
+    const bool real = n0 < g.nbase;
+    double xr[DB], aL1[DB], aL2[KIND == 1 ? DB : 1], aX[WANT_DX ? DB : 1];
+#pragma unroll
+    for (int k = 0; k < DB; ++k) {
+        xr[k] = (real && k < d) ? g.x[n0 * d + k] : 0.0;
+        aL1[k] = 0.0;
+        if (KIND == 1) aL2[k] = 0.0;
+        if (WANT_DX) aX[k] = 0.0;
+    }
+    double s_a1 = 0, s_af = 0, s_nu = 0, s_a2 = 0, s_lsf = 0;
+    if (KIND == 1)
+        for (int s = 0; s < xdiv; ++s) dfs[s * GT + tid] = 0.0;
+
+    // diagonal k_nn terms (once per column)
+    if (g.gknn && blockIdx.y == 0 && real) {
+        for (int s = 0; s < xdiv; ++s) {
+            const int64_t n = c0 + s;
+            const double gk = g.gknn[n];
+            if (KIND == 0) s_a1 += gk;
+            else {
+                const double fn = g.f[n];
+                s_a1 += gk * (nu * fn * fn + af);
+                s_nu += gk * a1 * fn * fn;
+                s_af += gk * a1;
+                s_a2 += gk;
+                // d knn / d f accumulated into df_part row 0 below via dfdiag
+            }
+        }
+    }
+
+    for (int mm = 0; mm < GM; ++mm) {
+        const int m = m0 + mm;
+        if (m >= g.M) break;   // uniform across the block
+        double dzf_loc = 0.0;
+        if (real) {
+            const double* grow = g.G + (int64_t)m * g.ldk;
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DB; ++k) {
+                if (k < d) {
+                    double df = xr[k] - zs[mm][k];
+                    double t1 = df * il1[k];
+                    d1 += t1 * t1;
+                    if (KIND == 1) { double t2 = df * il2[k]; d2 += t2 * t2; }
+                }
+            }
+            const double E1 = exp(-0.5 * d1);
+            double W1 = 0.0, W2 = 0.0;
+            if (KIND == 0) {
+                double Gs = 0.0;
+                for (int s = 0; s < xdiv; ++s) Gs += grow[c0 + s];
+                s_a1 += Gs * E1;
+                W1 = Gs * a1 * E1;
+            } else {
+                const double E2 = exp(-0.5 * d2);
+                const double zfm = zfs[mm];
+                double G2s = 0.0;
+                for (int s = 0; s < xdiv; ++s) {
+                    const int64_t n = c0 + s;
+                    const double Gv = grow[n];
+                    const double fn = g.f[n];
+                    const double fd = (fn - zfm) * ilf;
+                    const double Ef = exp(-0.5 * fd * fd);
+                    const double inner = nu * fn * zfm + af * Ef;
+                    const double GE1 = Gv * E1;
+                    s_a1 += GE1 * inner;
+                    s_nu += GE1 * a1 * fn * zfm;
+                    s_af += GE1 * a1 * Ef;
+                    s_lsf += GE1 * a1 * af * Ef * fd * fd * ilf;
+                    W1 += GE1 * a1 * inner;
+                    G2s += Gv;
+                    const double t = GE1 * a1 * af * Ef * fd * ilf;   // G a1 E1 af Ef (fn - zf)/lsf^2
+                    const double dfn = GE1 * a1 * nu * zfm - t;
+                    dzf_loc += GE1 * a1 * nu * fn + t;
+                    dfs[s * GT + tid] += dfn;   // per-column f gradient over this block's rows
+                }
+                s_a2 += G2s * E2;
+                W2 = G2s * a2 * E2;
+            }
+#pragma unroll
+            for (int k = 0; k < DB; ++k) {
+                if (k < d) {
+                    double df = xr[k] - zs[mm][k];
+                    double t1 = df * il1[k];
+                    aL1[k] += W1 * t1 * t1;
+                    double gx = W1 * t1 * il1[k];
+                    if (KIND == 1) {
+                        double t2 = df * il2[k];
+                        aL2[k] += W2 * t2 * t2;
+                        gx += W2 * t2 * il2[k];
+                    }
+                    if (WANT_DX) aX[k] -= gx;
+                }
+            }
+        }
+        if (KIND == 1) {
+            double tot = wave_sum(dzf_loc);
+            if (lane == 0) atomicAdd(&dzf_s[mm], tot);   // LDS ds_add_f64, 2 adders per slot
+        }
+    }
+    // ---- diagonal df term + zero-fill df_part for padded / non-real columns
+    if (KIND == 1) {
+        for (int s = 0; s < xdiv; ++s) {
+            const int64_t n = c0 + s;
+            if (n >= g.Np) break;
+            double v = real ? dfs[s * GT + tid] : 0.0;
+            if (real && g.gknn && blockIdx.y == 0) v += g.gknn[n] * a1 * 2.0 * nu * g.f[n];
+            g.df_part[(int64_t)blockIdx.y * g.Np + n] = v;
+        }
+    }
+    if (WANT_DX && real) {
+        double* dxp = g.dx_part + ((int64_t)blockIdx.y * g.nbase + n0) * d;
+#pragma unroll
+        for (int k = 0; k < DB; ++k)
+            if (k < d) dxp[k] = aX[k];
+    }
+    // ---- block reduction of the hyper-parameter sums
+    const int H = (KIND == 0) ? 1 + d : 5 + 2 * d;
+    {
+        double v;
+        v = wave_sum(s_a1); if (lane == 0) red[wave][0] = v;
+        if (KIND == 1) {
+            v = wave_sum(s_af); if (lane == 0) red[wave][1] = v;
+            v = wave_sum(s_nu); if (lane == 0) red[wave][2] = v;
+            v = wave_sum(s_a2); if (lane == 0) red[wave][3] = v;
+            v = wave_sum(s_lsf); if (lane == 0) red[wave][4] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < DB; ++k) {
+            if (k < d) {
+                v = wave_sum(aL1[k]);
+                if (lane == 0) red[wave][(KIND == 0 ? 1 : 5) + k] = v * il1[k];
+                if (KIND == 1) {
+                    v = wave_sum(aL2[k]);
+                    if (lane == 0) red[wave][5 + d + k] = v * il2[k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* hp = g.hyp_part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * H;
+    if (tid < H) hp[tid] = red[0][tid] + red[1][tid];
+    if (KIND == 1 && tid < GM) g.dzf_part[(int64_t)blockIdx.x * g.Mp + m0 + tid] = dzf_s[tid];
+}
+
+// out[j] (+)= scale * sum_p part[p*stride + j]
+__global__ void sum_partials_kernel(const double* part, int64_t P, int64_t stride, double* out, int64_t len,
+                                    double scale, int accumulate) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= len) return;
+    double v = 0.0;
+    for (int64_t p = 0; p < P; ++p) v += part[p * stride + j];
+    v *= scale;
+    out[j] = accumulate ? out[j] + v : v;
+}
+
+// out[b] = sum_{s<div} in[b*div + s]
+__global__ void group_sum_kernel(const double* in, double* out, int64_t nout, int div, int accumulate) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nout) return;
+    double v = 0.0;
+    for (int s = 0; s < div; ++s) v += in[j * div + s];
+    out[j] = accumulate ? out[j] + v : v;
+}
+
+int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* out, int64_t len, double scale,
+                        int accumulate, hipStream_t s) {
+    if (len <= 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, part, P, stride, out,
+                       len, scale, accumulate);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+static inline int d_bucket(int d) { return d <= 2 ? 2 : (d <= 8 ? 8 : 32); }
+
+void gram_grid(const GramArgs& g, dim3* grid) {
+    int64_t nb_cols = (g.Np + g.xdiv - 1) / g.xdiv;   // base rows incl. the ones that only own padded columns
+    *grid = dim3((unsigned)((nb_cols + GT - 1) / GT), (unsigned)(g.Mp / GM), 1);
+}
+
+int launch_gram_fwd(const GramArgs& g, hipStream_t s) {
+    if (g.d < 1 || g.d > 32) return MOBOCMF_BAD_ARG;
+    dim3 grid;
+    gram_grid(g, &grid);
+    const int db = d_bucket(g.d);
+#define GF(K, D) hipLaunchKernelGGL((gram_fwd_kernel<K, D>), grid, dim3(GT), 0, s, g)
+    if (g.kind == 0) { if (db == 2) GF(0, 2); else if (db == 8) GF(0, 8); else GF(0, 32); }
+    else { if (db == 2) GF(1, 2); else if (db == 8) GF(1, 8); else GF(1, 32); }
+#undef GF
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+int launch_gram_bwd(const GramArgs& g, bool want_dx, hipStream_t s) {
+    if (g.d < 1 || g.d > 32) return MOBOCMF_BAD_ARG;
+    dim3 grid;
+    gram_grid(g, &grid);
+    const int db = d_bucket(g.d);
+    if (g.xdiv > 48) return MOBOCMF_BAD_ARG;
+    const size_t shm = g.kind == 1 ? (size_t)g.xdiv * GT * sizeof(double) : 0;
+#define GB(K, D)                                                                                    \
+    do {                                                                                            \
+        if (want_dx) hipLaunchKernelGGL((gram_bwd_kernel<K, D, true>), grid, dim3(GT), shm, s, g);   \
+        else hipLaunchKernelGGL((gram_bwd_kernel<K, D, false>), grid, dim3(GT), shm, s, g);          \
+    } while (0)
+    if (g.kind == 0) { if (db == 2) GB(0, 2); else if (db == 8) GB(0, 8); else GB(0, 32); }
+    else { if (db == 2) GB(1, 2); else if (db == 8) GB(1, 8); else GB(1, 32); }
+#undef GB
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
