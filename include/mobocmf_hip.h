@@ -124,6 +124,14 @@ int mobocmf_adam_step(double* param, const double* grad, double* exp_avg, double
                       int64_t n, double lr, double beta1, double beta2, double eps, int64_t step,
                       mobocmf_stream_t stream);
 
+/* The f64 MFMA GEMM used by the layer (exposed for tests and for the roofline measurement of bench.py):
+ * C[Mr x Nc] (+)= alpha * A[Mr x Kd] * B, B is [Kd x Nc] (trans_b = 0) or [Nc x Kd] (trans_b = 1).
+ * Mr, Nc multiples of 128, Kd multiple of 16, leading dimensions even, pointers 16-byte aligned.
+ * tri: bit 0 A lower-triangular, bit 1 A upper-triangular, bit 2 B lower, bit 3 B upper (square operands). */
+int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
+                     const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t accumulate,
+                     mobocmf_stream_t stream);
+
 /* Host-side, synchronising: copies the device word and returns MOBOCMF_OK or MOBOCMF_NOT_PD (pivot in *pivot). */
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream);
 

@@ -398,6 +398,15 @@ int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* 
     return MOBOCMF_OK;
 }
 
+int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
+                     const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t accumulate,
+                     mobocmf_stream_t stream) {
+    if (!A || !B || !C || Mr <= 0 || Nc <= 0 || Kd <= 0 || (lda & 1) || (ldb & 1)) return MOBOCMF_BAD_ARG;
+    GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, Mr, Nc, Kd, tri, alpha);
+    g.accumulate = accumulate;
+    return launch_gemm(g, trans_b != 0, 1, (hipStream_t)stream);
+}
+
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream) {
     int32_t h = 0;
     if (hipMemcpyAsync(&h, info, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)

@@ -292,3 +292,16 @@ def check_info(info):
         return piv.value
     _lib.check(rc, "mobocmf_check_info")
     return 0
+
+
+def gemm_f64(A, B, C=None, tri=0, trans_b=False, alpha=1.0, accumulate=False):
+    """C (+)= alpha * A @ (B.T if trans_b else B) on the f64 MFMA kernel (tile-aligned shapes only)."""
+    lib = _lib.require_device()
+    A, B = _prep(A), _prep(B)
+    Mr, Kd = A.shape
+    Nc = B.shape[0] if trans_b else B.shape[1]
+    if C is None:
+        C = torch.empty(Mr, Nc, dtype=torch.float64, device=A.device)
+    _lib.check(lib.mobocmf_gemm_f64(tri, int(trans_b), Mr, Nc, Kd, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C),
+                                    C.stride(0), alpha, int(accumulate), _stream()), "mobocmf_gemm_f64")
+    return C

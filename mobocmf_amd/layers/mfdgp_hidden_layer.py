@@ -1,0 +1,295 @@
+"""One variational GP layer of the MFDGP -- host mirror of mobocmf/layers/mfdgp_hidden_layer.py.
+
+Same constructor arguments, attributes and call convention as the reference class (``:26-188``,
+``:232-286``, ``:520-559``); the arithmetic that the reference reaches through GPyTorch's
+``UnwhitenedVariationalStrategy`` runs in the HIP library (mobocmf_amd.functional.layer_forward).
+"""
+import warnings
+
+import torch
+from torch import nn
+
+from .. import functional as F
+from .. import gp
+
+
+class NotPSDError(RuntimeError):
+    """K_mm + jitter not positive definite after the jitter retries (gpytorch NotPSDError)."""
+
+
+class UnwhitenedVariationalStrategy(nn.Module):
+    """Parameter holder for q(u) and the (fixed) inducing inputs of layer 0."""
+
+    def __init__(self, model, inducing_points, variational_distribution, learn_inducing_locations=False,
+                 jitter_val=None):
+        super().__init__()
+        object.__setattr__(self, "model", model)       # not registered: avoids a module cycle (as GPyTorch does)
+        if learn_inducing_locations:
+            self.register_parameter("_inducing_points", nn.Parameter(inducing_points.clone()))
+        else:
+            self.register_buffer("_inducing_points", inducing_points.clone())
+        self._variational_distribution = variational_distribution
+        self.jitter_val = F.JITTER if jitter_val is None else jitter_val
+        self.register_buffer("variational_params_initialized", torch.tensor(1))
+        self._kl_cache = None
+
+    def __getstate__(self):
+        # the memoised KL is a graph tensor: never copied / pickled (deepcopy + dill of the fitter must work)
+        state = self.__dict__.copy()
+        state["_kl_cache"] = None
+        return state
+
+    @property
+    def inducing_points(self):
+        return self._inducing_points
+
+    @property
+    def variational_distribution(self):
+        return self._variational_distribution()
+
+    # pieces the HIP call consumes
+    @property
+    def Zx(self):
+        return self._inducing_points
+
+    @property
+    def zf(self):
+        return None
+
+    def kl_divergence(self):
+        """KL(q(u) || p(u)); reuses the value the last training forward produced (GPyTorch memoises the
+        prior the same way), otherwise evaluates it with a one-row layer call."""
+        if self._kl_cache is not None:
+            return self._kl_cache
+        return self.model._moments(self.Zx[:1], None if self.zf is None else self.zf[:1].detach(), 1, False)[2]
+
+
+class MFDGUnwhitenedVariationalStrategy(UnwhitenedVariationalStrategy):
+    """Layers >= 1: Z~ = [Z_x, mean of the previous layer at Z_x] recomputed on every access
+    (mfdgp_hidden_layer.py:542-559).  With Z_x shared by all layers GPyTorch's ``torch.equal`` shortcut makes
+    that mean exactly the previous layer's variational mean m_{l-1}; gradient flows into it.
+    For l >= 2 the same rule is the documented extension."""
+
+    def __init__(self, model, inducing_points, variational_distribution, learn_inducing_locations=True,
+                 jitter_val=None, previous_layer=None):
+        super().__init__(model, inducing_points, variational_distribution, learn_inducing_locations, jitter_val)
+        self.previous_layer = previous_layer            # registered sub-module, as in the reference
+
+    @property
+    def original_inducing_points(self):
+        return self._inducing_points
+
+    @property
+    def Zx(self):
+        return self._inducing_points[:, :-1] if self.previous_layer is not None else self._inducing_points
+
+    @property
+    def zf(self):
+        if self.previous_layer is None:
+            return self._inducing_points[:, -1]
+        return self.previous_layer.variational_strategy._variational_distribution.variational_mean
+
+    @property
+    def inducing_points(self):
+        if self.previous_layer is None:
+            return self._inducing_points
+        return torch.cat((self.Zx, self.zf[:, None]), 1)
+
+
+class MFDGPHiddenLayer(nn.Module):
+
+    def __init__(self, num_layer, input_dims, inducing_points, inducing_values, num_fidelities, init_lengthscale,
+                 y_high_std=1.0, num_samples_for_acquisition=25, previously_trained_layer=None,
+                 init_params_to_prior_and_fix_them=False, previous_layer_in_hierarchy=None, only_hf=False):
+        super().__init__()
+        self.init_params_to_prior_and_fix_them = init_params_to_prior_and_fix_them
+        self.num_layer = num_layer
+        self.input_dims = input_dims
+        num_inducing = inducing_points.shape[0]
+        self.num_inducing = num_inducing
+        self.kind = 0 if num_layer == 0 else 1
+        self.check_pd = True          # sync + jitter retry after every Cholesky (psd_safe_cholesky semantics)
+
+        if num_layer == 0:
+            covar_module = gp.ScaleKernel(gp.RBFKernel(ard_num_dims=input_dims, active_dims=list(range(input_dims))))
+            covar_module.base_kernel.initialize(lengthscale=init_lengthscale)
+            covar_module.initialize(outputscale=1.0)
+            if init_params_to_prior_and_fix_them:
+                covar_module.base_kernel.initialize(lengthscale=0.25 * input_dims)
+                covar_module.initialize(outputscale=1.0)
+        else:
+            D_range = list(range(input_dims))
+            k_x_1 = gp.ScaleKernel(gp.RBFKernel(ard_num_dims=input_dims - 1, active_dims=D_range[0:input_dims - 1]))
+            k_f = gp.ScaleKernel(gp.RBFKernel(ard_num_dims=1, active_dims=D_range[input_dims - 1:input_dims]))
+            k_x_2 = gp.ScaleKernel(gp.RBFKernel(ard_num_dims=input_dims - 1, active_dims=D_range[0:input_dims - 1]))
+            k_lin = gp.LinearKernel(active_dims=D_range[input_dims - 1:input_dims])
+            k_x_1.base_kernel.initialize(lengthscale=init_lengthscale * 10.0)
+            k_f.base_kernel.initialize(lengthscale=1.0)
+            k_x_2.base_kernel.initialize(lengthscale=init_lengthscale)
+            if only_hf:   # mfdgp_hidden_layer_only_hf.py:85-89
+                k_lin.initialize(variance=torch.zeros(1))
+                k_x_1.initialize(outputscale=0.0)
+                k_f.initialize(outputscale=0.0)
+                k_x_2.initialize(outputscale=1.0)
+            else:
+                k_lin.initialize(variance=torch.ones(1))
+                k_x_1.initialize(outputscale=1.0)
+                k_f.initialize(outputscale=1.0)
+                k_x_2.initialize(outputscale=0.01)
+            if init_params_to_prior_and_fix_them:
+                k_x_1.base_kernel.initialize(lengthscale=10 * 0.25 * (input_dims - 1))
+                k_f.base_kernel.initialize(lengthscale=1.0)
+                k_x_2.base_kernel.initialize(lengthscale=0.25 * (input_dims - 1))
+                k_lin.initialize(variance=torch.ones(1))
+                k_x_1.initialize(outputscale=1.0)
+                k_f.initialize(outputscale=1.0)
+                k_x_2.initialize(outputscale=0.01)
+            covar_module = k_x_1 * (k_lin + k_f) + k_x_2
+
+        if previously_trained_layer is not None:
+            covar_module.load_state_dict(previously_trained_layer.covar_module.state_dict())
+
+        variational_distribution = gp.CholeskyVariationalDistribution(num_inducing_points=num_inducing,
+                                                                      mean_init_std=0.0)
+        if num_layer == num_fidelities - 1:
+            cov = gp.gram_cpu_init(covar_module, self.kind, inducing_points) * (1e-2 * y_high_std ** 2) ** 2
+            init_dist = gp.MultivariateNormal(inducing_values, covariance_matrix=cov)
+        else:
+            init_dist = gp.MultivariateNormal(inducing_values, covariance_matrix=torch.eye(num_inducing) * 1e-8)
+        variational_distribution.initialize_variational_distribution(init_dist)
+
+        if num_layer == 0:
+            variational_strategy = UnwhitenedVariationalStrategy(self, inducing_points, variational_distribution,
+                                                                 learn_inducing_locations=False)
+        else:
+            variational_strategy = MFDGUnwhitenedVariationalStrategy(
+                self, inducing_points, variational_distribution, learn_inducing_locations=False,
+                previous_layer=previous_layer_in_hierarchy)
+        self.variational_strategy = variational_strategy
+        self.covar_module = covar_module
+
+        if previously_trained_layer is not None:
+            samples = previously_trained_layer.samples.detach().clone().reshape(-1, 1)   # (S,1) as intended
+        else:
+            samples = torch.normal(mean=torch.zeros([num_samples_for_acquisition]),
+                                   std=torch.ones([num_samples_for_acquisition]))[:, None]
+        self.register_buffer("samples", samples)
+        self.num_samples_for_acquisition = num_samples_for_acquisition
+        self._eval_mode = False
+
+        if init_params_to_prior_and_fix_them or (only_hf and num_layer > 0):
+            fix_all = init_params_to_prior_and_fix_them
+            if num_layer == 0:
+                self.covar_module.base_kernel.raw_lengthscale.requires_grad = False
+                self.covar_module.raw_outputscale.requires_grad = False
+            else:
+                k1 = self.covar_module.kernels[0].kernels[0]
+                kf = self.covar_module.kernels[0].kernels[1].kernels[1]
+                kl = self.covar_module.kernels[0].kernels[1].kernels[0]
+                k2 = self.covar_module.kernels[1]
+                for p in (k1.base_kernel.raw_lengthscale, k1.raw_outputscale, kf.base_kernel.raw_lengthscale,
+                          kf.raw_outputscale, kl.raw_variance):
+                    p.requires_grad = False
+                if fix_all:
+                    k2.base_kernel.raw_lengthscale.requires_grad = False
+                    k2.raw_outputscale.requires_grad = False
+
+    # ------------------------------------------------------------------ reference helpers
+    def print_lengthscales_and_outputscale(self, custom_print):
+        cm = self.covar_module
+        if self.num_layer == 0:
+            custom_print({"l0_lengthscale:": cm.base_kernel.lengthscale.detach().cpu().numpy().flatten(),
+                          "l0_outputscale:": cm.outputscale.detach().cpu().numpy().item()})
+        else:
+            k1, kf = cm.kernels[0].kernels[0], cm.kernels[0].kernels[1].kernels[1]
+            kl, k2 = cm.kernels[0].kernels[1].kernels[0], cm.kernels[1]
+            a1, af = k1.outputscale.item(), kf.outputscale.item()
+            custom_print({"l1_lengthscale_x1:": k1.base_kernel.lengthscale.detach().cpu().numpy().flatten(),
+                          "l1_lengthscale_f:": kf.base_kernel.lengthscale.detach().cpu().numpy().flatten(),
+                          "l1_lengthscale_x2:": k2.base_kernel.lengthscale.detach().cpu().numpy().flatten(),
+                          "l1_alpha_x1:": a1, "l1_alpha_f:": af, "l1_alpha_x1f:": a1 * af,
+                          "l1_alpha_x2:": k2.outputscale.item(), "l1_nu_lin:": kl.variance.item()})
+
+    def train_mode(self):
+        self._eval_mode = False
+
+    def eval_mode(self):
+        self._eval_mode = True
+
+    # ------------------------------------------------------------------ the hot path
+    def _moments(self, x, f, xdiv, want_dx):
+        """(mean, var, kl) for layer rows X~ = [x[n/xdiv], f[n]] through the HIP library."""
+        vs = self.variational_strategy
+        vd = vs._variational_distribution
+        Zx, zf = vs.Zx, vs.zf
+        assert x.shape[-1] == Zx.shape[-1], "wrong input dimensionality for this layer"
+        hyp = gp.pack_hypers(self.covar_module, self.kind)
+        branch = 0 if self.training else 1
+        if self._info is None or self._info.device != x.device:
+            self._info = torch.zeros((), dtype=torch.int32, device=x.device)
+        jit = vs.jitter_val
+        for attempt in range(4):
+            out = F.layer_forward(x, f, Zx, zf, hyp, vd.variational_mean, vd.chol_variational_covar, self.kind,
+                                  xdiv=xdiv, branch=branch, jitter=jit, want_dx=want_dx, info_out=self._info)
+            if not self.check_pd:
+                break
+            pivot = F.check_info(self._info)
+            if pivot == 0:
+                break
+            if attempt == 3:
+                raise NotPSDError(f"K_mm not positive definite (pivot {pivot}) after adding jitter {jit:.1e}")
+            jit = vs.jitter_val + 1e-8 * (10 ** attempt)      # psd_safe_cholesky retry ladder
+            warnings.warn(f"K_mm not positive definite, retrying with jitter {jit:.1e}", RuntimeWarning)
+        return out
+
+    _info = None
+
+    def _layer_call(self, x, f, xdiv=1, want_dx=False):
+        vs = self.variational_strategy
+        vd = vs._variational_distribution
+        if self.training:
+            vs._kl_cache = None
+        # GPyTorch shortcut: inputs identical to the inducing inputs -> q(u) itself
+        if xdiv == 1 and x.shape[0] == vs.Zx.shape[0] and torch.equal(x, vs.Zx) and \
+                (f is None or torch.equal(f, vs.zf)):
+            L = torch.tril(vd.chol_variational_covar)
+            return vd.variational_mean, (L * L).sum(1).clamp_min(F.MIN_VARIANCE)
+        mean, var, kl = self._moments(x, f, xdiv, want_dx)
+        vs._kl_cache = kl
+        return mean, var
+
+    def forward(self, x):
+        """Reference signature (:232-243): x = cat[Z~, X~] -> prior N(0, k(x, x)).  The lazy prior is never
+        materialised on this path; kept for API compatibility."""
+        raise NotImplementedError("the lazy prior over cat[Z, X] is consumed inside the HIP layer call")
+
+    def __call__(self, x, *other_inputs, eps=None, xdiv=1, want_dx=False, **kwargs):
+        """Layer 0: ``layer(x)``.  Layers >= 1: ``layer(x, previous_output)`` (mfdgp_hidden_layer.py:245-286).
+
+        ``x`` holds the base rows; this layer processes ``x.shape[0] * xdiv`` rows (row n uses x[n // xdiv]).
+        ``eps`` (optional, N' values) replaces the N(0,1) draw of the training branch (:274).
+        """
+        if not len(other_inputs):
+            mean, var = self._layer_call(x, None, xdiv, want_dx)
+            return gp.MultivariateNormal(mean[None, :], var[None, :])      # shape (1, N): SURVEY A.2
+        inp = other_inputs[0]
+        n_rows = x.shape[0] * xdiv
+        if isinstance(inp, gp.MultivariateNormal):
+            mean_p, var_p = inp.mean.reshape(-1), inp.variance.reshape(-1)
+            fdiv = n_rows // mean_p.numel()
+            if self._eval_mode:
+                S = self.num_samples_for_acquisition
+                assert n_rows % S == 0, "eval_mode expects inputs tiled num_samples_for_acquisition-fold"
+                e = self.samples.reshape(-1).to(mean_p.dtype).repeat(n_rows // S)
+            elif eps is not None:
+                e = eps.reshape(-1)
+            else:
+                # reference draws float32 N(0,1) on the CPU RNG; here float64 on the device RNG
+                e = torch.randn(n_rows, dtype=mean_p.dtype, device=mean_p.device)
+            f = F.propagate(mean_p, var_p, e, fdiv)
+        else:
+            f = inp.reshape(-1)
+            if f.numel() != n_rows:
+                f = f.repeat_interleave(n_rows // f.numel())
+        mean, var = self._layer_call(x, f, xdiv, want_dx)
+        return gp.MultivariateNormal(mean, var)

@@ -1,0 +1,206 @@
+"""Multi-fidelity deep GP -- host mirror of mobocmf/models/mfdgp.py (same constructor, attributes,
+``forward`` / ``predict`` / ``predict_for_acquisition`` / ``fix_variational_hypers*`` surface).
+
+Extensions (documented in DESIGN.md; defaults reproduce the reference):
+  * ``num_inducing`` / ``inducing_points``: decouple M from N (reference: Z = all training inputs, F6).
+  * ``num_samples_for_training`` (S): S-fold sample replication through layers >= 1 during training
+    (reference: exactly one sample, F7); the ELBO then averages the S samples of each row.
+  * more than two fidelities: Z~_l = [Z_x, m_{l-1}] for every l >= 1 (reference works for 2 only, F8).
+"""
+from enum import Enum
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import functional as F
+from .. import gp
+from ..layers.mfdgp_hidden_layer import MFDGPHiddenLayer
+from ..util.util import compute_dist, triu_indices
+
+
+class TL(Enum):  # type of lengthscale (mfdgp.py:15-18)
+    ONES = 1
+    MEDIAN = 2
+    CENTESIMAL = 3
+
+
+class _DeepGPVariationalStrategy:
+    def __init__(self, model):
+        self.model = model
+
+    def kl_divergence(self):
+        """Sum over all layers (every ApproximateGP sub-module counted once)."""
+        return sum(getattr(self.model, self.model.name_hidden_layer + str(i)).variational_strategy.kl_divergence()
+                   for i in range(self.model.num_hidden_layers))
+
+
+class MFDGP(nn.Module):
+
+    def __init__(self, x_train, y_train, fidelities, num_fidelities, type_lengthscale=TL.MEDIAN,
+                 num_samples_for_acquisition=25, previously_trained_model=None, ini_inducing_using_layer_0=False,
+                 use_only_highest_fidelity=False, init_params_to_prior_and_fix_them=False,
+                 num_inducing=None, inducing_points=None, num_samples_for_training=1, median_mode="reference"):
+        super().__init__()
+        self.init_params_to_prior_and_fix_them = init_params_to_prior_and_fix_them
+        self._eval_mode = False
+        self.num_samples_for_acquisition = num_samples_for_acquisition
+        self.num_samples_for_training = num_samples_for_training
+        self.use_only_highest_fidelity = use_only_highest_fidelity
+        self.ini_inducing_using_layer_0 = ini_inducing_using_layer_0
+        self.median_mode = median_mode
+        self.input_dims = x_train.shape[-1]
+        x_train, y_train, fidelities = x_train.detach().cpu(), y_train.detach().cpu(), fidelities.detach().cpu()
+        y_high_std = np.std(y_train[(fidelities == num_fidelities - 1).flatten()].numpy())
+
+        if inducing_points is None and num_inducing is not None:
+            inducing_points = x_train[:num_inducing]
+        self._Zx_user = inducing_points
+
+        hidden_layers = []
+        for i in range(num_fidelities):
+            Z, u = self.find_good_initial_inducing_points_and_values(x_train, y_train, fidelities, i)
+            init_ls = self.get_init_lengthscale(type_lengthscale, inputs=x_train[(fidelities == i).flatten(), :])
+            prev = None if previously_trained_model is None else \
+                getattr(previously_trained_model, previously_trained_model.name_hidden_layer + str(i))
+            hidden_layers.append(MFDGPHiddenLayer(
+                input_dims=self.input_dims + (0 if i == 0 else 1), num_layer=i, inducing_points=Z, inducing_values=u,
+                num_fidelities=num_fidelities, init_lengthscale=init_ls, y_high_std=y_high_std,
+                num_samples_for_acquisition=num_samples_for_acquisition, previously_trained_layer=prev,
+                init_params_to_prior_and_fix_them=init_params_to_prior_and_fix_them,
+                previous_layer_in_hierarchy=hidden_layers[-1] if i > 0 else None,
+                only_hf=use_only_highest_fidelity and i > 0))
+
+        self.name_hidden_layer = "hidden_layer_"
+        self.name_hidden_layer_likelihood = "hidden_layer_likelihood_"
+        self.name_hidden_layer_likelihood_noiseless = "hidden_layer_likelihood_noiseless_"
+        self.num_hidden_layers = num_fidelities
+        self.num_fidelities = num_fidelities
+
+        for i, hidden_layer in enumerate(hidden_layers):
+            y_std = np.std(y_train[(fidelities == i).flatten()].numpy())
+            setattr(self, self.name_hidden_layer + str(i), hidden_layer)
+            likelihood = gp.GaussianLikelihood(noise_constraint=gp.Interval(lower_bound=1e-8, upper_bound=0.1 * y_std))
+            likelihood.noise = 1e-2 * y_high_std if i == self.num_fidelities - 1 else 1e-6
+            setattr(self, self.name_hidden_layer_likelihood + str(i), likelihood)
+        self.variational_strategy = _DeepGPVariationalStrategy(self)
+
+    # ------------------------------------------------------------------ init heuristics
+    def get_init_lengthscale(self, type_lengthscale, inputs=None):
+        if type_lengthscale == TL.ONES:
+            return torch.ones(self.input_dims)
+        if type_lengthscale == TL.MEDIAN:
+            dists = compute_dist(inputs)
+            if self.median_mode == "reference":       # as written at mfdgp.py:143-144 (row-indexing quirk)
+                return torch.sqrt(torch.median(dists[triu_indices(inputs.shape[0], 1)]))
+            rows, cols = torch.triu_indices(inputs.shape[0], inputs.shape[0], offset=1)
+            return torch.sqrt(torch.median(dists[rows, cols]))
+        if type_lengthscale == TL.CENTESIMAL:
+            return 0.01 * torch.ones(self.input_dims)
+        raise ValueError("Wrong type of lengthscale.")
+
+    def find_good_initial_inducing_points_and_values(self, x_train, y_train, fidelities, layer):
+        """mfdgp.py:290-317 with the O(M N^2) loop replaced by one argmin over distances."""
+        if self._Zx_user is not None:
+            inducing_points = self._Zx_user
+        elif self.use_only_highest_fidelity:
+            inducing_points = x_train[fidelities[:, 0] == layer, :]
+        else:
+            inducing_points = x_train
+        sel = fidelities[:, 0] == layer
+        xs, ys = x_train[sel, :], y_train[sel, :]
+        d2 = (xs ** 2).sum(1)[None, :] - 2.0 * inducing_points @ xs.T + (inducing_points ** 2).sum(1)[:, None]
+        inducing_values = torch.zeros(inducing_points.shape[0])                 # float32, as the reference (B.4)
+        inducing_values[:] = ys[torch.argmin(d2, 1), 0]
+        if layer != 0:
+            inducing_points = torch.cat((inducing_points, inducing_values[:, None].to(inducing_points.dtype)), 1)
+        return inducing_points, inducing_values
+
+    # ------------------------------------------------------------------ modes
+    def _layers(self):
+        return [getattr(self, self.name_hidden_layer + str(i)) for i in range(self.num_hidden_layers)]
+
+    def train_mode(self):
+        for layer in self._layers():
+            layer.train_mode()
+        self._eval_mode = False
+
+    def eval_mode(self):
+        for layer in self._layers():
+            layer.eval_mode()
+        self._eval_mode = True
+
+    def set_check_pd(self, value):
+        """False: no host sync after the Cholesky on the training fast path (NaNs then surface in the loss)."""
+        for layer in self._layers():
+            layer.check_pd = bool(value)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inputs, max_fidelity=None, eps=None, want_dx=False, _xdiv=None):
+        """List of per-layer predictive distributions (mfdgp.py:174-196).
+
+        train mode: layer 0 sees the N rows; layers >= 1 see N * num_samples_for_training rows (row n*S+s is
+        sample s of input row n).  ``eps``: optional list, eps[l] (N*S values) for layer l >= 1.
+        eval_mode: the caller tiled the inputs (mfdgp.py:248), eps = the layer's fixed ``samples``.
+        """
+        num_layers = self.num_hidden_layers if max_fidelity is None else max_fidelity + 1
+        S = 1 if self._eval_mode else self.num_samples_for_training
+        if _xdiv is not None:
+            S = _xdiv
+        l_outputs = [None] * num_layers
+        output_layer = None
+        for i in range(num_layers):
+            hidden_layer = getattr(self, self.name_hidden_layer + str(i))
+            if i == 0:
+                output_layer = hidden_layer(inputs, want_dx=want_dx)
+            else:
+                if self.use_only_highest_fidelity:
+                    output_layer = output_layer.mean * 0.0
+                output_layer = hidden_layer(inputs, output_layer, eps=None if eps is None else eps[i], xdiv=S,
+                                            want_dx=want_dx)
+            l_outputs[i] = output_layer
+        return l_outputs
+
+    def fix_variational_hypers(self, value):
+        for i in range(self.num_hidden_layers):
+            getattr(self, self.name_hidden_layer_likelihood + str(i)).raw_noise.requires_grad = not value
+        for layer in self._layers():
+            layer.variational_strategy._variational_distribution.chol_variational_covar.requires_grad = not value
+
+    def fix_variational_hypers_cond(self, value):
+        for i in range(self.num_hidden_layers):
+            getattr(self, self.name_hidden_layer_likelihood + str(i)).raw_noise.requires_grad = not value
+        for layer in self._layers():
+            for _, param in layer.covar_module.named_parameters():
+                param.requires_grad = not value
+
+    # ------------------------------------------------------------------ prediction
+    def predict(self, test_x, fidelity_layer=0, want_dx=False, _xdiv=None):
+        assert 0 <= fidelity_layer < self.num_fidelities
+        likelihood = getattr(self, self.name_hidden_layer_likelihood + str(fidelity_layer))
+        preds = likelihood(self(test_x, max_fidelity=fidelity_layer, want_dx=want_dx, _xdiv=_xdiv)[fidelity_layer])
+        return preds.mean, preds.variance
+
+    def predict_for_acquisition(self, test_x, fidelity_layer=0):
+        """Moments over the S = num_samples_for_acquisition fixed samples (mfdgp.py:237-262).  Layer 0 is
+        evaluated once per test point (its S tiled copies are identical); layers >= 1 see the S-fold rows."""
+        if len(test_x.shape) > 2:
+            assert test_x.shape[1] == 1
+            test_x = test_x[:, 0, :]
+        S = self.num_samples_for_acquisition
+        self.eval_mode()
+        try:
+            mus_tilde, vars_tilde = self.predict(test_x, fidelity_layer=fidelity_layer,
+                                                 want_dx=test_x.requires_grad, _xdiv=S)
+        finally:
+            self.train_mode()
+        if fidelity_layer == 0:          # no sampling below layer 0: the S copies coincide
+            return mus_tilde.reshape(-1), vars_tilde.reshape(-1)
+        return F.acq_moments(mus_tilde, vars_tilde, S)
+
+    # ------------------------------------------------------------------ function sampling (RFF): SURVEY row N2
+    def sample_function_from_each_layer(self):
+        raise NotImplementedError("RFF posterior function sampling (SURVEY section 8(f) row N2) is not built yet")
+
+    def sample_function_from_prior_each_layer(self):
+        raise NotImplementedError("RFF prior function sampling (SURVEY section 8(f) row N2) is not built yet")

@@ -1,0 +1,142 @@
+"""Trainer/orchestrator -- host mirror of mobocmf/util/blackbox_mfdgp_fitter.py (unconditioned training:
+``MFDGPHandler`` :22-39, ``BlackBoxMFDGPFitter.__init__`` :43-81, ``initialize_mfdgp`` :84-115,
+``_train_mfdgp`` :117-152, ``train_mfdgps`` :154-178; the ELBO step is :161-171).
+
+MI355X additions: ``device`` (models and data live on the GPU), ``num_inducing`` / ``num_samples_for_training``
+pass-through, and surrogate sharding over ranks (one process per GPU, see mobocmf_amd.parallel).
+Conditioned training (:245-354) and Pareto sampling (:181-225) are SURVEY rows N1/N2 (not built yet).
+"""
+import sys
+from copy import deepcopy
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+from ..mlls.variational_elbo_mf import VariationalELBOMF
+from ..models.mfdgp import MFDGP, TL
+
+ITER_PRINT = 1000
+
+
+class MFDGPHandler:
+
+    MAX_TRIES_FOR_FEASIBLE_GRID = 50
+
+    def __init__(self, x_train, y_train, fidelities_train, num_fidelities, batch_size, type_lengthscale,
+                 previously_trained_model=None, init_params_to_prior_and_fix_them=False,
+                 use_only_highest_fidelity=False, device="cuda", **model_kwargs):
+        self.mfdgp = MFDGP(x_train, y_train, fidelities_train, num_fidelities=num_fidelities,
+                           type_lengthscale=type_lengthscale, previously_trained_model=previously_trained_model,
+                           use_only_highest_fidelity=use_only_highest_fidelity,
+                           init_params_to_prior_and_fix_them=init_params_to_prior_and_fix_them, **model_kwargs)
+        self.mfdgp.double()  # float64 end to end, as the reference (:32)
+        self.mfdgp.to(device)
+        self.elbo = VariationalELBOMF(self.mfdgp, x_train.shape[-2], num_fidelities=num_fidelities)
+        dev = torch.device(device)
+        self.train_dataset = TensorDataset(x_train.double().to(dev), y_train.double().to(dev),
+                                           fidelities_train.double().to(dev))
+        self.batch_size = batch_size
+        self.train_loader = DataLoader(self.train_dataset, batch_size=batch_size, shuffle=True)
+        self.iter_train_loader = None
+        self.num_data = x_train.shape[0]
+        self.num_fidelities = num_fidelities
+
+
+class BlackBoxMFDGPFitter:
+
+    def __init__(self, num_fidelities, batch_size, lr_1=0.003, lr_2=0.001, num_epochs_1=5000, num_epochs_2=15000,
+                 pareto_set_size=50, opt_grid_size=1000, eps=1e-8, decoupled_evals=False,
+                 type_lengthscale=TL.MEDIAN, device="cuda", **model_kwargs):
+        self.num_obj = 0
+        self.num_con = 0
+        self.models_uncond_trained = False
+        self.mfdgp_handlers_objs = {}
+        self.mfdgp_handlers_cons = {}
+        self.thresholds_cons = torch.tensor([], dtype=torch.double)
+        self.x_train = None
+        self.objs_train = torch.tensor([], dtype=torch.double)
+        self.cons_train = torch.tensor([], dtype=torch.double)
+        self.num_fidelities = num_fidelities
+        self.batch_size = batch_size
+        self.points_to_sample = batch_size
+        self.lr_1, self.lr_2 = lr_1, lr_2
+        self.num_epochs_1, self.num_epochs_2 = num_epochs_1, num_epochs_2
+        self.pareto_set_size = pareto_set_size
+        self.opt_grid_size = opt_grid_size
+        self.eps = eps
+        self.decoupled_evals = decoupled_evals
+        self.type_lengthscale = type_lengthscale
+        self.device = device
+        self.model_kwargs = model_kwargs
+        self.verbose = True
+
+    def initialize_mfdgp(self, x_train, y_train, fidelities, blackbox_name, threshold_constraint=0.0,
+                         is_constraint=False, previously_trained_model=None,
+                         init_params_to_prior_and_fix_them=False, use_only_highest_fidelity=False):
+        if self.x_train is None:
+            self.x_train = x_train
+        else:
+            assert torch.equal(self.x_train, x_train), "The inputs for this new mfdgp do not match with inputs for " \
+                "previous mfdgp models. This class is not currently prepared for a decoupled evaluation setting."
+        handler = MFDGPHandler(x_train, y_train, fidelities, self.num_fidelities, self.batch_size,
+                               type_lengthscale=self.type_lengthscale,
+                               previously_trained_model=previously_trained_model,
+                               init_params_to_prior_and_fix_them=init_params_to_prior_and_fix_them,
+                               use_only_highest_fidelity=use_only_highest_fidelity, device=self.device,
+                               **self.model_kwargs)
+        if is_constraint:
+            self.cons_train = torch.cat((self.cons_train, y_train.cpu().double()), 1)
+            self.mfdgp_handlers_cons[blackbox_name] = handler
+            self.thresholds_cons = torch.cat((self.thresholds_cons, torch.tensor([threshold_constraint]).double()), 0)
+            self.num_con += 1
+        else:
+            self.objs_train = torch.cat((self.objs_train, y_train.cpu().double()), 1)
+            self.mfdgp_handlers_objs[blackbox_name] = handler
+            self.num_obj += 1
+
+    def _handlers(self):
+        return [("OBJ", n, h) for n, h in enumerate(self.mfdgp_handlers_objs.values())] + \
+               [("CON", n, h) for n, h in enumerate(self.mfdgp_handlers_cons.values())]
+
+    def get_model(self, blackbox_name, is_constraint=False):
+        d = self.mfdgp_handlers_cons if is_constraint else self.mfdgp_handlers_objs
+        return d[blackbox_name].mfdgp
+
+    def _train_mfdgp(self, func_update_model, fix_variational_hypers, num_epochs, lr):
+        opts = []
+        for _, _, h in self._handlers():
+            h.mfdgp.fix_variational_hypers(fix_variational_hypers)
+            opts.append(torch.optim.Adam([{"params": h.mfdgp.parameters()}], lr=lr))
+        for (tag, n, h), optimizer in zip(self._handlers(), opts):
+            for i in range(num_epochs):
+                loss_iter, kl_iter = func_update_model(h.mfdgp, h.elbo, optimizer, h.train_loader)
+                if self.verbose and ((i % ITER_PRINT) == 0 or (i + 1) == num_epochs):
+                    print("[%s: " % tag, n, "] Epoch:", i, "/", num_epochs, ". Avg. Neg. ELBO per epoch:",
+                          loss_iter.item(), "\t KL per epoch:", kl_iter.item())
+                    sys.stdout.flush()
+
+    @staticmethod
+    def update_model(model, elbo, optimizer, train_loader):
+        """One epoch = the reference's ``_update_model`` closure (:156-173); one ELBO step per batch."""
+        loss_iter = 0.0
+        kl_iter = 0.0
+        for (x_batch, y_batch, fidelities) in train_loader:
+            optimizer.zero_grad()
+            output = model(x_batch)
+            res = elbo(output, y_batch.T, fidelities)
+            loss, kl = -res[0], res[1]
+            loss.backward()
+            optimizer.step()
+            loss_iter += loss.detach()
+            kl_iter += kl.detach()
+        return loss_iter, kl_iter
+
+    def train_mfdgps(self):
+        self._train_mfdgp(self.update_model, fix_variational_hypers=True, num_epochs=self.num_epochs_1, lr=self.lr_1)
+        self._train_mfdgp(self.update_model, fix_variational_hypers=False, num_epochs=self.num_epochs_2, lr=self.lr_2)
+        self.models_uncond_trained = True
+
+    def copy_uncond(self):
+        """Deep copy of the fitter (:372-397): the models are plain tensors, so ``deepcopy`` just works."""
+        return deepcopy(self)

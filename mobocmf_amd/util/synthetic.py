@@ -85,3 +85,42 @@ def forrester_problem(output=0):
     y = np.vstack((y1, y0))[:, 0]
     fid = np.concatenate((np.ones(4), np.zeros(12)))
     return x, y, fid
+
+
+def model_from_problem(prob, num_samples_for_training=None, num_samples_for_acquisition=None, device="cuda"):
+    """``mobocmf_amd.models.MFDGP`` carrying exactly the parameters of a problem dict (section 8(d): parameters are
+    explicit inputs so that parity / throughput runs do not depend on the init heuristics)."""
+    import torch
+
+    from .. import gp
+    from ..models import MFDGP, TL
+
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    S = prob["S"]
+    model = MFDGP(t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], num_fidelities=prob["L"],
+                  type_lengthscale=TL.ONES, inducing_points=t(prob["Zx"]),
+                  num_samples_for_acquisition=num_samples_for_acquisition or S,
+                  num_samples_for_training=num_samples_for_training or S)
+    model.double()
+    with torch.no_grad():
+        for l, lay in enumerate(prob["layers"]):
+            layer = getattr(model, f"hidden_layer_{l}")
+            h, cm = lay["hyp"], layer.covar_module
+            if l == 0:
+                cm.base_kernel.lengthscale = t(h["ls"])
+                cm.outputscale = t(h["alpha"])
+            else:
+                k1, kf = cm.kernels[0].kernels[0], cm.kernels[0].kernels[1].kernels[1]
+                kl, k2 = cm.kernels[0].kernels[1].kernels[0], cm.kernels[1]
+                k1.base_kernel.lengthscale, k1.outputscale = t(h["ls1"]), t(h["a1"])
+                kf.base_kernel.lengthscale, kf.outputscale = t(h["lsf"]), t(h["af"])
+                k2.base_kernel.lengthscale, k2.outputscale = t(h["ls2"]), t(h["a2"])
+                kl.variance = t(h["nu"])
+                layer.samples.copy_(t(prob["samples"][l]).reshape(-1, 1))
+            vd = layer.variational_strategy._variational_distribution
+            vd.variational_mean.copy_(t(lay["m"]))
+            vd.chol_variational_covar.copy_(t(lay["L_S"]))
+            lik = getattr(model, f"hidden_layer_likelihood_{l}")
+            lik.raw_noise_constraint = gp.Interval(1e-8, 1.0)
+            lik.noise = t(prob["noise"][l])
+    return model.to(device)
