@@ -57,6 +57,7 @@ def load():
     """Loads the shared library (no GPU needed for loading / symbol checks)."""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  -- first: the HIP runtime torch ships must be the one this library binds to
         if not os.path.exists(LIB_PATH):
             raise MobocmfError(f"HIP extension missing: {LIB_PATH} (run mobocmf_amd/csrc/build.sh or "
                                "__graft_entry__.build()); there is no CPU fallback")

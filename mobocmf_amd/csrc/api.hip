@@ -10,7 +10,8 @@ void gram_grid(const GramArgs& g, dim3* grid);
 int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* out, int64_t len, double scale,
                         int accumulate, hipStream_t s);
 int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, int32_t* info, hipStream_t s);
-int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, hipStream_t s);
+int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
+                 int64_t ws_elems, hipStream_t s);
 int launch_pad_tril(const double* src, int64_t lds, int M, double* dst, int Mp, hipStream_t s);
 int launch_pad_vec(const double* src, int64_t n, double* dst, int64_t np, hipStream_t s);
 int launch_transpose(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
@@ -19,7 +20,7 @@ int launch_gemv_rows(const double* Mat, int64_t ld, const double* vec, double* o
 int launch_gemv_long(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double* part,
                      hipStream_t s);
 int launch_kl(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* kl,
-              hipStream_t s);
+              double* part, hipStream_t s);
 int launch_moments_finish(const double* qpart, const double* mupart, const double* rpart, int nrb, int64_t Np, int64_t N,
                           const double* knn, int branch, double min_var, double* q, double* r, double* varraw,
                           double* mean, double* var, hipStream_t s);
@@ -83,6 +84,7 @@ Dims dims_of(const mobocmf_layer_desc* d) {
     int sk = (1024 + ntl - 1) / ntl;
     if (sk > ksteps / 8) sk = (int)(ksteps / 8);
     if (sk > 128) sk = 128;
+    if (sk >= 8) sk &= ~7;
     if (sk < 1) sk = 1;
     D.splitk = sk;
     GramArgs g = {};
@@ -110,7 +112,8 @@ bool carve_saved(Bump& b, const Dims& D, Saved& S) {
 }
 
 struct ScratchF {
-    double *Dinv, *T, *qpart, *mupart, *rpart;
+    double *Dinv, *T, *qpart, *mupart, *rpart, *ws;
+    int64_t ws_elems;
 };
 bool carve_scratch_fwd(Bump& b, const Dims& D, ScratchF& S) {
     S.Dinv = b.take((int64_t)(D.Mp / NB) * NB * NB);
@@ -118,6 +121,8 @@ bool carve_scratch_fwd(Bump& b, const Dims& D, ScratchF& S) {
     S.qpart = b.take((int64_t)D.nrb * D.Np);
     S.mupart = b.take((int64_t)D.nrb * D.Np);
     S.rpart = b.take((int64_t)D.nrb * D.Np);
+    S.ws_elems = (int64_t)16 * D.Mp * D.Mp;
+    S.ws = b.take(S.ws_elems);
     return b.ok;
 }
 
@@ -129,7 +134,7 @@ bool carve_scratch_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, Scra
     int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
     S.gmu = b.take(D.Np); S.gv = b.take(D.Np); S.gv2 = b.take(D.Np); S.cgv = b.take(D.Np);
     S.dA = b.take(mn); S.dK = b.take(mn);
-    S.slabs = b.take((int64_t)D.splitk * mm);
+    S.slabs = b.take((int64_t)(D.splitk > 16 ? D.splitk : 16) * mm);
     for (int i = 0; i < 8; ++i) S.W[i] = b.take(mm);
     S.da = b.take(D.Mp);
     S.gpart = b.take((int64_t)D.Mp * 16);
@@ -214,7 +219,7 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     TRY(launch_gram_fwd(g, s));
     TRY(launch_potrf(S.L, Mp, Mp, F.Dinv, info, s));
     HIP_TRY(hipMemsetAsync(S.Linv, 0, mm * sizeof(double), s));
-    TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, s));
+    TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
     TRY(launch_transpose(S.Linv, Mp, S.LinvT, Mp, Mp, Mp, s));
     TRY(launch_pad_tril(L_S, D.M, D.M, S.LSp, Mp, s));
     TRY(launch_pad_vec(m, D.M, S.mp, Mp, s));
@@ -223,11 +228,11 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     {
         GemmArgs ga = gemm_args(S.Linv, Mp, S.LSp, Mp, S.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
         ga.lower_out = 1;
-        TRY(launch_gemm(ga, false, 1, s));
+        TRY(launch_gemm_auto(ga, false, F.ws, F.ws_elems, s));
     }
     TRY(launch_transpose(S.U, Mp, S.UT, Mp, Mp, Mp, s));
     TRY(launch_gemv_rows(S.Linv, Mp, S.mp, S.a, Mp, Mp, 1.0, 0, s));
-    TRY(launch_kl(S.L, S.LSp, S.U, S.a, D.M, Mp, kl, s));
+    TRY(launch_kl(S.L, S.LSp, S.U, S.a, D.M, Mp, kl, F.qpart, s));
 
     // K_mn, k_nn
     g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
@@ -312,12 +317,13 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
         TRY(launch_sum_partials(B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, g_x, D.nbase * desc->d, 1.0, 0, s));
 
     // ---- M x M chain
+    const int64_t slab_elems = (int64_t)(D.splitk > 16 ? D.splitk : 16) * mm;
     TRY(launch_add_kl_terms(dU, S.U, B.da, S.a, g_kl, Mp, s));
     // dLinv += dU_tot L_S^T + da m^T  (then exact lower triangle)
     {
         GemmArgs ga = gemm_args(dU, Mp, S.LSp, Mp, dLinv, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);
         ga.lower_out = 1; ga.accumulate = 1;
-        TRY(launch_gemm(ga, true, 1, s));
+        TRY(launch_gemm_auto(ga, true, B.slabs, slab_elems, s));
     }
     TRY(launch_rank1_add(dLinv, B.da, S.mp, Mp, s));
     TRY(launch_tril_inplace(dLinv, Mp, Mp, s));
@@ -327,28 +333,28 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     {
         GemmArgs ga = gemm_args(S.LinvT, Mp, dU, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
         ga.lower_out = 1;
-        TRY(launch_gemm(ga, false, 1, s));
+        TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
         TRY(launch_gls_out(T1, S.LSp, g_kl, D.M, Mp, g_LS, s));
     }
     // dL = -tril(L^-T dLinv L^-T) + gkl diag(1/L_ii)
     {
         GemmArgs ga = gemm_args(S.LinvT, Mp, dLinv, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
-        TRY(launch_gemm(ga, false, 1, s));
+        TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
         GemmArgs gb = gemm_args(T1, Mp, S.LinvT, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_B, 1.0);
         gb.lower_out = 1;
-        TRY(launch_gemm(gb, false, 1, s));
+        TRY(launch_gemm_auto(gb, false, B.slabs, slab_elems, s));
         TRY(launch_dl_from_t2(T2, S.L, g_kl, D.M, Mp, dL, s));
     }
     // Cholesky backward: dKmm = sym(L^-T Phi(L^T dL) L^-1)
     {
         TRY(launch_transpose(S.L, Mp, LT, Mp, Mp, Mp, s));
         GemmArgs ga = gemm_args(LT, Mp, dL, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
-        TRY(launch_gemm(ga, false, 1, s));
+        TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
         TRY(launch_phi(T2, Mp, T1, s));
         GemmArgs gb = gemm_args(S.LinvT, Mp, T1, Mp, T4, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
-        TRY(launch_gemm(gb, false, 1, s));
+        TRY(launch_gemm_auto(gb, false, B.slabs, slab_elems, s));
         GemmArgs gc = gemm_args(T4, Mp, S.Linv, Mp, T2, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);
-        TRY(launch_gemm(gc, false, 1, s));
+        TRY(launch_gemm_auto(gc, false, B.slabs, slab_elems, s));
         TRY(launch_symmetrize(T2, Mp, Gm, s));
     }
     // Gram backward of K_mm (both arguments are Z~)

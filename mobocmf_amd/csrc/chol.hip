@@ -229,9 +229,43 @@ __global__ __launch_bounds__(256) void trtri_level0_kernel(const double* L, int6
 }
 
 // Linv (Mp x Mp, pre-zeroed above the block diagonal by the caller) = L^-1.  T = scratch Mp x Mp.
-int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, hipStream_t s) {
+// Power-of-two block counts: recursive doubling, [[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]], every level
+// is two (batched) MFMA GEMMs; otherwise block row by block row.
+int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
+                 int64_t ws_elems, hipStream_t s) {
     const int nb = Mp / TILE;
     hipLaunchKernelGGL(trtri_level0_kernel, dim3(nb), dim3(256), 0, s, L, ld, Dinv, Linv, (int64_t)Mp);
+    if ((nb & (nb - 1)) == 0) {
+        for (int sz = TILE; sz < Mp; sz *= 2) {
+            const int nmerge = Mp / (2 * sz);
+            const int64_t bs = (int64_t)2 * sz * Mp + 2 * sz;     // origin stride between merges (Linv / T, ld Mp)
+            GemmArgs g = {};
+            g.A = L + (int64_t)sz * ld;  g.lda = ld;              // L21
+            g.B = Linv;                  g.ldb = Mp;              // Linv11 (lower)
+            g.C = T + (int64_t)sz * Mp;  g.ldc = Mp;
+            g.Mr = sz; g.Nc = sz; g.Kd = sz; g.tri = TRI_LOWER_B; g.alpha = 1.0;
+            GemmArgs h = {};
+            h.A = Linv + (int64_t)sz * Mp + sz; h.lda = Mp;       // Linv22 (lower)
+            h.B = T + (int64_t)sz * Mp;         h.ldb = Mp;
+            h.C = Linv + (int64_t)sz * Mp;      h.ldc = Mp;
+            h.Mr = sz; h.Nc = sz; h.Kd = sz; h.tri = TRI_LOWER_A; h.alpha = -1.0;
+            int rc;
+            if (nmerge > 1) {
+                g.batched = h.batched = nmerge;
+                g.strideA = (int64_t)2 * sz * ld + 2 * sz; g.strideB = bs; g.strideC = bs;
+                h.strideA = bs; h.strideB = bs; h.strideC = bs;
+                rc = launch_gemm(g, false, 1, s);
+                if (rc) return rc;
+                rc = launch_gemm(h, false, 1, s);
+            } else {
+                rc = launch_gemm_auto(g, false, ws, ws_elems, s);
+                if (rc) return rc;
+                rc = launch_gemm_auto(h, false, ws, ws_elems, s);
+            }
+            if (rc) return rc;
+        }
+        return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+    }
     for (int i = 1; i < nb; ++i) {
         // T[128 x i*128] = L[i, 0:i] * Linv[0:i, 0:i]       (B lower triangular)
         GemmArgs g = {};
@@ -246,7 +280,7 @@ int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double
         g.Kd = (int64_t)i * TILE;
         g.tri = TRI_LOWER_B;
         g.alpha = 1.0;
-        int rc = launch_gemm(g, false, 1, s);
+        int rc = launch_gemm_auto(g, false, ws, ws_elems, s);
         if (rc) return rc;
         // Linv[i, 0:i] = -Linv[i,i] * T
         GemmArgs h = {};

@@ -38,7 +38,7 @@ struct GemmArgs {
     // batching (only without split-K): blockIdx.z selects the batch
     int64_t strideA, strideB, strideC;
     int batched;
-    // operand scaling: B[k][n] *= bscale[n] (B_T=0)  /  B_T: B[j][k] *= bscale[k]
+    // B_T=1: weights of the contraction index, sum_k A[i][k] bscale[k] B[j][k];  EPI_DA: column scale of the product
     const double* bscale;
     // epilogues
     int epi;
@@ -51,6 +51,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s);
+int launch_gemm_auto(const GemmArgs& g, bool B_T, double* ws, int64_t ws_elems, hipStream_t s);
 // out[i][j] = scale * sum_z slabs[z][i][j]  (lower_only: zero above the diagonal), Mr x Mr
 int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, double* out, int64_t ld, int Mr,
                         double scale, int lower_only, int accumulate, hipStream_t s);

@@ -118,25 +118,38 @@ int launch_gemv_long(const double* Mat, int64_t ld, const double* vec, double* o
     return CHECK_LAUNCH();
 }
 
-// KL = 0.5 * (2 sum log L_ii - sum log LS_ii^2 + |U|_F^2 + |a|^2 - M)      (SURVEY A.4), single block
-__global__ void kl_kernel(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp,
-                          double* kl) {
+// KL = 0.5 * (2 sum log L_ii - sum log LS_ii^2 + |U|_F^2 + |a|^2 - M)      
+// stage 1: one block per 4 rows of U (lower triangle) -> partial sums; stage 2: one block adds them
+__global__ void kl_part_kernel(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp,
+                               double* part) {
     __shared__ double sh[4];
     double s = 0.0;
-    for (int i = threadIdx.x; i < M; i += 256) {
-        double l = L[(int64_t)i * Mp + i], ls = LSp[(int64_t)i * Mp + i];
-        s += 2.0 * log(l) - log(ls * ls) + a[i] * a[i];
+    const int r0 = blockIdx.x * 4;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = r0 + rr;
+        if (i >= M) break;
+        const double* u = U + (int64_t)i * Mp;
+        for (int j = threadIdx.x; j <= i; j += 256) s += u[j] * u[j];
+        if (threadIdx.x == 0) {
+            double l = L[(int64_t)i * Mp + i], ls = LSp[(int64_t)i * Mp + i];
+            s += 2.0 * log(l) - log(ls * ls) + a[i] * a[i];
+        }
     }
-    for (int64_t e = threadIdx.x; e < (int64_t)M * M; e += 256) {
-        int i = (int)(e / M), j = (int)(e % M);
-        if (j <= i) { double u = U[(int64_t)i * Mp + j]; s += u * u; }
-    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void kl_final_kernel(const double* part, int np, int M, double* kl) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) s += part[i];
     s = block_sum(s, sh);
     if (threadIdx.x == 0) kl[0] = 0.5 * (s - (double)M);
 }
 int launch_kl(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* kl,
-              hipStream_t s) {
-    hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(256), 0, s, L, LSp, U, a, M, Mp, kl);
+              double* part, hipStream_t s) {
+    const int nb = (M + 3) / 4;
+    hipLaunchKernelGGL(kl_part_kernel, dim3(nb), dim3(256), 0, s, L, LSp, U, a, M, Mp, part);
+    hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nb, M, kl);
     return CHECK_LAUNCH();
 }
 

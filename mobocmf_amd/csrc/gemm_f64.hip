@@ -1,19 +1,25 @@
-// FP64 MFMA GEMM for gfx950 (v_mfma_f64_16x16x4_f64), the dominant kernel of the MFDGP layer.
+// FP64 MFMA GEMM for gfx950, the dominant kernel of the MFDGP layer.
 //
 //   C[Mr x Nc] (+)= alpha * A[Mr x Kd] * B        B_T=0: B is [Kd x Nc] (n contiguous)
 //                                                 B_T=1: B is [Nc x Kd] (k contiguous)  -> A * B^T
 //
-// Workgroup = 256 threads = 4 wavefronts (2 x 2), tile 128 x 128, K step 16, register-prefetched
-// double-buffered LDS (2 x 36 KiB -> 2 workgroups per CU).  Each wavefront owns a 64 x 64 block =
-// 4 x 4 MFMA tiles (16 accumulators x 4 f64 = 128 VGPRs).  Operand fragments for the 16x16x4 f64 MFMA:
-// lane l holds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; accumulator register r of lane l is
-// C[row = (l>>4) + 4r][col = l&15].
-// LDS images are padded so every ds_read_b64 of a fragment is bank-conflict free:
-//   A / B_T tiles [128][16+2]  (row stride 36 dwords = 4*odd mod 64)
-//   B tiles       [16][128+16] (row stride 288 dwords = 32 mod 64)
-// Triangular operands (A = L^-1 lower, or upper) only visit the non-zero k range of their row block.
-// blockIdx.x -> tile mapping is XCD-aware: blocks b, b+8, ... share an XCD (and its L2), so the row
-// blocks that re-read the same 128-column panel of B are dealt to the same XCD back to back.
+// Matrix instruction: v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X (tools/mfma_peak.hip): it sustains
+// 73 TFLOP/s = the FP64 vector rate, whereas v_mfma_f64_16x16x4_f64 sustains only 36 TFLOP/s.  Its four
+// independent 4x4x4 blocks are used as four column groups of one 4 x 16 output strip: lane
+// (kk = l>>4, b = (l>>2)&3, i = l&3) holds A[row i][k] -- the same 4 rows in every block, an LDS broadcast
+// read -- and B[k][col 4b+j]; result lane (i = l>>4, col = l&15) (layout verified with one-hot operands,
+// tools/probe_mfma444.hip; cbsz/abid broadcast is a no-op for this instruction).
+//
+// Workgroup = 256 threads = 4 wavefronts (2 x 2), tile 128 x 128, K step 16.  Each wavefront owns 64 x 64 =
+// 64 accumulator registers (128 VGPRs).  Tiles are staged global -> LDS by global_load_lds_dwordx4 (LDS-DMA,
+// no staging VGPRs, no ds_write), double buffered: stage t+1 is in flight while stage t is multiplied.
+// LDS-DMA writes 64 lanes x 16 B contiguously, so the LDS images are unpadded; bank conflicts of the fragment
+// reads are removed by an XOR swizzle of the 16-byte chunk applied on the SOURCE address of the DMA and on
+// the fragment read (same involution on both sides):
+//   A / B_T image [128 rows][16 k]   : chunk ^= ((row >> 1) & 1) << 2
+//   B image       [16 k][128 cols]   : chunk ^= ((k >> 2) & 1) << 3
+// Within a K step lane group kk handles k = 4*kk + ks (ks = 0..3), so that per-k weights are contiguous.
+// Triangular operands only visit the non-zero k range of their tile.  blockIdx -> tile mapping is XCD-aware.
 #include "common.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -22,50 +28,120 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 #define BM 128
 #define BN 128
 #define BK 16
-#define LDA_S (BK + 2)
-#define LDB_S (BN + 16)
-#define AS_ELEMS (BM * LDA_S)                                   // 2304 doubles
-#define BS_ELEMS ((BK * LDB_S) > (BN * LDA_S) ? (BK * LDB_S) : (BN * LDA_S))  // 2304 doubles
+#define TILE_ELEMS (BM * BK)   // 2048 doubles = 16 KiB per operand tile
+
+__device__ __forceinline__ void glds16(const double* gsrc, double* lds_wave_base) {
+    // 64 lanes x 16 B: lane l lands at lds_wave_base + 16*l bytes
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 template <bool B_T>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * (AS_ELEMS + BS_ELEMS)];
-    double* As0 = lds;
-    double* Bs0 = lds + 2 * AS_ELEMS;
-
-    // ---- XCD-aware tile mapping: id -> (xcd, slot); slot -> (local column block, row block)
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * TILE_ELEMS];   // [buf][A | B]
+    // ---- block id -> (tile, k-slice).  Blocks b, b+8, ... share an XCD (and its L2):
+    //  * no split-K: the row blocks that re-read the same 128-column panel of B run back to back on one XCD;
+    //  * split-K: all tiles of one k-slice (they share the slice's rows of A and B) run back to back on one XCD.
     int64_t id = blockIdx.x;
-    int64_t ntile = (int64_t)nrb * ncb;
-    int rb;
+    int rb, z = 0;
     int64_t cb;
-    if ((ncb & 7) == 0) {
-        int64_t xcd = id & 7, slot = id >> 3;
-        cb = (slot / nrb) * 8 + xcd;
-        rb = nrb - 1 - (int)(slot % nrb);   // long (triangular) row blocks first
-    } else {
+    if (g.batched) {
+        z = blockIdx.z;
         cb = id / nrb;
         rb = nrb - 1 - (int)(id % nrb);
+    } else if (splitk > 1) {
+        const int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
+        int64_t t;
+        if ((splitk & 7) == 0) {
+            const int64_t xcd = id & 7, seq = id >> 3;
+            t = seq % ntile;
+            z = (int)((seq / ntile) * 8 + xcd);
+        } else {
+            t = id % ntile;
+            z = (int)(id / ntile);
+        }
+        if (g.lower_out) {
+            int r = 0;
+            while ((int64_t)(r + 1) * (r + 2) / 2 <= t) ++r;
+            rb = r;
+            cb = t - (int64_t)r * (r + 1) / 2;
+        } else {
+            cb = t / nrb;
+            rb = (int)(t % nrb);
+        }
+    } else {
+        // plain launch: nslot row-block slots per column block.  With a triangular A the work of row block rb is
+        // proportional to rb+1 (lower) / nrb-rb (upper); workgroups are dealt to CUs round-robin, so unequal tiles
+        // leave most CUs idle (measured: triangular as slow as dense).  `pair` makes every workgroup do the two
+        // row blocks (p, nrb-1-p): equal work for all.
+        const int nslot = pair ? (nrb + 1) / 2 : nrb;
+        int sl;
+        if ((ncb & 7) == 0) {
+            int64_t xcd = id & 7, slot = id >> 3;
+            cb = (slot / nslot) * 8 + xcd;
+            sl = (int)(slot % nslot);
+        } else {
+            cb = id / nslot;
+            sl = (int)(id % nslot);
+        }
+        rb = pair ? sl : nrb - 1 - sl;
     }
-    (void)ntile;
     if (g.lower_out && cb > rb) return;
 
-    const int z = blockIdx.z;
     const double* A = g.A;
     const double* B = g.B;
     double* C = g.C;
-    int64_t k0 = 0, k1 = g.Kd;
     if (g.batched) {
         A += z * g.strideA;
         B += z * g.strideB;
         C += z * g.strideC;
-    } else if (splitk > 1) {
-        int64_t nk = g.Kd / BK;
-        int64_t per = (nk + splitk - 1) / splitk;
-        k0 = z * per * BK;
-        k1 = k0 + per * BK;
-        if (k1 > g.Kd) k1 = g.Kd;
-        C += z * g.slab_stride;
     }
+    if (!g.batched && splitk > 1) C += z * g.slab_stride;
+    const int nparts = (pair && rb != nrb - 1 - rb) ? 2 : 1;
+    const int rb_first = rb;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+
+    // ---- LDS-DMA staging maps (one instruction = 64 lanes x 16 B = 1 KiB of the image)
+    // A / B_T image: lane -> (row = 8*wave + l/8 (+32 per round), physical chunk l%8); source chunk swizzled
+    const int a_row = tid >> 3;
+    const int a_lchk = (tid & 7) ^ (((a_row >> 1) & 1) << 2);
+    const double* Ag0 = A + (int64_t)a_row * g.lda + a_lchk * 2;
+    // B image: lane -> (k = wave (+4 per round), physical chunk l); source chunk ^ 8 on odd rounds
+    const double* Bg = B_T ? B + (cb * BN + a_row) * g.ldb + a_lchk * 2
+                           : B + (int64_t)wave * g.ldb + cb * BN;
+    auto stage = [&](const double* Ag, int64_t k, int buf) {
+        double* As = lds + buf * 2 * TILE_ELEMS;
+        double* Bs = As + TILE_ELEMS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) glds16(Ag + (int64_t)(32 * r) * g.lda + k, As + (r * 4 + wave) * 128);
+        if (B_T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) glds16(Bg + (int64_t)(32 * r) * g.ldb + k, Bs + (r * 4 + wave) * 128);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                glds16(Bg + (k + 4 * r) * g.ldb + ((lane ^ ((r & 1) << 3)) * 2), Bs + (r * 4 + wave) * 128);
+        }
+    };
+
+    // ---- fragment read offsets (doubles)
+    const int swA = ((lane >> 1) & 1) << 2;
+    int colA[4];   // k = 4*lk + ks inside a [row][16] image
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) colA[ks] = (((2 * lk + (ks >> 1)) ^ swA) << 1) + (ks & 1);
+    const int a_base = (wr * 64 + (lane & 3)) * BK;                 // + (mt*16 + 4r)*BK + colA[ks]
+    const int bt_base = (wc * 64 + li) * BK;                        // B_T: + nt*16*BK + colA[ks]
+    // B: k row = 4*lk + ks, column chunk (wc*32 + nt*8 + li/2) ^ ((lk&1)<<3)  ==  nt ^ (lk&1)
+    const int bn_base = (4 * lk) * BN + wc * 64 + li;               // + ks*BN + (nt ^ (lk&1))*16
+
+  for (int part = 0; part < nparts; ++part) {
+    rb = part ? nrb - 1 - rb_first : rb_first;
+    int64_t k0 = 0, k1 = g.Kd;
     if (g.tri & TRI_LOWER_A) {
         int64_t e = (int64_t)(rb + 1) * BM;
         if (k1 > e) k1 = e;
@@ -82,56 +158,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         int64_t e = (cb + 1) * BN;
         if (k1 > e) k1 = e;
     }
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 15, lk = lane >> 4;
-
-    // global -> register staging maps
-    const int a_row = tid >> 3, a_chk = tid & 7;        // A (and B_T): 4 x (32 rows apart), 16 B chunk of the 128 B row
-    const int b_row = tid >> 6, b_chk = tid & 63;       // B: 4 x (4 rows apart), 16 B chunk of the 1 KiB row
-    const double* Ag = A + ((int64_t)rb * BM + a_row) * g.lda + a_chk * 2;
-    const double* Bg;
-    if (B_T) Bg = B + (cb * BN + a_row) * g.ldb + a_chk * 2;
-    else Bg = B + (int64_t)b_row * g.ldb + cb * BN + b_chk * 2;
-
-    v2f64 ra[4], rbv[4];
-    auto load_stage = [&](int64_t k) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ra[r] = *(const v2f64*)(Ag + (int64_t)(32 * r) * g.lda + k);
-        if (B_T) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rbv[r] = *(const v2f64*)(Bg + (int64_t)(32 * r) * g.ldb + k);
-            if (g.bscale) {
-                v2f64 sc = *(const v2f64*)(g.bscale + k + a_chk * 2);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rbv[r] *= sc;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rbv[r] = *(const v2f64*)(Bg + (k + 4 * r) * g.ldb);
-            if (g.bscale) {
-                v2f64 sc = *(const v2f64*)(g.bscale + cb * BN + b_chk * 2);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rbv[r] *= sc;
-            }
-        }
-    };
-    auto store_stage = [&](int buf) {
-        double* As = As0 + buf * AS_ELEMS;
-        double* Bs = Bs0 + buf * BS_ELEMS;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *(v2f64*)(As + (a_row + 32 * r) * LDA_S + a_chk * 2) = ra[r];
-        if (B_T) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) *(v2f64*)(Bs + (a_row + 32 * r) * LDA_S + a_chk * 2) = rbv[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) *(v2f64*)(Bs + (b_row + 4 * r) * LDB_S + b_chk * 2) = rbv[r];
-        }
-    };
+    if (!g.batched && splitk > 1) {   // slice the tile's own non-zero k range
+        int64_t nkt = k1 > k0 ? (k1 - k0) / BK : 0;
+        int64_t per = (nkt + splitk - 1) / splitk;
+        int64_t b = k0 + z * per * BK, e = b + per * BK;
+        k0 = b < k1 ? b : k1;
+        k1 = e < k1 ? e : k1;
+    }
+    const double* Ag = Ag0 + (int64_t)rb * BM * g.lda;
 
     v4f64 acc[4][4];
 #pragma unroll
@@ -140,32 +174,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
     const int64_t nk = (k1 > k0) ? (k1 - k0) / BK : 0;
-    if (nk > 0) {
-        load_stage(k0);
-        store_stage(0);
-    }
-    __syncthreads();
+    if (nk > 0) stage(Ag, k0, 0);
+    __syncthreads();   // (emits s_waitcnt vmcnt(0): the DMA of stage 0 has landed for every wavefront)
     for (int64_t kt = 0; kt < nk; ++kt) {
         const int buf = (int)(kt & 1);
-        if (kt + 1 < nk) load_stage(k0 + (kt + 1) * BK);
-        const double* As = As0 + buf * AS_ELEMS + (wr * 64 + li) * LDA_S + lk;
-        const double* Bs = B_T ? (Bs0 + buf * BS_ELEMS + (wc * 64 + li) * LDA_S + lk)
-                               : (Bs0 + buf * BS_ELEMS + lk * LDB_S + wc * 64 + li);
+        if (kt + 1 < nk) stage(Ag, k0 + (kt + 1) * BK, buf ^ 1);
+        const double* As = lds + buf * 2 * TILE_ELEMS;
+        const double* Bs = As + TILE_ELEMS;
+        v4f64 w4;
+        if (B_T && g.bscale) w4 = *(const v4f64*)(g.bscale + k0 + kt * BK + 4 * lk);   // weights of k = 4*lk + ks
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            double af[4], bf[4];
+            double bf[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = As[t * 16 * LDA_S + ks * 4];
+            for (int t = 0; t < 4; ++t)
+                bf[t] = B_T ? Bs[bt_base + t * 16 * BK + colA[ks]] : Bs[bn_base + ks * BN + ((t ^ (lk & 1)) << 4)];
+            if (B_T && g.bscale) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bf[t] = B_T ? Bs[t * 16 * LDA_S + ks * 4] : Bs[ks * 4 * LDB_S + t * 16];
+                for (int t = 0; t < 4; ++t) bf[t] *= w4[ks];
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                double af[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) af[r] = As[a_base + (i * 16 + 4 * r) * BK + colA[ks]];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[r], bf[j], acc[i][j][r], 0, 0, 0);
+            }
         }
-        if (kt + 1 < nk) store_stage(buf ^ 1);
-        __syncthreads();
+        __syncthreads();   // all reads of buf done + DMA into buf^1 landed (vmcnt(0) before the barrier)
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -177,16 +217,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         for (int nt = 0; nt < 4; ++nt) {
             const int64_t col = col0 + nt * 16;
             const double gm = g.gmu[col], cg = g.cgv[col];
+            const double cs = g.alpha * (g.bscale ? g.bscale[col] : 1.0);   // column scaling commutes with A*
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = row0 + mt * 16 + 4 * r;
                     C[row * g.ldc + col] =
-                        g.alpha * acc[mt][nt][r] + g.avec[row] * gm - 2.0 * g.Aaux[row * g.ldc + col] * cg;
+                        cs * acc[mt][nt][r] + g.avec[row] * gm - 2.0 * g.Aaux[row * g.ldc + col] * cg;
                 }
         }
-        return;
+        continue;   // LDS was not touched after the main loop's last barrier
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -231,35 +272,52 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
             if (g.coldot_part)
                 g.coldot_part[(int64_t)rb * g.Nc + cb * BN + tid] = red[2 * BN + tid] + red[3 * BN + tid];
         }
+        __syncthreads();   // `red` aliases the staging buffers of the next part
     }
+  }   // parts
 }
 
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
     if (g.Mr % BM || g.Nc % BN || g.Kd % BK) return MOBOCMF_BAD_ARG;
     int nrb = g.Mr / BM;
     int64_t ncb = g.Nc / BN;
-    int zdim = g.batched ? g.batched : (splitk > 1 ? splitk : 1);
-    dim3 grid((unsigned)(nrb * ncb), 1, (unsigned)zdim);
+    dim3 grid;
+    int pair = 0;
+    if (g.batched) {
+        grid = dim3((unsigned)(nrb * ncb), 1, (unsigned)g.batched);
+        splitk = 1;
+    } else if (splitk > 1) {
+        int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
+        grid = dim3((unsigned)(ntile * splitk), 1, 1);
+    } else {
+        pair = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !g.lower_out && nrb > 1) ? 1 : 0;
+        grid = dim3((unsigned)((pair ? (nrb + 1) / 2 : nrb) * ncb), 1, 1);
+        splitk = 1;
+    }
     if (B_T)
-        hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, s, g, nrb, ncb, g.batched ? 1 : splitk);
+        hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
     else
-        hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, s, g, nrb, ncb, g.batched ? 1 : splitk);
+        hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
+// out[i][j] (+)= sum_z slabs[z][i][j]   (rows x cols, slabs dense with ld = cols); lower_only: tiles above the
+// diagonal are neither read nor written, elements above the diagonal inside diagonal tiles are zeroed if `tril`
 __global__ void reduce_slabs_kernel(const double* slabs, int64_t slab_stride, int nslab, double* out, int64_t ld,
-                                    int Mr, double scale, int lower_only, int accumulate) {
+                                    int rows, int64_t cols, double scale, int lower_only, int tril, int accumulate) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)Mr * Mr) return;
-    int i = (int)(idx / Mr), j = (int)(idx % Mr);
-    double v = 0.0;
-    // tiles strictly above the diagonal were never written by a lower_out GEMM: never read them
-    if (!lower_only || (j / TILE) <= (i / TILE)) {
-        const double* p = slabs + (int64_t)i * Mr + j;
-        for (int z = 0; z < nslab; ++z) v += p[z * slab_stride];
-        v *= scale;
-        if (lower_only && j > i) v = 0.0;
+    if (idx >= (int64_t)rows * cols) return;
+    int i = (int)(idx / cols);
+    int64_t j = idx % cols;
+    if (lower_only && (j / TILE) > (i / TILE)) {
+        if (tril && !accumulate) out[(int64_t)i * ld + j] = 0.0;
+        return;
     }
+    double v = 0.0;
+    const double* p = slabs + (int64_t)i * cols + j;
+    for (int z = 0; z < nslab; ++z) v += p[z * slab_stride];
+    v *= scale;
+    if (tril && j > i) v = 0.0;
     if (accumulate) v += out[(int64_t)i * ld + j];
     out[(int64_t)i * ld + j] = v;
 }
@@ -268,6 +326,37 @@ int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, dou
                         double scale, int lower_only, int accumulate, hipStream_t s) {
     int64_t n = (int64_t)Mr * Mr;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, slab_stride,
-                       nslab, out, ld, Mr, scale, lower_only, accumulate);
+                       nslab, out, ld, Mr, (int64_t)Mr, scale, lower_only, lower_only, accumulate);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
+
+// Small-grid GEMMs (M x M operands: a handful of 128x128 tiles on 256 CUs) are bound by one CU's MFMA rate:
+// slice k over more workgroups into slabs, then add the slabs.  ws must hold splitk * Mr * Nc doubles.
+int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems, hipStream_t s) {
+    GemmArgs g = g0;
+    const int nrb = g.Mr / BM;
+    const int64_t ncb = g.Nc / BN;
+    const int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
+    int64_t nk = g.Kd / BK;
+    if (g.tri) nk = (nk + 1) / 2;
+    int sk = 1;
+    if (!g.batched && g.epi == EPI_STORE && ntile < 96 && nk >= 8) {
+        sk = (int)(192 / ntile);
+        if (sk > nk / 4) sk = (int)(nk / 4);
+        if (sk >= 8) sk &= ~7;
+        if ((int64_t)sk * g.Mr * g.Nc > ws_elems) sk = (int)(ws_elems / ((int64_t)g.Mr * g.Nc));
+        if (sk >= 8) sk &= ~7;
+    }
+    if (sk < 2) return launch_gemm(g0, B_T, 1, s);
+    g.C = ws;
+    g.ldc = g.Nc;
+    g.slab_stride = (int64_t)g.Mr * g.Nc;
+    g.accumulate = 0;
+    int rc = launch_gemm(g, B_T, sk, s);
+    if (rc) return rc;
+    int64_t n = (int64_t)g.Mr * g.Nc;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double*)ws,
+                       g.slab_stride, sk, g0.C, g0.ldc, g.Mr, g.Nc, 1.0, g0.lower_out, 0, g0.accumulate);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+

@@ -306,6 +306,23 @@ __global__ void sum_partials_kernel(const double* part, int64_t P, int64_t strid
     out[j] = accumulate ? out[j] + v : v;
 }
 
+// many partials, few outputs: one block per output j, threads stride over the partials
+__global__ void sum_partials_wide_kernel(const double* part, int64_t P, int64_t stride, double* out, int64_t len,
+                                         double scale, int accumulate) {
+    __shared__ double sh[4];
+    const int64_t j = blockIdx.x;
+    double v = 0.0;
+    for (int64_t p = threadIdx.x; p < P; p += 256) v += part[p * stride + j];
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = (sh[0] + sh[1] + sh[2] + sh[3]) * scale;
+        out[j] = accumulate ? out[j] + v : v;
+    }
+}
+
 // out[b] = sum_{s<div} in[b*div + s]
 __global__ void group_sum_kernel(const double* in, double* out, int64_t nout, int div, int accumulate) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,6 +335,11 @@ __global__ void group_sum_kernel(const double* in, double* out, int64_t nout, in
 int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* out, int64_t len, double scale,
                         int accumulate, hipStream_t s) {
     if (len <= 0) return MOBOCMF_OK;
+    if (P >= 64 && len <= 4096) {
+        hipLaunchKernelGGL(sum_partials_wide_kernel, dim3((unsigned)len), dim3(256), 0, s, part, P, stride, out, len,
+                           scale, accumulate);
+        return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+    }
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, part, P, stride, out,
                        len, scale, accumulate);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
