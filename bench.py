@@ -53,17 +53,21 @@ def build_surrogates(cfg, outputs, device):
     return sur
 
 
-def one_step(sur, cfg, gen):
+def one_step(sur, cfg, gens, streams):
+    """One ELBO step of every surrogate.  The surrogates are independent (blackbox_mfdgp_fitter.py:134-152 loops
+    over them sequentially), so each one runs on its own HIP stream: the latency-bound M x M chains (Cholesky,
+    triangular inverse, Cholesky backward) of one surrogate overlap the MFMA GEMMs of the others."""
     losses = []
-    for model, elbo, opt, (x, y, fid) in sur:
-        opt.zero_grad(set_to_none=True)
-        eps = [None] + [torch.randn(cfg["N"] * cfg["S"], dtype=torch.float64, device=x.device, generator=gen)
-                        for _ in range(1, cfg["L"])]
-        out = model(x, eps=eps)
-        res = elbo(out, y.T, fid)
-        (-res[0]).backward()
-        opt.step()
-        losses.append(res[0].detach())
+    for (model, elbo, opt, (x, y, fid)), gen, st in zip(sur, gens, streams):
+        with torch.cuda.stream(st):
+            opt.zero_grad(set_to_none=True)
+            eps = [None] + [torch.randn(cfg["N"] * cfg["S"], dtype=torch.float64, device=x.device, generator=gen)
+                            for _ in range(1, cfg["L"])]
+            out = model(x, eps=eps)
+            res = elbo(out, y.T, fid)
+            (-res[0]).backward()
+            opt.step()
+            losses.append(res[0].detach())
     return losses
 
 
@@ -147,6 +151,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="run the surrogates back to back on one stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,11 +171,17 @@ def main():
     n_out = 3 if args.config == "C3" else min(cfg["outputs"], 3) if args.config != "C5" else 1
     outputs = list(range(rank * n_out, rank * n_out + n_out))
     sur = build_surrogates(cfg, outputs, device)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + rank)
+    gens = []
+    for i in range(len(sur)):
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1234 + 16 * rank + i)
+        gens.append(gen)
+    streams = [torch.cuda.Stream(device=device) for _ in sur] if not args.single_stream else \
+        [torch.cuda.current_stream(device)] * len(sur)
+    torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step(sur, cfg, gen)
+        one_step(sur, cfg, gens, streams)
 
     def barrier():
         torch.cuda.synchronize()
@@ -181,7 +192,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = one_step(sur, cfg, gen)
+        losses = one_step(sur, cfg, gens, streams)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -9,7 +9,7 @@ int launch_gram_bwd(const GramArgs& g, bool want_dx, hipStream_t s);
 void gram_grid(const GramArgs& g, dim3* grid);
 int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* out, int64_t len, double scale,
                         int accumulate, hipStream_t s);
-int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, int32_t* info, hipStream_t s);
+int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, double* Ld, int32_t* info, hipStream_t s);
 int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
                  int64_t ws_elems, hipStream_t s);
 int launch_pad_tril(const double* src, int64_t lds, int M, double* dst, int Mp, hipStream_t s);
@@ -112,11 +112,12 @@ bool carve_saved(Bump& b, const Dims& D, Saved& S) {
 }
 
 struct ScratchF {
-    double *Dinv, *T, *qpart, *mupart, *rpart, *ws;
+    double *Dinv, *Ld, *T, *qpart, *mupart, *rpart, *ws;
     int64_t ws_elems;
 };
 bool carve_scratch_fwd(Bump& b, const Dims& D, ScratchF& S) {
     S.Dinv = b.take((int64_t)(D.Mp / NB) * NB * NB);
+    S.Ld = b.take((int64_t)(D.Mp / NB) * NB * NB);
     S.T = b.take((int64_t)D.Mp * D.Mp);
     S.qpart = b.take((int64_t)D.nrb * D.Np);
     S.mupart = b.take((int64_t)D.nrb * D.Np);
@@ -217,7 +218,7 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     g.x = Zx; g.f = zf; g.nbase = D.M; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp;
     g.K = S.L; g.ldk = Mp; g.Mp = Mp; g.Np = Mp; g.knn = nullptr; g.jitter = desc->jitter; g.is_kmm = 1;
     TRY(launch_gram_fwd(g, s));
-    TRY(launch_potrf(S.L, Mp, Mp, F.Dinv, info, s));
+    TRY(launch_potrf(S.L, Mp, Mp, F.Dinv, F.Ld, info, s));
     HIP_TRY(hipMemsetAsync(S.Linv, 0, mm * sizeof(double), s));
     TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
     TRY(launch_transpose(S.Linv, Mp, S.LinvT, Mp, Mp, Mp, s));

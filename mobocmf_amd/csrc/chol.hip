@@ -56,7 +56,11 @@ __device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[N
 }
 
 // grid.x = number of 64-row blocks at/below the diagonal of panel jb; block = 64 threads (1 wavefront)
-__global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, int32_t* info) {
+// NOTE: every workgroup re-factorises the diagonal block from A, so block 0 must NOT overwrite it in place
+// (a workgroup that is scheduled late -- e.g. when other streams occupy the CUs -- would read L_jj instead of
+// A_jj).  The factor goes to the side buffer Ld; finish_l_kernel copies it into the diagonal at the end.
+__global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
+                                                         int32_t* info) {
     const int lane = threadIdx.x;
     const int bi = blockIdx.x;
     const int64_t j0 = (int64_t)jb * NB;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
     for (int c = 0; c < NB; ++c) a[c] = drow[c];
     int fail = chol64_rows(a, lane);
     if (bi == 0) {
-        double* wrow = A + (j0 + lane) * ld + j0;
+        double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
         if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
@@ -157,16 +161,26 @@ int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
-int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, int32_t* info, hipStream_t s) {
+// strict upper triangle <- 0, diagonal 64x64 blocks <- the factors kept in Ld
+__global__ void finish_l_kernel(double* A, int64_t ld, int n, const double* Ld) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * n) return;
+    int i = (int)(idx / n), j = (int)(idx % n);
+    if (j > i) A[(int64_t)i * ld + j] = 0.0;
+    else if (i / NB == j / NB) A[(int64_t)i * ld + j] = Ld[(int64_t)(i / NB) * NB * NB + (i % NB) * NB + (j % NB)];
+}
+
+// Dinv and Ld: (Mp/64) x 64 x 64 doubles each
+int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, double* Ld, int32_t* info, hipStream_t s) {
     const int nblk = Mp / NB;
     HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), s));
     for (int jb = 0; jb < nblk; ++jb) {
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk - jb), dim3(64), 0, s, A, ld, jb, Dinv, info);
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk - jb), dim3(64), 0, s, A, ld, jb, Dinv, Ld, info);
         int nt = nblk - jb - 1;
         if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, ld, jb);
     }
     int64_t n2 = (int64_t)Mp * Mp;
-    hipLaunchKernelGGL(tril_inplace_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, A, ld, Mp);
+    hipLaunchKernelGGL(finish_l_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, A, ld, Mp, (const double*)Ld);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 

@@ -129,14 +129,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }
     };
 
-    // ---- fragment read offsets (doubles)
+    // ---- fragment read offsets (doubles).  k pairs (2*kp', 2*kp'+1) are adjacent: one ds_read_b128 per pair.
+    // kpair p (0,1) covers ks = 2p, 2p+1, i.e. k = 4*lk + 2p + {0,1}: logical 16-B chunk 2*lk + p.
     const int swA = ((lane >> 1) & 1) << 2;
-    int colA[4];   // k = 4*lk + ks inside a [row][16] image
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) colA[ks] = (((2 * lk + (ks >> 1)) ^ swA) << 1) + (ks & 1);
-    const int a_base = (wr * 64 + (lane & 3)) * BK;                 // + (mt*16 + 4r)*BK + colA[ks]
-    const int bt_base = (wc * 64 + li) * BK;                        // B_T: + nt*16*BK + colA[ks]
-    // B: k row = 4*lk + ks, column chunk (wc*32 + nt*8 + li/2) ^ ((lk&1)<<3)  ==  nt ^ (lk&1)
+    const int colP0 = ((2 * lk + 0) ^ swA) << 1, colP1 = ((2 * lk + 1) ^ swA) << 1;
+    const int a_base = (wr * 64 + (lane & 3)) * BK;                 // + (mt*16 + 4r)*BK + colP
+    const int bt_base = (wc * 64 + li) * BK;                        // B_T: + nt*16*BK + colP
+    // B: k row = 4*lk + ks, 16-col group nt stored at group nt ^ (lk&1)
     const int bn_base = (4 * lk) * BN + wc * 64 + li;               // + ks*BN + (nt ^ (lk&1))*16
 
   for (int part = 0; part < nparts; ++part) {
@@ -176,35 +175,64 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     const int64_t nk = (k1 > k0) ? (k1 - k0) / BK : 0;
     if (nk > 0) stage(Ag, k0, 0);
     __syncthreads();   // (emits s_waitcnt vmcnt(0): the DMA of stage 0 has landed for every wavefront)
+    v4f64 w_nxt = (v4f64){1.0, 1.0, 1.0, 1.0};
+    if (B_T && g.bscale && nk > 0) w_nxt = *(const v4f64*)(g.bscale + k0 + 4 * lk);
     for (int64_t kt = 0; kt < nk; ++kt) {
         const int buf = (int)(kt & 1);
-        if (kt + 1 < nk) stage(Ag, k0 + (kt + 1) * BK, buf ^ 1);
+        const v4f64 w4 = w_nxt;    // weights of k = 4*lk + ks of this stage (B_T contraction weights)
+        if (kt + 1 < nk) {
+            // the weight load is issued BEFORE the DMA so that waiting for it never drains the DMA (vmcnt is in order)
+            if (B_T && g.bscale) w_nxt = *(const v4f64*)(g.bscale + k0 + (kt + 1) * BK + 4 * lk);
+            stage(Ag, k0 + (kt + 1) * BK, buf ^ 1);
+        }
         const double* As = lds + buf * 2 * TILE_ELEMS;
         const double* Bs = As + TILE_ELEMS;
-        v4f64 w4;
-        if (B_T && g.bscale) w4 = *(const v4f64*)(g.bscale + k0 + kt * BK + 4 * lk);   // weights of k = 4*lk + ks
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            double bf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                bf[t] = B_T ? Bs[bt_base + t * 16 * BK + colA[ks]] : Bs[bn_base + ks * BN + ((t ^ (lk & 1)) << 4)];
-            if (B_T && g.bscale) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) bf[t] *= w4[ks];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                double af[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) af[r] = As[a_base + (i * 16 + 4 * r) * BK + colA[ks]];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[r], bf[j], acc[i][j][r], 0, 0, 0);
-            }
-        }
+        // Software pipeline over 8 groups g = (kpair p, row tile mt): the A fragments of group g+1 (4 x ds_read_b128)
+        // and, at a kpair boundary, the B fragments of the next kpair are read while the 32 MFMAs of group g issue.
+        // sched_barrier(0) pins the group boundaries so the register allocator sees two fragment sets, not eight.
+        // (written with literal indices through macros: lambdas / late-unrolled loops left the fragment arrays in scratch)
+        v2f64 a0[4], a1[4];          // A fragment sets (even / odd group)
+        double b0[2][4], b1[2][4];   // B fragment sets (kpair 0 / 1): [ks&1][nt]
+#define LOAD_A(dst, P, MT)                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
+        dst[r] = *(const v2f64*)(As + a_base + ((MT) * 16 + 4 * r) * BK + ((P) ? colP1 : colP0));
+#define LOAD_B(dst, P)                                                                                      \
+    if (B_T) {                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+            v2f64 v = *(const v2f64*)(Bs + bt_base + t * 16 * BK + ((P) ? colP1 : colP0));                  \
+            dst[0][t] = v[0];                                                                               \
+            dst[1][t] = v[1];                                                                               \
+        }                                                                                                   \
+        if (g.bscale) {                                                                                     \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+                dst[0][t] *= w4[2 * (P)];                                                                   \
+                dst[1][t] *= w4[2 * (P) + 1];                                                               \
+            }                                                                                               \
+        }                                                                                                   \
+    } else {                                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                      \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                  \
+                dst[e][t] = Bs[bn_base + (2 * (P) + e) * BN + ((t ^ (lk & 1)) << 4)];                       \
+    }
+#define MMA(asrc, bsrc, MT)                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+                acc[MT][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(asrc[r][e], bsrc[e][j], acc[MT][j][r], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+        LOAD_B(b0, 0)
+        LOAD_A(a0, 0, 0)
+        LOAD_A(a1, 0, 1) MMA(a0, b0, 0)
+        LOAD_A(a0, 0, 2) MMA(a1, b0, 1)
+        LOAD_A(a1, 0, 3) MMA(a0, b0, 2)
+        LOAD_A(a0, 1, 0) LOAD_B(b1, 1) MMA(a1, b0, 3)
+        LOAD_A(a1, 1, 1) MMA(a0, b1, 0)
+        LOAD_A(a0, 1, 2) MMA(a1, b1, 1)
+        LOAD_A(a1, 1, 3) MMA(a0, b1, 2)
+        MMA(a1, b1, 3)
+#undef LOAD_A
+#undef LOAD_B
+#undef MMA
         __syncthreads();   // all reads of buf done + DMA into buf^1 landed (vmcnt(0) before the barrier)
     }
 
