@@ -142,7 +142,7 @@ def test_ref_equiv_sequence_matches_whitened():
     e1 = O.elbo(st, x, y, fid, eps=eps, S=2, ref_equiv=False)
     e2 = O.elbo(st, x, y, fid, eps=eps, S=2, ref_equiv=True)
     assert abs(e1[0] - e2[0]) / abs(e1[0]) < 1e-9
-    assert abs(e1[1] - e2[1]) / abs(e1[1]) < 1e-12
+    assert abs(e1[1] - e2[1]) / abs(e1[1]) < 1e-9    # expanded-norm distances round differently
 
 
 def test_D7_finite_difference_gradients():
