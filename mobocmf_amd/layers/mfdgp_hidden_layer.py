@@ -87,7 +87,12 @@ class MFDGUnwhitenedVariationalStrategy(UnwhitenedVariationalStrategy):
     def zf(self):
         if self.previous_layer is None:
             return self._inducing_points[:, -1]
-        return self.previous_layer.variational_strategy._variational_distribution.variational_mean
+        prev_m = self.previous_layer.variational_strategy._variational_distribution.variational_mean
+        if prev_m.shape[0] != self._inducing_points.shape[0]:
+            # only-highest-fidelity ablation: the layers have different inducing inputs, and the kernel of this
+            # layer ignores the f column (a_x1 = a_f = nu = 0, mfdgp_hidden_layer_only_hf.py:85-89): any value does
+            return self._inducing_points[:, -1]
+        return prev_m
 
     @property
     def inducing_points(self):

@@ -34,9 +34,9 @@ def all_gather_moments(local):
     if w == 1:
         return local
     local = local.contiguous()
-    out = torch.empty((w,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local)
-    return out.reshape((w * local.shape[0],) + tuple(local.shape[1:]))
+    out = torch.empty((w * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)      # concatenation along dim 0, rank order
+    return out
 
 
 def coupled_acquisition(local_acq):

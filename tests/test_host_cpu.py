@@ -1,0 +1,148 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol of include/mobocmf_hip.h, the host mirror of
+the reference surface behaves (construction, init heuristics, parameter tree, freezing, deepcopy/dill), and the
+product path fails loudly without a GPU (no CPU fallback)."""
+import copy
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mobocmf_amd.util import synthetic
+from oracle import mfdgp_oracle as O
+from tests.helpers import to_t
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mobocmf_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mobocmf_hip.h")).read()
+    declared = set(re.findall(r"^int (mobocmf_\w+)\(", hdr, flags=re.M))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mobocmf_version() >= 100           # host-only call, no GPU needed
+
+
+def test_workspace_query_and_bad_args():
+    from mobocmf_amd import functional as F
+    saved, scratch = F.workspace_bytes(F.make_desc(1, 8, 512, 65536, 8))
+    assert saved > 3 * 512 * 65536 * 8 and scratch > 2 * 512 * 65536 * 8
+    from mobocmf_amd import _lib
+    with pytest.raises(_lib.MobocmfError):
+        F.workspace_bytes(F.make_desc(1, 40, 512, 65536, 8))      # d > 32
+    with pytest.raises(_lib.MobocmfError):
+        F.workspace_bytes(F.make_desc(0, 2, 8, 13, 2))            # Np % xdiv != 0
+
+
+def _forrester_model(**kw):
+    from mobocmf_amd.models import MFDGP
+    x, y, fid = synthetic.forrester_problem(0)
+    return MFDGP(to_t(x), to_t(y)[:, None], to_t(fid)[:, None], 2, **kw), (x, y, fid)
+
+
+def test_model_surface_and_init_heuristics_match_reference_rules():
+    model, (x, y, fid) = _forrester_model()
+    model.double()
+    assert model.num_hidden_layers == 2 and model.name_hidden_layer == "hidden_layer_"
+    l0, l1 = model.hidden_layer_0, model.hidden_layer_1
+    xt, yt, ft = to_t(x), to_t(y), to_t(fid)
+    # lengthscale: the as-written MEDIAN rule, float32-rounded like the reference (B.4)
+    ls_lo = float(O.median_lengthscale(xt[ft == 0]))
+    ls_hi = float(O.median_lengthscale(xt[ft == 1]))
+    assert float(l0.covar_module.base_kernel.lengthscale) == pytest.approx(ls_lo, rel=1e-6)
+    k1 = l1.covar_module.kernels[0].kernels[0]
+    k2 = l1.covar_module.kernels[1]
+    kf = l1.covar_module.kernels[0].kernels[1].kernels[1]
+    klin = l1.covar_module.kernels[0].kernels[1].kernels[0]
+    assert float(k1.base_kernel.lengthscale) == pytest.approx(10 * ls_hi, rel=1e-6)
+    assert float(k2.base_kernel.lengthscale) == pytest.approx(ls_hi, rel=1e-6)
+    assert float(kf.base_kernel.lengthscale) == pytest.approx(1.0, rel=1e-6)
+    assert float(k1.outputscale) == pytest.approx(1.0, rel=1e-6) and float(k2.outputscale) == pytest.approx(0.01, rel=1e-5)
+    assert float(klin.variance) == pytest.approx(1.0, rel=1e-6)
+    # inducing inputs = all training inputs; q(u) mean = nearest same-fidelity target (mfdgp.py:290-317)
+    assert torch.equal(l0.variational_strategy.inducing_points, xt)
+    m0 = O.nearest_same_fidelity_values(xt, yt, ft, xt, 0)
+    vd0 = l0.variational_strategy._variational_distribution
+    assert torch.allclose(vd0.variational_mean, m0, rtol=1e-6)
+    assert torch.allclose(torch.diagonal(vd0.chol_variational_covar), torch.full((16,), 1e-4, dtype=torch.float64), rtol=1e-5)
+    # layer 1 inducing inputs recomputed from layer 0's variational mean, differentiable
+    Z1 = l1.variational_strategy.inducing_points
+    assert Z1.shape == (16, 2) and torch.equal(Z1[:, 1], vd0.variational_mean)
+    assert Z1.requires_grad
+    # likelihood bounds and initial noise (mfdgp.py:113-121)
+    lik1 = model.hidden_layer_likelihood_1
+    y_high_std = np.std(y[fid == 1])
+    assert float(lik1.noise) == pytest.approx(1e-2 * y_high_std, rel=1e-5)
+    assert lik1.raw_noise_constraint.upper_bound == pytest.approx(0.1 * y_high_std)
+    assert float(model.hidden_layer_likelihood_0.noise) == pytest.approx(1e-6, rel=1e-3)
+    assert l1.samples.shape == (25, 1)
+
+
+def test_fix_variational_hypers_toggles_what_the_reference_toggles():
+    model, _ = _forrester_model()
+    model.fix_variational_hypers(True)
+    for i in range(2):
+        assert not getattr(model, f"hidden_layer_likelihood_{i}").raw_noise.requires_grad
+        layer = getattr(model, f"hidden_layer_{i}")
+        assert not layer.variational_strategy._variational_distribution.chol_variational_covar.requires_grad
+        assert layer.variational_strategy._variational_distribution.variational_mean.requires_grad
+        assert all(p.requires_grad for p in layer.covar_module.parameters())
+    model.fix_variational_hypers(False)
+    model.fix_variational_hypers_cond(True)
+    assert not any(p.requires_grad for p in model.hidden_layer_1.covar_module.parameters())
+    # parameters() de-duplicates the previous layer registered under layer 1's strategy
+    names = [n for n, _ in model.named_parameters()]
+    assert len(names) == len(set(names)) == 15
+
+
+def test_deepcopy_and_dill_roundtrip_on_cpu():
+    import dill
+    model, _ = _forrester_model()
+    m2 = copy.deepcopy(model)
+    assert m2.hidden_layer_1.variational_strategy.previous_layer is m2.hidden_layer_0
+    buf = io.BytesIO()
+    dill.dump(model, buf)
+    m3 = dill.loads(buf.getvalue())
+    for (n, p), (_, q) in zip(model.named_parameters(), m3.named_parameters()):
+        assert torch.equal(p, q), n
+
+
+def test_only_highest_fidelity_ablation_and_extensions():
+    model, _ = _forrester_model(use_only_highest_fidelity=True)
+    cm = model.hidden_layer_1.covar_module
+    assert float(cm.kernels[0].kernels[0].outputscale) == 0.0 and float(cm.kernels[1].outputscale) == pytest.approx(1.0)
+    assert not cm.kernels[0].kernels[0].raw_outputscale.requires_grad
+    assert model.hidden_layer_1.variational_strategy.inducing_points.shape[0] == 4     # high-fidelity points only
+    prob = synthetic.make_problem(d=3, L=3, M=10, N=16, S=2, seed=7)
+    m3 = synthetic.model_from_problem(prob, device="cpu")
+    assert m3.num_hidden_layers == 3 and m3.hidden_layer_2.variational_strategy.Zx.shape == (10, 3)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mobocmf_amd import _lib
+    model, (x, _, _) = _forrester_model()
+    model.double()
+    with pytest.raises(_lib.MobocmfError):
+        model(to_t(x))
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mobocmf_amd")):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in re.sub(r"#.*", "", src).replace("cpu-oracle", ""), fn
+
+
+def test_synthetic_problems_are_deterministic():
+    a = synthetic.make_problem(d=8, L=2, M=16, N=64, S=2, output=1, seed=3)
+    b = synthetic.make_problem(d=8, L=2, M=16, N=64, S=2, output=1, seed=3)
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["eps"][1], b["eps"][1])
+    assert (a["fid"][:16] == 1).all() and (a["fid"][16:] == 0).all()

@@ -1,0 +1,60 @@
+"""N > 1 path on CPU: world-size-2 gloo processes exercise the surrogate sharding table and the single all-gather
+exchange (posterior moments / coupled acquisition) of mobocmf_amd.parallel."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobocmf_amd import parallel
+    names = ["obj1", "obj2", "con1", "con2", "con3"]
+    mine, owner = parallel.shard_blackboxes(names)
+    # every rank holds 2 surrogates' (mus, vars) on a 7-point grid; values encode (rank, surrogate)
+    local = torch.stack([torch.full((2, 7), float(10 * rank + k), dtype=torch.float64) for k in range(2)])
+    gathered = parallel.all_gather_moments(local)
+    acq_local = torch.full((2, 7), float(rank + 1), dtype=torch.float64)
+    total = parallel.coupled_acquisition(acq_local)
+    q.put((rank, mine, owner, gathered.shape, gathered[:, 0, 0].tolist(), total.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_exchange():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, mine0, owner0, shape0, g0, t0), (r1, mine1, owner1, shape1, g1, t1) = res
+    assert owner0 == owner1 and sorted(mine0 + mine1) == sorted(owner0)
+    assert mine0 == ["obj1", "con1", "con3"] and mine1 == ["obj2", "con2"]
+    assert tuple(shape0) == (4, 2, 7) and g0 == g1 == [0.0, 1.0, 10.0, 11.0]      # rank order, identical everywhere
+    assert t0 == t1 == [6.0] * 7                                                     # 2*1 + 2*2
+
+
+def test_world_size_1_degenerates_to_identity():
+    from mobocmf_amd import parallel
+    x = torch.arange(6, dtype=torch.float64).reshape(1, 2, 3)
+    assert torch.equal(parallel.all_gather_moments(x), x)
+    mine, owner = parallel.shard_blackboxes(["a", "b"], rank=0, world_size=1)
+    assert mine == ["a", "b"]
