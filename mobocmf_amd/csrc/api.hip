@@ -26,7 +26,13 @@ int launch_moments_finish(const double* qpart, const double* mupart, const doubl
                           double* mean, double* var, hipStream_t s);
 int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
                             const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
-                            double* gv, double* gv2, double* cgv, hipStream_t s);
+                            double* gv, double* gv2, double* cgv, int32_t* nclamped, hipStream_t s);
+int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, double* out, int Mp, const int32_t* flag,
+                            const double* fallback, hipStream_t s);
+int launch_dutot(const double* X, const double* U, const double* da, const double* a, const double* gkl, int Mp,
+                 double* dU, double* da_tot, hipStream_t s);
+int launch_y_combine(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
+                     double* Y, hipStream_t s);
 int launch_add_kl_terms(double* dU, const double* U, double* da, const double* a, const double* gkl, int Mp, hipStream_t s);
 int launch_rank1_add(double* X, const double* u, const double* v, int Mp, hipStream_t s);
 int launch_dl_from_t2(const double* T2, const double* L, const double* gkl, int M, int Mp, double* dL, hipStream_t s);
@@ -128,7 +134,7 @@ bool carve_scratch_fwd(Bump& b, const Dims& D, ScratchF& S) {
 }
 
 struct ScratchB {
-    double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *W[8], *da, *gpart, *hyp_part, *df_part, *dzf_part, *dx_part,
+    double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *W[10], *da, *da_tot, *flag, *gpart, *hyp_part, *df_part, *dzf_part, *dx_part,
         *hyp_part2, *df_part2, *dzf_part2, *gzf_tmp;
 };
 bool carve_scratch_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, ScratchB& S) {
@@ -136,8 +142,10 @@ bool carve_scratch_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, Scra
     S.gmu = b.take(D.Np); S.gv = b.take(D.Np); S.gv2 = b.take(D.Np); S.cgv = b.take(D.Np);
     S.dA = b.take(mn); S.dK = b.take(mn);
     S.slabs = b.take((int64_t)(D.splitk > 16 ? D.splitk : 16) * mm);
-    for (int i = 0; i < 8; ++i) S.W[i] = b.take(mm);
+    for (int i = 0; i < 10; ++i) S.W[i] = b.take(mm);
     S.da = b.take(D.Mp);
+    S.da_tot = b.take(D.Mp);
+    S.flag = b.take(4);
     S.gpart = b.take((int64_t)D.Mp * 16);
     S.hyp_part = b.take((int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H);
     S.hyp_part2 = b.take((int64_t)D.ggrid_mm.x * D.ggrid_mm.y * D.H);
@@ -270,23 +278,36 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     if (!carve_saved(bs, D, S) || !carve_scratch_bwd(bb, D, desc, B)) return MOBOCMF_WORKSPACE_TOO_SMALL;
     const int Mp = D.Mp;
     const int64_t Np = D.Np, mm = (int64_t)Mp * Mp;
-    double *dU = B.W[0], *dLinv = B.W[1], *T1 = B.W[2], *T2 = B.W[3], *dL = B.W[4], *LT = B.W[5], *T4 = B.W[6],
-           *Gm = B.W[7];
+    double *H = B.W[0], *Hc = B.W[1], *G1 = B.W[2], *G2 = B.W[3], *X = B.W[4], *dU = B.W[5], *Y = B.W[6], *T1 = B.W[7],
+           *T2 = B.W[8], *LT = B.W[9];
+    double *dL = G1, *T4 = G2, *Gm = X;   // reused once their first content is dead
+    int32_t* nclamped = (int32_t*)B.flag;
+    const int64_t slab_elems = (int64_t)(D.splitk > 16 ? D.splitk : 16) * mm;
 
     TRY(launch_moments_bwd_prep(g_mean, g_var, S.knn, S.q, S.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
-                                B.gv2, B.cgv, s));
+                                B.gv2, B.cgv, nclamped, s));
     // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
     {
         GemmArgs ga = gemm_args(S.U, Mp, S.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
         ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = S.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = S.A;
         TRY(launch_gemm(ga, false, 1, s));
     }
-    // dU = tril(A diag(2 gv) C^T)      (split-K over N')
+    // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
+    //   dU = 2 tril(A diag(gv) C^T) = 2 tril(H U),   dA A^T = 2 U U^T H + a da^T - 2 Hc,  Hc = A diag(cgv) A^T.
+    // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
+    // (skip_if_zero) when no column is clamped.
     {
-        GemmArgs ga = gemm_args(S.A, Np, S.C, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
-        ga.bscale = B.gv2; ga.lower_out = 1; ga.slab_stride = mm;
+        GemmArgs ga = gemm_args(S.A, Np, S.A, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
+        ga.bscale = B.gv; ga.lower_out = 1; ga.slab_stride = mm;
         TRY(launch_gemm(ga, true, D.splitk, s));
-        TRY(launch_reduce_slabs(B.slabs, mm, D.splitk, dU, Mp, Mp, 1.0, 1, 0, s));
+        TRY(launch_reduce_slabs_sym(B.slabs, mm, D.splitk, H, Mp, nullptr, nullptr, s));
+        if (desc->branch == 0) {
+            ga.bscale = B.cgv; ga.skip_if_zero = nclamped;
+            TRY(launch_gemm(ga, true, D.splitk, s));
+            TRY(launch_reduce_slabs_sym(B.slabs, mm, D.splitk, Hc, Mp, nclamped, H, s));
+        } else {
+            Hc = H;
+        }
     }
     // da = A gmu
     TRY(launch_gemv_long(S.A, Np, B.gmu, B.da, Mp, Np, B.gpart, s));
@@ -294,13 +315,6 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     {
         GemmArgs ga = gemm_args(S.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
         TRY(launch_gemm(ga, false, 1, s));
-    }
-    // dLinv = tril(dA K^T)
-    {
-        GemmArgs ga = gemm_args(B.dA, Np, S.K, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
-        ga.lower_out = 1; ga.slab_stride = mm;
-        TRY(launch_gemm(ga, true, D.splitk, s));
-        TRY(launch_reduce_slabs(B.slabs, mm, D.splitk, dLinv, Mp, Mp, 1.0, 1, 0, s));
     }
     // Gram backward of K_mn and k_nn
     GramArgs g = {};
@@ -317,19 +331,23 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     if (desc->want_dx)
         TRY(launch_sum_partials(B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, g_x, D.nbase * desc->d, 1.0, 0, s));
 
-    // ---- M x M chain
-    const int64_t slab_elems = (int64_t)(D.splitk > 16 ? D.splitk : 16) * mm;
-    TRY(launch_add_kl_terms(dU, S.U, B.da, S.a, g_kl, Mp, s));
-    // dLinv += dU_tot L_S^T + da m^T  (then exact lower triangle)
+    // ---- M x M chain:  dL = -tril(L^-T [dA A^T + dU_tot U^T + da_tot a^T]) + gkl diag(1/L_ii)
     {
-        GemmArgs ga = gemm_args(dU, Mp, S.LSp, Mp, dLinv, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);
-        ga.lower_out = 1; ga.accumulate = 1;
-        TRY(launch_gemm_auto(ga, true, B.slabs, slab_elems, s));
+        GemmArgs g1 = gemm_args(S.UT, Mp, H, Mp, G1, Mp, Mp, Mp, Mp, TRI_UPPER_A, 1.0);          // G1 = U^T H
+        TRY(launch_gemm_auto(g1, false, B.slabs, slab_elems, s));
+        GemmArgs g2 = gemm_args(S.U, Mp, G1, Mp, G2, Mp, Mp, Mp, Mp, TRI_LOWER_A, 1.0);          // G2 = U U^T H
+        TRY(launch_gemm_auto(g2, false, B.slabs, slab_elems, s));
+        GemmArgs g3 = gemm_args(H, Mp, S.U, Mp, X, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);            // X = H U (lower tiles)
+        g3.lower_out = 1;
+        TRY(launch_gemm_auto(g3, false, B.slabs, slab_elems, s));
+        TRY(launch_dutot(X, S.U, B.da, S.a, g_kl, Mp, dU, B.da_tot, s));
+        TRY(launch_y_combine(G2, Hc, S.a, B.da, B.da_tot, Mp, Y, s));
+        GemmArgs g4 = gemm_args(dU, Mp, S.U, Mp, Y, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);   // Y += dU_tot U^T
+        g4.accumulate = 1;
+        TRY(launch_gemm_auto(g4, true, B.slabs, slab_elems, s));
     }
-    TRY(launch_rank1_add(dLinv, B.da, S.mp, Mp, s));
-    TRY(launch_tril_inplace(dLinv, Mp, Mp, s));
-    // g_m = L^-T da
-    TRY(launch_gemv_rows(S.LinvT, Mp, B.da, g_m, D.M, Mp, 1.0, 0, s));
+    // g_m = L^-T da_tot
+    TRY(launch_gemv_rows(S.LinvT, Mp, B.da_tot, g_m, D.M, Mp, 1.0, 0, s));
     // g_LS = tril(L^-T dU_tot) - gkl diag(1/LS_ii)
     {
         GemmArgs ga = gemm_args(S.LinvT, Mp, dU, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
@@ -337,13 +355,11 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
         TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
         TRY(launch_gls_out(T1, S.LSp, g_kl, D.M, Mp, g_LS, s));
     }
-    // dL = -tril(L^-T dLinv L^-T) + gkl diag(1/L_ii)
+    // dL
     {
-        GemmArgs ga = gemm_args(S.LinvT, Mp, dLinv, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        GemmArgs ga = gemm_args(S.LinvT, Mp, Y, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A, 1.0);
+        ga.lower_out = 1;
         TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
-        GemmArgs gb = gemm_args(T1, Mp, S.LinvT, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_B, 1.0);
-        gb.lower_out = 1;
-        TRY(launch_gemm_auto(gb, false, B.slabs, slab_elems, s));
         TRY(launch_dl_from_t2(T2, S.L, g_kl, D.M, Mp, dL, s));
     }
     // Cholesky backward: dKmm = sym(L^-T Phi(L^T dL) L^-1)

@@ -40,6 +40,7 @@ struct GemmArgs {
     int batched;
     // B_T=1: weights of the contraction index, sum_k A[i][k] bscale[k] B[j][k];  EPI_DA: column scale of the product
     const double* bscale;
+    const int32_t* skip_if_zero;   // device word: the whole launch is a no-op when it is 0 (rarely needed passes)
     // epilogues
     int epi;
     double* colsq_part;    // EPI_COLSTATS: [Mr/TILE][Nc] partial column sums of C^2

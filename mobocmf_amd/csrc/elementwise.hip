@@ -188,7 +188,7 @@ int launch_moments_finish(const double* qpart, const double* mupart, const doubl
 // backward prep: gmu (padded), gv = g_var * [varraw > min_var], gv2 = 2*gv, cgv = gv * [branch || knn - q > 0]
 __global__ void moments_bwd_prep_kernel(const double* g_mean, const double* g_var, const double* knn, const double* q,
                                         const double* varraw, int branch, double min_var, int64_t N, int64_t Np,
-                                        double* gmu, double* gv, double* gv2, double* cgv) {
+                                        double* gmu, double* gv, double* gv2, double* cgv, int32_t* nclamped) {
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= Np) return;
     double gm = 0.0, g = 0.0, c = 0.0;
@@ -196,6 +196,7 @@ __global__ void moments_bwd_prep_kernel(const double* g_mean, const double* g_va
         gm = g_mean ? g_mean[n] : 0.0;
         g = (g_var && varraw[n] > min_var) ? g_var[n] : 0.0;   // clamp_min passes gradient only above the floor
         c = (branch || knn[n] - q[n] > 0.0) ? g : 0.0;
+        if (c != g) atomicAdd(nclamped, 1);                      // columns where clamp(k_nn - q, 0) is active (rare)
     }
     gmu[n] = gm;
     gv[n] = g;
@@ -204,9 +205,64 @@ __global__ void moments_bwd_prep_kernel(const double* g_mean, const double* g_va
 }
 int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
                             const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
-                            double* gv, double* gv2, double* cgv, hipStream_t s) {
+                            double* gv, double* gv2, double* cgv, int32_t* nclamped, hipStream_t s) {
+    if (hipMemsetAsync(nclamped, 0, sizeof(int32_t), s) != hipSuccess) return MOBOCMF_HIP_ERROR;
     hipLaunchKernelGGL(moments_bwd_prep_kernel, GRID1(Np), 0, s, g_mean, g_var, knn, q, varraw, branch, min_var, N, Np,
-                       gmu, gv, gv2, cgv);
+                       gmu, gv, gv2, cgv, nclamped);
+    return CHECK_LAUNCH();
+}
+
+// H (full symmetric) from the slabs of a lower_out syrk: out[i][j] = sum_z slab[z][max-tile order].  If `flag` is
+// given and *flag == 0 the slabs were never written (kernel skipped): out = fallback instead.
+__global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride, int nslab, double* out, int Mp,
+                                        const int32_t* flag, const double* fallback) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    if (flag && *flag == 0) {
+        out[idx] = fallback[idx];
+        return;
+    }
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    const double* p = (j / TILE <= i / TILE) ? slabs + (int64_t)i * Mp + j : slabs + (int64_t)j * Mp + i;
+    double v = 0.0;
+    for (int z = 0; z < nslab; ++z) v += p[z * slab_stride];
+    out[idx] = v;
+}
+int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, double* out, int Mp, const int32_t* flag,
+                            const double* fallback, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_slabs_sym_kernel, GRID1((int64_t)Mp * Mp), 0, s, slabs, slab_stride, nslab, out, Mp, flag,
+                       fallback);
+    return CHECK_LAUNCH();
+}
+
+// dU_tot = 2 tril(X) + gkl U  (X = H U, lower tiles valid);  da_tot = da + gkl a
+__global__ void dutot_kernel(const double* X, const double* U, const double* da, const double* a, const double* gkl,
+                             int Mp, double* dU, double* da_tot) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double g = gkl ? gkl[0] : 0.0;
+    if (idx < (int64_t)Mp * Mp) {
+        int i = (int)(idx / Mp), j = (int)(idx % Mp);
+        dU[idx] = j <= i ? 2.0 * X[idx] + g * U[idx] : 0.0;
+    }
+    if (idx < Mp) da_tot[idx] = da[idx] + g * a[idx];
+}
+int launch_dutot(const double* X, const double* U, const double* da, const double* a, const double* gkl, int Mp,
+                 double* dU, double* da_tot, hipStream_t s) {
+    hipLaunchKernelGGL(dutot_kernel, GRID1((int64_t)Mp * Mp), 0, s, X, U, da, a, gkl, Mp, dU, da_tot);
+    return CHECK_LAUNCH();
+}
+
+// Y = 2 G2 - 2 Hc + a da^T + da_tot a^T
+__global__ void y_combine_kernel(const double* G2, const double* Hc, const double* a, const double* da,
+                                 const double* da_tot, int Mp, double* Y) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    Y[idx] = 2.0 * (G2[idx] - Hc[idx]) + a[i] * da[j] + da_tot[i] * a[j];
+}
+int launch_y_combine(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
+                     double* Y, hipStream_t s) {
+    hipLaunchKernelGGL(y_combine_kernel, GRID1((int64_t)Mp * Mp), 0, s, G2, Hc, a, da, da_tot, Mp, Y);
     return CHECK_LAUNCH();
 }
 

@@ -39,6 +39,7 @@ __device__ __forceinline__ void glds16(const double* gsrc, double* lds_wave_base
 template <bool B_T>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_ELEMS];   // [buf][A | B]
+    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     // ---- block id -> (tile, k-slice).  Blocks b, b+8, ... share an XCD (and its L2):
     //  * no split-K: the row blocks that re-read the same 128-column panel of B run back to back on one XCD;
     //  * split-K: all tiles of one k-slice (they share the slice's rows of A and B) run back to back on one XCD.

@@ -116,6 +116,48 @@ def test_clamp_branch_and_min_variance_gradients():
     _close(mg.grad, m.grad, 1e-6, "g_m")
 
 
+@pytest.mark.parametrize("kind", [0, 1])
+def test_clamped_columns_take_the_separate_syrk_path(kind):
+    """clamp(k_nn - q, 0) active in SOME columns (forced robustly with a negative jitter on a well-conditioned
+    K_mm: q > k_nn at the inducing rows): the backward must then use Hc = A diag(c gv) A^T != H."""
+    from mobocmf_amd import functional as F
+    d, M, nbase, jit = 2, 8, 40, -2e-3
+    x, f, Zx, zf, hyp, m, L_S = _mk(kind, d, M, nbase, 1, seed=21)
+    for k in ("ls", "ls1", "ls2"):
+        if k in hyp:
+            hyp[k] = hyp[k] * 0.0 + 0.15                      # short lengthscale: K_mm ~ diagonal, PD with jitter < 0
+    x = torch.cat([Zx, x[M:]], 0)                             # first M data rows sit on the inducing inputs
+    if kind == 1:
+        f = torch.cat([zf, f[M:]], 0)
+    rng = np.random.default_rng(5)
+    w = [torch.tensor(rng.standard_normal(nbase)), torch.tensor(rng.standard_normal(nbase)), torch.tensor(0.2)]
+    leaves = [m, L_S] + [hyp[k] for k in hyp] + ([f, zf] if kind == 1 else [])
+    for l in leaves:
+        l.requires_grad_(True)
+    Xt = x if kind == 0 else torch.cat([x, f[:, None]], 1)
+    Zt = Zx if kind == 0 else torch.cat([Zx, zf[:, None]], 1)
+    mean_o, var_o, _ = O.layer_moments(hyp, Xt, Zt, m, L_S, jitter=jit, training=True, shortcut=False)
+    kl_o = O.kl_layer(hyp, Zt, m, L_S, jitter=jit)
+    ((w[0] * mean_o).sum() + (w[1] * var_o).sum() + w[2] * kl_o).backward()
+    A = torch.linalg.solve_triangular(torch.linalg.cholesky(O.gram(hyp, Zt, Zt) + jit * torch.eye(M)), O.gram(hyp, Zt, Xt), upper=False)
+    nclamp = int(((O.gram_diag(hyp, Xt) - (A * A).sum(0)) <= 0).sum())
+    assert 0 < nclamp < nbase, nclamp
+    dev = torch.device("cuda")
+    gdev = lambda t, rg=True: None if t is None else t.detach().to(dev).requires_grad_(rg)
+    fg, zfg, mg, LSg = gdev(f), gdev(zf), gdev(m), gdev(L_S)
+    hg = _pack(kind, {k: v.detach() for k, v in hyp.items()}).to(dev).requires_grad_(True)
+    mean, var, kl = F.layer_forward(x.to(dev), fg, Zx.to(dev), zfg, hg, mg, LSg, kind, jitter=jit)
+    _close(mean, mean_o.detach(), 1e-9, "mean")
+    _close(var, var_o.detach(), 1e-8, "var")
+    ((w[0].to(dev) * mean).sum() + (w[1].to(dev) * var).sum() + w[2].to(dev) * kl).backward()
+    _close(mg.grad, m.grad, 1e-7, "g_m")
+    _close(LSg.grad, torch.tril(L_S.grad), 1e-7, "g_LS")
+    _close(hg.grad, _pack(kind, {k: v.grad for k, v in hyp.items()}), 1e-7, "g_hyp")
+    if kind == 1:
+        _close(fg.grad, f.grad, 1e-7, "g_f")
+        _close(zfg.grad, zf.grad, 1e-7, "g_zf")
+
+
 def test_not_pd_is_reported():
     from mobocmf_amd import functional as F
     dev = torch.device("cuda")
