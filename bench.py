@@ -38,6 +38,21 @@ def algorithmic_flops(cfg):
     return 3.0 * tot
 
 
+def build_graphed(cfg, outputs, device, use_graph):
+    """One GraphedELBOStep (HIP-graph replay of the whole step) per surrogate, each on its own stream."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.util.graphed_step import GraphedELBOStep
+    steps = []
+    for o in outputs:
+        prob = synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=cfg["M"], N=cfg["N"], S=cfg["S"], output=o % 3, seed=o)
+        model = synthetic.model_from_problem(prob, device=device)
+        elbo = VariationalELBOMF(model, cfg["N"], cfg["L"])
+        t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=device)
+        steps.append(GraphedELBOStep(model, elbo, t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], lr=1e-3,
+                                     use_graph=use_graph))
+    return steps
+
+
 def build_surrogates(cfg, outputs, device):
     from mobocmf_amd.mlls import VariationalELBOMF
     sur = []
@@ -179,6 +194,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="run the surrogates back to back on one stream")
+    ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying HIP graphs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -197,7 +213,16 @@ def main():
     cfg = dict(synthetic.CONFIGS[args.config])
     n_out = 3 if args.config == "C3" else min(cfg["outputs"], 3) if args.config != "C5" else 1
     outputs = list(range(rank * n_out, rank * n_out + n_out))
-    sur = build_surrogates(cfg, outputs, device)
+    torch.manual_seed(1234 + rank)
+    if not args.eager:
+        gsteps = build_graphed(cfg, outputs, device, use_graph=True)
+        sur = [(g.model, g.elbo, g.optimizer, (g.x, g.y, g.fid)) for g in gsteps]
+
+        def one_step(*_a):
+            return [g.step()[0] for g in gsteps]
+    else:
+        sur = build_surrogates(cfg, outputs, device)
+        one_step = globals()["one_step"]
     gens = []
     for i in range(len(sur)):
         gen = torch.Generator(device=device)
@@ -262,7 +287,7 @@ def main():
             "per_surrogate_steps_per_s": value / n_sur,
             "step_flops_algorithmic": algorithmic_flops(cfg),
             "step_fp64_frac": algorithmic_flops(cfg) * value / world / (FP64_PEAK_TFLOPS * 1e12),
-            "exchange_ms": exchange_ms, "finite": finite,
+            "exchange_ms": exchange_ms, "finite": finite, "step_issue": "eager" if args.eager else "hip-graph replay",
         }
         if not args.no_roofline:
             line["roofline"] = measure_dominant_kernel(cfg, device)

@@ -227,13 +227,13 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     g.K = S.L; g.ldk = Mp; g.Mp = Mp; g.Np = Mp; g.knn = nullptr; g.jitter = desc->jitter; g.is_kmm = 1;
     TRY(launch_gram_fwd(g, s));
     TRY(launch_potrf(S.L, Mp, Mp, F.Dinv, F.Ld, info, s));
-    HIP_TRY(hipMemsetAsync(S.Linv, 0, mm * sizeof(double), s));
+    TRY(launch_zero32(S.Linv, mm * 2, s));
     TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
     TRY(launch_transpose(S.Linv, Mp, S.LinvT, Mp, Mp, Mp, s));
     TRY(launch_pad_tril(L_S, D.M, D.M, S.LSp, Mp, s));
     TRY(launch_pad_vec(m, D.M, S.mp, Mp, s));
     // U = L^-1 L_S (lower x lower), a = L^-1 m
-    HIP_TRY(hipMemsetAsync(S.U, 0, mm * sizeof(double), s));
+    TRY(launch_zero32(S.U, mm * 2, s));
     {
         GemmArgs ga = gemm_args(S.Linv, Mp, S.LSp, Mp, S.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
         ga.lower_out = 1;

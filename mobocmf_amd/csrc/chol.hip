@@ -173,7 +173,7 @@ __global__ void finish_l_kernel(double* A, int64_t ld, int n, const double* Ld) 
 // Dinv and Ld: (Mp/64) x 64 x 64 doubles each
 int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, double* Ld, int32_t* info, hipStream_t s) {
     const int nblk = Mp / NB;
-    HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), s));
+    if (launch_zero32(info, 1, s)) return MOBOCMF_HIP_ERROR;
     for (int jb = 0; jb < nblk; ++jb) {
         hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk - jb), dim3(64), 0, s, A, ld, jb, Dinv, Ld, info);
         int nt = nblk - jb - 1;

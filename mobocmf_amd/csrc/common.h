@@ -57,6 +57,10 @@ int launch_gemm_auto(const GemmArgs& g, bool B_T, double* ws, int64_t ws_elems, 
 int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, double* out, int64_t ld, int Mr,
                         double scale, int lower_only, int accumulate, hipStream_t s);
 
+// zero-fill by a kernel (32-bit words); used instead of hipMemsetAsync so that a captured step contains only
+// kernel nodes (a replayed memset node was observed to leave 0xFE bytes in a 4-byte word on ROCm 7.2)
+int launch_zero32(void* ptr, int64_t nwords, hipStream_t s);
+
 // ------------------------------------------------------------------ Gram (gram.hip)
 struct GramArgs {
     int kind, d, xdiv, zdiv;

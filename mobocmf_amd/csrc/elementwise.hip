@@ -31,6 +31,16 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR)
 
+__global__ void zero32_kernel(uint32_t* p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+int launch_zero32(void* ptr, int64_t nwords, hipStream_t s) {
+    if (nwords <= 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(zero32_kernel, GRID1(nwords), 0, s, (uint32_t*)ptr, nwords);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ M x M helpers
 // dst (Mp x Mp) = tril(src (M x M, ld lds)) zero padded
 __global__ void pad_tril_kernel(const double* src, int64_t lds, int M, double* dst, int Mp) {
@@ -206,7 +216,7 @@ __global__ void moments_bwd_prep_kernel(const double* g_mean, const double* g_va
 int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
                             const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
                             double* gv, double* gv2, double* cgv, int32_t* nclamped, hipStream_t s) {
-    if (hipMemsetAsync(nclamped, 0, sizeof(int32_t), s) != hipSuccess) return MOBOCMF_HIP_ERROR;
+    if (launch_zero32(nclamped, 1, s)) return MOBOCMF_HIP_ERROR;
     hipLaunchKernelGGL(moments_bwd_prep_kernel, GRID1(Np), 0, s, g_mean, g_var, knn, q, varraw, branch, min_var, N, Np,
                        gmu, gv, gv2, cgv, nclamped);
     return CHECK_LAUNCH();

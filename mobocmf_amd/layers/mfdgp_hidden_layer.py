@@ -248,15 +248,24 @@ class MFDGPHiddenLayer(nn.Module):
         return out
 
     _info = None
+    _shortcut_last = False
 
     def _layer_call(self, x, f, xdiv=1, want_dx=False):
         vs = self.variational_strategy
         vd = vs._variational_distribution
         if self.training:
             vs._kl_cache = None
-        # GPyTorch shortcut: inputs identical to the inducing inputs -> q(u) itself
-        if xdiv == 1 and x.shape[0] == vs.Zx.shape[0] and torch.equal(x, vs.Zx) and \
-                (f is None or torch.equal(f, vs.zf)):
+        # GPyTorch shortcut: inputs identical to the inducing inputs -> q(u) itself.
+        # torch.equal synchronises, which a stream capture forbids: while capturing, the verdict of the last eager
+        # call (the warm-up pass on the same static inputs) is reused.
+        if xdiv != 1 or x.shape[0] != vs.Zx.shape[0]:
+            hit = False
+        elif x.is_cuda and torch.cuda.is_current_stream_capturing():
+            hit = self._shortcut_last
+        else:
+            hit = bool(torch.equal(x, vs.Zx) and (f is None or torch.equal(f, vs.zf)))
+            self._shortcut_last = hit
+        if hit:
             L = torch.tril(vd.chol_variational_covar)
             return vd.variational_mean, (L * L).sum(1).clamp_min(F.MIN_VARIANCE)
         mean, var, kl = self._moments(x, f, xdiv, want_dx)

@@ -130,6 +130,11 @@ class MFDGP(nn.Module):
             layer.eval_mode()
         self._eval_mode = True
 
+    def clear_kl_cache(self):
+        """Forget the KL memoised by the last forward (it keeps that iteration's autograd graph alive)."""
+        for layer in self._layers():
+            layer.variational_strategy._kl_cache = None
+
     def set_check_pd(self, value):
         """False: no host sync after the Cholesky on the training fast path (NaNs then surface in the loss)."""
         for layer in self._layers():
@@ -144,6 +149,8 @@ class MFDGP(nn.Module):
         eval_mode: the caller tiled the inputs (mfdgp.py:248), eps = the layer's fixed ``samples``.
         """
         num_layers = self.num_hidden_layers if max_fidelity is None else max_fidelity + 1
+        if self.training:
+            self.clear_kl_cache()      # drop the previous iteration's graph (and its AccumulateGrad nodes) up front
         S = 1 if self._eval_mode else self.num_samples_for_training
         if _xdiv is not None:
             S = _xdiv

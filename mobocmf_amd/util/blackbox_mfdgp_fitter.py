@@ -132,9 +132,44 @@ class BlackBoxMFDGPFitter:
             kl_iter += kl.detach()
         return loss_iter, kl_iter
 
-    def train_mfdgps(self):
-        self._train_mfdgp(self.update_model, fix_variational_hypers=True, num_epochs=self.num_epochs_1, lr=self.lr_1)
-        self._train_mfdgp(self.update_model, fix_variational_hypers=False, num_epochs=self.num_epochs_2, lr=self.lr_2)
+    def _train_mfdgp_graphed(self, fix_variational_hypers, num_epochs, lr):
+        """Full-batch fast path: every surrogate's ELBO step is captured into a HIP graph (mobocmf_amd.util.graphed_step)
+        and the independent surrogates advance in lockstep on separate streams (the reference loops over them one
+        after the other, :134-152; they share nothing, so the result only differs in which N(0,1) draws each gets)."""
+        from .graphed_step import GraphedELBOStep
+        steps = []
+        for tag, n, h in self._handlers():
+            h.mfdgp.fix_variational_hypers(fix_variational_hypers)
+            x, y, fid = h.train_dataset.tensors
+            steps.append((tag, n, GraphedELBOStep(h.mfdgp, h.elbo, x, y, fid, lr=lr)))
+        for i in range(num_epochs):
+            for _, _, g in steps:
+                g.step()
+            if (i % ITER_PRINT) == 0 or (i + 1) == num_epochs:
+                for tag, n, g in steps:
+                    g.check()
+                    if self.verbose:
+                        print("[%s: " % tag, n, "] Epoch:", i, "/", num_epochs, ". Avg. Neg. ELBO per epoch:",
+                              g.loss.item(), "\t KL per epoch:", g.kl.item())
+                        sys.stdout.flush()
+        for _, _, g in steps:
+            g.stream.synchronize()
+            g.model.set_check_pd(True)
+
+    def train_mfdgps(self, use_graphs=None):
+        """2-phase Adam schedule of the reference (:175-176).  ``use_graphs`` (default: automatically when every
+        handler trains on the full batch, as all the reference's examples do) selects the HIP-graph fast path."""
+        full_batch = all(h.batch_size >= h.num_data for _, _, h in self._handlers())
+        if use_graphs is None:
+            use_graphs = full_batch and str(self.device).startswith("cuda")
+        if use_graphs and not full_batch:
+            raise ValueError("the graphed step needs batch_size >= number of training points")
+        if use_graphs:
+            self._train_mfdgp_graphed(True, self.num_epochs_1, self.lr_1)
+            self._train_mfdgp_graphed(False, self.num_epochs_2, self.lr_2)
+        else:
+            self._train_mfdgp(self.update_model, fix_variational_hypers=True, num_epochs=self.num_epochs_1, lr=self.lr_1)
+            self._train_mfdgp(self.update_model, fix_variational_hypers=False, num_epochs=self.num_epochs_2, lr=self.lr_2)
         self.models_uncond_trained = True
 
     def copy_uncond(self):

@@ -1,0 +1,87 @@
+"""The ELBO step (zero_grad + MFDGP.forward + VariationalELBOMF + backward + Adam, blackbox_mfdgp_fitter.py:161-171)
+captured once into a HIP graph and replayed.
+
+A step of one surrogate is ~300 small launches (M x M Cholesky chain, partial reductions, elementwise glue) around a
+dozen large GEMMs; issued eagerly from Python that costs ~2 ms of host time per step -- more than the GPU needs for
+the small configurations (C1, C2) and half of what it needs at C3.  All library calls only enqueue work on the
+caller's stream and use caller-owned memory, so the whole step is capturable; a replay costs tens of microseconds.
+Fresh eps is drawn inside the graph (torch's captured Philox state advances on every replay).
+"""
+import torch
+
+
+class GraphedELBOStep:
+    """step() == one full-batch ELBO step on static (x, y, fidelities).  Falls back to eager with ``use_graph=False``."""
+
+    def __init__(self, model, elbo, x, y, fidelities, lr, betas=(0.9, 0.999), eps=1e-8, use_graph=True, stream=None,
+                 warmup=3, fixed_eps=None):
+        self.model, self.elbo = model, elbo
+        self.x, self.y, self.fid = x, y, fidelities
+        self.use_graph = use_graph
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=x.device)
+        self.S = model.num_samples_for_training
+        self.L = model.num_hidden_layers
+        params = [p for p in model.parameters()]
+        self.optimizer = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, capturable=True)   # same arithmetic with and without capture
+        self.loss = torch.zeros((), dtype=torch.float64, device=x.device)
+        self.kl = torch.zeros((), dtype=torch.float64, device=x.device)
+        self.graph = None
+        self.fixed_eps = fixed_eps     # list (eps[l] for layer l >= 1) reused every step: deterministic tests
+        model.set_check_pd(False)      # no host sync inside the step; call check() when a verdict is needed
+        model.clear_kl_cache()         # an older graph would pin AccumulateGrad nodes to another stream (capture-illegal)
+        if use_graph:
+            self._capture(warmup)
+
+    def _eager(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        n = self.x.shape[0] * self.S
+        eps = self.fixed_eps if self.fixed_eps is not None else \
+            [None] + [torch.randn(n, dtype=torch.float64, device=self.x.device) for _ in range(1, self.L)]
+        out = self.model(self.x, eps=eps)
+        res = self.elbo(out, self.y.T, self.fid)
+        (-res[0]).backward()
+        self.optimizer.step()
+        self.loss.copy_(-res[0].detach())
+        self.kl.copy_(res[1].detach())
+        self.model.clear_kl_cache()
+
+    def _capture(self, warmup):
+        cur = torch.cuda.current_stream(self.x.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            # the side-stream warm-up also sizes the per-stream scratch arena and the optimizer state
+            snapshot = [p.detach().clone() for p in self.model.parameters()]
+            for _ in range(warmup):
+                self._eager()
+            with torch.no_grad():           # warm-up steps must not count as training
+                for p, s0 in zip(self.model.parameters(), snapshot):
+                    p.copy_(s0)
+                for st in self.optimizer.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            self.optimizer.zero_grad(set_to_none=True)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self._eager()
+        cur.wait_stream(self.stream)
+
+    def step(self):
+        """Enqueues one step on ``self.stream``; ``self.loss`` / ``self.kl`` hold the step's -ELBO and scaled KL."""
+        with torch.cuda.stream(self.stream):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._eager()
+        return self.loss, self.kl
+
+    def check(self):
+        """Synchronising: raises if a Cholesky of the last step failed or the loss is not finite."""
+        from .. import functional as F
+        from ..layers.mfdgp_hidden_layer import NotPSDError
+        self.stream.synchronize()
+        for layer in self.model._layers():
+            if layer._info is not None and F.check_info(layer._info) != 0:
+                raise NotPSDError("K_mm not positive definite in layer %d" % layer.num_layer)
+        if not bool(torch.isfinite(self.loss)):
+            raise FloatingPointError("non-finite ELBO")

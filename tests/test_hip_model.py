@@ -250,6 +250,29 @@ def test_shortcut_and_reference_tiled_eval_path():
     assert rel(mus, mus2) < 1e-10 and rel(vs, vs2) < 1e-9
 
 
+def test_graphed_step_equals_eager_step():
+    """HIP-graph replay of the whole ELBO step == the eager step (same fixed eps): identical trajectories."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.util.graphed_step import GraphedELBOStep
+    prob = synthetic.make_problem(d=3, L=2, M=20, N=60, S=2, seed=9)
+    t = lambda a: to_t(a).to(DEV)
+    losses = []
+    for use_graph in (False, True):
+        model = build_model(prob, S_train=2)
+        elbo = VariationalELBOMF(model, 60, 2)
+        g = GraphedELBOStep(model, elbo, t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], lr=1e-2,
+                            use_graph=use_graph, fixed_eps=[None, t(prob["eps"][1])])
+        ls = []
+        for _ in range(6):
+            l, _ = g.step()
+            g.stream.synchronize()
+            ls.append(float(l))
+        g.check()
+        losses.append(ls)
+    assert losses[0] == losses[1]
+    assert losses[0][-1] < losses[0][0]
+
+
 def test_fitter_trains_forrester():
     """The reference's example flow (examples/example_acquisition_mfdgp_forrester/...py:106-114) with short
     schedules: the negative ELBO must decrease and the high-fidelity fit must interpolate the data."""
@@ -261,8 +284,11 @@ def test_fitter_trains_forrester():
     h = fitter.mfdgp_handlers_objs["obj1"]
     xb, yb, fb = h.train_dataset.tensors
     e0 = h.elbo(h.mfdgp(xb), yb.T, fb)[0].item()
-    fitter.train_mfdgps()
+    fitter.train_mfdgps()                      # full batch -> HIP-graph fast path
     e1 = h.elbo(h.mfdgp(xb), yb.T, fb)[0].item()
     assert e1 > e0
+    fitter.num_epochs_1 = fitter.num_epochs_2 = 20
+    fitter.train_mfdgps(use_graphs=False)      # the reference's eager DataLoader loop still works
+    assert h.elbo(h.mfdgp(xb), yb.T, fb)[0].item() > e0
     fc = fitter.copy_uncond()
     assert fc.mfdgp_handlers_objs["obj1"].mfdgp is not h.mfdgp
