@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="run the surrogates back to back on one stream")
+    ap.add_argument("--surrogates", type=int, default=0, help="surrogates per GPU (default: the config's 3)")
     ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying HIP graphs")
     args = ap.parse_args()
 
@@ -212,6 +213,8 @@ def main():
 
     cfg = dict(synthetic.CONFIGS[args.config])
     n_out = 3 if args.config == "C3" else min(cfg["outputs"], 3) if args.config != "C5" else 1
+    if args.surrogates:
+        n_out = args.surrogates
     outputs = list(range(rank * n_out, rank * n_out + n_out))
     torch.manual_seed(1234 + rank)
     if not args.eager:

@@ -87,7 +87,7 @@ Dims dims_of(const mobocmf_layer_desc* d) {
     D.H = hyp_len(d->kind, d->d);
     int ntl = D.nrb * (D.nrb + 1) / 2;
     int64_t ksteps = D.Np / 16;
-    int sk = (1024 + ntl - 1) / ntl;
+    int sk = 512 / ntl;   // one round of <= 512 resident workgroups (2 per CU): fewer, longer slices = fewer slabs to add
     if (sk > ksteps / 8) sk = (int)(ksteps / 8);
     if (sk > 128) sk = 128;
     if (sk >= 8) sk &= ~7;

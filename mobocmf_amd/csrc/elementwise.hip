@@ -226,17 +226,20 @@ int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const dou
 // given and *flag == 0 the slabs were never written (kernel skipped): out = fallback instead.
 __global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride, int nslab, double* out, int Mp,
                                         const int32_t* flag, const double* fallback) {
+    // one thread per element of the LOWER tiles (coalesced slab reads); it also writes the mirrored element
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Mp * Mp) return;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
     if (flag && *flag == 0) {
         out[idx] = fallback[idx];
         return;
     }
-    int i = (int)(idx / Mp), j = (int)(idx % Mp);
-    const double* p = (j / TILE <= i / TILE) ? slabs + (int64_t)i * Mp + j : slabs + (int64_t)j * Mp + i;
+    if (j / TILE > i / TILE) return;
+    const double* p = slabs + (int64_t)i * Mp + j;
     double v = 0.0;
     for (int z = 0; z < nslab; ++z) v += p[z * slab_stride];
     out[idx] = v;
+    if (j / TILE < i / TILE) out[(int64_t)j * Mp + i] = v;     // strictly-upper tiles mirror the lower ones
 }
 int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, double* out, int Mp, const int32_t* flag,
                             const double* fallback, hipStream_t s) {

@@ -175,7 +175,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 
     const int64_t nk = (k1 > k0) ? (k1 - k0) / BK : 0;
     if (nk > 0) stage(Ag, k0, 0);
-    __syncthreads();   // (emits s_waitcnt vmcnt(0): the DMA of stage 0 has landed for every wavefront)
+    // LDS-DMA data is ordered for other wavefronts' ds_reads only by the issuing wavefront's vmcnt wait followed by
+    // a barrier; the waits are written out (hipcc adds them only when it sees the DMA in the same scheduling scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     v4f64 w_nxt = (v4f64){1.0, 1.0, 1.0, 1.0};
     if (B_T && g.bscale && nk > 0) w_nxt = *(const v4f64*)(g.bscale + k0 + 4 * lk);
     for (int64_t kt = 0; kt < nk; ++kt) {
@@ -188,6 +191,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }
         const double* As = lds + buf * 2 * TILE_ELEMS;
         const double* Bs = As + TILE_ELEMS;
+        // 16-row groups of a triangular A that are structurally zero for this K step (inside the diagonal block) are
+        // skipped: bit mt of `act` = group mt of this wavefront has a non-zero entry in k in [kk, kk+16)
+        int act = 15;
+        if (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) {
+            const int64_t kk = k0 + kt * BK;
+            const int64_t r0 = (int64_t)rb * BM + wr * 64;
+            act = 0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bool nz = (g.tri & TRI_LOWER_A) ? (kk <= r0 + mt * 16 + 15) : (kk + 15 >= r0 + mt * 16);
+                act |= nz ? (1 << mt) : 0;
+            }
+            act = __builtin_amdgcn_readfirstlane(act);
+        }
         // Software pipeline over 8 groups g = (kpair p, row tile mt): the A fragments of group g+1 (4 x ds_read_b128)
         // and, at a kpair boundary, the B fragments of the next kpair are read while the 32 MFMAs of group g issue.
         // sched_barrier(0) pins the group boundaries so the register allocator sees two fragment sets, not eight.
@@ -216,10 +233,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
                 dst[e][t] = Bs[bn_base + (2 * (P) + e) * BN + ((t ^ (lk & 1)) << 4)];                       \
     }
 #define MMA(asrc, bsrc, MT)                                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                          \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
-                acc[MT][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(asrc[r][e], bsrc[e][j], acc[MT][j][r], 0, 0, 0); \
+    if (act & (1 << (MT))) {                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+                    acc[MT][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(asrc[r][e], bsrc[e][j], acc[MT][j][r], 0, 0, 0); \
+    }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);
         LOAD_B(b0, 0)
         LOAD_A(a0, 0, 0)
@@ -234,7 +253,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #undef LOAD_A
 #undef LOAD_B
 #undef MMA
-        __syncthreads();   // all reads of buf done + DMA into buf^1 landed (vmcnt(0) before the barrier)
+        // all LDS reads of buf returned (lgkmcnt) and this wavefront's DMA into buf^1 landed (vmcnt) before the barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 
     // ------------------------------------------------------------------ epilogue
