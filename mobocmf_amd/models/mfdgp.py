@@ -90,8 +90,14 @@ class MFDGP(nn.Module):
         if type_lengthscale == TL.ONES:
             return torch.ones(self.input_dims)
         if type_lengthscale == TL.MEDIAN:
+            n = inputs.shape[0]
+            if n > 20000:
+                raise ValueError("TL.MEDIAN needs the full n x n distance matrix; pass type_lengthscale=TL.ONES (or "
+                                 "set the lengthscales explicitly) for n > 20000")
             dists = compute_dist(inputs)
-            if self.median_mode == "reference":       # as written at mfdgp.py:143-144 (row-indexing quirk)
+            # as written at mfdgp.py:143-144 the 2 x K index tensor selects ROWS: (2, K, n) elements, i.e.
+            # O(n^3) memory -- reproduced only while that fits in ~1 GiB, otherwise the intended upper-triangle median
+            if self.median_mode == "reference" and n * (n - 1) * n * 8 < 2 ** 30:
                 return torch.sqrt(torch.median(dists[triu_indices(inputs.shape[0], 1)]))
             rows, cols = torch.triu_indices(inputs.shape[0], inputs.shape[0], offset=1)
             return torch.sqrt(torch.median(dists[rows, cols]))
