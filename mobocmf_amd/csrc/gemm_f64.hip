@@ -340,7 +340,9 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
         grid = dim3((unsigned)(ntile * splitk), 1, 1);
     } else {
-        pair = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !g.lower_out && nrb > 1) ? 1 : 0;
+        // pairing balances the work per workgroup; it only pays when there are more tiles than resident workgroup
+        // slots (2 per CU), otherwise the longest single tile is the critical path and pairing lengthens it
+        pair = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !g.lower_out && nrb > 1 && (int64_t)nrb * ncb > 512) ? 1 : 0;
         grid = dim3((unsigned)((pair ? (nrb + 1) / 2 : nrb) * ncb), 1, 1);
         splitk = 1;
     }

@@ -14,7 +14,11 @@
 #define GM 32    // inducing rows per block
 
 
-template <int KIND, int DB>
+// XD > 0: compile-time xdiv (the S sample replicas of a row): f values live in registers, the replica loop is
+// unrolled and K is written with 16-byte stores.  XD == 0: run-time xdiv.
+typedef double v2f64_t __attribute__((ext_vector_type(2)));
+
+template <int KIND, int DB, int XD>
 __global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
     __shared__ double zs[GM][DB];
     __shared__ double zfs[GM];
@@ -40,13 +44,22 @@ __global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
     __syncthreads();
 
     const int64_t n0 = (int64_t)blockIdx.x * GT + tid;
-    const int xdiv = g.xdiv;
+    const int xdiv = XD ? XD : g.xdiv;
     const int64_t c0 = n0 * xdiv;
     if (c0 >= g.Np) return;
     const bool real = n0 < g.nbase;
     double xr[DB];
 #pragma unroll
     for (int k = 0; k < DB; ++k) xr[k] = (real && k < d) ? g.x[n0 * d + k] : 0.0;
+    double fr[XD ? XD : 1];
+    if (XD && KIND == 1) {
+#pragma unroll
+        for (int s = 0; s < XD; s += 2) {
+            v2f64_t v = real ? *(const v2f64_t*)(g.f + c0 + s) : (v2f64_t){0.0, 0.0};
+            fr[s] = v[0];
+            fr[s + 1] = v[1];
+        }
+    }
 
     if (g.knn && blockIdx.y == 0) {
         for (int s = 0; s < xdiv; ++s) {
@@ -87,6 +100,21 @@ __global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
             if (g.is_kmm && c0 == m) v += g.jitter;
             krow[c0] = v;   // kind 0 layers always have xdiv == 1 for Kmm; general loop below for replicas
             for (int s = 1; s < xdiv; ++s) krow[c0 + s] = a1 * E1;
+        } else if (XD) {
+            const double E2 = exp(-0.5 * d2);
+            const double zfm = zfs[mm];
+            const double c1 = a1 * E1, c2 = a2 * E2;
+#pragma unroll
+            for (int s = 0; s < XD; s += 2) {
+                v2f64_t v;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double fn = fr[s + e];
+                    const double fd = (fn - zfm) * ilf;
+                    v[e] = c1 * (nu * fn * zfm + af * exp(-0.5 * fd * fd)) + c2;
+                }
+                *(v2f64_t*)(krow + c0 + s) = v;
+            }
         } else {
             const double E2 = exp(-0.5 * d2);
             const double zfm = zfs[mm];
@@ -116,7 +144,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Backward: consumes G = dL/dK (and gknn) and produces per-block partial sums (deterministic two-stage
 // reduction, no float atomics across workgroups).
-template <int KIND, int DB, bool WANT_DX>
+template <int KIND, int DB, bool WANT_DX, int XD>
 __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
     __shared__ double zs[GM][DB];
     __shared__ double zfs[GM];
@@ -148,9 +176,19 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
     __syncthreads();
 
     const int64_t n0 = (int64_t)blockIdx.x * GT + tid;
-    const int xdiv = g.xdiv;
+    const int xdiv = XD ? XD : g.xdiv;
     const int64_t c0 = n0 * xdiv;
     const bool real = n0 < g.nbase;
+    double fr[XD ? XD : 1], dfa[XD ? XD : 1];   // XD > 0: f and the df accumulators live in registers
+    if (XD) {
+#pragma unroll
+        for (int s = 0; s < XD; s += 2) {
+            v2f64_t v = real ? *(const v2f64_t*)(g.f + c0 + s) : (v2f64_t){0.0, 0.0};
+            fr[s] = v[0];
+            fr[s + 1] = v[1];
+            dfa[s] = dfa[s + 1] = 0.0;
+        }
+    }
     double xr[DB], aL1[DB], aL2[KIND == 1 ? DB : 1], aX[WANT_DX ? DB : 1];
 #pragma unroll
     for (int k = 0; k < DB; ++k) {
@@ -160,7 +198,7 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
         if (WANT_DX) aX[k] = 0.0;
     }
     double s_a1 = 0, s_af = 0, s_nu = 0, s_a2 = 0, s_lsf = 0;
-    if (KIND == 1)
+    if (KIND == 1 && !XD)
         for (int s = 0; s < xdiv; ++s) dfs[s * GT + tid] = 0.0;
 
     // diagonal k_nn terms (once per column)
@@ -207,10 +245,7 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
                 const double E2 = exp(-0.5 * d2);
                 const double zfm = zfs[mm];
                 double G2s = 0.0;
-                for (int s = 0; s < xdiv; ++s) {
-                    const int64_t n = c0 + s;
-                    const double Gv = grow[n];
-                    const double fn = g.f[n];
+                auto body = [&](double Gv, double fn, double& dfacc) {
                     const double fd = (fn - zfm) * ilf;
                     const double Ef = exp(-0.5 * fd * fd);
                     const double inner = nu * fn * zfm + af * Ef;
@@ -222,9 +257,22 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
                     W1 += GE1 * a1 * inner;
                     G2s += Gv;
                     const double t = GE1 * a1 * af * Ef * fd * ilf;   // G a1 E1 af Ef (fn - zf)/lsf^2
-                    const double dfn = GE1 * a1 * nu * zfm - t;
                     dzf_loc += GE1 * a1 * nu * fn + t;
-                    dfs[s * GT + tid] += dfn;   // per-column f gradient over this block's rows
+                    dfacc += GE1 * a1 * nu * zfm - t;                 // per-column f gradient over this block's rows
+                };
+                if (XD) {
+#pragma unroll
+                    for (int s = 0; s < XD; s += 2) {
+                        const v2f64_t Gp = *(const v2f64_t*)(grow + c0 + s);
+                        body(Gp[0], fr[s], dfa[s]);
+                        body(Gp[1], fr[s + 1], dfa[s + 1]);
+                    }
+                } else {
+                    for (int s = 0; s < xdiv; ++s) {
+                        double acc = 0.0;
+                        body(grow[c0 + s], g.f[c0 + s], acc);
+                        dfs[s * GT + tid] += acc;
+                    }
                 }
                 s_a2 += G2s * E2;
                 W2 = G2s * a2 * E2;
@@ -255,7 +303,7 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
         for (int s = 0; s < xdiv; ++s) {
             const int64_t n = c0 + s;
             if (n >= g.Np) break;
-            double v = real ? dfs[s * GT + tid] : 0.0;
+            double v = real ? (XD ? dfa[XD ? s : 0] : dfs[s * GT + tid]) : 0.0;
             if (real && g.gknn && blockIdx.y == 0) v += g.gknn[n] * a1 * 2.0 * nu * g.f[n];
             g.df_part[(int64_t)blockIdx.y * g.Np + n] = v;
         }
@@ -357,9 +405,13 @@ int launch_gram_fwd(const GramArgs& g, hipStream_t s) {
     dim3 grid;
     gram_grid(g, &grid);
     const int db = d_bucket(g.d);
-#define GF(K, D) hipLaunchKernelGGL((gram_fwd_kernel<K, D>), grid, dim3(GT), 0, s, g)
-    if (g.kind == 0) { if (db == 2) GF(0, 2); else if (db == 8) GF(0, 8); else GF(0, 32); }
-    else { if (db == 2) GF(1, 2); else if (db == 8) GF(1, 8); else GF(1, 32); }
+#define GF(K, D, X) hipLaunchKernelGGL((gram_fwd_kernel<K, D, X>), grid, dim3(GT), 0, s, g)
+    // fast replica paths (f in registers, 16-byte stores) for the usual S = 8 / 16 of layers >= 1
+    const bool vec_ok = g.kind == 1 && !g.is_kmm && ((uintptr_t)g.f % 16 == 0) && ((uintptr_t)g.K % 16 == 0) && (g.ldk % 2 == 0);
+    if (g.kind == 0) { if (db == 2) GF(0, 2, 0); else if (db == 8) GF(0, 8, 0); else GF(0, 32, 0); }
+    else if (vec_ok && g.xdiv == 8) { if (db == 2) GF(1, 2, 8); else if (db == 8) GF(1, 8, 8); else GF(1, 32, 8); }
+    else if (vec_ok && g.xdiv == 16) { if (db == 2) GF(1, 2, 16); else if (db == 8) GF(1, 8, 16); else GF(1, 32, 16); }
+    else { if (db == 2) GF(1, 2, 0); else if (db == 8) GF(1, 8, 0); else GF(1, 32, 0); }
 #undef GF
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
@@ -371,13 +423,16 @@ int launch_gram_bwd(const GramArgs& g, bool want_dx, hipStream_t s) {
     const int db = d_bucket(g.d);
     if (g.xdiv > 48) return MOBOCMF_BAD_ARG;
     const size_t shm = g.kind == 1 ? (size_t)g.xdiv * GT * sizeof(double) : 0;
-#define GB(K, D)                                                                                    \
-    do {                                                                                            \
-        if (want_dx) hipLaunchKernelGGL((gram_bwd_kernel<K, D, true>), grid, dim3(GT), shm, s, g);   \
-        else hipLaunchKernelGGL((gram_bwd_kernel<K, D, false>), grid, dim3(GT), shm, s, g);          \
+#define GB(K, D, X)                                                                                    \
+    do {                                                                                               \
+        if (want_dx) hipLaunchKernelGGL((gram_bwd_kernel<K, D, true, X>), grid, dim3(GT), (X) ? 0 : shm, s, g);   \
+        else hipLaunchKernelGGL((gram_bwd_kernel<K, D, false, X>), grid, dim3(GT), (X) ? 0 : shm, s, g);          \
     } while (0)
-    if (g.kind == 0) { if (db == 2) GB(0, 2); else if (db == 8) GB(0, 8); else GB(0, 32); }
-    else { if (db == 2) GB(1, 2); else if (db == 8) GB(1, 8); else GB(1, 32); }
+    const bool vec_ok = g.kind == 1 && ((uintptr_t)g.f % 16 == 0) && ((uintptr_t)g.G % 16 == 0) && (g.ldk % 2 == 0);
+    if (g.kind == 0) { if (db == 2) GB(0, 2, 0); else if (db == 8) GB(0, 8, 0); else GB(0, 32, 0); }
+    else if (vec_ok && g.xdiv == 8) { if (db == 2) GB(1, 2, 8); else if (db == 8) GB(1, 8, 8); else GB(1, 32, 8); }
+    else if (vec_ok && g.xdiv == 16) { if (db == 2) GB(1, 2, 16); else if (db == 8) GB(1, 8, 16); else GB(1, 32, 16); }
+    else { if (db == 2) GB(1, 2, 0); else if (db == 8) GB(1, 8, 0); else GB(1, 32, 0); }
 #undef GB
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
