@@ -1,0 +1,135 @@
+"""JES acquisition on MFDGP surrogates -- host mirror of mobocmf/acquisition_functions/JESMOC_MFDGP.py
+(``_JES_MFDGP.forward`` :38-52, ``JESMOC_MFDGP`` :55-184).
+
+The per-black-box value 0.5 * clamp(log v_uncond - log v_cond, 0) runs on the HIP path (predict_for_acquisition of
+both models + functional.jes) and is differentiable w.r.t. X.  botorch's ``optimize_acqf`` (absent here, SURVEY row
+N3) is replaced by ``optimize_acqf_multistart``: the same recipe -- ``raw_samples`` uniform candidates, the best
+``num_restarts`` refined by projected gradient ascent (Adam) for ``maxiter`` steps, ALL restarts in one batch so every
+iteration is a single pair of model evaluations.  With surrogates sharded over ranks the coupled acquisition is the
+all-gather + sum of mobocmf_amd.parallel.coupled_acquisition.
+"""
+import torch
+
+from .. import functional as F
+from .. import parallel
+
+
+class _JES_MFDGP:
+
+    def __init__(self, fidelity, mfdgp_uncond, mfdgp_cond, model=None):
+        assert model is None
+        self.fidelity = fidelity
+        self.mfdgp_uncond = mfdgp_uncond
+        self.mfdgp_cond = mfdgp_cond
+
+    def forward(self, X):
+        """Evaluate JES at X (T, d) or (T, 1, d).  Both models are switched to ``.eval()`` (full predictive branch,
+        no clamp) exactly as the reference does (:42-50)."""
+        self.mfdgp_uncond.eval()
+        _, v_u = self.mfdgp_uncond.predict_for_acquisition(X, self.fidelity)
+        self.mfdgp_uncond.train()
+        self.mfdgp_cond.eval()
+        _, v_c = self.mfdgp_cond.predict_for_acquisition(X, self.fidelity)
+        self.mfdgp_cond.train()
+        return F.jes(v_u, v_c)
+
+    __call__ = forward
+
+
+def optimize_acqf_multistart(acq_function, bounds, num_restarts=5, raw_samples=200, maxiter=200, lr=0.02,
+                             generator=None):
+    """Maximise ``acq_function`` over the box ``bounds`` (2, d).  Returns (candidate (1, d), value)."""
+    lo, hi = bounds[0], bounds[1]
+    d = lo.numel()
+    dev, dt = lo.device, lo.dtype
+    with torch.no_grad():
+        Xraw = lo + (hi - lo) * torch.rand(raw_samples, d, dtype=dt, device=dev, generator=generator)
+        vals = acq_function(Xraw)
+        X = Xraw[torch.topk(vals, min(num_restarts, raw_samples)).indices].clone()
+    X.requires_grad_(True)
+    opt = torch.optim.Adam([X], lr=lr * float((hi - lo).mean()))
+    best_x, best_v = X.detach().clone(), acq_function(X.detach())
+    for _ in range(maxiter):
+        opt.zero_grad()
+        v = acq_function(X)
+        (-v.sum()).backward()
+        opt.step()
+        with torch.no_grad():
+            X.clamp_(min=lo, max=hi)
+            v = acq_function(X)
+            better = v > best_v
+            best_v = torch.where(better, v, best_v)
+            best_x[better] = X[better]
+    k = int(torch.argmax(best_v))
+    return best_x[k:k + 1].detach(), best_v[k].detach()
+
+
+class JESMOC_MFDGP:
+
+    def __init__(self, model, num_fidelities=1, model_cond=None, standard_bounds=None, eval_highest_fidelity=False):
+        self.standard_bounds = standard_bounds
+        self.eval_highest_fidelity = eval_highest_fidelity
+        self.blackbox_mfdgp_fitter_uncond = model.copy_uncond()
+        if model_cond is None:
+            # reference: sample a Pareto solution (RFF + MOOP) unless one was provided
+            if getattr(model, "pareto_set", None) is None:
+                raise NotImplementedError("provide the Pareto solution with fitter.set_pareto_solution(...) "
+                                          "(RFF posterior sampling + MOOP is SURVEY row N2, not built)")
+            self.pareto_set, self.pareto_front = model.pareto_set, model.pareto_front
+            model.train_conditioned_mfdgps()
+            self.blackbox_mfdgp_fitter_cond = model
+        else:
+            self.pareto_set, self.pareto_front = model_cond.pareto_set, model_cond.pareto_front
+            self.blackbox_mfdgp_fitter_cond = model_cond
+        self.num_fidelities = num_fidelities
+        self.objectives, self.constraints, self.costs_blackboxes = {}, {}, {}
+        for n_f in range(num_fidelities):
+            self.objectives[n_f] = {}
+            self.constraints[n_f] = {}
+            self.costs_blackboxes[n_f] = {"total": 0.0}
+
+    def add_blackbox(self, fidelity, blackbox_name, cost_evaluation=1.0, is_constraint=False):
+        mfdgp_uncond = self.blackbox_mfdgp_fitter_uncond.get_model(blackbox_name, is_constraint=is_constraint)
+        mfdgp_cond = self.blackbox_mfdgp_fitter_cond.get_model(blackbox_name, is_constraint=is_constraint)
+        jes_mfdgp = _JES_MFDGP(fidelity, mfdgp_uncond, mfdgp_cond)
+        (self.constraints if is_constraint else self.objectives)[fidelity][blackbox_name] = jes_mfdgp
+        self.costs_blackboxes[fidelity]["total"] += cost_evaluation
+        self.costs_blackboxes[fidelity][blackbox_name] = cost_evaluation
+        return jes_mfdgp
+
+    def decoupled_acq(self, X, fidelity, blackbox_name, is_constraint=True):
+        d = self.constraints if is_constraint else self.objectives
+        return d[fidelity][blackbox_name](X.double())
+
+    def coupled_acq(self, X, fidelity):
+        """Sum over all black-boxes (:125-135).  Sharded surrogates: each rank adds its own, one all-gather sums."""
+        X = X.double()
+        local = [obj(X) for obj in self.objectives[fidelity].values()] + \
+                [con(X) for con in self.constraints[fidelity].values()]
+        if not local:
+            local = [torch.zeros(X.shape[0], dtype=X.dtype, device=X.device)]
+        acq = torch.stack(local).sum(0)
+        _, w = parallel.world()
+        if w > 1:
+            acq = acq + (parallel.coupled_acquisition(acq.detach()[None]) - acq.detach())
+        return acq
+
+    def _optimize(self, fidelity, **kw):
+        return optimize_acqf_multistart(lambda x: self.coupled_acq(x, fidelity=fidelity), self.standard_bounds,
+                                        num_restarts=5, raw_samples=200, maxiter=kw.get("maxiter", 200))
+
+    def get_nextpoint_coupled(self, iteration=None, verbose=False, maxiter=200):
+        """Next point + fidelity by cost-weighted acquisition (:137-184)."""
+        fids = [self.num_fidelities - 1] if self.eval_highest_fidelity else list(range(self.num_fidelities))
+        best = None
+        for fidelity in fids:
+            cand, val = self._optimize(fidelity, maxiter=maxiter)
+            cost = self.costs_blackboxes[0 if self.eval_highest_fidelity else fidelity]["total"]
+            w = val / cost
+            if best is None or best[0] < w:
+                best = (w, cand, fidelity)
+        w, cand, fidelity = best
+        if verbose:
+            print("Iter:", iteration, "Acquisition:", float(w * self.costs_blackboxes[fidelity]["total"]),
+                  " Evaluating fidelity", fidelity, "at", cand[0].cpu().numpy())
+        return cand[0, :], fidelity

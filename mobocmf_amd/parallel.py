@@ -43,3 +43,23 @@ def coupled_acquisition(local_acq):
     """Sum over ALL black-boxes of the per-black-box acquisition (JESMOC_MFDGP.py:125-135): each rank holds
     the (k_local, T) values of its own surrogates; one all-gather, then a local sum."""
     return all_gather_moments(local_acq).sum(0)
+
+
+def gather_with_local_grad(fm, fv, cm, cv):
+    """omega-factor coupling of the conditioned training (blackbox_mfdgp_fitter.py:317-341) when the surrogates are
+    sharded over ranks: every rank needs ALL models' (mean, var) at the 10 x~ points; its own rows keep their autograd
+    history, the other ranks' rows arrive as constants (one all-gather of 2 x 10 doubles per model).  Ranks must hold
+    the same number of objectives and of constraints.  World size 1: identity."""
+    _, w = world()
+    if w == 1:
+        return fm, fv, cm, cv
+    r, _ = world()
+
+    def mix(local):
+        if local.shape[0] == 0:
+            return local
+        allv = all_gather_moments(local.detach())
+        k = local.shape[0]
+        return torch.cat([allv[:r * k], local, allv[(r + 1) * k:]], 0)
+
+    return mix(fm), mix(fv), mix(cm), mix(cv)

@@ -19,6 +19,11 @@ from ..models.mfdgp import MFDGP, TL
 ITER_PRINT = 1000
 
 
+def _ncdf(z):
+    """Standard normal cdf (the reference uses torch.distributions Normal(0, 1).cdf, :18)."""
+    return 0.5 * (1.0 + torch.erf(z * 0.7071067811865476))
+
+
 class MFDGPHandler:
 
     MAX_TRIES_FOR_FEASIBLE_GRID = 50
@@ -172,6 +177,111 @@ class BlackBoxMFDGPFitter:
             self._train_mfdgp(self.update_model, fix_variational_hypers=False, num_epochs=self.num_epochs_2, lr=self.lr_2)
         self.models_uncond_trained = True
 
+    # ------------------------------------------------------------------ conditioned training
+    def set_pareto_solution(self, pareto_set, pareto_front):
+        """Pareto set (P, d) / front (P, n_obj) to condition on.  The reference obtains them from RFF posterior samples
+        + MOOP (:181-225, SURVEY row N2, not built here); any optimiser may provide them."""
+        dev = torch.device(self.device)
+        self.pareto_set = pareto_set.double().to(dev)
+        self.pareto_front = pareto_front.double().to(dev)
+
+    def loss_theta_factors(self, cs_mean, cs_var, threshold):
+        """:227-233."""
+        c = _ncdf((cs_mean - threshold) / torch.sqrt(cs_var))
+        return torch.sum(np.log(1.0 - self.eps) * c + np.log(self.eps) * (1.0 - c))
+
+    def loss_omega_factors(self, fs_mean, fs_var, cs_mean, cs_var, pareto_front):
+        """:235-243.  fs_* (n_obj, T), cs_* (n_con, T)."""
+        thr = self.thresholds_cons.to(fs_mean.device)
+        c = torch.ones(fs_mean.shape[-1], dtype=fs_mean.dtype, device=fs_mean.device)
+        if cs_mean.numel():
+            c = torch.prod(_ncdf((cs_mean - thr[:, None]) / torch.sqrt(cs_var)), 0)
+        c = c * torch.prod(_ncdf((pareto_front[:, :, None] - fs_mean) / torch.sqrt(fs_var)), 1)
+        return torch.sum(np.log(self.eps) * c + np.log(1 - self.eps) * (1.0 - c))
+
+    def conditioned_loss(self, x_tilde, eps=None):
+        """The joint loss of one conditioned-training iteration (:270-343).
+
+        The reference runs three forwards per model (training batch, Pareto set, x_tilde); the layer is separable over
+        rows, so here they are ONE forward on the concatenated rows: one Cholesky chain and one set of GEMMs per layer
+        instead of three.  ``eps``: optional {name: [None, eps_l1, ...]} with draws for the concatenated rows.
+        With surrogates sharded over ranks the omega factors need every model's (mean, var) at x_tilde: the local ones
+        carry gradient, the others arrive as constants through one all-gather (mobocmf_amd.parallel)."""
+        from .. import parallel
+        P, T = self.pareto_set.shape[0], x_tilde.shape[0]
+        loss = 0.0
+        tilde = {}
+        k = 0
+        for tag, i, h in self._handlers():
+            xb, yb, fb = h.train_dataset.tensors
+            B = xb.shape[0]
+            S = h.mfdgp.num_samples_for_training
+            top = h.num_fidelities - 1
+            out = h.mfdgp(torch.cat([xb, self.pareto_set, x_tilde], 0), eps=None if eps is None else eps[(tag, i)])
+            def sl(dist, a, b):          # rows [a, b) of the concatenated input (x rows-per-input-row of the layer)
+                rpb = dist.mean.numel() // (B + P + T)
+                return dist.mean.reshape(-1)[a * rpb:b * rpb], dist.variance.reshape(-1)[a * rpb:b * rpb]
+
+            from ..gp import MultivariateNormal as MVN
+            batch = [MVN(*sl(d, 0, B)) for d in out]
+            loss = loss - h.elbo(batch, yb.T, fb)[0] / B * h.num_data
+            mu_p, var_p = sl(out[top], B, B + P)
+            if tag == "OBJ":
+                pf = torch.full((P, 1), float(top), dtype=xb.dtype, device=xb.device)
+                pl = [None] * top + [MVN(mu_p, var_p)]
+                loss = loss - h.elbo(pl, self.pareto_front[:, i:i + 1].T, pf, include_kl_term=False)
+            else:
+                if S > 1:
+                    raise NotImplementedError("theta factors are defined for one sample per row (reference: S = 1)")
+                loss = loss - self.loss_theta_factors(mu_p, var_p, self.thresholds_cons[k].to(xb.device))
+                k += 1
+            tilde[(tag, i)] = sl(out[top], B + P, B + P + T)
+        fm = torch.stack([tilde[(t, i)][0] for t, i, _ in self._handlers() if t == "OBJ"])
+        fv = torch.stack([tilde[(t, i)][1] for t, i, _ in self._handlers() if t == "OBJ"])
+        cons = [(tilde[(t, i)][0], tilde[(t, i)][1]) for t, i, _ in self._handlers() if t == "CON"]
+        cm = torch.stack([c[0] for c in cons]) if cons else fm.new_zeros((0, T))
+        cv = torch.stack([c[1] for c in cons]) if cons else fm.new_zeros((0, T))
+        fm, fv, cm, cv = parallel.gather_with_local_grad(fm, fv, cm, cv)
+        return loss - self.loss_omega_factors(fm, fv, cm, cv, self.pareto_front)
+
+    def train_conditioned_mfdgps(self, num_iters=None):
+        """ONE Adam over all models' parameters, kernel hyper-parameters frozen (:245-268, :345-354)."""
+        params = []
+        for _, _, h in self._handlers():
+            h.mfdgp.fix_variational_hypers_cond(True)
+            h.mfdgp.set_check_pd(False)
+            params += list(h.mfdgp.parameters())
+        optimizer = torch.optim.Adam([{"params": params}], lr=self.lr_2)
+        num_iters = self.num_epochs_2 if num_iters is None else num_iters
+        d = self.pareto_set.shape[1]
+        for i in range(num_iters):
+            optimizer.zero_grad()
+            x_tilde = torch.rand(10, d, dtype=torch.float64, device=self.pareto_set.device)
+            loss = self.conditioned_loss(x_tilde)
+            loss.backward()
+            optimizer.step()
+            if self.verbose and ((i % ITER_PRINT) == 0 or (i + 1) == num_iters):
+                print("Iter:", i, "/", num_iters, ". Neg. ELBO per iter:", loss.item())
+                sys.stdout.flush()
+        for _, _, h in self._handlers():
+            h.iter_train_loader = None
+            h.mfdgp.set_check_pd(True)
+
+    def mfdgps_to_train_mode(self):
+        for _, _, h in self._handlers():
+            h.mfdgp.train()
+
+    def mfdgps_to_eval_mode(self):
+        for h in self.mfdgp_handlers_objs.values():
+            h.mfdgp.eval()
+        for h in self.mfdgp_handlers_cons.values():
+            h.mfdgp.train()                      # as written in the reference (:363-368, SURVEY B.7)
+
     def copy_uncond(self):
-        """Deep copy of the fitter (:372-397): the models are plain tensors, so ``deepcopy`` just works."""
-        return deepcopy(self)
+        """Deep copy of the fitter (:372-397): the models only hold tensors, so ``deepcopy`` just works."""
+        for _, _, h in self._handlers():
+            h.mfdgp.eval()
+        self_copy = deepcopy(self)
+        for _, _, h in self._handlers() + self_copy._handlers():
+            h.mfdgp.train()
+        return self_copy

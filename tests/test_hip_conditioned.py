@@ -1,0 +1,124 @@
+"""the conditioned-training loss (ELBO on the data + ELBO data term on the Pareto pseudo-observations
++ theta factors + omega factors, blackbox_mfdgp_fitter.py:227-343) on the HIP path vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from mobocmf_amd.util import synthetic
+from oracle import mfdgp_oracle as O
+from tests.helpers import oracle_state, to_t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _fitter(n_obj=2, n_con=1, N=12, M=8, d=2):
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.util.blackbox_mfdgp_fitter import BlackBoxMFDGPFitter, MFDGPHandler
+    from torch.utils.data import TensorDataset
+    fitter = BlackBoxMFDGPFitter(2, N, device=DEV)
+    fitter.verbose = False
+    probs = []
+    for o in range(n_obj + n_con):
+        prob = synthetic.make_problem(d=d, L=2, M=M, N=N, S=1, output=o, seed=o)
+        prob["noise"] = [np.array(1e-2), np.array(2e-2)]          # benign noise: well-scaled losses
+        probs.append(prob)
+        model = synthetic.model_from_problem(prob, num_samples_for_training=1, device=DEV)
+        h = MFDGPHandler.__new__(MFDGPHandler)
+        h.mfdgp, h.num_data, h.num_fidelities, h.batch_size = model, N, 2, N
+        h.elbo = VariationalELBOMF(model, N, 2)
+        t = lambda a: to_t(a).to(DEV)
+        h.train_dataset = TensorDataset(t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None])
+        h.iter_train_loader = None
+        (fitter.mfdgp_handlers_objs if o < n_obj else fitter.mfdgp_handlers_cons)["bb%d" % o] = h
+    fitter.num_obj, fitter.num_con = n_obj, n_con
+    fitter.thresholds_cons = torch.tensor([0.1] * n_con, dtype=torch.float64)
+    return fitter, probs
+
+
+def test_conditioned_loss_and_gradients_match_oracle():
+    n_obj, n_con, N, P, T, d = 2, 1, 12, 5, 10, 2
+    fitter, probs = _fitter(n_obj, n_con, N)
+    g = torch.Generator().manual_seed(0)
+    pareto_set = torch.rand(P, d, dtype=torch.float64, generator=g)
+    pareto_front = torch.randn(P, n_obj, dtype=torch.float64, generator=g) * 0.5
+    x_tilde = torch.rand(T, d, dtype=torch.float64, generator=g)
+    fitter.set_pareto_solution(pareto_set, pareto_front)
+    eps_all = {}
+    objs, cons = [], []
+    for idx, (tag, i, h) in enumerate(fitter._handlers()):
+        e = torch.randn(N + P + T, dtype=torch.float64, generator=g)
+        eps_all[(tag, i)] = [None, e.to(DEV)]
+        st = oracle_state(probs[idx], requires_grad=True)
+        rec = {"state": st, "x": to_t(probs[idx]["x"]), "y": to_t(probs[idx]["y"]), "fid": to_t(probs[idx]["fid"]),
+               "eps_batch": [None, e[:N]], "eps_pareto": [None, e[N:N + P]], "eps_tilde": [None, e[N + P:]]}
+        (objs if tag == "OBJ" else cons).append(rec)
+    loss_o = O.conditioned_loss(objs, cons, pareto_set, pareto_front, x_tilde, fitter.thresholds_cons, fitter.eps)
+    loss_o.backward()
+    loss = fitter.conditioned_loss(x_tilde.to(DEV), eps=eps_all)
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) / abs(float(loss_o)) < 1e-8
+    for rec, (tag, i, h) in zip(objs + cons, fitter._handlers()):
+        for l in range(2):
+            vd = getattr(h.mfdgp, f"hidden_layer_{l}").variational_strategy._variational_distribution
+            ref = rec["state"]["layers"][l]["m"].grad
+            err = float((vd.variational_mean.grad.cpu() - ref).abs().max() / ref.abs().max())
+            assert err < 1e-6, (tag, i, l, err)
+            refL = torch.tril(rec["state"]["layers"][l]["L_S"].grad)
+            errL = float((vd.chol_variational_covar.grad.cpu() - refL).abs().max() / refL.abs().max())
+            assert errL < 1e-6, (tag, i, l, errL)
+
+
+def test_conditioned_training_runs_and_reduces_the_loss():
+    fitter, _ = _fitter(2, 1, 12)
+    g = torch.Generator().manual_seed(1)
+    fitter.set_pareto_solution(torch.rand(5, 2, dtype=torch.float64, generator=g),
+                               torch.randn(5, 2, dtype=torch.float64, generator=g) * 0.3)
+    xt = torch.rand(10, 2, dtype=torch.float64, generator=g).to(DEV)
+    torch.manual_seed(0)
+    l0 = float(fitter.conditioned_loss(xt))
+    fitter.lr_2 = 5e-3
+    fitter.train_conditioned_mfdgps(num_iters=60)
+    torch.manual_seed(0)
+    l1 = float(fitter.conditioned_loss(xt))
+    assert np.isfinite(l1) and l1 < l0
+    # kernel hyper-parameters stay frozen in conditioned training (fix_variational_hypers_cond)
+    for _, _, h in fitter._handlers():
+        assert not any(p.requires_grad for p in h.mfdgp.hidden_layer_1.covar_module.parameters())
+    fc = fitter.copy_uncond()
+    assert fc.pareto_set is not fitter.pareto_set
+
+
+def test_jesmoc_next_point_flow():
+    """The reference's acquisition flow (JESMOC_MFDGP.__init__ :57-98, add_blackbox :101-116, coupled_acq :125-135,
+    get_nextpoint_coupled :151-184) on the mirrored classes; the coupled value equals the sum of the per-black-box
+    oracle JES values, and the optimiser returns a point inside the bounds that is at least as good as a random one."""
+    from mobocmf_amd.acquisition_functions import JESMOC_MFDGP
+    fitter, probs = _fitter(2, 1, 12)
+    g = torch.Generator().manual_seed(3)
+    fitter.set_pareto_solution(torch.rand(5, 2, dtype=torch.float64, generator=g),
+                               torch.randn(5, 2, dtype=torch.float64, generator=g) * 0.3)
+    fitter.lr_2, fitter.num_epochs_2 = 5e-3, 40
+    acq = JESMOC_MFDGP(fitter, num_fidelities=2,
+                       standard_bounds=torch.tensor([[0.0, 0.0], [1.0, 1.0]], dtype=torch.float64, device=DEV))
+    for f in range(2):
+        acq.add_blackbox(f, "bb0", cost_evaluation=1.0 if f == 0 else 10.0)
+        acq.add_blackbox(f, "bb1", cost_evaluation=1.0 if f == 0 else 10.0)
+        acq.add_blackbox(f, "bb2", cost_evaluation=1.0 if f == 0 else 10.0, is_constraint=True)
+    X = torch.rand(7, 2, dtype=torch.float64, generator=g).to(DEV)
+    total = acq.coupled_acq(X, fidelity=1)
+    parts = [acq.decoupled_acq(X, 1, n, is_constraint=(n == "bb2")) for n in ("bb0", "bb1", "bb2")]
+    assert torch.allclose(total, sum(parts))
+    assert (total >= 0).all()
+    # oracle value of one black-box
+    from tests.test_hip_model import _raw_from_model
+    mu, mc = acq.objectives[1]["bb0"].mfdgp_uncond, acq.objectives[1]["bb0"].mfdgp_cond
+    su = O.state_from_raw(_raw_from_model(mu, 2))
+    sc = O.state_from_raw(_raw_from_model(mc, 2))
+    su["samples"] = [None, mu.hidden_layer_1.samples.detach().cpu().double().reshape(-1)]
+    sc["samples"] = [None, mc.hidden_layer_1.samples.detach().cpu().double().reshape(-1)]
+    with torch.no_grad():
+        ref = O.jes_acquisition(su, sc, X.cpu(), 1, mu.num_samples_for_acquisition)
+    assert float((parts[0].detach().cpu() - ref).abs().max()) < 1e-6 * max(1.0, float(ref.abs().max()))
+    x_next, fid = acq.get_nextpoint_coupled(maxiter=15)
+    assert x_next.shape == (2,) and 0 <= fid < 2 and bool(((x_next >= 0) & (x_next <= 1)).all())

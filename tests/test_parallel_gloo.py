@@ -28,7 +28,12 @@ def _worker(rank, world, port, q):
     gathered = parallel.all_gather_moments(local)
     acq_local = torch.full((2, 7), float(rank + 1), dtype=torch.float64)
     total = parallel.coupled_acquisition(acq_local)
-    q.put((rank, mine, owner, gathered.shape, gathered[:, 0, 0].tolist(), total.tolist()))
+    # omega-factor coupling: own rows keep autograd history, the other rank's rows are constants
+    fm = torch.full((1, 3), float(rank + 1), dtype=torch.float64, requires_grad=True)
+    mixed = parallel.gather_with_local_grad(fm, fm * 2, fm[:0], fm[:0])
+    mixed[0].prod(0).sum().backward()
+    q.put((rank, mine, owner, gathered.shape, gathered[:, 0, 0].tolist(), total.tolist(),
+           mixed[0][:, 0].tolist(), fm.grad[0].tolist(), tuple(mixed[2].shape)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -45,7 +50,10 @@ def test_world_size_2_gloo_exchange():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, mine0, owner0, shape0, g0, t0), (r1, mine1, owner1, shape1, g1, t1) = res
+    (r0, mine0, owner0, shape0, g0, t0, mx0, gr0, cs0), (r1, mine1, owner1, shape1, g1, t1, mx1, gr1, cs1) = res
+    assert mx0 == mx1 == [1.0, 2.0]                      # rank order, own row in place
+    assert gr0 == [2.0] * 3 and gr1 == [1.0] * 3       # d(prod)/d(own) = the other rank's (constant) value
+    assert cs0 == (0, 3)
     assert owner0 == owner1 and sorted(mine0 + mine1) == sorted(owner0)
     assert mine0 == ["obj1", "con1", "con3"] and mine1 == ["obj2", "con2"]
     assert tuple(shape0) == (4, 2, 7) and g0 == g1 == [0.0, 1.0, 10.0, 11.0]      # rank order, identical everywhere
