@@ -1,0 +1,129 @@
+"""Random-Fourier-feature function samples from the prior / the variational posterior of an MFDGP layer
+(reference: mobocmf/layers/mfdgp_hidden_layer.py:288-514, numpy host code there as well).
+
+Weight-space view: f(x) = theta^T phi(x), phi(x) = sqrt(2 a / F) cos(W x + b) with W ~ N(0, 1) / lengthscale,
+b ~ U(0, 2 pi).  Layer >= 1 kernel a1 E1(x) (nu f f' + af Ef(f)) + a2 E2(x) has the feature map
+[ sqrt(nu) f phi_x1(x) ; phi_{x1 f}([x, f]) ; phi_x2(x) ]  (3F features; the middle block is the RBF on [x, f] with
+outputscale a1*af, sharing W_x1 and b_x1 with the first block, as the reference does).
+Posterior weights given q(u) = N(m, S) at the inducing inputs:  A = Phi Phi^T + s2 I,
+theta ~ N( A^-1 Phi m ,  s2 A^-1 + A^-1 Phi S Phi^T A^-1 ).
+
+Host-side float64 torch (CPU): F x F factorisations, not part of the ELBO hot path.  The returned callables take a
+numpy array (n, d) or (d,), like the reference's, and recurse through the previous layer's sample.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def _phi(x, W, b, alpha):
+    """(F, n) feature matrix."""
+    F = W.shape[0]
+    return math.sqrt(2.0 * alpha / F) * torch.cos(W @ x.T + b)
+
+
+def _posterior_weights(Phi, m, S, sigma2, gen):
+    A = Phi @ Phi.T + sigma2 * torch.eye(Phi.shape[0], dtype=Phi.dtype)
+    cA = torch.linalg.cholesky(A)
+    A_inv = torch.cholesky_inverse(cA)
+    mean = torch.cholesky_solve((Phi @ m)[:, None], cA)[:, 0]
+    AP = A_inv @ Phi
+    cov = sigma2 * A_inv + AP @ S @ AP.T
+    cov = 0.5 * (cov + cov.T)
+    jit = 0.0
+    for i in range(6):
+        Lc, info = torch.linalg.cholesky_ex(cov + jit * torch.eye(cov.shape[0], dtype=cov.dtype))
+        if int(info) == 0:
+            break
+        jit = 1e-12 * 10 ** i
+    z = torch.randn(Phi.shape[0], dtype=Phi.dtype, generator=gen)
+    return mean + Lc @ z
+
+
+def _as_callable(feature_fn, theta, prev):
+    """f(x, gradient=False): numpy in, numpy out -- (n,) values, or the (d,) gradient for a single point."""
+
+    def evaluate(xt):
+        f_prev = prev._torch(xt) if prev is not None else None
+        return theta @ feature_fn(xt, f_prev)
+
+    def wrapper(x, gradient=False):
+        xt = torch.as_tensor(np.asarray(x), dtype=torch.float64)
+        if xt.dim() == 1:
+            xt = xt[None, :]
+        if gradient:
+            assert xt.shape[0] == 1, "the gradient is defined for a single point (as in the reference)"
+            xt = xt.clone().requires_grad_(True)
+            (g,) = torch.autograd.grad(evaluate(xt).sum(), xt)
+            return g[0].numpy()
+        with torch.no_grad():
+            return evaluate(xt).numpy()
+
+    wrapper._torch = evaluate
+    return wrapper
+
+
+def _hypers(layer):
+    cm = layer.covar_module
+    g = lambda t: t.detach().cpu().double()
+    if layer.num_layer == 0:
+        return {"ls": g(cm.base_kernel.lengthscale).reshape(-1), "alpha": float(g(cm.outputscale))}
+    k1, kf = cm.kernels[0].kernels[0], cm.kernels[0].kernels[1].kernels[1]
+    kl, k2 = cm.kernels[0].kernels[1].kernels[0], cm.kernels[1]
+    return {"ls1": g(k1.base_kernel.lengthscale).reshape(-1), "a1": float(g(k1.outputscale)),
+            "lsf": g(kf.base_kernel.lengthscale).reshape(-1), "af": float(g(kf.outputscale)),
+            "ls2": g(k2.base_kernel.lengthscale).reshape(-1), "a2": float(g(k2.outputscale)),
+            "nu": float(g(kl.variance))}
+
+
+def _draw_features(h, d, F, gen, layer0):
+    rn = lambda *s: torch.randn(*s, dtype=torch.float64, generator=gen)
+    ru = lambda *s: 2.0 * math.pi * torch.rand(*s, dtype=torch.float64, generator=gen)
+    if layer0:
+        W, b = rn(F, d) / h["ls"], ru(F, 1)
+        return lambda x, f: _phi(x, W, b, h["alpha"])
+    W1, Wf, W2 = rn(F, d) / h["ls1"], rn(F) / h["lsf"], rn(F, d) / h["ls2"]
+    b1, b2 = ru(F, 1), ru(F, 1)
+    W1f = torch.cat([W1, Wf[:, None]], 1)
+
+    def feats(x, f):
+        xf = torch.cat([x, f[:, None]], 1)
+        return torch.cat([_phi(x, W1, b1, h["a1"]) * f * math.sqrt(h["nu"]),
+                          _phi(xf, W1f, b1, h["a1"] * h["af"]), _phi(x, W2, b2, h["a2"])], 0)
+
+    return feats
+
+
+def sample_from_posterior(layer, input_dim, prev_sample=None, nFeatures=500, sigma2=1e-6, generator=None):
+    """One function sample from the layer's variational posterior (reference :309-337 layer 0, :364-444 layer >= 1)."""
+    h = _hypers(layer)
+    vs = layer.variational_strategy
+    Z = vs.inducing_points.detach().cpu().double()
+    vd = vs._variational_distribution
+    m = vd.variational_mean.detach().cpu().double()
+    Ls = torch.tril(vd.chol_variational_covar.detach().cpu().double())
+    feats = _draw_features(h, input_dim, nFeatures, generator, layer.num_layer == 0)
+    if layer.num_layer == 0:
+        assert prev_sample is None
+        Phi = feats(Z, None)
+    else:
+        assert prev_sample is not None
+        Phi = feats(Z[:, :-1], Z[:, -1])          # the f column of Z~ is the previous layer's variational mean
+    theta = _posterior_weights(Phi, m, Ls @ Ls.T, sigma2, generator)
+    return _as_callable(feats, theta, prev_sample)
+
+
+def sample_from_prior(layer, input_dim, prev_sample=None, nFeatures=500, generator=None):
+    """One function sample from the synthetic-problem prior (reference :339-362, :446-514: fixed test hyper-parameters
+    lengthscale 0.25 d (x10 for x1), outputscales 1 / 1 / 0.01, nu 1)."""
+    d = input_dim
+    if layer.num_layer == 0:
+        h = {"ls": torch.full((d,), 0.25 * d, dtype=torch.float64), "alpha": 1.0}
+    else:
+        h = {"ls1": torch.full((d,), 2.5 * d, dtype=torch.float64), "a1": 1.0, "lsf": torch.ones(1, dtype=torch.float64),
+             "af": 1.0, "ls2": torch.full((d,), 0.25 * d, dtype=torch.float64), "a2": 0.01, "nu": 1.0}
+    feats = _draw_features(h, d, nFeatures, generator, layer.num_layer == 0)
+    nF = nFeatures if layer.num_layer == 0 else 3 * nFeatures
+    theta = torch.randn(nF, dtype=torch.float64, generator=generator)
+    return _as_callable(feats, theta, prev_sample)

@@ -212,8 +212,20 @@ class MFDGP(nn.Module):
         return F.acq_moments(mus_tilde, vars_tilde, S)
 
     # ------------------------------------------------------------------ function sampling (RFF): SURVEY row N2
-    def sample_function_from_each_layer(self):
-        raise NotImplementedError("RFF posterior function sampling (SURVEY section 8(f) row N2) is not built yet")
+    def sample_function_from_each_layer(self, nFeatures=500, generator=None):
+        """One posterior function sample per layer (mfdgp.py:264-275): list of callables f(x: ndarray) -> (n,)."""
+        from ..layers import rff
+        result, prev = [], None
+        for layer in self._layers():
+            prev = rff.sample_from_posterior(layer, self.input_dims, prev, nFeatures=nFeatures, generator=generator)
+            result.append(prev)
+        return result
 
-    def sample_function_from_prior_each_layer(self):
-        raise NotImplementedError("RFF prior function sampling (SURVEY section 8(f) row N2) is not built yet")
+    def sample_function_from_prior_each_layer(self, nFeatures=500, generator=None):
+        """Prior function samples used to build synthetic problems (mfdgp.py:277-288)."""
+        from ..layers import rff
+        result, prev = [], None
+        for layer in self._layers():
+            prev = rff.sample_from_prior(layer, self.input_dims, prev, nFeatures=nFeatures, generator=generator)
+            result.append(prev)
+        return result

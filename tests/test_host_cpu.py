@@ -146,3 +146,29 @@ def test_synthetic_problems_are_deterministic():
     b = synthetic.make_problem(d=8, L=2, M=16, N=64, S=2, output=1, seed=3)
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["eps"][1], b["eps"][1])
     assert (a["fid"][:16] == 1).all() and (a["fid"][16:] == 0).all()
+
+
+def test_rff_posterior_function_samples():
+    """weight-space samples f ~ q(f): at the inducing inputs their mean is the variational mean and
+    their spread is diag(S) (+ RFF / jitter error); a sample's gradient matches finite differences; layer >= 1
+    recurses through the previous layer's sample."""
+    prob = synthetic.make_problem(d=2, L=2, M=8, N=12, S=2, seed=3)
+    for lay in prob["layers"]:
+        lay["hyp"] = {k: (v * 0 + 0.6 if k.startswith("ls") and k != "lsf" else v) for k, v in lay["hyp"].items()}
+    model = synthetic.model_from_problem(prob, device="cpu")
+    Z = prob["Zx"]
+    g = torch.Generator().manual_seed(0)
+    vals = np.stack([model.sample_function_from_each_layer(nFeatures=400, generator=g)[0](Z) for _ in range(300)])
+    m0 = prob["layers"][0]["m"]
+    S0 = np.tril(prob["layers"][0]["L_S"]) @ np.tril(prob["layers"][0]["L_S"]).T
+    assert np.abs(vals.mean(0) - m0).max() < 4 * np.sqrt(np.diag(S0).max() / 300) + 0.02
+    assert np.abs(vals.std(0) - np.sqrt(np.diag(S0))).max() < 0.03
+    fs = model.sample_function_from_each_layer(nFeatures=200, generator=g)
+    x = np.array([0.3, 0.6])
+    for f in fs:
+        assert f(x).shape == (1,) and f(np.stack([x, x + 0.1])).shape == (2,)
+        gr = f(x, gradient=True)
+        fd = np.array([(f(x + 1e-6 * e)[0] - f(x - 1e-6 * e)[0]) / 2e-6 for e in np.eye(2)])
+        assert np.abs(gr - fd).max() < 1e-5 * max(1.0, np.abs(fd).max())
+    pr = model.sample_function_from_prior_each_layer(nFeatures=100, generator=g)
+    assert len(pr) == 2 and np.isfinite(pr[1](np.random.default_rng(0).random((5, 2)))).all()
