@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // kpair p (0,1) covers ks = 2p, 2p+1, i.e. k = 4*lk + 2p + {0,1}: logical 16-B chunk 2*lk + p.
     const int swA = ((lane >> 1) & 1) << 2;
     const int colP0 = ((2 * lk + 0) ^ swA) << 1, colP1 = ((2 * lk + 1) ^ swA) << 1;
-    const int a_base = (wr * 64 + (lane & 3)) * BK;                 // + (mt*16 + 4r)*BK + colP
+    // the two row-wavefronts own INTERLEAVED 16-row groups (group 2*mt + wr): inside a triangular diagonal block both
+    // then skip a similar share of structurally-zero groups (critical path 20/32 of a dense block instead of 26/32)
+    const int a_base = (wr * 16 + (lane & 3)) * BK;                 // + (mt*32 + 4r)*BK + colP
     const int bt_base = (wc * 64 + li) * BK;                        // B_T: + nt*16*BK + colP
     // B: k row = 4*lk + ks, 16-col group nt stored at group nt ^ (lk&1)
     const int bn_base = (4 * lk) * BN + wc * 64 + li;               // + ks*BN + (nt ^ (lk&1))*16
@@ -196,11 +198,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         int act = 15;
         if (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) {
             const int64_t kk = k0 + kt * BK;
-            const int64_t r0 = (int64_t)rb * BM + wr * 64;
+            const int64_t r0 = (int64_t)rb * BM + wr * 16;
             act = 0;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const bool nz = (g.tri & TRI_LOWER_A) ? (kk <= r0 + mt * 16 + 15) : (kk + 15 >= r0 + mt * 16);
+                const bool nz = (g.tri & TRI_LOWER_A) ? (kk <= r0 + mt * 32 + 15) : (kk + 15 >= r0 + mt * 32);
                 act |= nz ? (1 << mt) : 0;
             }
             act = __builtin_amdgcn_readfirstlane(act);
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         double b0[2][4], b1[2][4];   // B fragment sets (kpair 0 / 1): [ks&1][nt]
 #define LOAD_A(dst, P, MT)                                                                                  \
     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
-        dst[r] = *(const v2f64*)(As + a_base + ((MT) * 16 + 4 * r) * BK + ((P) ? colP1 : colP0));
+        dst[r] = *(const v2f64*)(As + a_base + ((MT) * 32 + 4 * r) * BK + ((P) ? colP1 : colP0));
 #define LOAD_B(dst, P)                                                                                      \
     if (B_T) {                                                                                              \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     }
 
     // ------------------------------------------------------------------ epilogue
-    const int64_t row0 = (int64_t)rb * BM + wr * 64 + lk;     // + mt*16 + 4*r
+    const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;     // + mt*32 + 4*r
     const int64_t col0 = cb * BN + wc * 64 + li;               // + nt*16
     if (g.epi == EPI_DA) {
         // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n]
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t row = row0 + mt * 16 + 4 * r;
+                    const int64_t row = row0 + mt * 32 + 4 * r;
                     C[row * g.ldc + col] =
                         cs * acc[mt][nt][r] + g.avec[row] * gm - 2.0 * g.Aaux[row * g.ldc + col] * cg;
                 }
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + mt * 16 + 4 * r;
+                const int64_t row = row0 + mt * 32 + 4 * r;
                 const int64_t col = col0 + nt * 16;
                 double v = g.alpha * acc[mt][nt][r];
                 if (g.accumulate) v += C[row * g.ldc + col];
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
                 for (int r = 0; r < 4; ++r) {
                     const double v = acc[mt][nt][r];
                     sq += v * v;
-                    if (g.coldot_part) dt += g.avec[row0 + mt * 16 + 4 * r] * v;
+                    if (g.coldot_part) dt += g.avec[row0 + mt * 32 + 4 * r] * v;
                 }
             sq += __shfl_xor(sq, 16);
             sq += __shfl_xor(sq, 32);
