@@ -16,19 +16,38 @@ __device__ __forceinline__ double bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c].  Returns the first
-// failed pivot (1-based) or 0.
-__device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane) {
+// The 64x64 routines below run in ONE wavefront with the block held row-per-lane in registers.  In the factorisation
+// column j of L is published once per step in LDS (LT[j][lane], conflict-free) and read back as wave-uniform 16-byte
+// broadcasts (two k per ds_read_b128) -- half the instructions of fetching every multiplier with a pair of v_readlane;
+// only the pivot is a cross-lane register read.  The triangular solve / inverse fetch their multipliers with
+// v_readlane (the LDS-broadcast form of those two made hipcc hoist ~1000 loads and spill).  No barriers: a single
+// wavefront's LDS traffic is program-ordered.
+typedef double v2f64c __attribute__((ext_vector_type(2)));
+
+// a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c]; LT[j][i] = L[i][j] (0 above the
+// diagonal), rd[j] = 1 / L[j][j].  Returns the first failed pivot (1-based) or 0.
+__device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd) {
     int fail = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        double ajj = bcast(a[j], j);
+        const double ajj = bcast(a[j], j);
         if (!(ajj > 0.0) && fail == 0) fail = j + 1;
-        double d = sqrt(ajj);
-        double lij = a[j] / d;          // lanes >= j: L[lane][j]  (lane j: d)
+        const double rinv = 1.0 / sqrt(ajj);
+        const double lij = a[j] * rinv;          // lanes >= j: L[lane][j]  (lane j: sqrt(ajj))
         a[j] = lij;
+        LT[j][lane] = lane >= j ? lij : 0.0;
+        if (lane == 0) rd[j] = rinv;
+        // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
+        if ((j + 1) & 1) {
+            if (j + 1 < NB) a[j + 1] -= lij * LT[j][j + 1];
+        }
 #pragma unroll
-        for (int k = j + 1; k < NB; ++k) a[k] -= lij * bcast(lij, k);   // valid for lanes >= k
+        for (int k = (j + 2) & ~1; k < NB; k += 2) {
+            const v2f64c c = *(const v2f64c*)&LT[j][k];
+            a[k] -= lij * c[0];
+            a[k + 1] -= lij * c[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     return fail;
 }
@@ -61,6 +80,8 @@ __device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[N
 // A_jj).  The factor goes to the side buffer Ld; finish_l_kernel copies it into the diagonal at the end.
 __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
                                                          int32_t* info) {
+    __shared__ __attribute__((aligned(16))) double LT[NB][NB];
+    __shared__ double rd[NB];
     const int lane = threadIdx.x;
     const int bi = blockIdx.x;
     const int64_t j0 = (int64_t)jb * NB;
@@ -68,7 +89,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
     const double* drow = A + (j0 + lane) * ld + j0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = drow[c];
-    int fail = chol64_rows(a, lane);
+    int fail = chol64_rows(a, lane, LT, rd);
     if (bi == 0) {
         double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
