@@ -36,7 +36,7 @@ __device__ __forceinline__ void glds16(const double* gsrc, double* lds_wave_base
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <bool B_T>
+template <bool B_T, bool TRI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_ELEMS];   // [buf][A | B]
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         // 16-row groups of a triangular A that are structurally zero for this K step (inside the diagonal block) are
         // skipped: bit mt of `act` = group mt of this wavefront has a non-zero entry in k in [kk, kk+16)
         int act = 15;
-        if (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) {
+        if (TRI && (g.tri & (TRI_LOWER_A | TRI_UPPER_A))) {
             const int64_t kk = k0 + kt * BK;
             const int64_t r0 = (int64_t)rb * BM + wr * 16;
             act = 0;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
                 dst[e][t] = Bs[bn_base + (2 * (P) + e) * BN + ((t ^ (lk & 1)) << 4)];                       \
     }
 #define MMA(asrc, bsrc, MT)                                                                                 \
-    if (act & (1 << (MT))) {                                                                                \
+    if (!TRI || (act & (1 << (MT)))) {                                                                      \
         _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
@@ -348,10 +348,14 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         grid = dim3((unsigned)((pair ? (nrb + 1) / 2 : nrb) * ncb), 1, 1);
         splitk = 1;
     }
+    // TRI instantiation: per-step skipping of structurally-zero row groups (its branches cost the dense loop ~5 %)
+    const bool tri = (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) != 0;
     if (B_T)
-        hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
+        hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
+    else if (tri)
+        hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
     else
-        hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
+        hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
