@@ -106,8 +106,16 @@ def measure_dominant_kernel(cfg, device, iters=20):
     torch.cuda.synchronize()
     sec = st.elapsed_time(en) * 1e-3 / iters
     flops = float(cfg["M"]) ** 2 * cfg["N"] * cfg["S"]          # algorithmic: M^2 N' (triangular product)
+    traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same shape)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")) as fh:
+            pm = json.load(fh)
+        if Mp == 512 and Np == 65536:
+            traffic = pm["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     return {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / sec / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
+            "frac": flops / sec / 1e12 / FP64_PEAK_TFLOPS, "traffic": traffic,
             "kernel": "gemm_f64_kernel<false> (A = L^-1 K_mn, %dx%dx%d lower-triangular)" % (Mp, Np, Mp),
             "kernel_ms": sec * 1e3, "flops_per_launch": flops}
 
@@ -195,6 +203,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="run the surrogates back to back on one stream")
     ap.add_argument("--surrogates", type=int, default=0, help="surrogates per GPU (default: the config's 3)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (CPU rehearsal of the multi-rank control flow)")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying HIP graphs")
     args = ap.parse_args()
 
@@ -203,13 +213,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE != --gpus")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     cfg = dict(synthetic.CONFIGS[args.config])
     n_out = 3 if args.config == "C3" else min(cfg["outputs"], 3) if args.config != "C5" else 1
@@ -251,7 +266,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = all(bool(torch.isfinite(l)) for l in losses)

@@ -34,9 +34,12 @@ def all_gather_moments(local):
     if w == 1:
         return local
     local = local.contiguous()
+    dev = local.device
+    if dev.type == "cuda" and dist.get_backend() == "gloo":
+        local = local.cpu()                       # CPU rehearsal of the multi-rank path (tests); RCCL takes HBM buffers
     out = torch.empty((w * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)      # concatenation along dim 0, rank order
-    return out
+    return out.to(dev)
 
 
 def coupled_acquisition(local_acq):
