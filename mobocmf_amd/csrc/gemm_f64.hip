@@ -36,7 +36,7 @@ __device__ __forceinline__ void glds16(const double* gsrc, double* lds_wave_base
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <bool B_T, bool TRI>
+template <bool B_T, bool TRI, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_ELEMS];   // [buf][A | B]
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // ------------------------------------------------------------------ epilogue
     const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;     // + mt*32 + 4*r
     const int64_t col0 = cb * BN + wc * 64 + li;               // + nt*16
-    if (g.epi == EPI_DA) {
+    if (EPI == EPI_DA) {
         // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n]
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
                 acc[mt][nt][r] = v;
                 C[row * g.ldc + col] = v;
             }
-    if (g.epi == EPI_COLSTATS) {
+    if (EPI == EPI_COLSTATS) {
         // partial column sums over this tile's 128 rows: per lane over its 16 rows, then across the
         // 4 lane groups of the wavefront (shuffles), then across the two row-wavefronts (LDS).
         double* red = lds;   // [2 stats][2 wr][128 cols]   (main-loop LDS is dead after the last barrier)
@@ -350,12 +350,20 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
     }
     // TRI instantiation: per-step skipping of structurally-zero row groups (its branches cost the dense loop ~5 %)
     const bool tri = (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) != 0;
-    if (B_T)
-        hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
-    else if (tri)
-        hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
-    else
-        hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair);
+#define LAUNCH(BT, TR, EP) hipLaunchKernelGGL((gemm_f64_kernel<BT, TR, EP>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair)
+    if (B_T) {
+        if (g.epi != EPI_STORE) return MOBOCMF_BAD_ARG;
+        LAUNCH(true, false, EPI_STORE);
+    } else if (tri) {
+        if (g.epi == EPI_COLSTATS) LAUNCH(false, true, EPI_COLSTATS);
+        else if (g.epi == EPI_DA) LAUNCH(false, true, EPI_DA);
+        else LAUNCH(false, true, EPI_STORE);
+    } else {
+        if (g.epi == EPI_COLSTATS) LAUNCH(false, false, EPI_COLSTATS);
+        else if (g.epi == EPI_DA) LAUNCH(false, false, EPI_DA);
+        else LAUNCH(false, false, EPI_STORE);
+    }
+#undef LAUNCH
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
