@@ -183,36 +183,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     __syncthreads();
     v4f64 w_nxt = (v4f64){1.0, 1.0, 1.0, 1.0};
     if (B_T && g.bscale && nk > 0) w_nxt = *(const v4f64*)(g.bscale + k0 + 4 * lk);
-    for (int64_t kt = 0; kt < nk; ++kt) {
-        const int buf = (int)(kt & 1);
-        const v4f64 w4 = w_nxt;    // weights of k = 4*lk + ks of this stage (B_T contraction weights)
-        if (kt + 1 < nk) {
-            // the weight load is issued BEFORE the DMA so that waiting for it never drains the DMA (vmcnt is in order)
-            if (B_T && g.bscale) w_nxt = *(const v4f64*)(g.bscale + k0 + (kt + 1) * BK + 4 * lk);
-            stage(Ag, k0 + (kt + 1) * BK, buf ^ 1);
-        }
-        const double* As = lds + buf * 2 * TILE_ELEMS;
-        const double* Bs = As + TILE_ELEMS;
-        // 16-row groups of a triangular A that are structurally zero for this K step (inside the diagonal block) are
-        // skipped: bit mt of `act` = group mt of this wavefront has a non-zero entry in k in [kk, kk+16)
-        int act = 15;
-        if (TRI && (g.tri & (TRI_LOWER_A | TRI_UPPER_A))) {
-            const int64_t kk = k0 + kt * BK;
-            const int64_t r0 = (int64_t)rb * BM + wr * 16;
-            act = 0;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const bool nz = (g.tri & TRI_LOWER_A) ? (kk <= r0 + mt * 32 + 15) : (kk + 15 >= r0 + mt * 32);
-                act |= nz ? (1 << mt) : 0;
-            }
-            act = __builtin_amdgcn_readfirstlane(act);
-        }
-        // Software pipeline over 8 groups g = (kpair p, row tile mt): the A fragments of group g+1 (4 x ds_read_b128)
-        // and, at a kpair boundary, the B fragments of the next kpair are read while the 32 MFMAs of group g issue.
-        // sched_barrier(0) pins the group boundaries so the register allocator sees two fragment sets, not eight.
-        // (written with literal indices through macros: lambdas / late-unrolled loops left the fragment arrays in scratch)
-        v2f64 a0[4], a1[4];          // A fragment sets (even / odd group)
-        double b0[2][4], b1[2][4];   // B fragment sets (kpair 0 / 1): [ks&1][nt]
+    // Software pipeline of one K step over 8 groups g = (kpair p, row tile mt): the A fragments of group g+1
+    // (4 x ds_read_b128) and, at a kpair boundary, the B fragments of the next kpair are read while the 32 MFMAs of
+    // group g issue.  sched_barrier(0) pins the group boundaries so the register allocator sees two fragment sets, not
+    // eight.  (Literal indices through macros: lambdas / late-unrolled loops left the fragment arrays in scratch.)
+    v2f64 a0[4], a1[4];          // A fragment sets (even / odd group)
+    double b0[2][4], b1[2][4];   // B fragment sets (kpair 0 / 1): [ks&1][nt]
 #define LOAD_A(dst, P, MT)                                                                                  \
     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
         dst[r] = *(const v2f64*)(As + a_base + ((MT) * 32 + 4 * r) * BK + ((P) ? colP1 : colP0));
@@ -234,31 +210,72 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
             _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                  \
                 dst[e][t] = Bs[bn_base + (2 * (P) + e) * BN + ((t ^ (lk & 1)) << 4)];                       \
     }
-#define MMA(asrc, bsrc, MT)                                                                                 \
-    if (!TRI || (act & (1 << (MT)))) {                                                                      \
-        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                      \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
-                    acc[MT][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(asrc[r][e], bsrc[e][j], acc[MT][j][r], 0, 0, 0); \
-    }                                                                                                       \
+#define MMA_DO(asrc, bsrc, MT)                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+                acc[MT][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(asrc[r][e], bsrc[e][j], acc[MT][j][r], 0, 0, 0);
+#define MMA_ALL(asrc, bsrc, MT) MMA_DO(asrc, bsrc, MT) __builtin_amdgcn_sched_barrier(0);
+#define MMA_IF(asrc, bsrc, MT)                                                                              \
+    if (act & (1 << (MT))) { MMA_DO(asrc, bsrc, MT) }                                                       \
     __builtin_amdgcn_sched_barrier(0);
-        LOAD_B(b0, 0)
-        LOAD_A(a0, 0, 0)
-        LOAD_A(a1, 0, 1) MMA(a0, b0, 0)
-        LOAD_A(a0, 0, 2) MMA(a1, b0, 1)
-        LOAD_A(a1, 0, 3) MMA(a0, b0, 2)
-        LOAD_A(a0, 1, 0) LOAD_B(b1, 1) MMA(a1, b0, 3)
-        LOAD_A(a1, 1, 1) MMA(a0, b1, 0)
-        LOAD_A(a0, 1, 2) MMA(a1, b1, 1)
-        LOAD_A(a1, 1, 3) MMA(a0, b1, 2)
-        MMA(a1, b1, 3)
+// K steps [KT0, KT1) of the pipeline.  COND = 1: inside a triangular diagonal block, 16-row groups that are structurally
+// zero for the step are skipped (bit mt of `act`); COND = 0: branch-free body.
+#define STAGE_LOOP(KT0, KT1, COND, MMA)                                                                     \
+    for (int64_t kt = (KT0); kt < (KT1); ++kt) {                                                            \
+        const int buf = (int)(kt & 1);                                                                      \
+        const v4f64 w4 = w_nxt;    /* contraction weights of k = 4*lk + ks of this step (B_T) */            \
+        if (kt + 1 < nk) {                                                                                  \
+            /* the weight load is issued BEFORE the DMA: waiting for it never drains the DMA (vmcnt is in order) */ \
+            if (B_T && g.bscale) w_nxt = *(const v4f64*)(g.bscale + k0 + (kt + 1) * BK + 4 * lk);           \
+            stage(Ag, k0 + (kt + 1) * BK, buf ^ 1);                                                         \
+        }                                                                                                   \
+        const double* As = lds + buf * 2 * TILE_ELEMS;                                                      \
+        const double* Bs = As + TILE_ELEMS;                                                                 \
+        int act = 15;                                                                                       \
+        if (COND) {                                                                                         \
+            const int64_t kk = k0 + kt * BK;                                                                \
+            const int64_t r0 = (int64_t)rb * BM + wr * 16;                                                  \
+            act = 0;                                                                                        \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                             \
+                const bool nz = (g.tri & TRI_LOWER_A) ? (kk <= r0 + mt * 32 + 15) : (kk + 15 >= r0 + mt * 32); \
+                act |= nz ? (1 << mt) : 0;                                                                  \
+            }                                                                                               \
+            act = __builtin_amdgcn_readfirstlane(act);                                                      \
+        }                                                                                                   \
+        (void)act;                                                                                          \
+        LOAD_B(b0, 0)                                                                                       \
+        LOAD_A(a0, 0, 0)                                                                                    \
+        LOAD_A(a1, 0, 1) MMA(a0, b0, 0)                                                                     \
+        LOAD_A(a0, 0, 2) MMA(a1, b0, 1)                                                                     \
+        LOAD_A(a1, 0, 3) MMA(a0, b0, 2)                                                                     \
+        LOAD_A(a0, 1, 0) LOAD_B(b1, 1) MMA(a1, b0, 3)                                                       \
+        LOAD_A(a1, 1, 1) MMA(a0, b1, 0)                                                                     \
+        LOAD_A(a0, 1, 2) MMA(a1, b1, 1)                                                                     \
+        LOAD_A(a1, 1, 3) MMA(a0, b1, 2)                                                                     \
+        MMA(a1, b1, 3)                                                                                      \
+        /* all LDS reads of buf returned (lgkmcnt) and this wavefront's DMA into buf^1 landed (vmcnt) */    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+        __syncthreads();                                                                                    \
+    }
+    if (TRI) {
+        // the 8 K steps of the diagonal block (last for a lower-, first for an upper-triangular A) take the skipping
+        // body, every other step the branch-free one
+        const int64_t nd = nk < 8 ? nk : 8;
+        const int64_t d0 = (g.tri & TRI_UPPER_A) ? nd : 0;
+        const int64_t d1 = (g.tri & TRI_LOWER_A) ? nk - nd : nk;
+        STAGE_LOOP(0, d0, 1, MMA_IF)
+        STAGE_LOOP(d0, d1, 0, MMA_ALL)
+        STAGE_LOOP(d1, nk, 1, MMA_IF)
+    } else {
+        STAGE_LOOP(0, nk, 0, MMA_ALL)
+    }
+#undef STAGE_LOOP
+#undef MMA_IF
+#undef MMA_ALL
+#undef MMA_DO
 #undef LOAD_A
 #undef LOAD_B
-#undef MMA
-        // all LDS reads of buf returned (lgkmcnt) and this wavefront's DMA into buf^1 landed (vmcnt) before the barrier
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
 
     // ------------------------------------------------------------------ epilogue
     const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;     // + mt*32 + 4*r
