@@ -1,0 +1,92 @@
+"""Edge cases of the C-ABI path: smallest sizes, ragged (non-tile-multiple) sizes, single row, many replicas,
+argument validation, and elementwise entry points vs plain torch float64 expressions."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mfdgp_oracle as O
+from tests.test_hip_layer import _close, _mk, _oracle, _pack
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+@pytest.mark.parametrize("kind,d,M,nbase,xdiv", [(0, 1, 1, 1, 1), (1, 1, 1, 1, 1), (0, 3, 2, 1, 1), (1, 2, 3, 1, 25),
+                                                 (1, 7, 129, 1, 5), (0, 4, 127, 385, 1), (1, 2, 65, 129, 2)])
+def test_tiny_and_ragged_shapes(kind, d, M, nbase, xdiv):
+    from mobocmf_amd import functional as F
+    x, f, Zx, zf, hyp, m, L_S = _mk(kind, d, M, nbase, xdiv, seed=M + nbase)
+    Np = nbase * xdiv
+    w = [torch.ones(Np, dtype=torch.float64), 0.5 * torch.ones(Np, dtype=torch.float64), torch.tensor(1.0)]
+    mean_o, var_o, kl_o = _oracle(kind, x, f, Zx, zf, hyp, m, L_S, xdiv, 0, w)
+    g = lambda t, rg=True: None if t is None else t.detach().to(DEV).requires_grad_(rg)
+    fg, zfg, mg, LSg = g(f), g(zf), g(m), g(L_S)
+    hg = _pack(kind, {k: v.detach() for k, v in hyp.items()}).to(DEV).requires_grad_(True)
+    mean, var, kl = F.layer_forward(x.detach().to(DEV), fg, Zx.to(DEV), zfg, hg, mg, LSg, kind, xdiv=xdiv)
+    _close(mean, mean_o, 1e-9, "mean")
+    _close(var, var_o, 1e-8, "var")
+    _close(kl, kl_o, 1e-9, "kl")
+    (mean.sum() + 0.5 * var.sum() + kl).backward()
+    _close(mg.grad, m.grad, 1e-7, "g_m")
+    _close(hg.grad, _pack(kind, {k: v.grad for k, v in hyp.items()}), 1e-7, "g_hyp")
+
+
+def test_argument_validation():
+    from mobocmf_amd import _lib
+    from mobocmf_amd import functional as F
+    x, f, Zx, zf, hyp, m, L_S = _mk(1, 2, 8, 12, 1, seed=0)
+    t = lambda a: a.to(DEV)
+    h = _pack(1, hyp).to(DEV)
+    with pytest.raises(_lib.MobocmfError):            # kind 1 without f
+        F.layer_forward(t(x), None, t(Zx), t(zf), h, t(m), t(L_S), 1)
+    with pytest.raises(_lib.MobocmfError):            # wrong hyper-parameter length
+        F.layer_forward(t(x), t(f), t(Zx), t(zf), h[:-1], t(m), t(L_S), 1)
+    with pytest.raises(_lib.MobocmfError):            # float32 is refused: the path is float64 end to end
+        F.layer_forward(t(x).float(), t(f), t(Zx), t(zf), h, t(m), t(L_S), 1)
+    with pytest.raises(_lib.MobocmfError):            # CPU tensors are refused: no CPU fallback
+        F.layer_forward(x, f, Zx, zf, _pack(1, hyp), m, L_S, 1)
+
+
+def test_elementwise_entry_points_match_torch():
+    from mobocmf_amd import functional as F
+    g = torch.Generator(device="cuda").manual_seed(0)
+    r = lambda *s: torch.randn(*s, dtype=torch.float64, device=DEV, generator=g)
+    # propagate (mfdgp_hidden_layer.py:272-274) with 3 replicas per row, incl. gradients
+    mean, var, eps = r(50).requires_grad_(True), (r(50).abs() + 0.1).requires_grad_(True), r(150)
+    out = F.propagate(mean, var, eps, 3)
+    ref = mean.repeat_interleave(3) + var.repeat_interleave(3).sqrt() * eps
+    assert torch.allclose(out, ref, rtol=1e-14)
+    gm, gv = torch.autograd.grad((out * eps).sum(), [mean, var])
+    gm_r, gv_r = torch.autograd.grad((ref * eps).sum(), [mean, var])
+    assert torch.allclose(gm, gm_r, rtol=1e-12) and torch.allclose(gv, gv_r, rtol=1e-12)
+    # masked expected log-likelihood (variational_elbo_mf.py:31-35), empty mask -> exactly 0
+    y, fid = r(50), (torch.arange(50, device=DEV) % 3 == 0).double()
+    mu, v, tau = r(150).requires_grad_(True), (r(150).abs() + 0.2).requires_grad_(True), torch.tensor([0.3], dtype=torch.float64, device=DEV, requires_grad=True)
+    val = F.elbo_data(mu, v, y, fid, tau, 1.0, div=3)
+    yy, mm = y.repeat_interleave(3), fid.repeat_interleave(3) == 1
+    ref = (-0.5 * (((yy - mu) ** 2 + v) / tau + torch.log(tau) + np.log(2 * np.pi)))[mm].sum() / 3
+    assert torch.allclose(val, ref, rtol=1e-12)
+    ga = torch.autograd.grad(val, [mu, v, tau])
+    gb = torch.autograd.grad(ref, [mu, v, tau])
+    for a, b in zip(ga, gb):
+        assert torch.allclose(a, b, rtol=1e-10, atol=1e-14)
+    assert float(F.elbo_data(mu, v, y, fid, tau, 7.0, div=3)) == 0.0
+    # acquisition moments (mfdgp.py:258-260) and the fused Adam update vs torch.optim.Adam
+    mt, vt = r(40).requires_grad_(True), (r(40).abs() + 0.1).requires_grad_(True)
+    mus, vs = F.acq_moments(mt, vt, 8)
+    mus_r = mt.reshape(5, 8).mean(1)
+    vs_r = (vt + mt ** 2).reshape(5, 8).mean(1) - mus_r ** 2
+    assert torch.allclose(mus, mus_r, rtol=1e-13) and torch.allclose(vs, vs_r, rtol=1e-12)
+    ga = torch.autograd.grad((mus * 2 + vs.log()).sum(), [mt, vt])
+    gb = torch.autograd.grad((mus_r * 2 + vs_r.log()).sum(), [mt, vt])
+    assert all(torch.allclose(a, b, rtol=1e-10) for a, b in zip(ga, gb))
+    p = r(1000)
+    p_ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-2)
+    ea, es = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        grad = r(1000)
+        p_ref.grad = grad.clone()
+        opt.step()
+        F.adam_step(p, grad, ea, es, step, 1e-2)
+    assert torch.allclose(p, p_ref.detach(), rtol=1e-12, atol=1e-14)
