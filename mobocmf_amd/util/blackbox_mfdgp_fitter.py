@@ -7,6 +7,7 @@ pass-through, and surrogate sharding over ranks (one process per GPU, see mobocm
 Conditioned training (:245-354) and Pareto sampling (:181-225) are SURVEY rows N1/N2 (not built yet).
 """
 import sys
+import warnings
 from copy import deepcopy
 
 import numpy as np
@@ -147,12 +148,23 @@ class BlackBoxMFDGPFitter:
             h.mfdgp.fix_variational_hypers(fix_variational_hypers)
             x, y, fid = h.train_dataset.tensors
             steps.append((tag, n, GraphedELBOStep(h.mfdgp, h.elbo, x, y, fid, lr=lr)))
+        from ..layers.mfdgp_hidden_layer import NotPSDError
+        for _, _, g in steps:
+            g.snapshot()
         for i in range(num_epochs):
             for _, _, g in steps:
                 g.step()
             if (i % ITER_PRINT) == 0 or (i + 1) == num_epochs:
                 for tag, n, g in steps:
-                    g.check()
+                    try:
+                        g.check()
+                        g.snapshot()
+                    except (NotPSDError, FloatingPointError) as err:
+                        # a replayed graph cannot retry with more jitter: roll back to the last verified state and
+                        # finish this surrogate's phase eagerly (per-step jitter ladder, as the reference)
+                        warnings.warn("%s %d: %s -- rolling back %d epochs and continuing eagerly" %
+                                      (tag, n, err, ITER_PRINT))
+                        g.restore_and_go_eager()
                     if self.verbose:
                         print("[%s: " % tag, n, "] Epoch:", i, "/", num_epochs, ". Avg. Neg. ELBO per epoch:",
                               g.loss.item(), "\t KL per epoch:", g.kl.item())

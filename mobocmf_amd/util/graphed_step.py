@@ -26,6 +26,7 @@ class GraphedELBOStep:
         self.loss = torch.zeros((), dtype=torch.float64, device=x.device)
         self.kl = torch.zeros((), dtype=torch.float64, device=x.device)
         self.graph = None
+        self._snap = None
         self.fixed_eps = fixed_eps     # list (eps[l] for layer l >= 1) reused every step: deterministic tests
         model.set_check_pd(False)      # no host sync inside the step; call check() when a verdict is needed
         model.clear_kl_cache()         # an older graph would pin AccumulateGrad nodes to another stream (capture-illegal)
@@ -74,6 +75,30 @@ class GraphedELBOStep:
             else:
                 self._eager()
         return self.loss, self.kl
+
+    # ------------------------------------------------------------------ snapshot / fallback
+    def snapshot(self):
+        """Clone of parameters + optimizer state (taken at points where check() passed)."""
+        with torch.cuda.stream(self.stream):
+            self._snap = ([p.detach().clone() for p in self.model.parameters()],
+                          [{k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                           for st in self.optimizer.state.values()])
+
+    def restore_and_go_eager(self):
+        """After a failed Cholesky inside a replayed step (no host-side jitter retry is possible there): roll back to
+        the last good snapshot and continue eagerly with the psd_safe_cholesky jitter ladder (check_pd=True), which is
+        what the reference does at every step."""
+        self.stream.synchronize()
+        ps, sts = self._snap
+        with torch.no_grad():
+            for p, s0 in zip(self.model.parameters(), ps):
+                p.copy_(s0)
+            for st, s0 in zip(self.optimizer.state.values(), sts):
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(s0[k])
+        self.graph = None
+        self.model.set_check_pd(True)
 
     def check(self):
         """Synchronising: raises if a Cholesky of the last step failed or the loss is not finite."""

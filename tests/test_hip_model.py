@@ -292,3 +292,31 @@ def test_fitter_trains_forrester():
     assert h.elbo(h.mfdgp(xb), yb.T, fb)[0].item() > e0
     fc = fitter.copy_uncond()
     assert fc.mfdgp_handlers_objs["obj1"].mfdgp is not h.mfdgp
+
+
+def test_graphed_step_rollback_to_eager():
+    """A failed Cholesky inside a replayed step cannot be retried with more jitter there: the step object rolls back to
+    its last verified snapshot and continues eagerly (per-step jitter ladder, the reference's behaviour)."""
+    from mobocmf_amd.layers import NotPSDError
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.util.graphed_step import GraphedELBOStep
+    prob = synthetic.make_problem(d=2, L=2, M=12, N=30, S=1, seed=5)
+    model = build_model(prob, S_train=1)
+    elbo = VariationalELBOMF(model, 30, 2)
+    t = lambda a: to_t(a).to(DEV)
+    g = GraphedELBOStep(model, elbo, t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], lr=1e-3)
+    g.step(); g.check(); g.snapshot()
+    good = [p.detach().clone() for p in model.parameters()]
+    model.hidden_layer_0.variational_strategy.jitter_val = -10.0        # K_mm - 10 I: certainly not PD
+    g2 = GraphedELBOStep(model, elbo, g.x, g.y, g.fid, lr=1e-3)           # captured with the bad jitter
+    g2._snap = g._snap
+    g2.step()
+    with pytest.raises((NotPSDError, FloatingPointError)):
+        g2.check()
+    model.hidden_layer_0.variational_strategy.jitter_val = 1e-6
+    g2.restore_and_go_eager()
+    for p, q in zip(model.parameters(), g._snap[0]):
+        assert torch.equal(p, q)
+    l, _ = g2.step()
+    g2.check()
+    assert g2.graph is None and bool(torch.isfinite(l))
