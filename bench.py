@@ -38,10 +38,13 @@ def algorithmic_flops(cfg):
     return 3.0 * tot
 
 
-def build_graphed(cfg, outputs, device, use_graph):
-    """One GraphedELBOStep (HIP-graph replay of the whole step) per surrogate, each on its own stream."""
+def build_graphed(cfg, outputs, device, use_graph, shard_rows=False):
+    """One GraphedELBOStep (HIP-graph replay of the whole step) per surrogate, each on its own stream.
+    shard_rows: every rank holds the SAME surrogates and 1/W of their batch rows (SURVEY 8(e) level 2)."""
     from mobocmf_amd.mlls import VariationalELBOMF
     from mobocmf_amd.util.graphed_step import GraphedELBOStep
+    if shard_rows:
+        from mobocmf_amd.parallel import RowShardedELBOStep as GraphedELBOStep
     steps = []
     for o in outputs:
         prob = synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=cfg["M"], N=cfg["N"], S=cfg["S"], output=o % 3, seed=o)
@@ -206,6 +209,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (CPU rehearsal of the multi-rank control flow)")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying HIP graphs")
+    ap.add_argument("--shard", default="surrogates", choices=["surrogates", "rows"],
+                    help="surrogates: each rank trains its own surrogates (weak scaling, default); rows: all ranks train "
+                         "the same surrogates on 1/W of the batch rows + one gradient all-reduce per step (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -230,10 +236,13 @@ def main():
     n_out = 3 if args.config == "C3" else min(cfg["outputs"], 3) if args.config != "C5" else 1
     if args.surrogates:
         n_out = args.surrogates
-    outputs = list(range(rank * n_out, rank * n_out + n_out))
+    rows = args.shard == "rows"
+    outputs = list(range(n_out)) if rows else list(range(rank * n_out, rank * n_out + n_out))
     torch.manual_seed(1234 + rank)
+    if rows and args.eager:
+        raise SystemExit("--shard rows runs through RowShardedELBOStep (graph | all-reduce | graph)")
     if not args.eager:
-        gsteps = build_graphed(cfg, outputs, device, use_graph=True)
+        gsteps = build_graphed(cfg, outputs, device, use_graph=True, shard_rows=rows)
         sur = [(g.model, g.elbo, g.optimizer, (g.x, g.y, g.fid)) for g in gsteps]
 
         def one_step(*_a):
@@ -291,17 +300,18 @@ def main():
     finite = finite and bool(torch.isfinite(gathered).all())
 
     if rank == 0:
-        n_sur = n_out * world
+        n_sur = n_out if rows else n_out * world
         value = n_sur * args.steps / elapsed
         line = {
             "metric": "ELBO steps/sec (MFDGP d=%d M=%d N=%d S=%d)" % (cfg["d"], cfg["M"], cfg["N"], cfg["S"]),
             "value": value, "unit": "ELBO steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if rows else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic d=%d, %d fidelities, M=%d, N=%d, S=%d, %d surrogates per GPU "
                                    "(2 objectives + 1 constraint), full batch, Adam" %
                                    (args.config, cfg["d"], cfg["L"], cfg["M"], cfg["N"], cfg["S"], n_out),
-                       "surrogates_per_gpu": n_out, "parallelism": "surrogate-per-rank x%d" % world},
+                       "surrogates_per_gpu": n_out, "parallelism": ("row-sharded x%d + grad all-reduce" if rows else "surrogate-per-rank x%d") % world},
             "per_surrogate_steps_per_s": value / n_sur,
             "step_flops_algorithmic": algorithmic_flops(cfg),
             "step_fp64_frac": algorithmic_flops(cfg) * value / world / (FP64_PEAK_TFLOPS * 1e12),

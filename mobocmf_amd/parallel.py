@@ -66,3 +66,103 @@ def gather_with_local_grad(fm, fv, cm, cv):
         return torch.cat([allv[:r * k], local, allv[(r + 1) * k:]], 0)
 
     return mix(fm), mix(fv), mix(cm), mix(cv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Level 2 of SURVEY 8(e): ONE surrogate over several GPUs.  The N rows of the batch are sharded over the ranks
+# (each rank therefore owns N/W * S of the N' columns of every layer's K_mn panel); parameters, K_mm and its
+# Cholesky chain (M^3/3, tiny) are replicated; the gradients of the M^2-sized objects and the hyper-parameters
+# need ONE all-reduce(sum) per step, and the two scalars of the ELBO ride in the same buffer.
+# ---------------------------------------------------------------------------------------------------------------
+def shard_rows(n, rank=None, world_size=None, device=None):
+    """Row indices of this rank: rank, rank + W, rank + 2W, ... (strided, so ragged N and the fidelity mix stay balanced)."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    return torch.arange(rank, n, world_size, device=device)
+
+
+def all_reduce_sum_(buf):
+    """In-place sum over the ranks (RCCL on HBM buffers; the gloo rehearsal hops through the host)."""
+    import torch.distributed as dist
+    _, w = world()
+    if w == 1:
+        return buf
+    if buf.device.type == "cuda" and dist.get_backend() == "gloo":
+        host = buf.cpu()
+        dist.all_reduce(host)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf)
+    return buf
+
+
+class GradBucket:
+    """One flat float64 buffer holding every trainable parameter's gradient (+ ``extra`` trailing scalars); the
+    parameters' ``.grad`` are views into it, so backward accumulates straight into the buffer that is all-reduced."""
+
+    def __init__(self, params, extra=0):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n + extra, dtype=torch.float64, device=dev)
+        off = 0
+        for p in self.params:
+            assert p.dtype == torch.float64
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.extra = self.flat[n:]
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def all_reduce(self):
+        all_reduce_sum_(self.flat)
+
+
+def _graphed_base():
+    from .util.graphed_step import GraphedELBOStep
+    return GraphedELBOStep
+
+
+class RowShardedELBOStep(_graphed_base()):
+    """The ELBO step of ONE surrogate with its batch rows sharded over the ranks of the default process group.
+
+    Every rank builds the same model from the same full data set (identical initialisation), keeps rows
+    ``shard_rows(N)`` of (x, y, fidelities) and runs the unmodified hot path on them.  ``VariationalELBOMF`` scales
+    the KL by (local batch / num_data) (variational_elbo_mf.py:44-47), so the local ELBOs sum to the full-batch ELBO
+    exactly and the summed gradients are the full-batch gradients: all ranks then apply the same Adam update and stay
+    bit-identical replicas.  Per step: graph(forward + backward) | all-reduce of one bucket | graph(Adam).
+    ``fixed_eps`` (tests) is given for the FULL batch (N*S per layer) and sliced here."""
+
+    exchanges = True
+
+    def __init__(self, model, elbo, x, y, fidelities, lr, fixed_eps=None, **kw):
+        idx = shard_rows(x.shape[0], device=x.device)
+        S = model.num_samples_for_training
+        if fixed_eps is not None:
+            fixed_eps = [None if e is None else e.reshape(x.shape[0], S)[idx].reshape(-1).contiguous() for e in fixed_eps]
+        self.rows = idx
+        self.bucket = GradBucket(model.parameters(), extra=2)
+        super().__init__(model, elbo, x[idx].contiguous(), y[idx].contiguous(), fidelities[idx].contiguous(), lr,
+                         fixed_eps=fixed_eps, **kw)
+
+    def _fwd_bwd(self):
+        self.bucket.zero_()
+        n = self.x.shape[0] * self.S
+        eps = self.fixed_eps if self.fixed_eps is not None else \
+            [None] + [torch.randn(n, dtype=torch.float64, device=self.x.device) for _ in range(1, self.L)]
+        out = self.model(self.x, eps=eps)
+        res = self.elbo(out, self.y.T, self.fid)
+        (-res[0]).backward()
+        self.bucket.extra[0].copy_(-res[0].detach())
+        self.bucket.extra[1].copy_(res[1].detach())
+        self.model.clear_kl_cache()
+
+    def _exchange(self):
+        self.bucket.all_reduce()
+
+    def _update(self):
+        self.optimizer.step()
+        self.loss.copy_(self.bucket.extra[0])
+        self.kl.copy_(self.bucket.extra[1])

@@ -13,6 +13,8 @@ import torch
 class GraphedELBOStep:
     """step() == one full-batch ELBO step on static (x, y, fidelities).  Falls back to eager with ``use_graph=False``."""
 
+    exchanges = False      # True in subclasses whose step has a collective between backward and update
+
     def __init__(self, model, elbo, x, y, fidelities, lr, betas=(0.9, 0.999), eps=1e-8, use_graph=True, stream=None,
                  warmup=3, fixed_eps=None):
         self.model, self.elbo = model, elbo
@@ -26,6 +28,7 @@ class GraphedELBOStep:
         self.loss = torch.zeros((), dtype=torch.float64, device=x.device)
         self.kl = torch.zeros((), dtype=torch.float64, device=x.device)
         self.graph = None
+        self.graph_update = None
         self._snap = None
         self.fixed_eps = fixed_eps     # list (eps[l] for layer l >= 1) reused every step: deterministic tests
         model.set_check_pd(False)      # no host sync inside the step; call check() when a verdict is needed
@@ -33,7 +36,7 @@ class GraphedELBOStep:
         if use_graph:
             self._capture(warmup)
 
-    def _eager(self):
+    def _fwd_bwd(self):
         self.optimizer.zero_grad(set_to_none=True)
         n = self.x.shape[0] * self.S
         eps = self.fixed_eps if self.fixed_eps is not None else \
@@ -41,10 +44,21 @@ class GraphedELBOStep:
         out = self.model(self.x, eps=eps)
         res = self.elbo(out, self.y.T, self.fid)
         (-res[0]).backward()
-        self.optimizer.step()
         self.loss.copy_(-res[0].detach())
         self.kl.copy_(res[1].detach())
         self.model.clear_kl_cache()
+
+    def _exchange(self):
+        """Between backward and the update; a no-op for a surrogate that lives on one GPU (RowShardedELBOStep
+        all-reduces the gradient bucket here)."""
+
+    def _update(self):
+        self.optimizer.step()
+
+    def _eager(self):
+        self._fwd_bwd()
+        self._exchange()
+        self._update()
 
     def _capture(self, warmup):
         cur = torch.cuda.current_stream(self.x.device)
@@ -54,24 +68,40 @@ class GraphedELBOStep:
             snapshot = [p.detach().clone() for p in self.model.parameters()]
             for _ in range(warmup):
                 self._eager()
-            with torch.no_grad():           # warm-up steps must not count as training
-                for p, s0 in zip(self.model.parameters(), snapshot):
-                    p.copy_(s0)
-                for st in self.optimizer.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
-                            v.zero_()
-            self.optimizer.zero_grad(set_to_none=True)
+            self._reset_after_warmup(snapshot)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self._eager()
+            if not self.exchanges:
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self._eager()
+            else:       # the collective stays outside: graph | all-reduce | graph
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self._fwd_bwd()
+                self._exchange()
+                self.graph_update = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_update, stream=self.stream):
+                    self._update()
+                self._reset_after_warmup(snapshot)     # the capture pass above ran the exchange + nothing else for real
         cur.wait_stream(self.stream)
+
+    def _reset_after_warmup(self, snapshot):
+        with torch.no_grad():           # warm-up steps must not count as training
+            for p, s0 in zip(self.model.parameters(), snapshot):
+                p.copy_(s0)
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        if not self.exchanges:
+            self.optimizer.zero_grad(set_to_none=True)
 
     def step(self):
         """Enqueues one step on ``self.stream``; ``self.loss`` / ``self.kl`` hold the step's -ELBO and scaled KL."""
         with torch.cuda.stream(self.stream):
             if self.graph is not None:
                 self.graph.replay()
+                if self.exchanges:
+                    self._exchange()
+                    self.graph_update.replay()
             else:
                 self._eager()
         return self.loss, self.kl

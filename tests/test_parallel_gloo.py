@@ -66,3 +66,61 @@ def test_world_size_1_degenerates_to_identity():
     assert torch.equal(parallel.all_gather_moments(x), x)
     mine, owner = parallel.shard_blackboxes(["a", "b"], rank=0, world_size=1)
     assert mine == ["a", "b"]
+
+
+def _sharded_worker(rank, world, port, q):
+    """Level 2 of SURVEY 8(e): rows of ONE surrogate sharded over the ranks; the host logic (shard_rows, GradBucket,
+    the single all-reduce) is exercised with the oracle as the local compute (the HIP path needs a GPU)."""
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import oracle_state, small_problem, state_leaves, to_t
+    from mobocmf_amd import parallel
+    from oracle import mfdgp_oracle as O
+    prob = small_problem(d=2, L=2, M=6, N=11, S=3, seed=3)          # ragged: 11 rows over 2 ranks
+    x, y, fid = to_t(prob["x"]), to_t(prob["y"]).reshape(-1), to_t(prob["fid"]).reshape(-1)
+    N, S = x.shape[0], 3
+    eps = [None, to_t(prob["eps"][1]).reshape(-1)]
+    # full batch, computed redundantly on every rank: the expected result
+    st_full = oracle_state(prob, requires_grad=True)
+    e_full, kl_full = O.elbo(st_full, x, y, fid, eps=eps, S=S)
+    (-e_full).backward()
+    g_full = torch.cat([p.grad.reshape(-1) for p in state_leaves(st_full)])
+    # sharded
+    st = oracle_state(prob, requires_grad=True)
+    leaves = state_leaves(st)
+    bucket = parallel.GradBucket(leaves, extra=2)
+    idx = parallel.shard_rows(N)
+    eps_loc = [None, eps[1].reshape(N, S)[idx].reshape(-1)]
+    bucket.zero_()
+    e_loc, kl_loc = O.elbo(st, x[idx], y[idx], fid[idx], eps=eps_loc, S=S, num_data=N)
+    (-e_loc).backward()
+    bucket.extra[0] = -e_loc.detach()
+    bucket.extra[1] = kl_loc.detach()
+    bucket.all_reduce()
+    n = g_full.numel()
+    q.put((rank, idx.tolist(), float((bucket.flat[:n] - g_full).abs().max() / g_full.abs().max()),
+           float(bucket.extra[0] + e_full.detach()), float(bucket.extra[1] - kl_full.detach()),
+           all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in leaves)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_row_sharded_gradients_sum_to_full_batch():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4, 6, 8, 10] and res[1][1] == [1, 3, 5, 7, 9]
+    for _, _, gerr, de, dkl, views in res:
+        assert gerr < 1e-12 and abs(de) < 1e-10 and abs(dkl) < 1e-12 and views
