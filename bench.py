@@ -212,7 +212,12 @@ def main():
     ap.add_argument("--shard", default="surrogates", choices=["surrogates", "rows"],
                     help="surrogates: each rank trains its own surrogates (weak scaling, default); rows: all ranks train "
                          "the same surrogates on 1/W of the batch rows + one gradient all-reduce per step (strong scaling)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="serialise each surrogate's layers on one stream (no chain/panel split across streams)")
     args = ap.parse_args()
+    if args.no_overlap:
+        from mobocmf_amd.models import MFDGP
+        MFDGP.overlap_chains = False
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -61,7 +61,26 @@ typedef struct {
     int32_t want_dx; /* backward also returns d/dx (acquisition optimisation) */
     double jitter;   /* added to diag(K_mm); gpytorch variational_cholesky_jitter = 1e-6 */
     double min_var;  /* MultivariateNormal.variance clamp; gpytorch min_variance = 1e-10 */
+    int32_t phase;   /* MOBOCMF_PHASE_*: which half of the layer call to run (0 = both) */
+    int32_t reserved;
 } mobocmf_layer_desc;
+
+/* A layer call has two halves that only meet in `saved` (forward) / `scratch` (backward):
+ *   CHAIN  the M x M work that depends on the parameters alone: K_mm, its Cholesky and inverse, U = L^-1 L_S,
+ *          a = L^-1 m, the KL (forward); the M x M backward chain, Cholesky backward, Gram backward of K_mm (backward);
+ *   PANEL  the M x N' work: K_mn, A, C, moments (forward); dA, the weighted syrk, dK, Gram backward of K_mn (backward).
+ * Forward order: CHAIN then PANEL.  Backward order: PANEL then CHAIN (same private `scratch` for both calls).
+ * A caller may run the CHAIN halves of several layers on another stream, overlapping the latency-bound chain of one
+ * layer with the grid-filling PANEL work of another.  Pointers a half does not touch may be NULL.
+ * In a split backward the CHAIN half OVERWRITES g_zf / g_hyp with its own contribution (the caller adds the PANEL
+ * half's); CHAIN_ONLY additionally treats the PANEL half's contribution as zero (no upstream mean/var gradient). */
+#define MOBOCMF_PHASE_ALL 0
+#define MOBOCMF_PHASE_CHAIN 1
+#define MOBOCMF_PHASE_PANEL 2
+#define MOBOCMF_PHASE_CHAIN_ONLY 3   /* backward only */
+#define MOBOCMF_PHASE_PANEL_INPUTS 4 /* PANEL half with the parameters held constant: backward yields g_f / g_x (and the
+                                      * K_mn share of g_zf / g_hyp) but skips the M x M contractions the CHAIN half would
+                                      * consume -- acquisition optimisation against a fixed model */
 
 int mobocmf_version(void);
 /* 1 if the current HIP device is gfx950. */
@@ -70,6 +89,11 @@ int mobocmf_device_arch_ok(void);
 /* Bytes of the `saved` buffer (forward -> backward state: L, L^-1, U, K_mn, A, C, ...) and of the scratch
  * buffer (dead after each call). */
 int mobocmf_layer_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes);
+
+/* Leading bytes of `saved` that hold the CHAIN half's state (L, L^-1, U, a, ...).  They do not depend on Np: a caller
+ * whose parameters are fixed (acquisition optimisation) runs the CHAIN half once and copies these bytes to the front of
+ * the `saved` buffer of every later PANEL call. */
+int mobocmf_layer_chain_state_bytes(const mobocmf_layer_desc* desc, size_t* bytes);
 
 /* mean[Np], var[Np] (clamped at min_var), kl[1] = KL(q(u) || p(u)), info[1]. */
 int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,

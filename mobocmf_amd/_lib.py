@@ -17,7 +17,8 @@ _ERR = {1: "MOBOCMF_BAD_ARG", 2: "MOBOCMF_WORKSPACE_TOO_SMALL", 3: "MOBOCMF_HIP_
 class LayerDesc(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("d", ctypes.c_int32), ("M", ctypes.c_int32), ("xdiv", ctypes.c_int32),
                 ("Np", ctypes.c_int64), ("branch", ctypes.c_int32), ("want_dx", ctypes.c_int32),
-                ("jitter", ctypes.c_double), ("min_var", ctypes.c_double)]
+                ("jitter", ctypes.c_double), ("min_var", ctypes.c_double), ("phase", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class MobocmfError(RuntimeError):
@@ -35,6 +36,7 @@ SYMBOLS = {
     "mobocmf_version": [],
     "mobocmf_device_arch_ok": [],
     "mobocmf_layer_workspace_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
+    "mobocmf_layer_chain_state_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ)],
     "mobocmf_layer_forward": [ctypes.POINTER(LayerDesc)] + [_P] * 11 + [_P, _SZ, _P, _SZ, _P],
     "mobocmf_layer_backward": [ctypes.POINTER(LayerDesc)] + [_P] * 16 + [_P, _SZ, _P, _SZ, _P],
     "mobocmf_predictive_covariance": [ctypes.POINTER(LayerDesc), _P, _P, _P, _P, _I64, _P, _SZ, _P, _SZ, _P],

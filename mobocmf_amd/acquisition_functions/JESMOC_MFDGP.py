@@ -8,6 +8,8 @@ N3) is replaced by ``optimize_acqf_multistart``: the same recipe -- ``raw_sample
 iteration is a single pair of model evaluations.  With surrogates sharded over ranks the coupled acquisition is the
 all-gather + sum of mobocmf_amd.parallel.coupled_acquisition.
 """
+import contextlib
+
 import torch
 
 from .. import functional as F
@@ -34,6 +36,13 @@ class _JES_MFDGP:
         return F.jes(v_u, v_c)
 
     __call__ = forward
+
+    @contextlib.contextmanager
+    def frozen(self):
+        """Both models' parameters are constants while the acquisition is optimised: their M x M chains are computed
+        once (MFDGP.frozen_chains) instead of at each of the ~400 evaluations."""
+        with self.mfdgp_uncond.frozen_chains(), self.mfdgp_cond.frozen_chains():
+            yield self
 
 
 def optimize_acqf_multistart(acq_function, bounds, num_restarts=5, raw_samples=200, maxiter=200, lr=0.02,
@@ -115,8 +124,11 @@ class JESMOC_MFDGP:
         return acq
 
     def _optimize(self, fidelity, **kw):
-        return optimize_acqf_multistart(lambda x: self.coupled_acq(x, fidelity=fidelity), self.standard_bounds,
-                                        num_restarts=5, raw_samples=200, maxiter=kw.get("maxiter", 200))
+        with contextlib.ExitStack() as stack:       # fitted models: freeze every surrogate's chain for the whole search
+            for jes in list(self.objectives[fidelity].values()) + list(self.constraints[fidelity].values()):
+                stack.enter_context(jes.frozen())
+            return optimize_acqf_multistart(lambda x: self.coupled_acq(x, fidelity=fidelity), self.standard_bounds,
+                                            num_restarts=5, raw_samples=200, maxiter=kw.get("maxiter", 200))
 
     def get_nextpoint_coupled(self, iteration=None, verbose=False, maxiter=200):
         """Next point + fidelity by cost-weighted acquisition (:137-184)."""

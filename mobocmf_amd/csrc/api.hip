@@ -73,7 +73,8 @@ struct Dims {
 
 bool valid_desc(const mobocmf_layer_desc* d) {
     return d && (d->kind == 0 || d->kind == 1) && d->d >= 1 && d->d <= 32 && d->M >= 1 && d->xdiv >= 1 &&
-           d->xdiv <= 48 && d->Np >= 1 && d->Np % d->xdiv == 0 && (d->branch == 0 || d->branch == 1);
+           d->xdiv <= 48 && d->Np >= 1 && d->Np % d->xdiv == 0 && (d->branch == 0 || d->branch == 1) && d->phase >= 0 &&
+           d->phase <= MOBOCMF_PHASE_PANEL_INPUTS;
 }
 
 Dims dims_of(const mobocmf_layer_desc* d) {
@@ -108,10 +109,17 @@ struct Saved {
     double *L, *Linv, *LinvT, *U, *UT, *LSp, *a, *mp, *K, *A, *C, *knn, *q, *r, *varraw;
 };
 
-bool carve_saved(Bump& b, const Dims& D, Saved& S) {
-    int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
+// The CHAIN half's state comes first and does not depend on N': its leading bytes may be copied between the `saved`
+// buffers of calls that share the parameters (mobocmf_layer_chain_state_bytes).
+void carve_chain_state(Bump& b, const Dims& D, Saved& S) {
+    int64_t mm = (int64_t)D.Mp * D.Mp;
     S.L = b.take(mm); S.Linv = b.take(mm); S.LinvT = b.take(mm); S.U = b.take(mm); S.UT = b.take(mm); S.LSp = b.take(mm);
     S.a = b.take(D.Mp); S.mp = b.take(D.Mp);
+}
+
+bool carve_saved(Bump& b, const Dims& D, Saved& S) {
+    int64_t mn = (int64_t)D.Mp * D.Np;
+    carve_chain_state(b, D, S);
     S.K = b.take(mn); S.A = b.take(mn); S.C = b.take(mn);
     S.knn = b.take(D.Np); S.q = b.take(D.Np); S.r = b.take(D.Np); S.varraw = b.take(D.Np);
     return b.ok;
@@ -204,13 +212,27 @@ int mobocmf_layer_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_
     return MOBOCMF_OK;
 }
 
+int mobocmf_layer_chain_state_bytes(const mobocmf_layer_desc* desc, size_t* bytes) {
+    if (!valid_desc(desc) || !bytes) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc);
+    Bump b(nullptr, ~(size_t)0 >> 1);
+    Saved S;
+    carve_chain_state(b, D, S);
+    *bytes = b.off;
+    return MOBOCMF_OK;
+}
+
 int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
                           const double* zf, const double* hyp, const double* m, const double* L_S, double* mean,
                           double* var, double* kl, int32_t* info, void* saved, size_t saved_bytes, void* scratch,
                           size_t scratch_bytes, mobocmf_stream_t stream) {
-    if (!valid_desc(desc) || !x || !Zx || !hyp || !m || !L_S || !mean || !var || !kl || !info || !saved || !scratch)
+    if (!valid_desc(desc) || desc->phase == MOBOCMF_PHASE_CHAIN_ONLY || !Zx || !hyp || !saved || !scratch)
         return MOBOCMF_BAD_ARG;
-    if (desc->kind == 1 && (!f || !zf)) return MOBOCMF_BAD_ARG;
+    const bool do_chain = desc->phase == MOBOCMF_PHASE_ALL || desc->phase == MOBOCMF_PHASE_CHAIN;
+    const bool do_panel = desc->phase != MOBOCMF_PHASE_CHAIN;
+    if (do_chain && (!m || !L_S || !kl || !info)) return MOBOCMF_BAD_ARG;
+    if (do_panel && (!x || !mean || !var)) return MOBOCMF_BAD_ARG;
+    if (desc->kind == 1 && (!zf || (do_panel && !f))) return MOBOCMF_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     Dims D = dims_of(desc);
     Bump bs(saved, saved_bytes), bf(scratch, scratch_bytes);
@@ -220,11 +242,12 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     const int Mp = D.Mp;
     const int64_t Np = D.Np, mm = (int64_t)Mp * Mp;
 
-    // K_mm + jitter -> L (in place Cholesky)
     GramArgs g = {};
     g.kind = desc->kind; g.d = desc->d; g.xdiv = 1; g.zdiv = 1;
     g.x = Zx; g.f = zf; g.nbase = D.M; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp;
     g.K = S.L; g.ldk = Mp; g.Mp = Mp; g.Np = Mp; g.knn = nullptr; g.jitter = desc->jitter; g.is_kmm = 1;
+    if (do_chain) {
+    // K_mm + jitter -> L (in place Cholesky)
     TRY(launch_gram_fwd(g, s));
     TRY(launch_potrf(S.L, Mp, Mp, F.Dinv, F.Ld, info, s));
     TRY(launch_zero32(S.Linv, mm * 2, s));
@@ -242,6 +265,8 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     TRY(launch_transpose(S.U, Mp, S.UT, Mp, Mp, Mp, s));
     TRY(launch_gemv_rows(S.Linv, Mp, S.mp, S.a, Mp, Mp, 1.0, 0, s));
     TRY(launch_kl(S.L, S.LSp, S.U, S.a, D.M, Mp, kl, F.qpart, s));
+    }
+    if (!do_panel) return MOBOCMF_OK;
 
     // K_mn, k_nn
     g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
@@ -266,10 +291,15 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
                            const double* g_mean, const double* g_var, const double* g_kl, double* g_f, double* g_zf,
                            double* g_hyp, double* g_m, double* g_LS, double* g_x, void* saved, size_t saved_bytes,
                            void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
-    if (!valid_desc(desc) || !x || !Zx || !hyp || !m || !L_S || !g_hyp || !g_m || !g_LS || !saved || !scratch)
-        return MOBOCMF_BAD_ARG;
-    if (desc->kind == 1 && (!f || !zf || !g_f || !g_zf)) return MOBOCMF_BAD_ARG;
-    if (desc->want_dx && !g_x) return MOBOCMF_BAD_ARG;
+    if (!valid_desc(desc) || !Zx || !hyp || !g_hyp || !saved || !scratch) return MOBOCMF_BAD_ARG;
+    const bool inputs_only = desc->phase == MOBOCMF_PHASE_PANEL_INPUTS;   // parameters are constants: no H / Hc / da
+    const bool do_panel = desc->phase == MOBOCMF_PHASE_ALL || desc->phase == MOBOCMF_PHASE_PANEL || inputs_only;
+    const bool do_chain = desc->phase == MOBOCMF_PHASE_ALL || desc->phase == MOBOCMF_PHASE_CHAIN ||
+                          desc->phase == MOBOCMF_PHASE_CHAIN_ONLY;
+    const int acc = desc->phase == MOBOCMF_PHASE_ALL ? 1 : 0;   // split: the chain half reports its own g_hyp / g_zf
+    if (do_panel && (!x || !g_mean || !g_var || (desc->want_dx && !g_x))) return MOBOCMF_BAD_ARG;
+    if (do_chain && (!g_kl || !g_m || !g_LS)) return MOBOCMF_BAD_ARG;
+    if (desc->kind == 1 && (!zf || !g_zf || (do_panel && (!f || !g_f)))) return MOBOCMF_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     Dims D = dims_of(desc);
     Bump bs(saved, saved_bytes), bb(scratch, scratch_bytes);
@@ -284,6 +314,10 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     int32_t* nclamped = (int32_t*)B.flag;
     const int64_t slab_elems = (int64_t)(D.splitk > 16 ? D.splitk : 16) * mm;
 
+    if (desc->branch != 0) Hc = H;
+    GramArgs g = {};
+    g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
+    if (do_panel) {
     TRY(launch_moments_bwd_prep(g_mean, g_var, S.knn, S.q, S.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
                                 B.gv2, B.cgv, nclamped, s));
     // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
@@ -296,7 +330,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     //   dU = 2 tril(A diag(gv) C^T) = 2 tril(H U),   dA A^T = 2 U U^T H + a da^T - 2 Hc,  Hc = A diag(cgv) A^T.
     // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
     // (skip_if_zero) when no column is clamped.
-    {
+    if (!inputs_only) {
         GemmArgs ga = gemm_args(S.A, Np, S.A, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
         ga.bscale = B.gv; ga.lower_out = 1; ga.slab_stride = mm;
         TRY(launch_gemm(ga, true, D.splitk, s));
@@ -305,22 +339,18 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
             ga.bscale = B.cgv; ga.skip_if_zero = nclamped;
             TRY(launch_gemm(ga, true, D.splitk, s));
             TRY(launch_reduce_slabs_sym(B.slabs, mm, D.splitk, Hc, Mp, nclamped, H, s));
-        } else {
-            Hc = H;
         }
     }
     // da = A gmu
-    TRY(launch_gemv_long(S.A, Np, B.gmu, B.da, Mp, Np, B.gpart, s));
+    if (!inputs_only) TRY(launch_gemv_long(S.A, Np, B.gmu, B.da, Mp, Np, B.gpart, s));
     // dK = L^-T dA
     {
         GemmArgs ga = gemm_args(S.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
         TRY(launch_gemm(ga, false, 1, s));
     }
     // Gram backward of K_mn and k_nn
-    GramArgs g = {};
-    g.kind = desc->kind; g.d = desc->d; g.xdiv = desc->xdiv; g.zdiv = 1;
-    g.x = x; g.f = f; g.nbase = D.nbase; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp;
-    g.ldk = Np; g.Mp = Mp; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
+    g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
+    g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
     g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
     TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
     TRY(launch_sum_partials(B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, g_hyp, D.H, 1.0, 0, s));
@@ -330,6 +360,13 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     }
     if (desc->want_dx)
         TRY(launch_sum_partials(B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, g_x, D.nbase * desc->d, 1.0, 0, s));
+    }
+    if (!do_chain) return MOBOCMF_OK;
+    if (desc->phase == MOBOCMF_PHASE_CHAIN_ONLY) {      // no upstream mean/var gradient: H = Hc = 0, da = 0
+        TRY(launch_zero32(H, mm * 2, s));
+        if (Hc != H) TRY(launch_zero32(Hc, mm * 2, s));
+        TRY(launch_zero32(B.da, (int64_t)Mp * 2, s));
+    }
 
     // ---- M x M chain:  dL = -tril(L^-T [dA A^T + dU_tot U^T + da_tot a^T]) + gkl diag(1/L_ii)
     {
@@ -378,9 +415,9 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     g.xdiv = 1; g.x = Zx; g.f = zf; g.nbase = D.M; g.ldk = Mp; g.Np = Mp; g.G = Gm; g.gknn = nullptr;
     g.hyp_part = B.hyp_part2; g.df_part = B.df_part2; g.dzf_part = B.dzf_part2; g.dx_part = nullptr;
     TRY(launch_gram_bwd(g, false, s));
-    TRY(launch_sum_partials(B.hyp_part2, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, D.H, g_hyp, D.H, 1.0, 1, s));
+    TRY(launch_sum_partials(B.hyp_part2, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, D.H, g_hyp, D.H, 1.0, acc, s));
     if (desc->kind == 1) {
-        TRY(launch_sum_partials(B.df_part2, D.ggrid_mm.y, Mp, g_zf, D.M, 1.0, 1, s));
+        TRY(launch_sum_partials(B.df_part2, D.ggrid_mm.y, Mp, g_zf, D.M, 1.0, acc, s));
         TRY(launch_sum_partials(B.dzf_part2, D.ggrid_mm.x, Mp, g_zf, D.M, 1.0, 1, s));
     }
     return MOBOCMF_OK;

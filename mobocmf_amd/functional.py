@@ -48,9 +48,12 @@ def hyp_len(kind, d):
     return 1 + d if kind == 0 else 5 + 2 * d
 
 
-def make_desc(kind, d, M, Np, xdiv=1, branch=0, want_dx=False, jitter=JITTER, min_var=MIN_VARIANCE):
+PHASE_ALL, PHASE_CHAIN, PHASE_PANEL, PHASE_CHAIN_ONLY, PHASE_PANEL_INPUTS = 0, 1, 2, 3, 4
+
+
+def make_desc(kind, d, M, Np, xdiv=1, branch=0, want_dx=False, jitter=JITTER, min_var=MIN_VARIANCE, phase=PHASE_ALL):
     return LayerDesc(kind=kind, d=d, M=M, xdiv=xdiv, Np=Np, branch=branch, want_dx=int(want_dx), jitter=jitter,
-                     min_var=min_var)
+                     min_var=min_var, phase=phase, reserved=0)
 
 
 def workspace_bytes(desc):
@@ -120,6 +123,218 @@ class _LayerFn(torch.autograd.Function):
                                         _ptr(scratch), scratch.numel(), _stream())
         _lib.check(rc, "mobocmf_layer_backward")
         return (g_x, g_f, None, g_zf, g_hyp, g_m, g_LS, None, None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The same layer call in two halves (include/mobocmf_hip.h, MOBOCMF_PHASE_*): the CHAIN half depends on the
+# parameters alone, so a model launches it for every layer up front on a side stream and the latency-bound
+# M x M chains (one wavefront per Cholesky panel) run under the grid-filling PANEL work of the other layers.
+# Autograd runs each half's backward on the stream its forward ran on and orders them through the ``token``.
+# ------------------------------------------------------------------------------------------------------------
+_side_streams = {}
+
+
+def side_stream_for(main):
+    """The chain stream paired with ``main`` (one per (device, main stream))."""
+    key = (main.device.index, main.cuda_stream)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=main.device)
+        _side_streams[key] = st
+    return st
+
+
+class LayerPass:
+    """State shared by the two halves of one split layer call."""
+    __slots__ = ("kind", "d", "M", "Np", "xdiv", "branch", "jitter", "min_var", "want_dx", "info", "saved", "sb", "cb",
+                 "bscratch", "main", "side", "ready", "kl", "frozen")
+
+    def desc(self, phase):
+        return make_desc(self.kind, self.d, self.M, self.Np, self.xdiv, self.branch, self.want_dx, self.jitter,
+                         self.min_var, phase)
+
+
+class _ChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Zx, zf, hyp, m, L_S, P):
+        lib = _lib.require_device()
+        Zx, zf, hyp, m, L_S = (_prep(t) for t in (Zx, zf, hyp, m, L_S))
+        dev = Zx.device
+        desc = P.desc(PHASE_CHAIN)
+        P.sb, P.cb = workspace_bytes(desc)
+        P.saved = torch.empty(P.sb, dtype=torch.uint8, device=dev)
+        scratch = scratch_buffer(P.cb, dev)
+        kl = torch.empty((), dtype=torch.float64, device=dev)
+        token = torch.zeros(1, dtype=torch.float64, device=dev)
+        rc = lib.mobocmf_layer_forward(ctypes.byref(desc), None, None, _ptr(Zx), _ptr(zf), _ptr(hyp), _ptr(m), _ptr(L_S),
+                                       None, None, _ptr(kl), _ptr(P.info), _ptr(P.saved), P.sb, _ptr(scratch),
+                                       scratch.numel(), _stream())
+        _lib.check(rc, "mobocmf_layer_forward[chain]")
+        if P.main is not None:      # allocated here (side stream), consumed on the main stream
+            for t in (P.saved, kl, token):
+                t.record_stream(P.main)
+            for t in (hyp, zf, m, L_S):     # allocated on the main stream, read here
+                if t is not None:
+                    t.record_stream(P.side)
+        ctx.P = P
+        ctx.save_for_backward(*[t for t in (Zx, zf, hyp, m, L_S) if t is not None])
+        ctx.has_f = zf is not None
+        return token, kl
+
+    @staticmethod
+    def backward(ctx, g_token, g_kl):
+        lib = _lib.require_device()
+        P = ctx.P
+        ts = list(ctx.saved_tensors)
+        if ctx.has_f:
+            Zx, zf, hyp, m, L_S = ts
+        else:
+            Zx, hyp, m, L_S = ts
+            zf = None
+        dev = Zx.device
+        M = P.M
+        phase = PHASE_CHAIN
+        scratch = P.bscratch
+        P.bscratch = None
+        if scratch is None:         # the PANEL half took no part in this backward (only the KL was differentiated)
+            scratch = torch.empty(P.cb, dtype=torch.uint8, device=dev)
+            phase = PHASE_CHAIN_ONLY
+        if g_kl is None:
+            g_kl = torch.zeros((), dtype=torch.float64, device=dev)
+        g_kl = _prep(g_kl)
+        desc = P.desc(phase)
+        new = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)
+        g_zf = new(M) if ctx.has_f else None
+        g_hyp, g_m, g_LS = new(hyp.numel()), new(M), new(M, M)
+        rc = lib.mobocmf_layer_backward(ctypes.byref(desc), None, None, _ptr(Zx), _ptr(zf), _ptr(hyp), _ptr(m),
+                                        _ptr(L_S), None, None, _ptr(g_kl), None, _ptr(g_zf), _ptr(g_hyp), _ptr(g_m),
+                                        _ptr(g_LS), None, _ptr(P.saved), P.sb, _ptr(scratch), scratch.numel(), _stream())
+        _lib.check(rc, "mobocmf_layer_backward[chain]")
+        return None, g_zf, g_hyp, g_m, g_LS, None
+
+
+class _PanelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f, Zx, zf, hyp, token, P):
+        lib = _lib.require_device()
+        x, f, Zx, zf, hyp = (_prep(t) for t in (x, f, Zx, zf, hyp))
+        if x.shape[0] * P.xdiv != P.Np or x.shape[1] != P.d or (P.kind == 1 and (f is None or f.numel() != P.Np)):
+            raise _lib.MobocmfError("shape mismatch between the two halves of a split layer call")
+        dev = x.device
+        desc = P.desc(PHASE_PANEL)
+        scratch = scratch_buffer(P.cb, dev)
+        mean = torch.empty(P.Np, dtype=torch.float64, device=dev)
+        var = torch.empty(P.Np, dtype=torch.float64, device=dev)
+        rc = lib.mobocmf_layer_forward(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp), None, None,
+                                       _ptr(mean), _ptr(var), None, None, _ptr(P.saved), P.sb, _ptr(scratch),
+                                       scratch.numel(), _stream())
+        _lib.check(rc, "mobocmf_layer_forward[panel]")
+        ctx.P = P
+        ctx.save_for_backward(*[t for t in (x, f, Zx, zf, hyp) if t is not None])
+        ctx.has_f = f is not None
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, g_mean, g_var):
+        lib = _lib.require_device()
+        P = ctx.P
+        ts = list(ctx.saved_tensors)
+        if ctx.has_f:
+            x, f, Zx, zf, hyp = ts
+        else:
+            x, Zx, hyp = ts
+            f = zf = None
+        dev = x.device
+        g_mean, g_var = _prep(g_mean), _prep(g_var)
+        if P.frozen:        # constant parameters: nothing is handed to a CHAIN half
+            desc = P.desc(PHASE_PANEL_INPUTS)
+            scratch = scratch_buffer(P.cb, dev)
+        else:
+            desc = P.desc(PHASE_PANEL)
+            # private scratch: H, Hc, da stay in it until the CHAIN half (side stream) has consumed them
+            scratch = torch.empty(P.cb, dtype=torch.uint8, device=dev)
+            if P.side is not None:
+                scratch.record_stream(P.side)
+        new = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)
+        g_f = new(P.Np) if ctx.has_f else None
+        g_zf = new(P.M) if ctx.has_f else None
+        g_hyp = new(hyp.numel())
+        g_x = new(x.shape[0], P.d) if P.want_dx else None
+        rc = lib.mobocmf_layer_backward(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp), None, None,
+                                        _ptr(g_mean), _ptr(g_var), None, _ptr(g_f), _ptr(g_zf), _ptr(g_hyp), None, None,
+                                        _ptr(g_x), _ptr(P.saved), P.sb, _ptr(scratch), scratch.numel(), _stream())
+        _lib.check(rc, "mobocmf_layer_backward[panel]")
+        if P.frozen:
+            return g_x, g_f, None, None, None, None, None
+        P.bscratch = scratch
+        return g_x, g_f, None, g_zf, g_hyp, torch.zeros(1, dtype=torch.float64, device=dev), None
+
+
+def layer_chain(Zx, zf, hyp, m, L_S, kind, Np, xdiv=1, branch=0, jitter=JITTER, min_var=MIN_VARIANCE, want_dx=False,
+                info_out=None, main=None, side=None):
+    """CHAIN half of a layer call for N' = Np rows: returns (LayerPass, token); ``LayerPass.kl`` holds the KL.  Call it
+    under ``torch.cuda.stream(side)`` with ``main`` = the stream the PANEL half will run on (or both None: same stream)."""
+    P = LayerPass()
+    P.kind, P.d, P.M, P.Np, P.xdiv, P.branch = kind, Zx.shape[1], Zx.shape[0], Np, xdiv, branch
+    P.jitter, P.min_var, P.want_dx = jitter, min_var, want_dx
+    P.info = info_out if info_out is not None else torch.zeros((), dtype=torch.int32, device=Zx.device)
+    P.bscratch, P.main, P.side, P.frozen = None, main, side, False
+    token, P.kl = _ChainFn.apply(Zx, zf, hyp, m, L_S, P)
+    P.ready = None
+    if side is not None:
+        P.ready = torch.cuda.Event()
+        P.ready.record(side)
+    return P, token
+
+
+def layer_panel(P, token, x, f, Zx, zf, hyp):
+    """PANEL half: mean (N'), var (N').  Waits (stream-side) for the CHAIN half of the same pass."""
+    if P.ready is not None:
+        torch.cuda.current_stream(x.device).wait_event(P.ready)
+    return _PanelFn.apply(x, f, Zx, zf, hyp, token, P)
+
+
+class FrozenChain:
+    """CHAIN state of one layer for FIXED parameters (acquisition optimisation): computed once, then copied to the
+    front of the ``saved`` buffer of every PANEL call; gradients flow to the layer inputs only."""
+    __slots__ = ("kind", "d", "M", "branch", "jitter", "min_var", "state", "kl", "info", "Zx", "zf", "hyp")
+
+
+def freeze_chain(Zx, zf, hyp, m, L_S, kind, branch=1, jitter=JITTER, min_var=MIN_VARIANCE):
+    lib = _lib.require_device()
+    with torch.no_grad():
+        Zx, zf, hyp, m, L_S = (_prep(None if t is None else t.detach()) for t in (Zx, zf, hyp, m, L_S))
+        fc = FrozenChain()
+        fc.kind, fc.d, fc.M, fc.branch, fc.jitter, fc.min_var = kind, Zx.shape[1], Zx.shape[0], branch, jitter, min_var
+        fc.Zx, fc.zf, fc.hyp = Zx, zf, hyp
+        dev = Zx.device
+        desc = make_desc(kind, fc.d, fc.M, 1, 1, branch, False, jitter, min_var, PHASE_CHAIN)
+        nb = ctypes.c_size_t()
+        _lib.check(lib.mobocmf_layer_chain_state_bytes(ctypes.byref(desc), ctypes.byref(nb)), "chain_state_bytes")
+        sb, cb = workspace_bytes(desc)
+        saved = torch.empty(sb, dtype=torch.uint8, device=dev)
+        scratch = scratch_buffer(cb, dev)
+        fc.kl = torch.empty((), dtype=torch.float64, device=dev)
+        fc.info = torch.zeros((), dtype=torch.int32, device=dev)
+        rc = lib.mobocmf_layer_forward(ctypes.byref(desc), None, None, _ptr(Zx), _ptr(zf), _ptr(hyp), _ptr(m), _ptr(L_S),
+                                       None, None, _ptr(fc.kl), _ptr(fc.info), _ptr(saved), sb, _ptr(scratch),
+                                       scratch.numel(), _stream())
+        _lib.check(rc, "mobocmf_layer_forward[chain]")
+        fc.state = saved[:nb.value].clone()
+    return fc
+
+
+def layer_panel_frozen(fc, x, f, xdiv=1, want_dx=False):
+    """mean (N'), var (N') against a FrozenChain; differentiable w.r.t. f (and x if want_dx) only."""
+    P = LayerPass()
+    P.kind, P.d, P.M, P.Np, P.xdiv, P.branch = fc.kind, fc.d, fc.M, x.shape[0] * xdiv, xdiv, fc.branch
+    P.jitter, P.min_var, P.want_dx, P.info = fc.jitter, fc.min_var, want_dx, fc.info
+    P.bscratch = P.main = P.side = P.ready = None
+    P.kl, P.frozen = fc.kl, True
+    P.sb, P.cb = workspace_bytes(P.desc(PHASE_PANEL))
+    P.saved = torch.empty(P.sb, dtype=torch.uint8, device=x.device)
+    P.saved[:fc.state.numel()].copy_(fc.state)
+    return _PanelFn.apply(x, f, fc.Zx, fc.zf, fc.hyp, None, P)
 
 
 def layer_forward(x, f, Zx, zf, hyp, m, L_S, kind, xdiv=1, branch=0, jitter=JITTER, min_var=MIN_VARIANCE,

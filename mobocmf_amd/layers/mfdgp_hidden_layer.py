@@ -250,7 +250,42 @@ class MFDGPHiddenLayer(nn.Module):
     _info = None
     _shortcut_last = False
 
-    def _layer_call(self, x, f, xdiv=1, want_dx=False):
+    def launch_chain(self, n_rows, xdiv, want_dx, main, side):
+        """CHAIN half of the next call of this layer on ``n_rows`` rows (K_mm, Cholesky, L^-1, U, a, KL), issued
+        under ``torch.cuda.stream(side)``; hands back what ``__call__(..., chain=...)`` needs for the PANEL half."""
+        vs = self.variational_strategy
+        vd = vs._variational_distribution
+        Zx, zf = vs.Zx, vs.zf
+        if self._info is None or self._info.device != Zx.device:
+            self._info = torch.zeros((), dtype=torch.int32, device=Zx.device)
+        with torch.cuda.stream(main):
+            hyp = gp.pack_hypers(self.covar_module, self.kind)     # constraint transforms stay on the main stream
+            ev = torch.cuda.Event()
+            ev.record(main)
+        side.wait_event(ev)
+        P, token = F.layer_chain(Zx, zf, hyp, vd.variational_mean, vd.chol_variational_covar, self.kind, n_rows,
+                                 xdiv=xdiv, branch=0 if self.training else 1, jitter=vs.jitter_val, want_dx=want_dx,
+                                 info_out=self._info, main=main, side=side)
+        return P, token, hyp
+
+    def freeze_chain(self):
+        """CHAIN half for the current (fixed) parameters, with the psd_safe_cholesky jitter ladder of ``_moments``."""
+        vs = self.variational_strategy
+        vd = vs._variational_distribution
+        hyp = gp.pack_hypers(self.covar_module, self.kind)
+        jit = vs.jitter_val
+        for attempt in range(4):
+            fc = F.freeze_chain(vs.Zx, vs.zf, hyp, vd.variational_mean, vd.chol_variational_covar, self.kind,
+                                branch=0 if self.training else 1, jitter=jit)
+            pivot = F.check_info(fc.info)
+            if pivot == 0:
+                return fc
+            if attempt == 3:
+                raise NotPSDError(f"K_mm not positive definite (pivot {pivot}) after adding jitter {jit:.1e}")
+            jit = vs.jitter_val + 1e-8 * (10 ** attempt)
+            warnings.warn(f"K_mm not positive definite, retrying with jitter {jit:.1e}", RuntimeWarning)
+
+    def _layer_call(self, x, f, xdiv=1, want_dx=False, chain=None):
         vs = self.variational_strategy
         vd = vs._variational_distribution
         if self.training:
@@ -268,6 +303,13 @@ class MFDGPHiddenLayer(nn.Module):
         if hit:
             L = torch.tril(vd.chol_variational_covar)
             return vd.variational_mean, (L * L).sum(1).clamp_min(F.MIN_VARIANCE)
+        if isinstance(chain, F.FrozenChain):
+            return F.layer_panel_frozen(chain, x, f, xdiv=xdiv, want_dx=want_dx)
+        if chain is not None:
+            P, token, hyp = chain
+            mean, var = F.layer_panel(P, token, x, f, vs.Zx, vs.zf, hyp)
+            vs._kl_cache = P.kl
+            return mean, var
         mean, var, kl = self._moments(x, f, xdiv, want_dx)
         vs._kl_cache = kl
         return mean, var
@@ -277,14 +319,14 @@ class MFDGPHiddenLayer(nn.Module):
         materialised on this path; kept for API compatibility."""
         raise NotImplementedError("the lazy prior over cat[Z, X] is consumed inside the HIP layer call")
 
-    def __call__(self, x, *other_inputs, eps=None, xdiv=1, want_dx=False, **kwargs):
+    def __call__(self, x, *other_inputs, eps=None, xdiv=1, want_dx=False, chain=None, **kwargs):
         """Layer 0: ``layer(x)``.  Layers >= 1: ``layer(x, previous_output)`` (mfdgp_hidden_layer.py:245-286).
 
         ``x`` holds the base rows; this layer processes ``x.shape[0] * xdiv`` rows (row n uses x[n // xdiv]).
         ``eps`` (optional, N' values) replaces the N(0,1) draw of the training branch (:274).
         """
         if not len(other_inputs):
-            mean, var = self._layer_call(x, None, xdiv, want_dx)
+            mean, var = self._layer_call(x, None, xdiv, want_dx, chain)
             return gp.MultivariateNormal(mean[None, :], var[None, :])      # shape (1, N): SURVEY A.2
         inp = other_inputs[0]
         n_rows = x.shape[0] * xdiv
@@ -305,5 +347,5 @@ class MFDGPHiddenLayer(nn.Module):
             f = inp.reshape(-1)
             if f.numel() != n_rows:
                 f = f.repeat_interleave(n_rows // f.numel())
-        mean, var = self._layer_call(x, f, xdiv, want_dx)
+        mean, var = self._layer_call(x, f, xdiv, want_dx, chain)
         return gp.MultivariateNormal(mean, var)

@@ -9,6 +9,8 @@ Extensions (documented in DESIGN.md; defaults reproduce the reference):
 """
 from enum import Enum
 
+import contextlib
+
 import numpy as np
 import torch
 from torch import nn
@@ -162,17 +164,70 @@ class MFDGP(nn.Module):
             S = _xdiv
         l_outputs = [None] * num_layers
         output_layer = None
+        if self._frozen is not None:
+            chains = self._frozen_chains(num_layers)
+        else:
+            chains = self._launch_chains(inputs, num_layers, S, want_dx)
         for i in range(num_layers):
             hidden_layer = getattr(self, self.name_hidden_layer + str(i))
             if i == 0:
-                output_layer = hidden_layer(inputs, want_dx=want_dx)
+                output_layer = hidden_layer(inputs, want_dx=want_dx, chain=chains[i])
             else:
                 if self.use_only_highest_fidelity:
                     output_layer = output_layer.mean * 0.0
                 output_layer = hidden_layer(inputs, output_layer, eps=None if eps is None else eps[i], xdiv=S,
-                                            want_dx=want_dx)
+                                            want_dx=want_dx, chain=chains[i])
             l_outputs[i] = output_layer
         return l_outputs
+
+    _warned_off = False
+    _frozen = None
+
+    @contextlib.contextmanager
+    def frozen_chains(self):
+        """Inside this context the parameters are constants (acquisition optimisation against a fitted model,
+        JESMOC_MFDGP.py:137-184): the CHAIN half of every layer -- K_mm, its Cholesky and inverse, U, a: ~150 launches
+        of latency-bound M x M work -- is computed once per (layer, train/eval branch) and reused by every call, and
+        backward yields input gradients only.  Results are identical to recomputing the chain at every call."""
+        self._frozen = {}
+        try:
+            yield self
+        finally:
+            self._frozen = None
+
+    def _frozen_chains(self, num_layers):
+        out = []
+        for i in range(num_layers):
+            layer = getattr(self, self.name_hidden_layer + str(i))
+            key = (i, layer.training)
+            if key not in self._frozen:
+                self._frozen[key] = layer.freeze_chain()
+            out.append(self._frozen[key])
+        return out
+    overlap_chains = False                # opt-in (see DESIGN.md: HIP-graph replay of forked captures is slower on ROCm 7.2)
+    OVERLAP_MAX_ROWS = 1 << 21            # above this the private backward scratch per layer is not worth its memory
+
+    def _launch_chains(self, inputs, num_layers, S, want_dx):
+        """The parameter-only (CHAIN) half of every layer, issued up front on a side stream so the latency-bound M x M
+        work of layer l runs under the grid-filling panel work of the other layers -- forward here, and backward through
+        autograd, which replays each half on the stream its forward used.  Only without per-call host checks
+        (``set_check_pd(False)``: graphed / bench / fitter fast path); otherwise the layers run serially."""
+        layers = [getattr(self, self.name_hidden_layer + str(i)) for i in range(num_layers)]
+        if not (self.overlap_chains and inputs.is_cuda and num_layers > 1 and not any(l.check_pd for l in layers)
+                and inputs.shape[0] * S <= self.OVERLAP_MAX_ROWS):
+            return [None] * num_layers
+        main = torch.cuda.current_stream(inputs.device)
+        side = F.side_stream_for(main)
+        if not MFDGP._warned_off and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            # parameters feed both halves, i.e. both streams, on purpose; the engine orders the accumulation
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            MFDGP._warned_off = True
+        chains = []
+        with torch.cuda.stream(side):
+            for i, layer in enumerate(layers):
+                chains.append(layer.launch_chain(inputs.shape[0] * (1 if i == 0 else S), 1 if i == 0 else S, want_dx,
+                                                 main, side))
+        return chains
 
     def fix_variational_hypers(self, value):
         for i in range(self.num_hidden_layers):
