@@ -80,10 +80,9 @@ class JESMOC_MFDGP:
         self.eval_highest_fidelity = eval_highest_fidelity
         self.blackbox_mfdgp_fitter_uncond = model.copy_uncond()
         if model_cond is None:
-            # reference: sample a Pareto solution (RFF + MOOP) unless one was provided
+            # reference (:64-66): sample a Pareto solution (RFF posterior samples + MOOP) unless one was provided
             if getattr(model, "pareto_set", None) is None:
-                raise NotImplementedError("provide the Pareto solution with fitter.set_pareto_solution(...) "
-                                          "(RFF posterior sampling + MOOP is SURVEY row N2, not built)")
+                model.sample_and_store_pareto_solution()
             self.pareto_set, self.pareto_front = model.pareto_set, model.pareto_front
             model.train_conditioned_mfdgps()
             self.blackbox_mfdgp_fitter_cond = model

@@ -8,8 +8,9 @@ outputscale a1*af, sharing W_x1 and b_x1 with the first block, as the reference 
 Posterior weights given q(u) = N(m, S) at the inducing inputs:  A = Phi Phi^T + s2 I,
 theta ~ N( A^-1 Phi m ,  s2 A^-1 + A^-1 Phi S Phi^T A^-1 ).
 
-Host-side float64 torch (CPU): F x F factorisations, not part of the ELBO hot path.  The returned callables take a
-numpy array (n, d) or (d,), like the reference's, and recurse through the previous layer's sample.
+Host-side float64 torch: F x F factorisations on the CPU, not part of the ELBO hot path.  The returned callables take
+a numpy array (n, d) or (d,), like the reference's, and recurse through the previous layer's sample; large batches (the
+Pareto grid of MOOP, 1000 d^2 rows) are evaluated on the model's GPU with library ops, single points on the host.
 """
 import math
 
@@ -41,12 +42,30 @@ def _posterior_weights(Phi, m, S, sigma2, gen):
     return mean + Lc @ z
 
 
-def _as_callable(feature_fn, theta, prev):
-    """f(x, gradient=False): numpy in, numpy out -- (n,) values, or the (d,) gradient for a single point."""
+GRID_ROWS_ON_DEVICE = 4096      # batches at least this large are evaluated on the sample's device (the Pareto grid)
+
+
+class _OnDevice:
+    """Tensors of a sample, mirrored lazily on the devices they are evaluated on."""
+
+    def __init__(self, **tensors):
+        self._t = {torch.device("cpu"): tensors}
+
+    def on(self, dev):
+        dev = torch.device(dev)
+        if dev not in self._t:
+            self._t[dev] = {k: v.to(dev) for k, v in self._t[torch.device("cpu")].items()}
+        return self._t[dev]
+
+
+def _as_callable(feature_fn, theta, prev, device=None):
+    """f(x, gradient=False): numpy in, numpy out -- (n,) values, or the (d,) gradient for a single point.
+    Single points (the SLSQP refinements) stay on the host; grids of >= GRID_ROWS_ON_DEVICE rows run on ``device``."""
+    th = _OnDevice(theta=theta)
 
     def evaluate(xt):
         f_prev = prev._torch(xt) if prev is not None else None
-        return theta @ feature_fn(xt, f_prev)
+        return th.on(xt.device)["theta"] @ feature_fn(xt, f_prev)
 
     def wrapper(x, gradient=False):
         xt = torch.as_tensor(np.asarray(x), dtype=torch.float64)
@@ -58,6 +77,8 @@ def _as_callable(feature_fn, theta, prev):
             (g,) = torch.autograd.grad(evaluate(xt).sum(), xt)
             return g[0].numpy()
         with torch.no_grad():
+            if device is not None and xt.shape[0] >= GRID_ROWS_ON_DEVICE:
+                return evaluate(xt.to(device)).cpu().numpy()
             return evaluate(xt).numpy()
 
     wrapper._torch = evaluate
@@ -81,21 +102,27 @@ def _draw_features(h, d, F, gen, layer0):
     rn = lambda *s: torch.randn(*s, dtype=torch.float64, generator=gen)
     ru = lambda *s: 2.0 * math.pi * torch.rand(*s, dtype=torch.float64, generator=gen)
     if layer0:
-        W, b = rn(F, d) / h["ls"], ru(F, 1)
-        return lambda x, f: _phi(x, W, b, h["alpha"])
+        P = _OnDevice(W=rn(F, d) / h["ls"], b=ru(F, 1))
+
+        def feats0(x, f):
+            p = P.on(x.device)
+            return _phi(x, p["W"], p["b"], h["alpha"])
+
+        return feats0
     W1, Wf, W2 = rn(F, d) / h["ls1"], rn(F) / h["lsf"], rn(F, d) / h["ls2"]
     b1, b2 = ru(F, 1), ru(F, 1)
-    W1f = torch.cat([W1, Wf[:, None]], 1)
+    P = _OnDevice(W1=W1, W2=W2, b1=b1, b2=b2, W1f=torch.cat([W1, Wf[:, None]], 1))
 
     def feats(x, f):
+        p = P.on(x.device)
         xf = torch.cat([x, f[:, None]], 1)
-        return torch.cat([_phi(x, W1, b1, h["a1"]) * f * math.sqrt(h["nu"]),
-                          _phi(xf, W1f, b1, h["a1"] * h["af"]), _phi(x, W2, b2, h["a2"])], 0)
+        return torch.cat([_phi(x, p["W1"], p["b1"], h["a1"]) * f * math.sqrt(h["nu"]),
+                          _phi(xf, p["W1f"], p["b1"], h["a1"] * h["af"]), _phi(x, p["W2"], p["b2"], h["a2"])], 0)
 
     return feats
 
 
-def sample_from_posterior(layer, input_dim, prev_sample=None, nFeatures=500, sigma2=1e-6, generator=None):
+def sample_from_posterior(layer, input_dim, prev_sample=None, nFeatures=500, sigma2=1e-6, generator=None, device=None):
     """One function sample from the layer's variational posterior (reference :309-337 layer 0, :364-444 layer >= 1)."""
     h = _hypers(layer)
     vs = layer.variational_strategy
@@ -111,10 +138,10 @@ def sample_from_posterior(layer, input_dim, prev_sample=None, nFeatures=500, sig
         assert prev_sample is not None
         Phi = feats(Z[:, :-1], Z[:, -1])          # the f column of Z~ is the previous layer's variational mean
     theta = _posterior_weights(Phi, m, Ls @ Ls.T, sigma2, generator)
-    return _as_callable(feats, theta, prev_sample)
+    return _as_callable(feats, theta, prev_sample, device)
 
 
-def sample_from_prior(layer, input_dim, prev_sample=None, nFeatures=500, generator=None):
+def sample_from_prior(layer, input_dim, prev_sample=None, nFeatures=500, generator=None, device=None):
     """One function sample from the synthetic-problem prior (reference :339-362, :446-514: fixed test hyper-parameters
     lengthscale 0.25 d (x10 for x1), outputscales 1 / 1 / 0.01, nu 1)."""
     d = input_dim
@@ -126,4 +153,4 @@ def sample_from_prior(layer, input_dim, prev_sample=None, nFeatures=500, generat
     feats = _draw_features(h, d, nFeatures, generator, layer.num_layer == 0)
     nF = nFeatures if layer.num_layer == 0 else 3 * nFeatures
     theta = torch.randn(nF, dtype=torch.float64, generator=generator)
-    return _as_callable(feats, theta, prev_sample)
+    return _as_callable(feats, theta, prev_sample, device)

@@ -272,15 +272,21 @@ class MFDGP(nn.Module):
         from ..layers import rff
         result, prev = [], None
         for layer in self._layers():
-            prev = rff.sample_from_posterior(layer, self.input_dims, prev, nFeatures=nFeatures, generator=generator)
+            prev = rff.sample_from_posterior(layer, self.input_dims, prev, nFeatures=nFeatures, generator=generator,
+                                             device=self._sample_device())
             result.append(prev)
         return result
+
+    def _sample_device(self):
+        dev = next(self.parameters()).device
+        return dev if dev.type == "cuda" else None
 
     def sample_function_from_prior_each_layer(self, nFeatures=500, generator=None):
         """Prior function samples used to build synthetic problems (mfdgp.py:277-288)."""
         from ..layers import rff
         result, prev = [], None
         for layer in self._layers():
-            prev = rff.sample_from_prior(layer, self.input_dims, prev, nFeatures=nFeatures, generator=generator)
+            prev = rff.sample_from_prior(layer, self.input_dims, prev, nFeatures=nFeatures, generator=generator,
+                                         device=self._sample_device())
             result.append(prev)
         return result

@@ -189,10 +189,47 @@ class BlackBoxMFDGPFitter:
             self._train_mfdgp(self.update_model, fix_variational_hypers=False, num_epochs=self.num_epochs_2, lr=self.lr_2)
         self.models_uncond_trained = True
 
+    # ------------------------------------------------------------------ Pareto solution of posterior samples (row N2)
+    def _sample_and_store_pareto_solution(self, nFeatures=500, generator=None, rng=None):
+        """One posterior function sample per black-box (top layer), then the feasible Pareto set of the sampled
+        problem on a random grid + the training inputs (blackbox_mfdgp_fitter.py:181-216)."""
+        from .moop import MOOP, NotFeasiblePoints
+        samples_objs = [h.mfdgp.sample_function_from_each_layer(nFeatures=nFeatures, generator=generator)[-1]
+                        for h in self.mfdgp_handlers_objs.values()]
+        inputs = self.x_train.detach().cpu().double().numpy()
+        feasible = -1.0 * self.thresholds_cons.numpy()
+        optimizer = None
+        for _ in range(MFDGPHandler.MAX_TRIES_FOR_FEASIBLE_GRID):
+            samples_cons = [h.mfdgp.sample_function_from_each_layer(nFeatures=nFeatures, generator=generator)[-1]
+                            for h in self.mfdgp_handlers_cons.values()]
+            optimizer = MOOP(samples_objs, samples_cons, input_dim=inputs.shape[1],
+                             grid_size=self.opt_grid_size * inputs.shape[1], pareto_set_size=self.pareto_set_size,
+                             feasible_values=feasible, rng=rng)
+            res = optimizer.compute_pareto_solution_from_samples(inputs)
+            if res is not None:
+                break
+        else:   # no feasible grid point in any try: settle for the least infeasible points of the last samples
+            res = optimizer.compute_pareto_solution_from_samples(inputs, allow_negative_constraints=True)
+            if res is None:
+                raise NotFeasiblePoints("[ERROR] No feasible points were found in the constraint space! # tries: %d." %
+                                        MFDGPHandler.MAX_TRIES_FOR_FEASIBLE_GRID)
+        pareto_set, pareto_front, self.samples_objs, self.samples_cons = res
+        self.set_pareto_solution(pareto_set, pareto_front)
+        return self.pareto_set, self.pareto_front, self.samples_objs, self.samples_cons
+
+    def sample_and_store_pareto_solution(self, **kw):
+        from .moop import NotFeasiblePoints
+        while True:
+            try:
+                return self._sample_and_store_pareto_solution(**kw)
+            except NotFeasiblePoints:
+                print("Not feasible solution found, trying another time!")
+                sys.stdout.flush()
+
     # ------------------------------------------------------------------ conditioned training (SURVEY row N1)
     def set_pareto_solution(self, pareto_set, pareto_front):
-        """Pareto set (P, d) / front (P, n_obj) to condition on.  The reference obtains them from RFF posterior samples
-        + MOOP (:181-225, SURVEY row N2, not built here); any optimiser may provide them."""
+        """Pareto set (P, d) / front (P, n_obj) to condition on: from ``sample_and_store_pareto_solution`` (the
+        reference's route, :181-225) or from any other optimiser."""
         dev = torch.device(self.device)
         self.pareto_set = pareto_set.double().to(dev)
         self.pareto_front = pareto_front.double().to(dev)

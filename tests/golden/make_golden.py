@@ -54,6 +54,52 @@ def ref_helpers():
     np.savez(os.path.join(HERE, "ref_helpers.npz"), **out)
 
 
+def ref_moop():
+    """Outputs of the reference's own MOOP (numpy/scipy only, importable here) on seeded inputs: pins
+    mobocmf_amd/util/moop.py."""
+    sys.path.insert(0, "/root/reference")
+    from mobocmf.util.moop import MOOP as RefMOOP
+    from tests.helpers import moop_callable
+    out = {}
+    rng = np.random.default_rng(123)
+    for c, (n, k) in enumerate([(1, 2), (40, 1), (300, 2), (300, 3), (2000, 4), (5000, 2)]):
+        pts = rng.standard_normal((n, k))
+        if n > 10:
+            pts[5] = pts[3]                                   # exact duplicate
+            pts[7] = pts[3] + np.eye(k)[-1]                   # weakly dominated (ties in k-1 coordinates)
+            pts[::7] = np.round(pts[::7], 1)                  # ties in single coordinates
+        out[f"front_pts_{c}"] = pts
+        out[f"front_mask_{c}"] = RefMOOP.compute_pareto_front(pts.copy())
+        out[f"front_mask_sorted_{c}"] = RefMOOP([], [], k).obtain_indices_pareto(pts.copy())
+    for c, (n, k, size) in enumerate([(120, 2, 10), (400, 3, 50), (30, 2, 50), (200, 2, 2)]):
+        ps, pf = rng.uniform(size=(n, 4)), rng.standard_normal((n, k))
+        a, b = RefMOOP([], [], 4).compute_pareto_front_and_set_summary_y_space(ps, pf, size)
+        out[f"sum_set_{c}"], out[f"sum_front_{c}"], out[f"sum_size_{c}"] = ps, pf, np.array(size)
+        out[f"sum_out_set_{c}"], out[f"sum_out_front_{c}"] = a, b
+    # feasibility + constrained optimum + the whole extraction on analytic "samples" (d = 2)
+    cons = [moop_callable("lin", [-0.3, 1.0, 0.0]), moop_callable("lin", [0.8, 0.0, -1.0])]      # x0 >= 0.3, x1 <= 0.8
+    objs = [moop_callable("quad", [0.1, 0.2]), moop_callable("quad", [0.9, 0.9]), ]
+    grid = rng.uniform(size=(500, 2))
+    m = RefMOOP(objs, cons, 2, feasible_values=np.zeros(2))
+    out["feas_grid"] = grid
+    out["feas_out"] = m.find_feasible_grid(cons, grid, feasible_values=np.zeros(2))
+    hard = [moop_callable("lin", [-1.5, 1.0, 0.0]), moop_callable("lin", [-0.2, 0.0, -1.0])]     # infeasible on [0,1]^2
+    out["feas_none"] = np.array(m.find_feasible_grid(hard, grid, feasible_values=np.zeros(2)) is None)
+    out["feas_neg_out"] = m.find_feasible_grid(hard, grid, feasible_values=np.zeros(2), allow_negative_constraints=True)
+    fg = out["feas_out"]
+    for j, obj in enumerate(objs):
+        out[f"opt_x_{j}"] = m.optimize_obj_globally(obj, cons, obj(fg), fg)
+    for c, (objs_c, size) in enumerate([(objs, None), (objs, 7),
+                                        ([moop_callable("wave", [0.3, 1.1]), moop_callable("wave", [2.0, 0.4])], 12)]):
+        np.random.seed(77 + c)
+        inputs = rng.uniform(size=(9, 2))
+        res = RefMOOP(objs_c, cons, 2, grid_size=300, pareto_set_size=size,
+                      feasible_values=np.zeros(2)).compute_pareto_solution_from_samples(inputs)
+        out[f"sol_inputs_{c}"] = inputs
+        out[f"sol_set_{c}"], out[f"sol_front_{c}"] = res[0].numpy(), res[1].numpy()
+    np.savez(os.path.join(HERE, "ref_moop.npz"), **out)
+
+
 def oracle_case(name, prob, S, T=6):
     st = oracle_state(prob, requires_grad=True)
     x, y, fid = to_t(prob["x"]), to_t(prob["y"]), to_t(prob["fid"])
@@ -105,6 +151,7 @@ def forrester_state_problem(output):
 if __name__ == "__main__":
     if os.path.isdir("/root/reference"):
         ref_helpers()
+        ref_moop()
     for o in range(3):
         oracle_case(f"C1_forrester_out{o}", forrester_state_problem(o), S=4)
     for seed in range(3):

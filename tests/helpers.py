@@ -29,3 +29,20 @@ def state_leaves(state):
 
 def small_problem(d=2, L=2, M=8, N=12, S=3, output=0, seed=0):
     return synthetic.make_problem(d=d, L=L, M=M, N=N, S=S, output=output, seed=seed)
+
+
+# ---- analytic "function samples" for the MOOP fixtures (same callables on the reference side and in the tests)
+def moop_callable(kind, a):
+    """f(x, gradient=False) with the reference's calling convention (values (n,), gradient (d,) for one point)."""
+    a = np.asarray(a, dtype=np.float64)
+
+    def f(x, gradient=False):
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        if kind == "quad":                      # sum (x - a)^2
+            return 2.0 * (x[0] - a) if gradient else ((x - a) ** 2).sum(1)
+        if kind == "lin":                       # a[0] + a[1:] . x
+            return a[1:].copy() if gradient else a[0] + x @ a[1:]
+        if kind == "wave":                      # sum sin(3 x + a)
+            return 3.0 * np.cos(3.0 * x[0] + a) if gradient else np.sin(3.0 * x + a).sum(1)
+        raise ValueError(kind)
+    return f
