@@ -20,6 +20,16 @@ from ..models.mfdgp import MFDGP, TL
 ITER_PRINT = 1000
 
 
+def _prod(t, dim):
+    """Product over a (short) dimension as a chain of multiplications: torch.prod's backward counts zeros on the host
+    (.item()), which a stream capture forbids."""
+    parts = t.unbind(dim)
+    out = parts[0]
+    for p in parts[1:]:
+        out = out * p
+    return out
+
+
 def _ncdf(z):
     """Standard normal cdf (the reference uses torch.distributions Normal(0, 1).cdf, :18)."""
     return 0.5 * (1.0 + torch.erf(z * 0.7071067811865476))
@@ -234,6 +244,14 @@ class BlackBoxMFDGPFitter:
         self.pareto_set = pareto_set.double().to(dev)
         self.pareto_front = pareto_front.double().to(dev)
 
+    def _thresholds_on(self, device):
+        """Device copy of the constraint thresholds (uploaded once: a host->device copy is not capturable)."""
+        c = getattr(self, "_thr_cache", None)
+        if c is None or c[0] is not self.thresholds_cons or c[1].device != torch.device(device):
+            c = (self.thresholds_cons, self.thresholds_cons.to(device))
+            self._thr_cache = c
+        return c[1]
+
     def loss_theta_factors(self, cs_mean, cs_var, threshold):
         """:227-233."""
         c = _ncdf((cs_mean - threshold) / torch.sqrt(cs_var))
@@ -241,11 +259,11 @@ class BlackBoxMFDGPFitter:
 
     def loss_omega_factors(self, fs_mean, fs_var, cs_mean, cs_var, pareto_front):
         """:235-243.  fs_* (n_obj, T), cs_* (n_con, T)."""
-        thr = self.thresholds_cons.to(fs_mean.device)
+        thr = self._thresholds_on(fs_mean.device)
         c = torch.ones(fs_mean.shape[-1], dtype=fs_mean.dtype, device=fs_mean.device)
         if cs_mean.numel():
-            c = torch.prod(_ncdf((cs_mean - thr[:, None]) / torch.sqrt(cs_var)), 0)
-        c = c * torch.prod(_ncdf((pareto_front[:, :, None] - fs_mean) / torch.sqrt(fs_var)), 1)
+            c = _prod(_ncdf((cs_mean - thr[:, None]) / torch.sqrt(cs_var)), 0)
+        c = c * _prod(_ncdf((pareto_front[:, :, None] - fs_mean) / torch.sqrt(fs_var)), 1)
         return torch.sum(np.log(self.eps) * c + np.log(1 - self.eps) * (1.0 - c))
 
     def conditioned_loss(self, x_tilde, eps=None):
@@ -282,7 +300,7 @@ class BlackBoxMFDGPFitter:
             else:
                 if S > 1:
                     raise NotImplementedError("theta factors are defined for one sample per row (reference: S = 1)")
-                loss = loss - self.loss_theta_factors(mu_p, var_p, self.thresholds_cons[k].to(xb.device))
+                loss = loss - self.loss_theta_factors(mu_p, var_p, self._thresholds_on(xb.device)[k])
                 k += 1
             tilde[(tag, i)] = sl(out[top], B + P, B + P + T)
         fm = torch.stack([tilde[(t, i)][0] for t, i, _ in self._handlers() if t == "OBJ"])
@@ -293,25 +311,35 @@ class BlackBoxMFDGPFitter:
         fm, fv, cm, cv = parallel.gather_with_local_grad(fm, fv, cm, cv)
         return loss - self.loss_omega_factors(fm, fv, cm, cv, self.pareto_front)
 
-    def train_conditioned_mfdgps(self, num_iters=None):
-        """ONE Adam over all models' parameters, kernel hyper-parameters frozen (:245-268, :345-354)."""
-        params = []
+    def train_conditioned_mfdgps(self, num_iters=None, use_graphs=None):
+        """ONE Adam over all models' parameters, kernel hyper-parameters frozen (:245-268, :345-354).  On the GPU the
+        whole iteration (x~ draw, joint loss over all surrogates, backward, Adam) is replayed from a HIP graph; a failed
+        Cholesky inside a replay rolls back to the last verified state and continues eagerly (jitter ladder)."""
+        from .. import parallel
+        from ..layers.mfdgp_hidden_layer import NotPSDError
+        from .graphed_step import GraphedConditionedStep
         for _, _, h in self._handlers():
             h.mfdgp.fix_variational_hypers_cond(True)
-            h.mfdgp.set_check_pd(False)
-            params += list(h.mfdgp.parameters())
-        optimizer = torch.optim.Adam([{"params": params}], lr=self.lr_2)
         num_iters = self.num_epochs_2 if num_iters is None else num_iters
-        d = self.pareto_set.shape[1]
+        if use_graphs is None:
+            use_graphs = self.pareto_set.is_cuda and parallel.world()[1] == 1
+        step = GraphedConditionedStep(self, lr=self.lr_2, use_graph=use_graphs)
+        step.snapshot()
         for i in range(num_iters):
-            optimizer.zero_grad()
-            x_tilde = torch.rand(10, d, dtype=torch.float64, device=self.pareto_set.device)
-            loss = self.conditioned_loss(x_tilde)
-            loss.backward()
-            optimizer.step()
-            if self.verbose and ((i % ITER_PRINT) == 0 or (i + 1) == num_iters):
-                print("Iter:", i, "/", num_iters, ". Neg. ELBO per iter:", loss.item())
-                sys.stdout.flush()
+            step.step()
+            if (i % ITER_PRINT) == 0 or (i + 1) == num_iters:
+                try:
+                    step.check()
+                    step.snapshot()
+                except (NotPSDError, FloatingPointError) as err:
+                    warnings.warn("conditioned training: %s -- rolling back %d iterations and continuing eagerly" %
+                                  (err, ITER_PRINT))
+                    step.restore_and_go_eager()
+                if self.verbose:
+                    print("Iter:", i, "/", num_iters, ". Neg. ELBO per iter:", step.loss.item())
+                    sys.stdout.flush()
+        step.stream.synchronize()
+        torch.cuda.current_stream(self.pareto_set.device).wait_stream(step.stream)
         for _, _, h in self._handlers():
             h.iter_train_loader = None
             h.mfdgp.set_check_pd(True)

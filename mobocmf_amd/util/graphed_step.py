@@ -140,3 +140,62 @@ class GraphedELBOStep:
                 raise NotPSDError("K_mm not positive definite in layer %d" % layer.num_layer)
         if not bool(torch.isfinite(self.loss)):
             raise FloatingPointError("non-finite ELBO")
+
+
+class _ModelGroup:
+    """The models of a joint step seen as one (parameters / layers / housekeeping of GraphedELBOStep)."""
+
+    def __init__(self, models):
+        self.models = list(models)
+
+    def parameters(self):
+        for m in self.models:
+            yield from m.parameters()
+
+    def _layers(self):
+        for m in self.models:
+            yield from m._layers()
+
+    def clear_kl_cache(self):
+        for m in self.models:
+            m.clear_kl_cache()
+
+    def set_check_pd(self, value):
+        for m in self.models:
+            m.set_check_pd(value)
+
+
+class GraphedConditionedStep(GraphedELBOStep):
+    """One iteration of the conditioned training (blackbox_mfdgp_fitter.py:245-354: fresh x~ ~ U[0,1]^(10 x d), the joint
+    loss over ALL surrogates, one Adam) captured into a HIP graph.  ``fitter.conditioned_loss`` must be capture-safe
+    (no host reads); x~ is drawn inside the graph, so every replay sees new points."""
+
+    def __init__(self, fitter, lr, betas=(0.9, 0.999), eps=1e-8, use_graph=True, stream=None, warmup=3, n_tilde=10,
+                 fixed_x_tilde=None):
+        self.fitter = fitter
+        self.fixed_x_tilde = fixed_x_tilde      # deterministic tests: the same x~ at every iteration
+        models = [h.mfdgp for _, _, h in fitter._handlers()]
+        self.model = _ModelGroup(models)
+        dev = fitter.pareto_set.device
+        self.device, self.d, self.n_tilde = dev, fitter.pareto_set.shape[1], n_tilde
+        self.use_graph = use_graph
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.optimizer = torch.optim.Adam([{"params": list(self.model.parameters())}], lr=lr, betas=betas, eps=eps,
+                                          capturable=True)
+        self.loss = torch.zeros((), dtype=torch.float64, device=dev)
+        self.kl = torch.zeros((), dtype=torch.float64, device=dev)
+        self.graph = self.graph_update = self._snap = None
+        self.x = fitter.pareto_set            # (only its device is used by the base class)
+        self.model.set_check_pd(False)
+        self.model.clear_kl_cache()
+        if use_graph:
+            self._capture(warmup)
+
+    def _fwd_bwd(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        x_tilde = self.fixed_x_tilde if self.fixed_x_tilde is not None else \
+            torch.rand(self.n_tilde, self.d, dtype=torch.float64, device=self.device)
+        loss = self.fitter.conditioned_loss(x_tilde)
+        loss.backward()
+        self.loss.copy_(loss.detach())
+        self.model.clear_kl_cache()

