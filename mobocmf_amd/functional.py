@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory, streams and the autograd tape; 
 the layer runs in libmobocmf_hip.so.  Tensors must be CUDA(HIP) float64; there is no CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -34,6 +35,27 @@ def _prep(t):
     return t.contiguous()
 
 
+_POISON = bool(int(os.environ.get("MOBOCMF_POISON", "0")))   # debugging aid: NaN-fill every workspace before use
+
+
+def _poison(buf):
+    if _POISON and not torch.cuda.is_current_stream_capturing():
+        buf[:buf.numel() // 8 * 8].view(torch.float64).fill_(float("nan"))
+    return buf
+
+
+def _empty(*shape, dtype=torch.float64, device=None):
+    """Output allocation; NaN-filled under MOBOCMF_POISON so that a kernel leaving part of an output unwritten shows."""
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if _POISON and dtype == torch.float64 and not torch.cuda.is_current_stream_capturing():
+        t.fill_(float("nan"))
+    return t
+
+
+def _empty_like(t):
+    return _empty(t.shape, dtype=t.dtype, device=t.device)
+
+
 def scratch_buffer(nbytes, device):
     """Per (device, stream) scratch, grown on demand; dead after each C call."""
     key = (device.index, torch.cuda.current_stream().cuda_stream)
@@ -41,7 +63,7 @@ def scratch_buffer(nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
         _scratch[key] = buf
-    return buf
+    return _poison(buf)
 
 
 def hyp_len(kind, d):
@@ -81,11 +103,11 @@ class _LayerFn(torch.autograd.Function):
         desc = make_desc(kind, d, M, Np, xdiv, branch, want_dx, jitter, min_var)
         sb, cb = workspace_bytes(desc)
         dev = x.device
-        saved = torch.empty(sb, dtype=torch.uint8, device=dev)
+        saved = _poison(torch.empty(sb, dtype=torch.uint8, device=dev))
         scratch = scratch_buffer(cb, dev)
-        mean = torch.empty(Np, dtype=torch.float64, device=dev)
-        var = torch.empty(Np, dtype=torch.float64, device=dev)
-        kl = torch.empty((), dtype=torch.float64, device=dev)
+        mean = _empty(Np, device=dev)
+        var = _empty(Np, device=dev)
+        kl = _empty((), device=dev)
         info = info_out if info_out is not None else torch.zeros((), dtype=torch.int32, device=dev)
         rc = lib.mobocmf_layer_forward(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp), _ptr(m),
                                        _ptr(L_S), _ptr(mean), _ptr(var), _ptr(kl), _ptr(info), _ptr(saved), sb,
@@ -112,7 +134,7 @@ class _LayerFn(torch.autograd.Function):
         g_mean, g_var, g_kl = (_prep(t) for t in (g_mean, g_var, g_kl))
         _, cb = workspace_bytes(desc)
         scratch = scratch_buffer(cb, dev)
-        new = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)
+        new = lambda *s: _empty(*s, device=dev)
         g_f = new(desc.Np) if ctx.has_f else None
         g_zf = new(M) if ctx.has_f else None
         g_hyp, g_m, g_LS = new(hyp.numel()), new(M), new(M, M)
@@ -162,9 +184,9 @@ class _ChainFn(torch.autograd.Function):
         dev = Zx.device
         desc = P.desc(PHASE_CHAIN)
         P.sb, P.cb = workspace_bytes(desc)
-        P.saved = torch.empty(P.sb, dtype=torch.uint8, device=dev)
+        P.saved = _poison(torch.empty(P.sb, dtype=torch.uint8, device=dev))
         scratch = scratch_buffer(P.cb, dev)
-        kl = torch.empty((), dtype=torch.float64, device=dev)
+        kl = _empty((), device=dev)
         token = torch.zeros(1, dtype=torch.float64, device=dev)
         rc = lib.mobocmf_layer_forward(ctypes.byref(desc), None, None, _ptr(Zx), _ptr(zf), _ptr(hyp), _ptr(m), _ptr(L_S),
                                        None, None, _ptr(kl), _ptr(P.info), _ptr(P.saved), P.sb, _ptr(scratch),
@@ -197,13 +219,13 @@ class _ChainFn(torch.autograd.Function):
         scratch = P.bscratch
         P.bscratch = None
         if scratch is None:         # the PANEL half took no part in this backward (only the KL was differentiated)
-            scratch = torch.empty(P.cb, dtype=torch.uint8, device=dev)
+            scratch = _poison(torch.empty(P.cb, dtype=torch.uint8, device=dev))
             phase = PHASE_CHAIN_ONLY
         if g_kl is None:
             g_kl = torch.zeros((), dtype=torch.float64, device=dev)
         g_kl = _prep(g_kl)
         desc = P.desc(phase)
-        new = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)
+        new = lambda *s: _empty(*s, device=dev)
         g_zf = new(M) if ctx.has_f else None
         g_hyp, g_m, g_LS = new(hyp.numel()), new(M), new(M, M)
         rc = lib.mobocmf_layer_backward(ctypes.byref(desc), None, None, _ptr(Zx), _ptr(zf), _ptr(hyp), _ptr(m),
@@ -223,8 +245,8 @@ class _PanelFn(torch.autograd.Function):
         dev = x.device
         desc = P.desc(PHASE_PANEL)
         scratch = scratch_buffer(P.cb, dev)
-        mean = torch.empty(P.Np, dtype=torch.float64, device=dev)
-        var = torch.empty(P.Np, dtype=torch.float64, device=dev)
+        mean = _empty(P.Np, device=dev)
+        var = _empty(P.Np, device=dev)
         rc = lib.mobocmf_layer_forward(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp), None, None,
                                        _ptr(mean), _ptr(var), None, None, _ptr(P.saved), P.sb, _ptr(scratch),
                                        scratch.numel(), _stream())
@@ -252,10 +274,10 @@ class _PanelFn(torch.autograd.Function):
         else:
             desc = P.desc(PHASE_PANEL)
             # private scratch: H, Hc, da stay in it until the CHAIN half (side stream) has consumed them
-            scratch = torch.empty(P.cb, dtype=torch.uint8, device=dev)
+            scratch = _poison(torch.empty(P.cb, dtype=torch.uint8, device=dev))
             if P.side is not None:
                 scratch.record_stream(P.side)
-        new = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)
+        new = lambda *s: _empty(*s, device=dev)
         g_f = new(P.Np) if ctx.has_f else None
         g_zf = new(P.M) if ctx.has_f else None
         g_hyp = new(hyp.numel())
@@ -312,9 +334,9 @@ def freeze_chain(Zx, zf, hyp, m, L_S, kind, branch=1, jitter=JITTER, min_var=MIN
         nb = ctypes.c_size_t()
         _lib.check(lib.mobocmf_layer_chain_state_bytes(ctypes.byref(desc), ctypes.byref(nb)), "chain_state_bytes")
         sb, cb = workspace_bytes(desc)
-        saved = torch.empty(sb, dtype=torch.uint8, device=dev)
+        saved = _poison(torch.empty(sb, dtype=torch.uint8, device=dev))
         scratch = scratch_buffer(cb, dev)
-        fc.kl = torch.empty((), dtype=torch.float64, device=dev)
+        fc.kl = _empty((), device=dev)
         fc.info = torch.zeros((), dtype=torch.int32, device=dev)
         rc = lib.mobocmf_layer_forward(ctypes.byref(desc), None, None, _ptr(Zx), _ptr(zf), _ptr(hyp), _ptr(m), _ptr(L_S),
                                        None, None, _ptr(fc.kl), _ptr(fc.info), _ptr(saved), sb, _ptr(scratch),
@@ -332,7 +354,7 @@ def layer_panel_frozen(fc, x, f, xdiv=1, want_dx=False):
     P.bscratch = P.main = P.side = P.ready = None
     P.kl, P.frozen = fc.kl, True
     P.sb, P.cb = workspace_bytes(P.desc(PHASE_PANEL))
-    P.saved = torch.empty(P.sb, dtype=torch.uint8, device=x.device)
+    P.saved = _poison(torch.empty(P.sb, dtype=torch.uint8, device=x.device))
     P.saved[:fc.state.numel()].copy_(fc.state)
     return _PanelFn.apply(x, f, fc.Zx, fc.zf, fc.hyp, None, P)
 
@@ -353,17 +375,17 @@ def predictive_covariance(x, f, Zx, zf, hyp, m, L_S, kind, xdiv=1, jitter=JITTER
         desc = make_desc(kind, d, M, Np, xdiv, 1, False, jitter, MIN_VARIANCE)
         sb, cb = workspace_bytes(desc)
         dev = x.device
-        saved = torch.empty(sb, dtype=torch.uint8, device=dev)
+        saved = _poison(torch.empty(sb, dtype=torch.uint8, device=dev))
         scratch = scratch_buffer(cb, dev)
-        mean = torch.empty(Np, dtype=torch.float64, device=dev)
-        var = torch.empty(Np, dtype=torch.float64, device=dev)
-        kl = torch.empty((), dtype=torch.float64, device=dev)
+        mean = _empty(Np, device=dev)
+        var = _empty(Np, device=dev)
+        kl = _empty((), device=dev)
         info = torch.zeros((), dtype=torch.int32, device=dev)
         _lib.check(lib.mobocmf_layer_forward(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp),
                                              _ptr(m), _ptr(L_S), _ptr(mean), _ptr(var), _ptr(kl), _ptr(info),
                                              _ptr(saved), sb, _ptr(scratch), scratch.numel(), _stream()),
                    "mobocmf_layer_forward")
-        cov = torch.empty(Np, Np, dtype=torch.float64, device=dev)
+        cov = _empty(Np, Np, device=dev)
         _lib.check(lib.mobocmf_predictive_covariance(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(hyp), _ptr(cov), Np,
                                                      _ptr(saved), sb, _ptr(scratch), scratch.numel(), _stream()),
                    "mobocmf_predictive_covariance")
@@ -378,7 +400,7 @@ class _PropagateFn(torch.autograd.Function):
         n = eps.numel()
         if mean.numel() * div != n:
             raise _lib.MobocmfError("propagate: eps must have mean.numel()*div entries")
-        out = torch.empty(n, dtype=torch.float64, device=mean.device)
+        out = _empty(n, device=mean.device)
         _lib.check(lib.mobocmf_propagate_forward(_ptr(mean), _ptr(var), _ptr(eps), _ptr(out), n, div, _stream()),
                    "mobocmf_propagate_forward")
         ctx.save_for_backward(var, eps)
@@ -390,7 +412,7 @@ class _PropagateFn(torch.autograd.Function):
         lib = _lib.require_device()
         var, eps = ctx.saved_tensors
         g = _prep(g)
-        gm, gv = torch.empty_like(var), torch.empty_like(var)
+        gm, gv = _empty_like(var), _empty_like(var)
         _lib.check(lib.mobocmf_propagate_backward(_ptr(var), _ptr(eps), _ptr(g), _ptr(gm), _ptr(gv), eps.numel(),
                                                   ctx.div, _stream()), "mobocmf_propagate_backward")
         return gm, gv, None, None
@@ -409,7 +431,7 @@ class _ElboDataFn(torch.autograd.Function):
         n = mean.numel()
         if y.numel() * div != n or fid.numel() != y.numel():
             raise _lib.MobocmfError("elbo_data: shape mismatch")
-        out = torch.empty((), dtype=torch.float64, device=mean.device)
+        out = _empty((), device=mean.device)
         scratch = scratch_buffer(8192, mean.device)
         _lib.check(lib.mobocmf_elbo_data_forward(_ptr(mean), _ptr(var), _ptr(y), _ptr(fid), _ptr(tau), float(level), n,
                                                  div, _ptr(out), _ptr(scratch), scratch.numel(), _stream()),
@@ -423,8 +445,8 @@ class _ElboDataFn(torch.autograd.Function):
         lib = _lib.require_device()
         mean, var, y, fid, tau = ctx.saved_tensors
         g = _prep(g)
-        gm, gv = torch.empty_like(mean), torch.empty_like(var)
-        gt = torch.empty_like(tau)
+        gm, gv = _empty_like(mean), _empty_like(var)
+        gt = _empty_like(tau)
         scratch = scratch_buffer(8192, mean.device)
         _lib.check(lib.mobocmf_elbo_data_backward(_ptr(mean), _ptr(var), _ptr(y), _ptr(fid), _ptr(tau), ctx.level,
                                                   mean.numel(), ctx.div, _ptr(g), _ptr(gm), _ptr(gv), _ptr(gt),
@@ -444,8 +466,8 @@ class _AcqMomentsFn(torch.autograd.Function):
         lib = _lib.require_device()
         mu_t, var_t = _prep(mu_t.reshape(-1)), _prep(var_t.reshape(-1))
         T = mu_t.numel() // S
-        mus = torch.empty(T, dtype=torch.float64, device=mu_t.device)
-        vs = torch.empty_like(mus)
+        mus = _empty(T, device=mu_t.device)
+        vs = _empty_like(mus)
         _lib.check(lib.mobocmf_acq_moments_forward(_ptr(mu_t), _ptr(var_t), _ptr(mus), _ptr(vs), T, S, _stream()),
                    "mobocmf_acq_moments_forward")
         ctx.save_for_backward(mu_t)
@@ -457,7 +479,7 @@ class _AcqMomentsFn(torch.autograd.Function):
         lib = _lib.require_device()
         (mu_t,) = ctx.saved_tensors
         g_mus, g_vars = _prep(g_mus), _prep(g_vars)
-        gm, gv = torch.empty_like(mu_t), torch.empty_like(mu_t)
+        gm, gv = _empty_like(mu_t), _empty_like(mu_t)
         _lib.check(lib.mobocmf_acq_moments_backward(_ptr(mu_t), _ptr(g_mus), _ptr(g_vars), _ptr(gm), _ptr(gv),
                                                     mu_t.numel() // ctx.S, ctx.S, _stream()),
                    "mobocmf_acq_moments_backward")
@@ -474,7 +496,7 @@ class _JesFn(torch.autograd.Function):
     def forward(ctx, vu, vc):
         lib = _lib.require_device()
         vu, vc = _prep(vu.reshape(-1)), _prep(vc.reshape(-1))
-        out = torch.empty_like(vu)
+        out = _empty_like(vu)
         _lib.check(lib.mobocmf_jes_forward(_ptr(vu), _ptr(vc), _ptr(out), vu.numel(), _stream()), "mobocmf_jes_forward")
         ctx.save_for_backward(vu, vc, out)
         return out
@@ -516,7 +538,7 @@ def gemm_f64(A, B, C=None, tri=0, trans_b=False, alpha=1.0, accumulate=False):
     Mr, Kd = A.shape
     Nc = B.shape[0] if trans_b else B.shape[1]
     if C is None:
-        C = torch.empty(Mr, Nc, dtype=torch.float64, device=A.device)
+        C = _empty(Mr, Nc, device=A.device)
     _lib.check(lib.mobocmf_gemm_f64(tri, int(trans_b), Mr, Nc, Kd, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C),
                                     C.stride(0), alpha, int(accumulate), _stream()), "mobocmf_gemm_f64")
     return C

@@ -90,3 +90,33 @@ def test_elementwise_entry_points_match_torch():
         opt.step()
         F.adam_step(p, grad, ea, es, step, 1e-2)
     assert torch.allclose(p, p_ref.detach(), rtol=1e-12, atol=1e-14)
+
+
+def test_no_uninitialised_workspace_or_output_reads(monkeypatch):
+    """With every workspace and output NaN-filled before use (MOBOCMF_POISON), ragged shapes still give the same finite
+    ELBO, gradients and acquisition moments: no kernel reads memory it (or an earlier kernel of the call) did not write."""
+    from mobocmf_amd import functional as F
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from tests.test_hip_model import build_model
+    from mobocmf_amd.util import synthetic
+    from tests.helpers import to_t
+    cfg = dict(d=3, L=3, M=37, N=141, S=3, seed=13)
+    prob = synthetic.make_problem(**cfg)
+    t = lambda a: to_t(a).to("cuda")
+    x, y, fid = t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None]
+    eps = [None] + [t(e) for e in prob["eps"][1:]]
+    res = []
+    for poison in (False, True):
+        monkeypatch.setattr(F, "_POISON", poison)
+        model = build_model(prob, S_train=3, S_acq=3)
+        elbo = VariationalELBOMF(model, cfg["N"], cfg["L"])
+        r = elbo(model(x, eps=eps), y.T, fid)
+        (-r[0]).backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+        model.eval()
+        X = x[:11].clone().requires_grad_(True)
+        mus, vs = model.predict_for_acquisition(X, 2)
+        (mus.sum() + vs.sum()).backward()
+        res.append((r[0].detach(), r[1].detach(), g, mus.detach(), vs.detach(), X.grad.clone()))
+    for a, b in zip(*res):
+        assert bool(torch.isfinite(b).all()) and torch.equal(a, b)

@@ -44,7 +44,16 @@ def _run(sharded, use_graph):
         losses.append(float(l))
     g.check()
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    _run.names = [(n, p.numel()) for n, p in model.named_parameters()]
     return losses, flat
+
+
+def _where(idx):
+    off = 0
+    for n, k in _run.names:
+        if idx < off + k:
+            return "%s[%d]" % (n, idx - off)
+        off += k
 
 
 def _worker(rank, world, port, use_graph, q):
@@ -74,7 +83,8 @@ def test_row_sharded_step_follows_full_batch_trajectory(use_graph):
     (_, l0, f0), (_, l1, f1) = res
     assert l0 == l1 and (f0 == f1).all()                                   # replicas stay bit-identical
     scale = float(ref_flat.abs().max())
-    assert float((torch.as_tensor(f0) - ref_flat).abs().max()) / scale < 1e-9       # summation order differs only
+    diff = (torch.as_tensor(f0) - ref_flat).abs()
+    assert float(diff.max()) / scale < 1e-9, (_where(int(diff.argmax())), float(diff.max()), ref_losses, l0)
     for a, b in zip(l0, ref_losses):
         assert abs(a - b) <= 1e-9 * abs(b)
     assert l0[-1] < l0[0]

@@ -6,7 +6,18 @@ import torch
 from oracle import mfdgp_oracle as O
 from tests.helpers import oracle_state, small_problem, state_leaves, to_t
 
-torch.set_default_dtype(torch.float64)
+import pytest
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _float64_default():
+    """torch.zeros / torch.eye / torch.rand below are float64 -- for THIS module only (a global default would leak into
+    every other test module of the session, and the mirrored model deliberately builds its constants at torch's default
+    dtype like the reference)."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 
 
 def _layer(prob, l):
