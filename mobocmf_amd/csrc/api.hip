@@ -279,6 +279,7 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
         TRY(launch_gemm(ga, false, 1, s));
         GemmArgs gc = gemm_args(S.UT, Mp, S.A, Np, S.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
         gc.epi = EPI_COLSTATS; gc.colsq_part = F.rpart; gc.coldot_part = nullptr; gc.avec = S.a;
+        gc.stream_out = (desc->branch == 0 && Np * Mp * 8 >= ((int64_t)64 << 20)) ? 1 : 0;   // C is next read in backward
         TRY(launch_gemm(gc, false, 1, s));
     }
     TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, D.nrb, Np, D.N, S.knn, desc->branch, desc->min_var, S.q, S.r,

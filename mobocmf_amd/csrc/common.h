@@ -40,6 +40,10 @@ struct GemmArgs {
     int batched;
     // B_T=1: weights of the contraction index, sum_k A[i][k] bscale[k] B[j][k];  EPI_DA: column scale of the product
     const double* bscale;
+    int stream_out;                // write C with non-temporal stores: for a panel whose next reader is far away (it
+                                   // would only evict what this and the next launches re-read; a panel consumed by the
+                                   // NEXT launch must stay cacheable -- streaming A cost the step 4 % although the
+                                   // kernel alone got 6 % faster)
     const int32_t* skip_if_zero;   // device word: the whole launch is a no-op when it is 0 (rarely needed passes)
     // epilogues
     int epi;

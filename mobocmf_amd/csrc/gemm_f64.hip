@@ -298,19 +298,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }
         continue;   // LDS was not touched after the main loop's last barrier
     }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + mt * 32 + 4 * r;
-                const int64_t col = col0 + nt * 16;
-                double v = g.alpha * acc[mt][nt][r];
-                if (g.accumulate) v += C[row * g.ldc + col];
-                acc[mt][nt][r] = v;
-                C[row * g.ldc + col] = v;
+#define STORE_TILE(ST)                                                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                       \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                   \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
+                const int64_t row = row0 + mt * 32 + 4 * r;                                                 \
+                const int64_t col = col0 + nt * 16;                                                         \
+                double v = g.alpha * acc[mt][nt][r];                                                        \
+                if (g.accumulate) v += C[row * g.ldc + col];                                                \
+                acc[mt][nt][r] = v;                                                                         \
+                ST(v, &C[row * g.ldc + col]);                                                               \
             }
+#define ST_PLAIN(v, p) (*(p) = (v))
+#define ST_STREAM(v, p) __builtin_nontemporal_store((v), (p))
+    if (g.stream_out) { STORE_TILE(ST_STREAM) } else { STORE_TILE(ST_PLAIN) }
+#undef STORE_TILE
     if (EPI == EPI_COLSTATS) {
         // partial column sums over this tile's 128 rows: per lane over its 16 rows, then across the
         // 4 lane groups of the wavefront (shuffles), then across the two row-wavefronts (LDS).
