@@ -34,3 +34,20 @@ def test_one_bo_iteration_end_to_end():
     X = torch.rand(16, 2, dtype=torch.float64, device="cuda")
     v = acq.coupled_acq(X, fidelity=1)
     assert v.shape == (16,) and bool(torch.isfinite(v).all()) and float(v.min()) >= 0.0
+
+
+def test_fitter_and_acquisition_survive_dill_round_trip():
+    """The reference's examples pickle the fitter and the acquisition object between stages
+    (example_acquisition_mfdgp_forrester.py:116-118,140-142): same values after the round trip."""
+    import dill
+    from bo_iteration_toy2d import run
+    fitter, acq, _, _ = run(epochs=30, cond_iters=10, acq_iters=3, grid=30, seed=1, verbose=False)
+    acq2 = dill.loads(dill.dumps(acq))
+    fitter2 = dill.loads(dill.dumps(fitter))
+    X = torch.rand(9, 2, dtype=torch.float64, device="cuda")
+    for f in (0, 1):
+        assert torch.equal(acq2.coupled_acq(X, fidelity=f), acq.coupled_acq(X, fidelity=f))
+    m1, v1 = fitter.get_model("obj2").predict_for_acquisition(X, 1)       # fixed samples: deterministic
+    m2, v2 = fitter2.get_model("obj2").predict_for_acquisition(X, 1)
+    assert torch.equal(m1, m2) and torch.equal(v1, v2)
+    assert np.allclose(fitter2.samples_objs[0](X.cpu().numpy()), fitter.samples_objs[0](X.cpu().numpy()), atol=1e-12)

@@ -121,7 +121,7 @@ def test_jesmoc_next_point_flow():
     """The reference's acquisition flow (JESMOC_MFDGP.__init__ :57-98, add_blackbox :101-116, coupled_acq :125-135,
     get_nextpoint_coupled :151-184) on the mirrored classes; the coupled value equals the sum of the per-black-box
     oracle JES values, and the optimiser returns a point inside the bounds that is at least as good as a random one."""
-    from mobocmf_amd.acquisition_functions import JESMOC_MFDGP
+    from mobocmf_amd.acquisition_functions.JESMOC_MFDGP import JESMOC_MFDGP
     fitter, probs = _fitter(2, 1, 12)
     g = torch.Generator().manual_seed(3)
     fitter.set_pareto_solution(torch.rand(5, 2, dtype=torch.float64, generator=g),
