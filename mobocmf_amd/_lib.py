@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmobocmf_hip.so")
+LIB_PATH = os.environ.get("MOBOCMF_HIP_LIB") or os.path.join(_HERE, "csrc", "libmobocmf_hip.so")   # override: A/B builds
 
 OK, BAD_ARG, WORKSPACE_TOO_SMALL, HIP_ERROR, NOT_PD, BAD_ARCH = range(6)
 _ERR = {1: "MOBOCMF_BAD_ARG", 2: "MOBOCMF_WORKSPACE_TOO_SMALL", 3: "MOBOCMF_HIP_ERROR", 4: "MOBOCMF_NOT_PD",
