@@ -9,7 +9,7 @@ int launch_gram_bwd(const GramArgs& g, bool want_dx, hipStream_t s);
 void gram_grid(const GramArgs& g, dim3* grid);
 int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* out, int64_t len, double scale,
                         int accumulate, hipStream_t s);
-int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, double* Ld, int32_t* info, hipStream_t s);
+int launch_potrf(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* info, hipStream_t s);
 int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
                  int64_t ws_elems, hipStream_t s);
 int launch_pad_tril(const double* src, int64_t lds, int M, double* dst, int Mp, hipStream_t s);
@@ -249,7 +249,7 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     if (do_chain) {
     // K_mm + jitter -> L (in place Cholesky)
     TRY(launch_gram_fwd(g, s));
-    TRY(launch_potrf(S.L, Mp, Mp, F.Dinv, F.Ld, info, s));
+    TRY(launch_potrf(S.L, Mp, Mp, D.M, F.Dinv, F.Ld, info, s));
     TRY(launch_zero32(S.Linv, mm * 2, s));
     TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
     TRY(launch_transpose(S.Linv, Mp, S.LinvT, Mp, Mp, Mp, s));

@@ -26,10 +26,12 @@ typedef double v2f64c __attribute__((ext_vector_type(2)));
 
 // a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c]; LT[j][i] = L[i][j] (0 above the
 // diagonal), rd[j] = 1 / L[j][j].  Returns the first failed pivot (1-based) or 0.
+// NACT (multiple of 16): rows/columns >= NACT of the block are padding (identity) and are left alone.
+template <int NACT>
 __device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd) {
     int fail = 0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < NACT; ++j) {
         const double ajj = bcast(a[j], j);
         if (!(ajj > 0.0) && fail == 0) fail = j + 1;
         const double rinv = 1.0 / sqrt(ajj);
@@ -39,10 +41,10 @@ __device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*L
         if (lane == 0) rd[j] = rinv;
         // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
         if ((j + 1) & 1) {
-            if (j + 1 < NB) a[j + 1] -= lij * LT[j][j + 1];
+            if (j + 1 < NACT) a[j + 1] -= lij * LT[j][j + 1];
         }
 #pragma unroll
-        for (int k = (j + 2) & ~1; k < NB; k += 2) {
+        for (int k = (j + 2) & ~1; k < NACT; k += 2) {
             const v2f64c c = *(const v2f64c*)&LT[j][k];
             a[k] -= lij * c[0];
             a[k + 1] -= lij * c[1];
@@ -53,20 +55,24 @@ __device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*L
 }
 
 // x[] = row `lane` of L^-1 given L rows in a[] (both lower triangular)
+template <int NACT>
 __device__ __forceinline__ void trinv64_rows(const double (&a)[NB], double (&x)[NB], int lane) {
 #pragma unroll
-    for (int k = NB - 1; k >= 0; --k) {
+    for (int k = NB - 1; k >= NACT; --k) x[k] = (lane == k) ? 1.0 : 0.0;      // identity padding
+#pragma unroll
+    for (int k = NACT - 1; k >= 0; --k) {
         double s = (lane == k) ? 1.0 : 0.0;
 #pragma unroll
-        for (int t = k + 1; t < NB; ++t) s -= x[t] * bcast(a[k], t);
+        for (int t = k + 1; t < NACT; ++t) s -= x[t] * bcast(a[k], t);          // L[t][k] = 0 for padded rows t
         x[k] = s / bcast(a[k], k);
     }
 }
 
 // row `lane` of B <- B L^-T  (forward substitution along the row)
+template <int NACT>
 __device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[NB]) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
+    for (int k = 0; k < NACT; ++k) {
         double s = b[k];
 #pragma unroll
         for (int t = 0; t < k; ++t) s -= b[t] * bcast(a[t], k);
@@ -78,6 +84,7 @@ __device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[N
 // NOTE: every workgroup re-factorises the diagonal block from A, so block 0 must NOT overwrite it in place
 // (a workgroup that is scheduled late -- e.g. when other streams occupy the CUs -- would read L_jj instead of
 // A_jj).  The factor goes to the side buffer Ld; finish_l_kernel copies it into the diagonal at the end.
+template <int NACT>
 __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
                                                          int32_t* info) {
     __shared__ __attribute__((aligned(16))) double LT[NB][NB];
@@ -89,14 +96,14 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
     const double* drow = A + (j0 + lane) * ld + j0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = drow[c];
-    int fail = chol64_rows(a, lane, LT, rd);
+    int fail = chol64_rows<NACT>(a, lane, LT, rd);
     if (bi == 0) {
         double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
         if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
         double x[NB];
-        trinv64_rows(a, x, lane);
+        trinv64_rows<NACT>(a, x, lane);
         double* irow = Dinv + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) irow[c] = (c <= lane) ? x[c] : 0.0;
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
         double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;
 #pragma unroll
         for (int c = 0; c < NB; ++c) b[c] = prow[c];
-        trsm64_rows(a, b);
+        trsm64_rows<NACT>(a, b);
 #pragma unroll
         for (int c = 0; c < NB; ++c) prow[c] = b[c];
     }
@@ -191,14 +198,38 @@ __global__ void finish_l_kernel(double* A, int64_t ld, int n, const double* Ld) 
     else if (i / NB == j / NB) A[(int64_t)i * ld + j] = Ld[(int64_t)(i / NB) * NB * NB + (i % NB) * NB + (j % NB)];
 }
 
-// Dinv and Ld: (Mp/64) x 64 x 64 doubles each
-int launch_potrf(double* A, int64_t ld, int Mp, double* Dinv, double* Ld, int32_t* info, hipStream_t s) {
+// Ld / Dinv blocks [b0, b1) <- identity (panels that lie entirely in the identity padding of K_mm)
+__global__ void identity_blocks_kernel(double* Dinv, double* Ld, int b0, int b1) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)(b1 - b0) * NB * NB) return;
+    const int e = (int)(idx % (NB * NB));
+    const double v = (e / NB == e % NB) ? 1.0 : 0.0;
+    Dinv[(int64_t)b0 * NB * NB + idx] = v;
+    Ld[(int64_t)b0 * NB * NB + idx] = v;
+}
+
+// Dinv and Ld: (Mp/64) x 64 x 64 doubles each.  M = real order: rows/columns >= M of A are identity padding, which the
+// factorisation leaves alone -- a 16-point problem padded to 128 costs 16 elimination steps, not 128.
+int launch_potrf(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* info, hipStream_t s) {
     const int nblk = Mp / NB;
+    const int nreal = (M + NB - 1) / NB;          // 64-blocks that hold real rows
     if (launch_zero32(info, 1, s)) return MOBOCMF_HIP_ERROR;
-    for (int jb = 0; jb < nblk; ++jb) {
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk - jb), dim3(64), 0, s, A, ld, jb, Dinv, Ld, info);
-        int nt = nblk - jb - 1;
+    for (int jb = 0; jb < nreal; ++jb) {
+        int nact = M - jb * NB;
+        nact = nact >= NB ? NB : (nact + 15) & ~15;
+        const dim3 grid(nreal - jb);              // blocks below the real rows are zero in these columns and stay zero
+#define PANEL(N) hipLaunchKernelGGL(potrf_panel_kernel<N>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, info)
+        if (nact == 16) PANEL(16);
+        else if (nact == 32) PANEL(32);
+        else if (nact == 48) PANEL(48);
+        else PANEL(64);
+#undef PANEL
+        int nt = nreal - jb - 1;
         if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, ld, jb);
+    }
+    if (nreal < nblk) {
+        int64_t n = (int64_t)(nblk - nreal) * NB * NB;
+        hipLaunchKernelGGL(identity_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Dinv, Ld, nreal, nblk);
     }
     int64_t n2 = (int64_t)Mp * Mp;
     hipLaunchKernelGGL(finish_l_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, A, ld, Mp, (const double*)Ld);

@@ -426,9 +426,67 @@ int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, dou
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
+// ---------------------------------------------------------------------------------- small operands
+// All dimensions <= 256 (the M x M chain of a surrogate with M <= 256 -- the sizes the reference's own BO runs live at):
+// the 128x128x16 MFMA pipeline is pure latency there (one to four workgroups walking 8-16 dependent K steps, ~20 us a
+// product, ~100 products per training step).  Here every workgroup owns a 16 x 16 block of C (one element per thread),
+// streams 16 x 16 operand blocks through LDS and applies the structural zeros of triangular operands on load, so the
+// result never depends on what lies in the unused triangle.  ~4 us a product.
+template <bool B_T>
+__global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
+    __shared__ double As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t r0 = (int64_t)blockIdx.y * 16, c0 = (int64_t)blockIdx.x * 16;
+    if (g.lower_out && c0 / BM > r0 / BM) return;        // same contract as the tiled kernel: lower 128-tiles only
+    int64_t k0 = 0, k1 = g.Kd;
+    if (g.tri & TRI_LOWER_A) k1 = k1 < r0 + 16 ? k1 : r0 + 16;
+    if (g.tri & TRI_UPPER_A) k0 = k0 > r0 ? k0 : r0;
+    if (g.tri & TRI_LOWER_B) k0 = k0 > c0 ? k0 : c0;
+    if (g.tri & TRI_UPPER_B) k1 = k1 < c0 + 16 ? k1 : c0 + 16;
+    double acc = 0.0;
+    for (int64_t k = k0; k < k1; k += 16) {
+        {   // A[r0 + ty][k + tx]
+            const int64_t i = r0 + ty, kk = k + tx;
+            double v = g.A[i * g.lda + kk];
+            if (((g.tri & TRI_LOWER_A) && kk > i) || ((g.tri & TRI_UPPER_A) && kk < i)) v = 0.0;
+            As[ty][tx] = v;
+        }
+        if (B_T) {   // B[c0 + ty][k + tx]  ->  Bs[k][col]
+            const int64_t j = c0 + ty, kk = k + tx;
+            double v = g.B[j * g.ldb + kk];
+            if (((g.tri & TRI_LOWER_B) && kk < j) || ((g.tri & TRI_UPPER_B) && kk > j)) v = 0.0;
+            Bs[tx][ty] = v;
+        } else {     // B[k + ty][c0 + tx]
+            const int64_t kk = k + ty, j = c0 + tx;
+            double v = g.B[kk * g.ldb + j];
+            if (((g.tri & TRI_LOWER_B) && kk < j) || ((g.tri & TRI_UPPER_B) && kk > j)) v = 0.0;
+            Bs[ty][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += As[ty][q] * Bs[q][tx];
+        __syncthreads();
+    }
+    double* c = g.C + (r0 + ty) * g.ldc + c0 + tx;
+    double v = g.alpha * acc;
+    if (g.accumulate) v += *c;
+    *c = v;
+}
+
+static bool small_gemm_ok(const GemmArgs& g) {
+    return !g.batched && g.epi == EPI_STORE && !g.bscale && !g.skip_if_zero && g.Mr <= 256 && g.Nc <= 256 && g.Kd <= 256 &&
+           g.Mr % 16 == 0 && g.Nc % 16 == 0 && g.Kd % 16 == 0;
+}
+
 // Small-grid GEMMs (M x M operands: a handful of 128x128 tiles on 256 CUs) are bound by one CU's MFMA rate:
 // slice k over more workgroups into slabs, then add the slabs.  ws must hold splitk * Mr * Nc doubles.
 int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems, hipStream_t s) {
+    if (small_gemm_ok(g0)) {
+        const dim3 grid((unsigned)(g0.Nc / 16), (unsigned)(g0.Mr / 16));
+        if (B_T) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, s, g0);
+        else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, s, g0);
+        return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+    }
     GemmArgs g = g0;
     const int nrb = g.Mr / BM;
     const int64_t ncb = g.Nc / BN;
