@@ -26,9 +26,99 @@ typedef double v2f64c __attribute__((ext_vector_type(2)));
 
 // a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c]; LT[j][i] = L[i][j] (0 above the
 // diagonal), rd[j] = 1 / L[j][j].  Returns the first failed pivot (1-based) or 0.
+__device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd) {
+    int fail = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double ajj = bcast(a[j], j);
+        if (!(ajj > 0.0) && fail == 0) fail = j + 1;
+        const double rinv = 1.0 / sqrt(ajj);
+        const double lij = a[j] * rinv;          // lanes >= j: L[lane][j]  (lane j: sqrt(ajj))
+        a[j] = lij;
+        LT[j][lane] = lane >= j ? lij : 0.0;
+        if (lane == 0) rd[j] = rinv;
+        // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
+        if ((j + 1) & 1) {
+            if (j + 1 < NB) a[j + 1] -= lij * LT[j][j + 1];
+        }
+#pragma unroll
+        for (int k = (j + 2) & ~1; k < NB; k += 2) {
+            const v2f64c c = *(const v2f64c*)&LT[j][k];
+            a[k] -= lij * c[0];
+            a[k + 1] -= lij * c[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return fail;
+}
+
+// x[] = row `lane` of L^-1 given L rows in a[] (both lower triangular)
+__device__ __forceinline__ void trinv64_rows(const double (&a)[NB], double (&x)[NB], int lane) {
+#pragma unroll
+    for (int k = NB - 1; k >= 0; --k) {
+        double s = (lane == k) ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = k + 1; t < NB; ++t) s -= x[t] * bcast(a[k], t);
+        x[k] = s / bcast(a[k], k);
+    }
+}
+
+// row `lane` of B <- B L^-T  (forward substitution along the row)
+__device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[NB]) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        double s = b[k];
+#pragma unroll
+        for (int t = 0; t < k; ++t) s -= b[t] * bcast(a[t], k);
+        b[k] = s / bcast(a[k], k);
+    }
+}
+
+// grid.x = number of 64-row blocks at/below the diagonal of panel jb; block = 64 threads (1 wavefront)
+// NOTE: every workgroup re-factorises the diagonal block from A, so block 0 must NOT overwrite it in place
+// (a workgroup that is scheduled late -- e.g. when other streams occupy the CUs -- would read L_jj instead of
+// A_jj).  The factor goes to the side buffer Ld; finish_l_kernel copies it into the diagonal at the end.
+__global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
+                                                         int32_t* info) {
+    __shared__ __attribute__((aligned(16))) double LT[NB][NB];
+    __shared__ double rd[NB];
+    const int lane = threadIdx.x;
+    const int bi = blockIdx.x;
+    const int64_t j0 = (int64_t)jb * NB;
+    double a[NB];
+    const double* drow = A + (j0 + lane) * ld + j0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = drow[c];
+    int fail = chol64_rows(a, lane, LT, rd);
+    if (bi == 0) {
+        double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
+        if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
+        double x[NB];
+        trinv64_rows(a, x, lane);
+        double* irow = Dinv + (int64_t)jb * NB * NB + lane * NB;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) irow[c] = (c <= lane) ? x[c] : 0.0;
+    } else {
+        double b[NB];
+        double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) b[c] = prow[c];
+        trsm64_rows(a, b);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) prow[c] = b[c];
+    }
+}
+
+// ---- padded variants (NACT = 16: rows/columns >= NACT of the block are identity padding and are left alone; only
+// this small instantiation is used -- 32 and 48 made hipcc spill, and so did a templated <64>, so the full block keeps
+// the plain routines above).
+// a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c]; LT[j][i] = L[i][j] (0 above the
+// diagonal), rd[j] = 1 / L[j][j].  Returns the first failed pivot (1-based) or 0.
 // NACT (multiple of 16): rows/columns >= NACT of the block are padding (identity) and are left alone.
 template <int NACT>
-__device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd) {
+__device__ __forceinline__ int chol64_pad_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd) {
     int fail = 0;
 #pragma unroll
     for (int j = 0; j < NACT; ++j) {
@@ -56,7 +146,7 @@ __device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*L
 
 // x[] = row `lane` of L^-1 given L rows in a[] (both lower triangular)
 template <int NACT>
-__device__ __forceinline__ void trinv64_rows(const double (&a)[NB], double (&x)[NB], int lane) {
+__device__ __forceinline__ void trinv64_pad_rows(const double (&a)[NB], double (&x)[NB], int lane) {
 #pragma unroll
     for (int k = NB - 1; k >= NACT; --k) x[k] = (lane == k) ? 1.0 : 0.0;      // identity padding
 #pragma unroll
@@ -70,7 +160,7 @@ __device__ __forceinline__ void trinv64_rows(const double (&a)[NB], double (&x)[
 
 // row `lane` of B <- B L^-T  (forward substitution along the row)
 template <int NACT>
-__device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[NB]) {
+__device__ __forceinline__ void trsm64_pad_rows(const double (&a)[NB], double (&b)[NB]) {
 #pragma unroll
     for (int k = 0; k < NACT; ++k) {
         double s = b[k];
@@ -85,7 +175,7 @@ __device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[N
 // (a workgroup that is scheduled late -- e.g. when other streams occupy the CUs -- would read L_jj instead of
 // A_jj).  The factor goes to the side buffer Ld; finish_l_kernel copies it into the diagonal at the end.
 template <int NACT>
-__global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
+__global__ __launch_bounds__(64) void potrf_panel_pad_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
                                                          int32_t* info) {
     __shared__ __attribute__((aligned(16))) double LT[NB][NB];
     __shared__ double rd[NB];
@@ -96,14 +186,14 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
     const double* drow = A + (j0 + lane) * ld + j0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = drow[c];
-    int fail = chol64_rows<NACT>(a, lane, LT, rd);
+    int fail = chol64_pad_rows<NACT>(a, lane, LT, rd);
     if (bi == 0) {
         double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
         if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
         double x[NB];
-        trinv64_rows<NACT>(a, x, lane);
+        trinv64_pad_rows<NACT>(a, x, lane);
         double* irow = Dinv + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) irow[c] = (c <= lane) ? x[c] : 0.0;
@@ -112,7 +202,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
         double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;
 #pragma unroll
         for (int c = 0; c < NB; ++c) b[c] = prow[c];
-        trsm64_rows<NACT>(a, b);
+        trsm64_pad_rows<NACT>(a, b);
 #pragma unroll
         for (int c = 0; c < NB; ++c) prow[c] = b[c];
     }
@@ -218,12 +308,8 @@ int launch_potrf(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld,
         int nact = M - jb * NB;
         nact = nact >= NB ? NB : (nact + 15) & ~15;
         const dim3 grid(nreal - jb);              // blocks below the real rows are zero in these columns and stay zero
-#define PANEL(N) hipLaunchKernelGGL(potrf_panel_kernel<N>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, info)
-        if (nact == 16) PANEL(16);
-        else if (nact == 32) PANEL(32);
-        else if (nact == 48) PANEL(48);
-        else PANEL(64);
-#undef PANEL
+        if (nact == 16) hipLaunchKernelGGL(potrf_panel_pad_kernel<16>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, info);
+        else hipLaunchKernelGGL(potrf_panel_kernel, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, info);
         int nt = nreal - jb - 1;
         if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, ld, jb);
     }

@@ -142,17 +142,29 @@ class ProductKernel(Kernel):
         self.kernels = nn.ModuleList(kernels)
 
 
-def pack_hypers(covar_module, kind):
-    """Constrained hyper-parameters in the C-ABI order (include/mobocmf_hip.h).  Differentiable."""
+def _hyper_sources(covar_module, kind):
+    """(module, raw parameter name) of every hyper-parameter in the C-ABI order (include/mobocmf_hip.h)."""
     if kind == 0:
-        return torch.cat([covar_module.outputscale.reshape(1), covar_module.base_kernel.lengthscale.reshape(-1)])
+        return [(covar_module, "raw_outputscale"), (covar_module.base_kernel, "raw_lengthscale")]
     k_x1 = covar_module.kernels[0].kernels[0]
     k_lin = covar_module.kernels[0].kernels[1].kernels[0]
     k_f = covar_module.kernels[0].kernels[1].kernels[1]
     k_x2 = covar_module.kernels[1]
-    return torch.cat([k_x1.outputscale.reshape(1), k_f.outputscale.reshape(1), k_lin.variance.reshape(1),
-                      k_x2.outputscale.reshape(1), k_f.base_kernel.lengthscale.reshape(1),
-                      k_x1.base_kernel.lengthscale.reshape(-1), k_x2.base_kernel.lengthscale.reshape(-1)])
+    return [(k_x1, "raw_outputscale"), (k_f, "raw_outputscale"), (k_lin, "raw_variance"), (k_x2, "raw_outputscale"),
+            (k_f.base_kernel, "raw_lengthscale"), (k_x1.base_kernel, "raw_lengthscale"),
+            (k_x2.base_kernel, "raw_lengthscale")]
+
+
+def pack_hypers(covar_module, kind):
+    """Constrained hyper-parameters in the C-ABI order (include/mobocmf_hip.h).  Differentiable.
+    All of them carry the softplus constraint, so the transform is applied ONCE to the concatenated raw values (two
+    launches instead of one softplus per parameter plus the concatenation -- the per-step glue that dominated the
+    small configurations); any other constraint falls back to transforming parameter by parameter."""
+    src = _hyper_sources(covar_module, kind)
+    raws = [getattr(m, n).reshape(-1) for m, n in src]
+    if all(type(getattr(m, n + "_constraint")) is Positive for m, n in src):
+        return torch.nn.functional.softplus(torch.cat(raws))
+    return torch.cat([getattr(m, n + "_constraint").transform(r) for (m, n), r in zip(src, raws)])
 
 
 def gram_cpu_init(covar_module, kind, X):
