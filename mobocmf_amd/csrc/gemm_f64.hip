@@ -359,8 +359,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
   }   // parts
 }
 
+static bool small_panel_ok(const GemmArgs& g, bool B_T, int splitk);
+template <int EPI> static int launch_small_panel(const GemmArgs& g, hipStream_t s);
+
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
     if (g.Mr % BM || g.Nc % BN || g.Kd % BK) return MOBOCMF_BAD_ARG;
+    if (small_panel_ok(g, B_T, splitk)) {
+        if (g.epi == EPI_COLSTATS) return launch_small_panel<EPI_COLSTATS>(g, s);
+        if (g.epi == EPI_DA) return launch_small_panel<EPI_DA>(g, s);
+        return launch_small_panel<EPI_STORE>(g, s);
+    }
     int nrb = g.Mr / BM;
     int64_t ncb = g.Nc / BN;
     dim3 grid;
@@ -471,6 +479,121 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
     double v = g.alpha * acc;
     if (g.accumulate) v += *c;
     *c = v;
+}
+
+// M x N' panel products of a small problem (K = Mp <= 256, at most two workgroups per CU in all): one workgroup per
+// (128-row block, 16 columns), 8 rows per thread, same epilogues and partial-sum layout as the tiled kernel.  The tiled
+// kernel -- and a first version of this one that walked K in 16-wide steps -- pays one global-load latency per K step
+// (8 dependent steps = ~28 us for a 128 x 128 x 128 product).  Here a workgroup pulls its whole 128 x 128 block of A and
+// 128 x 16 block of B into LDS at once (149 KB of the CU's 160 KB: every load of the block is in flight together),
+// then multiplies out of LDS.
+#define SP_LDA 129
+#define SP_LDB 17
+#define SP_LDS_BYTES ((BM * SP_LDA + BM * SP_LDB) * 8)
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_panel_kernel(GemmArgs g) {
+    extern __shared__ double sp_smem[];
+    double* As = sp_smem;                    // [128][SP_LDA]
+    double* Bs = sp_smem + BM * SP_LDA;      // [128][SP_LDB]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int rb = blockIdx.y;
+    const int64_t r0 = (int64_t)rb * BM, c0 = (int64_t)blockIdx.x * 16;
+    int64_t k0 = 0, k1 = g.Kd;               // multiples of 128 (Mr, Kd are)
+    if (g.tri & TRI_LOWER_A) k1 = k1 < r0 + BM ? k1 : r0 + BM;
+    if (g.tri & TRI_UPPER_A) k0 = r0;
+    double acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+    for (int64_t kc = k0; kc < k1; kc += BM) {
+        double va[8][8], vb[8];               // every load of the block in flight before the first use
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t row = r0 + ty + 16 * i;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) va[i][c] = g.A[row * g.lda + kc + c * 16 + tx];
+            vb[i] = g.B[(kc + ty + 16 * i) * g.ldb + c0 + tx];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t row = r0 + ty + 16 * i;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int64_t kk = kc + c * 16 + tx;
+                double v = va[i][c];
+                if (((g.tri & TRI_LOWER_A) && kk > row) || ((g.tri & TRI_UPPER_A) && kk < row)) v = 0.0;
+                As[(ty + 16 * i) * SP_LDA + c * 16 + tx] = v;
+            }
+            Bs[(ty + 16 * i) * SP_LDB + tx] = vb[i];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < BM; ++q) {
+            const double b = Bs[q * SP_LDB + tx];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += As[(ty + 16 * i) * SP_LDA + q] * b;
+        }
+        __syncthreads();
+    }
+    const int64_t col = c0 + tx;
+    if (EPI == EPI_DA) {
+        const double gm = g.gmu[col], cg = g.cgv[col];
+        const double cs = g.alpha * (g.bscale ? g.bscale[col] : 1.0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t row = r0 + ty + 16 * i;
+            g.C[row * g.ldc + col] = cs * acc[i] + g.avec[row] * gm - 2.0 * g.Aaux[row * g.ldc + col] * cg;
+        }
+        return;
+    }
+    double sq = 0.0, dt = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t row = r0 + ty + 16 * i;
+        double v = g.alpha * acc[i];
+        if (g.accumulate) v += g.C[row * g.ldc + col];
+        g.C[row * g.ldc + col] = v;
+        if (EPI == EPI_COLSTATS) {
+            sq += v * v;
+            if (g.coldot_part) dt += g.avec[row] * v;
+        }
+    }
+    if (EPI == EPI_COLSTATS) {
+        double* red = sp_smem;               // [2][16][17]; the operand blocks are dead after the last barrier
+        red[(0 * 16 + ty) * 17 + tx] = sq;
+        red[(1 * 16 + ty) * 17 + tx] = dt;
+        __syncthreads();
+        if (ty == 0) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                s0 += red[(0 * 16 + q) * 17 + tx];
+                s1 += red[(1 * 16 + q) * 17 + tx];
+            }
+            g.colsq_part[(int64_t)rb * g.Nc + col] = s0;
+            if (g.coldot_part) g.coldot_part[(int64_t)rb * g.Nc + col] = s1;
+        }
+    }
+}
+
+template <int EPI>
+static int launch_small_panel(const GemmArgs& g, hipStream_t s) {
+    static bool configured = false;          // first call happens in an eager warm-up, never under stream capture
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)small_panel_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SP_LDS_BYTES) != hipSuccess)
+            return MOBOCMF_HIP_ERROR;
+        configured = true;
+    }
+    const dim3 grid((unsigned)(g.Nc / 16), (unsigned)(g.Mr / BM));
+    hipLaunchKernelGGL(small_panel_kernel<EPI>, grid, dim3(256), SP_LDS_BYTES, s, g);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+static bool small_panel_ok(const GemmArgs& g, bool B_T, int splitk) {
+    return !B_T && splitk <= 1 && !g.batched && !g.skip_if_zero && !g.lower_out && !(g.tri & (TRI_LOWER_B | TRI_UPPER_B)) &&
+           g.Kd <= 256 && g.Mr <= 256 && g.Mr % BM == 0 && g.Nc % 16 == 0 && g.Kd % BM == 0 &&
+           (g.Nc / 16) * (g.Mr / BM) <= 512 && (g.epi == EPI_DA || !g.bscale);
 }
 
 static bool small_gemm_ok(const GemmArgs& g) {
