@@ -71,14 +71,14 @@ class GraphedELBOStep:
             self._reset_after_warmup(snapshot)
             self.graph = torch.cuda.CUDAGraph()
             if not self.exchanges:
-                with torch.cuda.graph(self.graph, stream=self.stream):
+                with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                     self._eager()
             else:       # the collective stays outside: graph | all-reduce | graph
-                with torch.cuda.graph(self.graph, stream=self.stream):
+                with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                     self._fwd_bwd()
                 self._exchange()
                 self.graph_update = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_update, stream=self.stream):
+                with torch.cuda.graph(self.graph_update, stream=self.stream, capture_error_mode="thread_local"):
                     self._update()
                 self._reset_after_warmup(snapshot)     # the capture pass above ran the exchange + nothing else for real
         cur.wait_stream(self.stream)
