@@ -12,7 +12,12 @@ DEV = torch.device("cuda")
 
 
 @pytest.mark.parametrize("kind,d,M,nbase,xdiv", [(0, 1, 1, 1, 1), (1, 1, 1, 1, 1), (0, 3, 2, 1, 1), (1, 2, 3, 1, 25),
-                                                 (1, 7, 129, 1, 5), (0, 4, 127, 385, 1), (1, 2, 65, 129, 2)])
+                                                 (1, 7, 129, 1, 5), (0, 4, 127, 385, 1), (1, 2, 65, 129, 2),
+                                                 # either side of the small-problem kernel thresholds (K = Mp <= 256,
+                                                 # <= 512 workgroups; Cholesky panels with <= 16 / > 16 real rows)
+                                                 (1, 3, 100, 2100, 4), (0, 6, 200, 5000, 1), (1, 2, 16, 40, 2),
+                                                 (1, 2, 17, 40, 2), (0, 3, 80, 64, 1), (1, 4, 256, 96, 3),
+                                                 (1, 4, 257, 96, 3)])
 def test_tiny_and_ragged_shapes(kind, d, M, nbase, xdiv):
     from mobocmf_amd import functional as F
     x, f, Zx, zf, hyp, m, L_S = _mk(kind, d, M, nbase, xdiv, seed=M + nbase)
