@@ -146,7 +146,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, steps=2):
+def cpu_baseline(cfg, steps=2, device=None):
     """Reference-equivalent float64 torch-CPU restatement (gpytorch unavailable): the oracle executing GPyTorch's
     op sequence + autograd + torch.optim.Adam, ONE surrogate at the full C3 size, 1 warm-up + `steps` timed steps."""
     import numpy as np
@@ -175,6 +175,7 @@ def cpu_baseline(cfg, steps=2):
     opt = torch.optim.Adam(O.flatten_raw(raw), lr=1e-3)
     x, y, fid = t(prob["x"]), t(prob["y"]), t(prob["fid"])
     eps = [None] + [t(e) for e in prob["eps"][1:]]
+    parity = parity_vs_oracle(O, cfg, prob, raw, x, y, fid, eps, device) if device is not None else None
     times = []
     for k in range(steps + 1):
         t0 = time.perf_counter()
@@ -193,7 +194,32 @@ def cpu_baseline(cfg, steps=2):
     return {"value": 1.0 / med, "unit": "ELBO steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "1 surrogate of C3 at full size (d=8 M=512 N=8192 S=8), 1 warm-up + %d timed steps, median; "
                       "reference-equivalent CPU restatement (gpytorch unavailable)" % steps,
-            "os_cpu_count": os.cpu_count(), "cpu_model": model, "sec_per_step": med}
+            "os_cpu_count": os.cpu_count(), "cpu_model": model, "sec_per_step": med}, parity
+
+
+def parity_vs_oracle(O, cfg, prob, raw, x, y, fid, eps, device, T=256):
+    """BASELINE.json's second metric (pred-var rel-err) at the headline size, in the CPU-baseline leg: ELBO of the same
+    surrogate (same parameters, same explicit eps) and predict_for_acquisition moments on T test points, HIP path vs the
+    oracle.  Tolerance of the north star: 1e-4 relative."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    with torch.no_grad():
+        state = O.state_from_raw(raw)
+        state["samples"] = [None if s_ is None else torch.as_tensor(s_, dtype=torch.float64) for s_ in prob["samples"]]
+        e_ref, _ = O.elbo(state, x, y, fid, eps=eps, S=cfg["S"], ref_equiv=True)
+        Xt = torch.as_tensor(synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=8, N=T, S=1, seed=98)["x"], dtype=torch.float64)
+        mu_ref, var_ref = O.predict_for_acquisition(state, Xt, cfg["L"] - 1, cfg["S"])
+        model = synthetic.model_from_problem(prob, device=device)
+        dv = lambda a: a.to(device)
+        e_gpu, _ = VariationalELBOMF(model, cfg["N"], cfg["L"])(model(dv(x), eps=[None] + [dv(e) for e in eps[1:]]),
+                                                                dv(y)[None, :], dv(fid)[:, None])
+        model.eval()
+        mu, var = model.predict_for_acquisition(dv(Xt), cfg["L"] - 1)
+    rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
+    return {"elbo_rel_err": abs(float(e_gpu) - float(e_ref)) / abs(float(e_ref)), "pred_mean_rel_err": rel(mu, mu_ref),
+            "pred_var_rel_err": rel(var, var_ref), "tolerance": 1e-4,
+            "against": "oracle (float64 CPU restatement, GPyTorch op order) -- %s seed 0 output 0, explicit eps; moments of "
+                       "predict_for_acquisition at %d test points, top fidelity, S=%d fixed samples; errors are max |diff| / "
+                       "max |oracle|" % (cfg.get("name", "headline config"), T, cfg["S"])}
 
 
 def main():
@@ -325,8 +351,9 @@ def main():
         if not args.no_roofline:
             line["roofline"] = measure_dominant_kernel(cfg, device)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg)
+            cb, parity = cpu_baseline(cfg, device=device)
             line["cpu_baseline"] = cb
+            line["parity"] = parity
             line["gpu_over_cpu"] = (value / n_sur) / cb["value"]
         print(json.dumps(line))
     if dist is not None:
