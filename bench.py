@@ -223,6 +223,11 @@ def parity_vs_oracle(O, cfg, prob, raw, x, y, fid, eps, device, T=256):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON record): library chatter written to fd 1 from native code (the RCCL
+    # banner, gloo's connection messages) is diverted to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -355,7 +360,8 @@ def main():
             line["cpu_baseline"] = cb
             line["parity"] = parity
             line["gpu_over_cpu"] = (value / n_sur) / cb["value"]
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
