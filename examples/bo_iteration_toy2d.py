@@ -30,12 +30,16 @@ def blackboxes():
     return {"obj1": (o1, hi(o1, 0.0), False), "obj2": (o2, hi(o2, 1.0), False), "con1": (c1, hi(c1, 2.0), True)}
 
 
-def run(epochs=300, cond_iters=200, acq_iters=50, n_low=14, n_high=6, grid=100, seed=0, device="cuda", verbose=True):
+def run(epochs=300, cond_iters=200, acq_iters=50, n_low=14, n_high=6, grid=100, seed=0, device="cuda", verbose=True,
+        data=None):
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     np.random.seed(seed)
-    x = rng.uniform(size=(n_low + n_high, 2))
-    fid = np.concatenate([np.zeros(n_low), np.ones(n_high)])
+    if data is None:
+        x = rng.uniform(size=(n_low + n_high, 2))
+        fid = np.concatenate([np.zeros(n_low), np.ones(n_high)])
+    else:
+        x, fid = data
     fitter = BlackBoxMFDGPFitter(2, x.shape[0], num_epochs_1=epochs, num_epochs_2=epochs, pareto_set_size=10,
                                  opt_grid_size=grid, type_lengthscale=TL.MEDIAN, device=device)
     fitter.verbose = False
@@ -65,9 +69,32 @@ def run(epochs=300, cond_iters=200, acq_iters=50, n_low=14, n_high=6, grid=100, 
     return fitter, acq, cand, fidelity
 
 
+def loop(iters=3, seed=0, verbose=True, **kw):
+    """``iters`` BO iterations as the reference's driver script runs them (toy_synthetic_2D_JESMOCMF.py:305-470): a fresh
+    fitter on the grown data set each time, the chosen point evaluated at the chosen fidelity for every black-box."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(size=(20, 2))
+    fid = np.concatenate([np.zeros(14), np.ones(6)])
+    history = []
+    for it in range(iters):
+        t0 = time.perf_counter()
+        _, _, cand, fidelity = run(seed=seed + it, data=(x, fid), verbose=False, **kw)
+        x = np.vstack([x, cand.detach().cpu().numpy()[None, :]])
+        fid = np.concatenate([fid, [float(fidelity)]])
+        history.append((cand.detach().cpu().numpy(), fidelity, time.perf_counter() - t0))
+        if verbose:
+            print("BO iteration %d: evaluate x = %s at fidelity %d  (%.1f s, %d points now)" %
+                  (it, np.round(history[-1][0], 4), fidelity, history[-1][2], x.shape[0]))
+    return x, fid, history
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=1, help="number of BO iterations (1 = a single, verbose iteration)")
     a = ap.parse_args()
-    run(epochs=a.epochs, seed=a.seed)
+    if a.iters > 1:
+        loop(iters=a.iters, seed=a.seed, epochs=a.epochs)
+    else:
+        run(epochs=a.epochs, seed=a.seed)

@@ -51,3 +51,10 @@ def test_fitter_and_acquisition_survive_dill_round_trip():
     m2, v2 = fitter2.get_model("obj2").predict_for_acquisition(X, 1)
     assert torch.equal(m1, m2) and torch.equal(v1, v2)
     assert np.allclose(fitter2.samples_objs[0](X.cpu().numpy()), fitter.samples_objs[0](X.cpu().numpy()), atol=1e-12)
+
+
+def test_two_bo_iterations_grow_the_data_set():
+    from bo_iteration_toy2d import loop
+    x, fid, hist = loop(iters=2, seed=3, verbose=False, epochs=40, cond_iters=20, acq_iters=5, grid=30)
+    assert x.shape == (22, 2) and fid.shape == (22,) and len(hist) == 2
+    assert np.all((x >= 0.0) & (x <= 1.0)) and set(np.unique(fid)) <= {0.0, 1.0}
