@@ -6,7 +6,7 @@ b ~ U(0, 2 pi).  Layer >= 1 kernel a1 E1(x) (nu f f' + af Ef(f)) + a2 E2(x) has 
 [ sqrt(nu) f phi_x1(x) ; phi_{x1 f}([x, f]) ; phi_x2(x) ]  (3F features; the middle block is the RBF on [x, f] with
 outputscale a1*af, sharing W_x1 and b_x1 with the first block, as the reference does).
 Posterior weights given q(u) = N(m, S) at the inducing inputs:  A = Phi Phi^T + s2 I,
-theta ~ N( A^-1 Phi m ,  s2 A^-1 + A^-1 Phi S Phi^T A^-1 ).
+theta ~ N( A^-1 Phi m ,  s2 A^-1 + A^-1 Phi S Phi^T A^-1 ), drawn by Matheron's rule with M x M algebra.
 
 Host-side float64 torch: F x F factorisations on the CPU, not part of the ELBO hot path.  The returned callables take
 a numpy array (n, d) or (d,), like the reference's, and recurse through the previous layer's sample; large batches (the
@@ -24,22 +24,29 @@ def _phi(x, W, b, alpha):
     return math.sqrt(2.0 * alpha / F) * torch.cos(W @ x.T + b)
 
 
-def _posterior_weights(Phi, m, S, sigma2, gen):
-    A = Phi @ Phi.T + sigma2 * torch.eye(Phi.shape[0], dtype=Phi.dtype)
-    cA = torch.linalg.cholesky(A)
-    A_inv = torch.cholesky_inverse(cA)
-    mean = torch.cholesky_solve((Phi @ m)[:, None], cA)[:, 0]
-    AP = A_inv @ Phi
-    cov = sigma2 * A_inv + AP @ S @ AP.T
-    cov = 0.5 * (cov + cov.T)
-    jit = 0.0
+def _posterior_weights(Phi, m, Ls, sigma2, gen):
+    """One draw of theta ~ N(A^-1 Phi m, s2 A^-1 + A^-1 Phi S Phi^T A^-1), A = Phi Phi^T + s2 I, S = Ls Ls^T -- the
+    distribution the reference samples with F x F factorisations (mfdgp_hidden_layer.py:296-307) -- by Matheron's
+    rule in the M-dimensional function space (M inducing points << F features):
+
+        theta = theta0 + Phi (Phi^T Phi + s2 I)^-1 (u - Phi^T theta0 - e),   theta0 ~ N(0, I_F), u ~ N(m, S), e ~ N(0, s2 I_M)
+
+    Same mean (push-through identity) and covariance (s2 A^-1 from the prior draw, A^-1 Phi S Phi^T A^-1 from u);
+    O(F M^2) instead of O(F^3)."""
+    nF, M = Phi.shape
+    rn = lambda n: torch.randn(n, dtype=Phi.dtype, generator=gen)
+    theta0, z, e = rn(nF), rn(M), rn(M) * math.sqrt(sigma2)
+    u = m + Ls @ z
+    G = Phi.T @ Phi
+    eye = torch.eye(M, dtype=Phi.dtype)
+    jit = sigma2
     for i in range(6):
-        Lc, info = torch.linalg.cholesky_ex(cov + jit * torch.eye(cov.shape[0], dtype=cov.dtype))
+        Lg, info = torch.linalg.cholesky_ex(G + jit * eye)
         if int(info) == 0:
             break
-        jit = 1e-12 * 10 ** i
-    z = torch.randn(Phi.shape[0], dtype=Phi.dtype, generator=gen)
-    return mean + Lc @ z
+        jit = sigma2 + 1e-10 * 10 ** i
+    rhs = u - Phi.T @ theta0 - e
+    return theta0 + Phi @ torch.cholesky_solve(rhs[:, None], Lg)[:, 0]
 
 
 GRID_ROWS_ON_DEVICE = 4096      # batches at least this large are evaluated on the sample's device (the Pareto grid)
@@ -137,7 +144,7 @@ def sample_from_posterior(layer, input_dim, prev_sample=None, nFeatures=500, sig
     else:
         assert prev_sample is not None
         Phi = feats(Z[:, :-1], Z[:, -1])          # the f column of Z~ is the previous layer's variational mean
-    theta = _posterior_weights(Phi, m, Ls @ Ls.T, sigma2, generator)
+    theta = _posterior_weights(Phi, m, Ls, sigma2, generator)
     return _as_callable(feats, theta, prev_sample, device)
 
 
