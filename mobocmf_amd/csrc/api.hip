@@ -247,24 +247,24 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     g.x = Zx; g.f = zf; g.nbase = D.M; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp;
     g.K = S.L; g.ldk = Mp; g.Mp = Mp; g.Np = Mp; g.knn = nullptr; g.jitter = desc->jitter; g.is_kmm = 1;
     if (do_chain) {
-    // K_mm + jitter -> L (in place Cholesky)
-    TRY(launch_gram_fwd(g, s));
-    TRY(launch_potrf(S.L, Mp, Mp, D.M, F.Dinv, F.Ld, info, s));
-    TRY(launch_zero32(S.Linv, mm * 2, s));
-    TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
-    TRY(launch_transpose(S.Linv, Mp, S.LinvT, Mp, Mp, Mp, s));
-    TRY(launch_pad_tril(L_S, D.M, D.M, S.LSp, Mp, s));
-    TRY(launch_pad_vec(m, D.M, S.mp, Mp, s));
-    // U = L^-1 L_S (lower x lower), a = L^-1 m
-    TRY(launch_zero32(S.U, mm * 2, s));
-    {
-        GemmArgs ga = gemm_args(S.Linv, Mp, S.LSp, Mp, S.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
-        ga.lower_out = 1;
-        TRY(launch_gemm_auto(ga, false, F.ws, F.ws_elems, s));
-    }
-    TRY(launch_transpose(S.U, Mp, S.UT, Mp, Mp, Mp, s));
-    TRY(launch_gemv_rows(S.Linv, Mp, S.mp, S.a, Mp, Mp, 1.0, 0, s));
-    TRY(launch_kl(S.L, S.LSp, S.U, S.a, D.M, Mp, kl, F.qpart, s));
+        // K_mm + jitter -> L (in place Cholesky)
+        TRY(launch_gram_fwd(g, s));
+        TRY(launch_potrf(S.L, Mp, Mp, D.M, F.Dinv, F.Ld, info, s));
+        TRY(launch_zero32(S.Linv, mm * 2, s));
+        TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
+        TRY(launch_transpose(S.Linv, Mp, S.LinvT, Mp, Mp, Mp, s));
+        TRY(launch_pad_tril(L_S, D.M, D.M, S.LSp, Mp, s));
+        TRY(launch_pad_vec(m, D.M, S.mp, Mp, s));
+        // U = L^-1 L_S (lower x lower), a = L^-1 m
+        TRY(launch_zero32(S.U, mm * 2, s));
+        {
+            GemmArgs ga = gemm_args(S.Linv, Mp, S.LSp, Mp, S.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
+            ga.lower_out = 1;
+            TRY(launch_gemm_auto(ga, false, F.ws, F.ws_elems, s));
+        }
+        TRY(launch_transpose(S.U, Mp, S.UT, Mp, Mp, Mp, s));
+        TRY(launch_gemv_rows(S.Linv, Mp, S.mp, S.a, Mp, Mp, 1.0, 0, s));
+        TRY(launch_kl(S.L, S.LSp, S.U, S.a, D.M, Mp, kl, F.qpart, s));
     }
     if (!do_panel) return MOBOCMF_OK;
 
@@ -319,48 +319,48 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     GramArgs g = {};
     g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
     if (do_panel) {
-    TRY(launch_moments_bwd_prep(g_mean, g_var, S.knn, S.q, S.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
-                                B.gv2, B.cgv, nclamped, s));
-    // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
-    {
-        GemmArgs ga = gemm_args(S.U, Mp, S.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
-        ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = S.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = S.A;
-        TRY(launch_gemm(ga, false, 1, s));
-    }
-    // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
-    //   dU = 2 tril(A diag(gv) C^T) = 2 tril(H U),   dA A^T = 2 U U^T H + a da^T - 2 Hc,  Hc = A diag(cgv) A^T.
-    // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
-    // (skip_if_zero) when no column is clamped.
-    if (!inputs_only) {
-        GemmArgs ga = gemm_args(S.A, Np, S.A, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
-        ga.bscale = B.gv; ga.lower_out = 1; ga.slab_stride = mm;
-        TRY(launch_gemm(ga, true, D.splitk, s));
-        TRY(launch_reduce_slabs_sym(B.slabs, mm, D.splitk, H, Mp, nullptr, nullptr, s));
-        if (desc->branch == 0) {
-            ga.bscale = B.cgv; ga.skip_if_zero = nclamped;
-            TRY(launch_gemm(ga, true, D.splitk, s));
-            TRY(launch_reduce_slabs_sym(B.slabs, mm, D.splitk, Hc, Mp, nclamped, H, s));
+        TRY(launch_moments_bwd_prep(g_mean, g_var, S.knn, S.q, S.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
+                                    B.gv2, B.cgv, nclamped, s));
+        // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
+        {
+            GemmArgs ga = gemm_args(S.U, Mp, S.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
+            ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = S.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = S.A;
+            TRY(launch_gemm(ga, false, 1, s));
         }
-    }
-    // da = A gmu
-    if (!inputs_only) TRY(launch_gemv_long(S.A, Np, B.gmu, B.da, Mp, Np, B.gpart, s));
-    // dK = L^-T dA
-    {
-        GemmArgs ga = gemm_args(S.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
-        TRY(launch_gemm(ga, false, 1, s));
-    }
-    // Gram backward of K_mn and k_nn
-    g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
-    g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
-    g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
-    TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
-    TRY(launch_sum_partials(B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, g_hyp, D.H, 1.0, 0, s));
-    if (desc->kind == 1) {
-        TRY(launch_sum_partials(B.df_part, D.ggrid_mn.y, Np, g_f, D.N, 1.0, 0, s));
-        TRY(launch_sum_partials(B.dzf_part, D.ggrid_mn.x, Mp, g_zf, D.M, 1.0, 0, s));
-    }
-    if (desc->want_dx)
-        TRY(launch_sum_partials(B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, g_x, D.nbase * desc->d, 1.0, 0, s));
+        // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
+        //   dU = 2 tril(A diag(gv) C^T) = 2 tril(H U),   dA A^T = 2 U U^T H + a da^T - 2 Hc,  Hc = A diag(cgv) A^T.
+        // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
+        // (skip_if_zero) when no column is clamped.
+        if (!inputs_only) {
+            GemmArgs ga = gemm_args(S.A, Np, S.A, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
+            ga.bscale = B.gv; ga.lower_out = 1; ga.slab_stride = mm;
+            TRY(launch_gemm(ga, true, D.splitk, s));
+            TRY(launch_reduce_slabs_sym(B.slabs, mm, D.splitk, H, Mp, nullptr, nullptr, s));
+            if (desc->branch == 0) {
+                ga.bscale = B.cgv; ga.skip_if_zero = nclamped;
+                TRY(launch_gemm(ga, true, D.splitk, s));
+                TRY(launch_reduce_slabs_sym(B.slabs, mm, D.splitk, Hc, Mp, nclamped, H, s));
+            }
+        }
+        // da = A gmu
+        if (!inputs_only) TRY(launch_gemv_long(S.A, Np, B.gmu, B.da, Mp, Np, B.gpart, s));
+        // dK = L^-T dA
+        {
+            GemmArgs ga = gemm_args(S.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
+            TRY(launch_gemm(ga, false, 1, s));
+        }
+        // Gram backward of K_mn and k_nn
+        g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
+        g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
+        g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
+        TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
+        TRY(launch_sum_partials(B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, g_hyp, D.H, 1.0, 0, s));
+        if (desc->kind == 1) {
+            TRY(launch_sum_partials(B.df_part, D.ggrid_mn.y, Np, g_f, D.N, 1.0, 0, s));
+            TRY(launch_sum_partials(B.dzf_part, D.ggrid_mn.x, Mp, g_zf, D.M, 1.0, 0, s));
+        }
+        if (desc->want_dx)
+            TRY(launch_sum_partials(B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, g_x, D.nbase * desc->d, 1.0, 0, s));
     }
     if (!do_chain) return MOBOCMF_OK;
     if (desc->phase == MOBOCMF_PHASE_CHAIN_ONLY) {      // no upstream mean/var gradient: H = Hc = 0, da = 0
