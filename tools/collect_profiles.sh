@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final
-rm -rf $O && mkdir -p $O
+rm -rf $O && mkdir -p $O   # (also delete the LOCAL gpurun_out/final before a new call: merged files accumulate)
 python bench.py > $O/bench_C3.json 2> $O/bench_C3.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_C3_profiled_run.json 2> $O/prof.err
