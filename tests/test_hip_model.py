@@ -320,3 +320,23 @@ def test_graphed_step_rollback_to_eager():
     l, _ = g2.step()
     g2.check()
     assert g2.graph is None and bool(torch.isfinite(l))
+
+
+def test_graph_replays_draw_fresh_eps():
+    """Each replay of the captured step must see NEW N(0,1) draws for the hidden-layer samples (the reference draws
+    them per call, mfdgp_hidden_layer.py:274): with a vanishing learning rate the loss then still changes from replay
+    to replay, by sampling noise only."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.util.graphed_step import GraphedELBOStep
+    prob = synthetic.make_problem(d=2, L=2, M=10, N=40, S=2, seed=4)
+    t = lambda a: to_t(a).to(DEV)
+    model = build_model(prob, S_train=2)
+    elbo = VariationalELBOMF(model, 40, 2)
+    g = GraphedELBOStep(model, elbo, t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], lr=1e-300)
+    ls = []
+    for _ in range(4):
+        g.step()
+        g.stream.synchronize()
+        ls.append(float(g.loss))
+    assert len(set(ls)) == 4
+    assert max(ls) - min(ls) < 0.5 * abs(ls[0])
