@@ -332,7 +332,7 @@ def test_graph_replays_draw_fresh_eps():
     t = lambda a: to_t(a).to(DEV)
     model = build_model(prob, S_train=2)
     elbo = VariationalELBOMF(model, 40, 2)
-    g = GraphedELBOStep(model, elbo, t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], lr=1e-300)
+    g = GraphedELBOStep(model, elbo, t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], lr=1e-12)
     ls = []
     for _ in range(4):
         g.step()
