@@ -619,7 +619,7 @@ int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems,
     int sk = 1;
     if (!g.batched && g.epi == EPI_STORE && ntile < 96 && nk >= 8) {
         sk = (int)(512 / ntile);      // up to one round of resident workgroups (the nk / 4 floor below keeps slices >= 4 steps)
-        if (sk > nk / 4) sk = (int)(nk / 4);
+        if (sk > nk / 2) sk = (int)(nk / 2);
         if (sk >= 8) sk &= ~7;
         if ((int64_t)sk * g.Mr * g.Nc > ws_elems) sk = (int)(ws_elems / ((int64_t)g.Mr * g.Nc));
         if (sk >= 8) sk &= ~7;
