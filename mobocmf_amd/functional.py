@@ -32,6 +32,10 @@ def _prep(t):
         raise _lib.MobocmfError("mobocmf_amd: expected a GPU tensor (the HIP path has no CPU fallback)")
     if t.dtype != torch.float64:
         raise _lib.MobocmfError("mobocmf_amd: the hot path is float64 end to end (got %s)" % t.dtype)
+    if t.device.index != torch.cuda.current_device():
+        # work is enqueued on the CURRENT device's stream: one process per GPU (torch.cuda.set_device first)
+        raise _lib.MobocmfError("mobocmf_amd: tensor on %s but the current device is cuda:%d -- call "
+                                "torch.cuda.set_device (one process per GPU)" % (t.device, torch.cuda.current_device()))
     return t.contiguous()
 
 
