@@ -125,3 +125,41 @@ def test_no_uninitialised_workspace_or_output_reads(monkeypatch):
         res.append((r[0].detach(), r[1].detach(), g, mus.detach(), vs.detach(), X.grad.clone()))
     for a, b in zip(*res):
         assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
+
+
+def _random_cases(n=24, seed=2024):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        kind = int(rng.integers(0, 2))
+        M = int(rng.integers(1, 301))
+        d = int(rng.integers(3 if M > 60 else 1, 13))        # many inducing points in 1-2 dims = ill-conditioned K_mm
+        nbase = int(rng.integers(1, 401))
+        xdiv = int(rng.choice([1, 1, 2, 3, 5, 8])) if kind == 1 else 1
+        out.append((kind, d, M, nbase, xdiv, int(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("kind,d,M,nbase,xdiv,branch", _random_cases())
+def test_randomised_shapes_match_oracle(kind, d, M, nbase, xdiv, branch):
+    """Seeded random shapes across every kernel-selection threshold: forward moments, KL and all gradients vs the oracle."""
+    from mobocmf_amd import functional as F
+    x, f, Zx, zf, hyp, m, L_S = _mk(kind, d, M, nbase, xdiv, seed=1000 + M + nbase)
+    Np = nbase * xdiv
+    rng = np.random.default_rng(M)
+    w = [torch.tensor(rng.standard_normal(Np)), torch.tensor(rng.standard_normal(Np)), torch.tensor(0.7)]
+    mean_o, var_o, kl_o = _oracle(kind, x, f, Zx, zf, hyp, m, L_S, xdiv, branch, w)
+    g = lambda t, rg=True: None if t is None else t.detach().to(DEV).requires_grad_(rg)
+    fg, zfg, mg, LSg = g(f), g(zf), g(m), g(L_S)
+    hg = _pack(kind, {k: v.detach() for k, v in hyp.items()}).to(DEV).requires_grad_(True)
+    mean, var, kl = F.layer_forward(x.detach().to(DEV), fg, Zx.to(DEV), zfg, hg, mg, LSg, kind, xdiv=xdiv, branch=branch)
+    _close(mean, mean_o, 1e-7, "mean")
+    _close(var, var_o, 1e-7, "var")
+    _close(kl, kl_o, 1e-8, "kl")
+    ((mean * w[0].to(DEV)).sum() + (var * w[1].to(DEV)).sum() + w[2].to(DEV) * kl).backward()
+    _close(mg.grad, m.grad, 1e-6, "g_m")
+    _close(LSg.grad, torch.tril(L_S.grad), 1e-6, "g_LS")
+    _close(hg.grad, _pack(kind, {k: v.grad for k, v in hyp.items()}), 1e-6, "g_hyp")
+    if kind == 1:
+        _close(fg.grad, f.grad, 1e-6, "g_f")
+        _close(zfg.grad, zf.grad, 1e-6, "g_zf")
