@@ -88,6 +88,11 @@ class MFDGP(nn.Module):
         self.variational_strategy = _DeepGPVariationalStrategy(self)
 
     # ------------------------------------------------------------------ init heuristics
+    def clip_inducing_values(self, x_0, x_1, y_1):
+        """Value of the nearest x_1 point for every x_0 point (mfdgp.py:125-135; unused by the reference's own callers)."""
+        d2 = (x_0 * x_0).sum(1, keepdim=True) - 2.0 * x_0 @ x_1.T + (x_1 * x_1).sum(1)[None, :]
+        return y_1[torch.argmin(d2, dim=1)]
+
     def get_init_lengthscale(self, type_lengthscale, inputs=None):
         if type_lengthscale == TL.ONES:
             return torch.ones(self.input_dims)

@@ -81,6 +81,8 @@ def test_model_surface_and_init_heuristics_match_reference_rules():
     assert lik1.raw_noise_constraint.upper_bound == pytest.approx(0.1 * y_high_std)
     assert float(model.hidden_layer_likelihood_0.noise) == pytest.approx(1e-6, rel=1e-3)
     assert l1.samples.shape == (25, 1)
+    x0, x1 = torch.tensor([[0.0], [0.9], [0.4]], dtype=torch.float64), torch.tensor([[1.0], [0.5], [0.1]], dtype=torch.float64)
+    assert model.clip_inducing_values(x0, x1, torch.tensor([10.0, 20.0, 30.0])).tolist() == [30.0, 10.0, 20.0]
 
 
 def test_fix_variational_hypers_toggles_what_the_reference_toggles():
