@@ -129,6 +129,22 @@ class JESMOC_MFDGP:
             return optimize_acqf_multistart(lambda x: self.coupled_acq(x, fidelity=fidelity), self.standard_bounds,
                                             num_restarts=5, raw_samples=200, maxiter=kw.get("maxiter", 200))
 
+    def _get_nextpoint_coupled_highest_fidelity(self, iteration=None, verbose=False, maxiter=200):
+        """Reference name (:137-149): search the highest fidelity only."""
+        keep, self.eval_highest_fidelity = self.eval_highest_fidelity, True
+        try:
+            return self.get_nextpoint_coupled(iteration=iteration, verbose=verbose, maxiter=maxiter)
+        finally:
+            self.eval_highest_fidelity = keep
+
+    def _get_nextpoint_coupled(self, iteration=None, verbose=False, maxiter=200):
+        """Reference name (:151-176): search every fidelity, pick the best cost-weighted value."""
+        keep, self.eval_highest_fidelity = self.eval_highest_fidelity, False
+        try:
+            return self.get_nextpoint_coupled(iteration=iteration, verbose=verbose, maxiter=maxiter)
+        finally:
+            self.eval_highest_fidelity = keep
+
     def get_nextpoint_coupled(self, iteration=None, verbose=False, maxiter=200):
         """Next point + fidelity by cost-weighted acquisition (:137-184)."""
         fids = [self.num_fidelities - 1] if self.eval_highest_fidelity else list(range(self.num_fidelities))
