@@ -84,6 +84,7 @@ class JESMOC_MFDGP:
             if getattr(model, "pareto_set", None) is None:
                 model.sample_and_store_pareto_solution()
             self.pareto_set, self.pareto_front = model.pareto_set, model.pareto_front
+            self.samples_objs, self.samples_cons = getattr(model, "samples_objs", None), getattr(model, "samples_cons", None)
             model.train_conditioned_mfdgps()
             self.blackbox_mfdgp_fitter_cond = model
         else:
