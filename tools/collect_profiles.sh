@@ -15,7 +15,7 @@ echo "pmc done"
 for a in "--config C1" "--config C2" "--config C5" "--config C4 --surrogates 1 --steps 3 --warmup 1" "--surrogates 1" "--config C2 --eager"; do
   python bench.py $a --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a', '|', round(d['value'],1), 'steps/s |', round(d['ms_per_step'],3), 'ms per bench step |', d['config']['surrogates_per_gpu'], 'surrogates')"
 done > $O/other_configs.txt
-python tools/gemm_bench.py > $O/gemm_bench.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rk -- python3 tools/gemm_bench.py > $O/gemm_bench.txt 2>&1   # roofline kernel in isolation: stats must agree with the HIP-event time
 python tools/acq_bench.py 50 > $O/acq_bench.txt 2>&1
 python tools/cond_bench.py 400 > $O/cond_bench.txt 2>&1
 du -sh $O
