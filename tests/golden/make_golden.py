@@ -1,7 +1,10 @@
 """Generates tests/golden/*.npz.  Run in the BUILD container only (needs /root/reference for the
 helper pins; the GPU box only ever reads the committed .npz files).
 
-Two kinds of vectors:
+Three kinds of vectors:
+  ref_moop.npz      outputs of the reference's own MOOP (mobocmf/util/moop.py: numpy/scipy only, importable here) on
+                    seeded inputs -- Pareto masks, front summaries, feasible grids, constrained optima, whole
+                    extractions: these pin mobocmf_amd/util/moop.py against the REAL reference.
   ref_helpers.npz   outputs of the pieces of the reference that ARE importable here
                     (mobocmf.util.util.compute_dist / triu_indices, the Forrester test functions,
                     the nearest-same-fidelity init loop of mfdgp.py:290-317 executed with the
