@@ -340,3 +340,23 @@ def test_graph_replays_draw_fresh_eps():
         ls.append(float(g.loss))
     assert len(set(ls)) == 4
     assert max(ls) - min(ls) < 0.5 * abs(ls[0])
+
+
+def test_only_highest_fidelity_ablation_trains_on_gpu():
+    """use_only_highest_fidelity (mfdgp.py:189-190: the previous layer's output is zeroed; the reference ships it as a
+    separate layer file): the model must train on the GPU path and ignore the low-fidelity targets' link."""
+    from mobocmf_amd.util.blackbox_mfdgp_fitter import BlackBoxMFDGPFitter
+    x, y, fid = synthetic.forrester_problem(0)
+    fitter = BlackBoxMFDGPFitter(2, 16, num_epochs_1=80, num_epochs_2=80, device=DEV)
+    fitter.verbose = False
+    fitter.initialize_mfdgp(to_t(x), to_t(y)[:, None], to_t(fid)[:, None], "obj1", use_only_highest_fidelity=True)
+    h = fitter.mfdgp_handlers_objs["obj1"]
+    assert h.mfdgp.use_only_highest_fidelity
+    xb, yb, fb = h.train_dataset.tensors
+    e0 = h.elbo(h.mfdgp(xb), yb.T, fb)[0].item()
+    fitter.train_mfdgps()
+    e1 = h.elbo(h.mfdgp(xb), yb.T, fb)[0].item()
+    assert np.isfinite(e1) and e1 > e0
+    h.mfdgp.eval()
+    mu, v = h.mfdgp.predict_for_acquisition(xb[:4], 1)
+    assert bool(torch.isfinite(mu).all()) and bool((v > 0).all())
