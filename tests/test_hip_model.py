@@ -360,3 +360,29 @@ def test_only_highest_fidelity_ablation_trains_on_gpu():
     h.mfdgp.eval()
     mu, v = h.mfdgp.predict_for_acquisition(xb[:4], 1)
     assert bool(torch.isfinite(mu).all()) and bool((v > 0).all())
+
+
+def test_warm_start_from_previously_trained_model_on_gpu():
+    """``previously_trained_model`` (mfdgp.py:22-25; the reference's BO loop can pass last iteration's surrogate): kernel
+    hyper-parameters and the fixed acquisition samples carry over from a model that lives on the GPU; the new model has
+    one more data point."""
+    from mobocmf_amd.util.blackbox_mfdgp_fitter import BlackBoxMFDGPFitter
+    x, y, fid = synthetic.forrester_problem(0)
+    fit1 = BlackBoxMFDGPFitter(2, 16, num_epochs_1=60, num_epochs_2=60, device=DEV)
+    fit1.verbose = False
+    fit1.initialize_mfdgp(to_t(x), to_t(y)[:, None], to_t(fid)[:, None], "obj1")
+    fit1.train_mfdgps()
+    prev = fit1.get_model("obj1")
+    x2, y2, f2 = np.vstack([x, [[0.85]]]), np.concatenate([y, [0.3]]), np.concatenate([fid, [1.0]])
+    fit2 = BlackBoxMFDGPFitter(2, 17, num_epochs_1=30, num_epochs_2=30, device=DEV)
+    fit2.verbose = False
+    fit2.initialize_mfdgp(to_t(x2), to_t(y2)[:, None], to_t(f2)[:, None], "obj1", previously_trained_model=prev)
+    new = fit2.get_model("obj1")
+    ls_prev = prev.hidden_layer_1.covar_module.kernels[1].base_kernel.lengthscale.detach()
+    ls_new = new.hidden_layer_1.covar_module.kernels[1].base_kernel.lengthscale.detach()
+    assert torch.allclose(ls_prev, ls_new) and torch.equal(prev.hidden_layer_1.samples, new.hidden_layer_1.samples)
+    assert new.hidden_layer_0.variational_strategy.inducing_points.shape[0] == 17
+    fit2.train_mfdgps()
+    h = fit2.mfdgp_handlers_objs["obj1"]
+    xb, yb, fb = h.train_dataset.tensors
+    assert np.isfinite(h.elbo(h.mfdgp(xb), yb.T, fb)[0].item())
