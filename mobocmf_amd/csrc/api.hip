@@ -17,8 +17,6 @@ int launch_pad_vec(const double* src, int64_t n, double* dst, int64_t np, hipStr
 int launch_transpose(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s);
 int launch_gemv_rows(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double scale,
                      int accumulate, hipStream_t s);
-int launch_gemv_long(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double* part,
-                     hipStream_t s);
 int launch_kl(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* kl,
               double* part, hipStream_t s);
 int launch_moments_finish(const double* qpart, const double* mupart, const double* rpart, int nrb, int64_t Np, int64_t N,
@@ -144,8 +142,8 @@ bool carve_scratch_fwd(Bump& b, const Dims& D, ScratchF& S) {
 }
 
 struct ScratchB {
-    double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *W[10], *da, *da_tot, *flag, *gpart, *hyp_part, *df_part, *dzf_part, *dx_part,
-        *hyp_part2, *df_part2, *dzf_part2, *gzf_tmp;
+    double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *W[10], *da, *da_tot, *flag, *hyp_part, *df_part, *dzf_part, *dx_part,
+        *hyp_part2, *df_part2, *dzf_part2, *gzf_tmp, *dapart;
 };
 bool carve_scratch_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, ScratchB& S) {
     int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
@@ -156,7 +154,7 @@ bool carve_scratch_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, Scra
     S.da = b.take(D.Mp);
     S.da_tot = b.take(D.Mp);
     S.flag = b.take(4);
-    S.gpart = b.take((int64_t)D.Mp * 16);
+    S.dapart = b.take((D.Np <= 8192 ? D.Np / 16 : D.Np / 64) * (int64_t)D.Mp);   // row-dot partials of the dA epilogue (gemm_rowdot_parts)
     S.hyp_part = b.take((int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H);
     S.hyp_part2 = b.take((int64_t)D.ggrid_mm.x * D.ggrid_mm.y * D.H);
     S.df_part = S.dzf_part = S.df_part2 = S.dzf_part2 = S.gzf_tmp = nullptr;
@@ -327,7 +325,9 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
         {
             GemmArgs ga = gemm_args(S.U, Mp, S.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
             ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = S.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = S.A;
+            ga.rowdot_part = inputs_only ? nullptr : B.dapart;      // da = A gmu rides in the epilogue (it reads A anyway)
             TRY(launch_gemm(ga, false, 1, s));
+            if (!inputs_only) TRY(launch_sum_partials(B.dapart, gemm_rowdot_parts(ga), Mp, B.da, Mp, 1.0, 0, s));
         }
         // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
         //   dU = 2 tril(A diag(gv) C^T) = 2 tril(H U),   dA A^T = 2 U U^T H + a da^T - 2 Hc,  Hc = A diag(cgv) A^T.
@@ -344,8 +344,6 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
                 TRY(launch_reduce_slabs_sym(B.slabs, mm, D.splitk, Hc, Mp, nclamped, H, s));
             }
         }
-        // da = A gmu
-        if (!inputs_only) TRY(launch_gemv_long(S.A, Np, B.gmu, B.da, Mp, Np, B.gpart, s));
         // dK = L^-T dA
         {
             GemmArgs ga = gemm_args(S.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);

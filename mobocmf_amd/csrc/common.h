@@ -40,6 +40,8 @@ struct GemmArgs {
     int batched;
     // B_T=1: weights of the contraction index, sum_k A[i][k] bscale[k] B[j][k];  EPI_DA: column scale of the product
     const double* bscale;
+    double* rowdot_part;           // EPI_DA (optional): partial row sums of Aaux[row][col] * gmu[col], [slice][Mr] with
+                                   // gemm_rowdot_parts(g) column slices -- da = A g_mean without another pass over A
     int stream_out;                // write C with non-temporal stores: for a panel whose next reader is far away (it
                                    // would only evict what this and the next launches re-read; a panel consumed by the
                                    // NEXT launch must stay cacheable -- streaming A cost the step 4 % although the
@@ -56,6 +58,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s);
+int gemm_rowdot_parts(const GemmArgs& g);   // number of column slices EPI_DA writes to rowdot_part
 int launch_gemm_auto(const GemmArgs& g, bool B_T, double* ws, int64_t ws_elems, hipStream_t s);
 // out[i][j] = scale * sum_z slabs[z][i][j]  (lower_only: zero above the diagonal), Mr x Mr
 int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, double* out, int64_t ld, int Mr,

@@ -99,35 +99,6 @@ int launch_gemv_rows(const double* Mat, int64_t ld, const double* vec, double* o
     return CHECK_LAUNCH();
 }
 
-// long-row gemv: out[row] = sum_n Mat[row][n] * vec[n], one block per (row, chunk) + partials
-__global__ void gemv_long_kernel(const double* Mat, int64_t ld, const double* vec, double* part, int64_t cols,
-                                 int nchunk) {
-    __shared__ double sh[4];
-    int row = blockIdx.y, ch = blockIdx.x;
-    int64_t per = (cols + nchunk - 1) / nchunk, b = ch * per, e = b + per < cols ? b + per : cols;
-    const double* p = Mat + (int64_t)row * ld;
-    double s = 0.0;
-    for (int64_t j = b + threadIdx.x; j < e; j += 256) s += p[j] * vec[j];
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) part[(int64_t)row * nchunk + ch] = s;
-}
-__global__ void gemv_long_finish_kernel(const double* part, int nchunk, double* out, int rows) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    double s = 0.0;
-    for (int c = 0; c < nchunk; ++c) s += part[(int64_t)r * nchunk + c];
-    out[r] = s;
-}
-int launch_gemv_long(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double* part,
-                     hipStream_t s) {
-    int nchunk = (int)((cols + 8191) / 8192);
-    if (nchunk < 1) nchunk = 1;
-    if (nchunk > 16) nchunk = 16;
-    hipLaunchKernelGGL(gemv_long_kernel, dim3(nchunk, rows), dim3(256), 0, s, Mat, ld, vec, part, cols, nchunk);
-    hipLaunchKernelGGL(gemv_long_finish_kernel, GRID1(rows), 0, s, part, nchunk, out, rows);
-    return CHECK_LAUNCH();
-}
-
 // KL = 0.5 * (2 sum log L_ii - sum log LS_ii^2 + |U|_F^2 + |a|^2 - M)      
 // stage 1: one block per 4 rows of U (lower triangle) -> partial sums; stage 2: one block adds them
 __global__ void kl_part_kernel(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp,

@@ -292,7 +292,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;     // + mt*32 + 4*r
     const int64_t col0 = cb * BN + wc * 64 + li;               // + nt*16
     if (EPI == EPI_DA) {
-        // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n]
+        // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n];   optionally rd[row] = sum_n Aaux[row][n] * gmu[n]
+        double rd[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rd[mt][r] = 0.0;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int64_t col = col0 + nt * 16;
@@ -303,8 +308,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = row0 + mt * 32 + 4 * r;
-                    C[row * g.ldc + col] =
-                        cs * acc[mt][nt][r] + g.avec[row] * gm - 2.0 * g.Aaux[row * g.ldc + col] * cg;
+                    const double av = g.Aaux[row * g.ldc + col];
+                    C[row * g.ldc + col] = cs * acc[mt][nt][r] + g.avec[row] * gm - 2.0 * av * cg;
+                    rd[mt][r] += av * gm;
+                }
+        }
+        if (g.rowdot_part) {
+            // the 16 lanes li of a lane group hold the same rows, different columns: butterfly over li, then one lane
+            // per lane group writes this wavefront's 64-column slice
+            double* out = g.rowdot_part + ((int64_t)cb * 2 + wc) * g.Mr;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = rd[mt][r];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    if (li == 0) out[row0 + mt * 32 + 4 * r] = v;
                 }
         }
         continue;   // LDS was not touched after the main loop's last barrier
@@ -542,7 +564,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t row = r0 + ty + 16 * i;
-            g.C[row * g.ldc + col] = cs * acc[i] + g.avec[row] * gm - 2.0 * g.Aaux[row * g.ldc + col] * cg;
+            const double av = g.Aaux[row * g.ldc + col];
+            g.C[row * g.ldc + col] = cs * acc[i] + g.avec[row] * gm - 2.0 * av * cg;
+            if (g.rowdot_part) {       // the 16 lanes tx of a row hold its 16 columns
+                double v = av * gm;
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (tx == 0) g.rowdot_part[(int64_t)blockIdx.x * g.Mr + row] = v;
+            }
         }
         return;
     }
@@ -594,6 +625,10 @@ static bool small_panel_ok(const GemmArgs& g, bool B_T, int splitk) {
     return !B_T && splitk <= 1 && !g.batched && !g.skip_if_zero && !g.lower_out && !(g.tri & (TRI_LOWER_B | TRI_UPPER_B)) &&
            g.Kd <= 256 && g.Mr <= 256 && g.Mr % BM == 0 && g.Nc % 16 == 0 && g.Kd % BM == 0 &&
            (g.Nc / 16) * (g.Mr / BM) <= 512 && (g.epi == EPI_DA || !g.bscale);
+}
+
+int gemm_rowdot_parts(const GemmArgs& g) {
+    return small_panel_ok(g, false, 1) ? (int)(g.Nc / 16) : (int)(2 * (g.Nc / BN));
 }
 
 static bool small_gemm_ok(const GemmArgs& g) {
