@@ -148,6 +148,15 @@ int mobocmf_adam_step(double* param, const double* grad, double* exp_avg, double
                       int64_t n, double lr, double beta1, double beta2, double eps, int64_t step,
                       mobocmf_stream_t stream);
 
+/* The same update for ALL parameter tensors of a model in one launch (<= 40 tensors per launch; more are chunked).
+ * The arrays of pointers / sizes are HOST arrays (copied into the kernel arguments, so a captured graph replays them);
+ * step_state is ONE device int64 holding the number of completed steps: the launch uses step_state[0] + 1 for the bias
+ * corrections and a trailing one-thread launch increments it (no host-side step count: capturable).  Tensors without a
+ * gradient are simply left out by the caller. */
+int mobocmf_adam_multi(int32_t n_tensors, double* const* params, const double* const* grads, double* const* exp_avg,
+                       double* const* exp_avg_sq, const int64_t* sizes, double lr, double beta1, double beta2, double eps,
+                       int64_t* step_state, mobocmf_stream_t stream);
+
 /* The f64 MFMA GEMM used by the layer (exposed for tests and for the roofline measurement of bench.py):
  * C[Mr x Nc] (+)= alpha * A[Mr x Kd] * B, B is [Kd x Nc] (trans_b = 0) or [Nc x Kd] (trans_b = 1).
  * Mr, Nc multiples of 128, Kd multiple of 16, leading dimensions even, pointers 16-byte aligned.

@@ -467,7 +467,64 @@ __global__ void adam_kernel(double* p, const double* g, double* m, double* v, co
     p[i] -= (lr / bc1) * mi / (sqrt(vi) / bc2_sqrt + eps);
 }
 
+// All parameter tensors of a model in ONE launch (torch's capturable Adam is seven foreach launches of ~28 us each at C3):
+// blockIdx.y = tensor, the pointer table travels by value in the kernel arguments (so a captured graph replays it), the
+// count of completed steps lives on the device and is advanced by a one-thread launch that follows in stream order.
+#define ADAM_MAX_TENSORS 40
+struct AdamTable {
+    double* p[ADAM_MAX_TENSORS];
+    const double* g[ADAM_MAX_TENSORS];
+    double* m[ADAM_MAX_TENSORS];
+    double* v[ADAM_MAX_TENSORS];
+    int64_t n[ADAM_MAX_TENSORS];
+};
+__global__ void adam_multi_kernel(AdamTable t, double lr, double b1, double b2, double eps, const int64_t* steps_done) {
+    const int64_t step = steps_done[0] + 1;
+    const int ti = blockIdx.y;
+    const int64_t n = t.n[ti];
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
+    double* p = t.p[ti];
+    const double* g = t.g[ti];
+    double* m = t.m[ti];
+    double* v = t.v[ti];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double gi = g[i];
+        const double mi = b1 * m[i] + (1.0 - b1) * gi;
+        const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + eps);
+    }
+}
+__global__ void adam_count_kernel(int64_t* steps_done) { steps_done[0] += 1; }
+
 extern "C" {
+
+int mobocmf_adam_multi(int32_t n_tensors, double* const* params, const double* const* grads, double* const* exp_avg,
+                       double* const* exp_avg_sq, const int64_t* sizes, double lr, double beta1, double beta2, double eps,
+                       int64_t* step_state, mobocmf_stream_t stream) {
+    if (n_tensors < 0 || !step_state || (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !sizes)))
+        return MOBOCMF_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n_tensors; base += ADAM_MAX_TENSORS) {
+        AdamTable t;
+        int cnt = n_tensors - base < ADAM_MAX_TENSORS ? n_tensors - base : ADAM_MAX_TENSORS;
+        int64_t nmax = 0;
+        for (int i = 0; i < cnt; ++i) {
+            t.p[i] = params[base + i]; t.g[i] = grads[base + i]; t.m[i] = exp_avg[base + i]; t.v[i] = exp_avg_sq[base + i];
+            t.n[i] = sizes[base + i];
+            if (t.n[i] < 0 || !t.p[i] || !t.g[i] || !t.m[i] || !t.v[i]) return MOBOCMF_BAD_ARG;
+            if (t.n[i] > nmax) nmax = t.n[i];
+        }
+        int64_t bx = (nmax + 1023) / 1024;       // 4 elements per thread in the grid-stride loop
+        if (bx < 1) bx = 1;
+        if (bx > 4096) bx = 4096;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, s, t, lr, beta1, beta2, eps,
+                           (const int64_t*)step_state);
+    }
+    hipLaunchKernelGGL(adam_count_kernel, dim3(1), dim3(1), 0, s, step_state);
+    return CHECK_LAUNCH();
+}
 
 int mobocmf_propagate_forward(const double* mean, const double* var, const double* eps, double* f_out, int64_t n_out,
                               int32_t div, mobocmf_stream_t stream) {

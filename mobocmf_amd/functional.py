@@ -524,6 +524,51 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
                                      param.numel(), lr, beta1, beta2, eps, int(step), _stream()), "mobocmf_adam_step")
 
 
+class FusedAdam:
+    """torch.optim.Adam (defaults: no weight decay, no amsgrad) over all parameters of a model in ONE launch of
+    mobocmf_adam_multi, with the step count on the device: capturable, and the update a captured graph replays.
+    Duck-types the little of torch.optim.Optimizer the fitter uses (zero_grad / step / state)."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for group in params for p in group["params"]] if params and isinstance(params[0], dict) \
+            else list(params)
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        dev = self.params[0].device
+        self.steps_done = torch.zeros((), dtype=torch.int64, device=dev)
+        self.state = {"__step__": {"step": self.steps_done}}
+        for i, p in enumerate(self.params):
+            if p.dtype != torch.float64 or not p.is_cuda:
+                raise _lib.MobocmfError("FusedAdam: float64 GPU parameters only")
+            self.state[i] = {"exp_avg": torch.zeros_like(p, memory_format=torch.contiguous_format),
+                             "exp_avg_sq": torch.zeros_like(p, memory_format=torch.contiguous_format)}
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self):
+        lib = _lib.require_device()
+        idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if not idx:
+            return
+        n = len(idx)
+        arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+        grads = [self.params[i].grad if self.params[i].grad.is_contiguous() else self.params[i].grad.contiguous() for i in idx]
+        for i in idx:
+            if not self.params[i].is_contiguous():
+                raise _lib.MobocmfError("FusedAdam: parameters must be contiguous")
+        P = arr([self.params[i].data_ptr() for i in idx])
+        G = arr([g.data_ptr() for g in grads])
+        M = arr([self.state[i]["exp_avg"].data_ptr() for i in idx])
+        V = arr([self.state[i]["exp_avg_sq"].data_ptr() for i in idx])
+        N = (ctypes.c_int64 * n)(*[self.params[i].numel() for i in idx])
+        _lib.check(lib.mobocmf_adam_multi(n, P, G, M, V, N, self.lr, self.betas[0], self.betas[1], self.eps,
+                                          _ptr(self.steps_done), _stream()), "mobocmf_adam_multi")
+
+
 def check_info(info):
     """Synchronising: raises if the last Cholesky reported a non-positive pivot."""
     lib = _lib.require_device()

@@ -123,7 +123,8 @@ class BlackBoxMFDGPFitter:
         opts = []
         for _, _, h in self._handlers():
             h.mfdgp.fix_variational_hypers(fix_variational_hypers)
-            opts.append(torch.optim.Adam([{"params": h.mfdgp.parameters()}], lr=lr))
+            from ..functional import FusedAdam
+            opts.append(FusedAdam(list(h.mfdgp.parameters()), lr=lr))      # torch.optim.Adam's update in one launch
         for (tag, n, h), optimizer in zip(self._handlers(), opts):
             for i in range(num_epochs):
                 loss_iter, kl_iter = func_update_model(h.mfdgp, h.elbo, optimizer, h.train_loader)

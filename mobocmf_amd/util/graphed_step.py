@@ -7,6 +7,8 @@ the small configurations (C1, C2) and half of what it needs at C3.  All library 
 caller's stream and use caller-owned memory, so the whole step is capturable; a replay costs tens of microseconds.
 Fresh eps is drawn inside the graph (torch's captured Philox state advances on every replay).
 """
+import os
+
 import torch
 
 
@@ -24,7 +26,11 @@ class GraphedELBOStep:
         self.S = model.num_samples_for_training
         self.L = model.num_hidden_layers
         params = [p for p in model.parameters()]
-        self.optimizer = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, capturable=True)   # same arithmetic with and without capture
+        from ..functional import FusedAdam
+        if os.environ.get("MOBOCMF_TORCH_ADAM"):      # A/B knob: torch's capturable Adam (seven foreach launches)
+            self.optimizer = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, capturable=True)
+        else:
+            self.optimizer = FusedAdam(params, lr=lr, betas=betas, eps=eps)     # one launch; step count on the device
         self.loss = torch.zeros((), dtype=torch.float64, device=x.device)
         self.kl = torch.zeros((), dtype=torch.float64, device=x.device)
         self.graph = None
@@ -180,8 +186,8 @@ class GraphedConditionedStep(GraphedELBOStep):
         self.device, self.d, self.n_tilde = dev, fitter.pareto_set.shape[1], n_tilde
         self.use_graph = use_graph
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
-        self.optimizer = torch.optim.Adam([{"params": list(self.model.parameters())}], lr=lr, betas=betas, eps=eps,
-                                          capturable=True)
+        from ..functional import FusedAdam
+        self.optimizer = FusedAdam(list(self.model.parameters()), lr=lr, betas=betas, eps=eps)
         self.loss = torch.zeros((), dtype=torch.float64, device=dev)
         self.kl = torch.zeros((), dtype=torch.float64, device=dev)
         self.graph = self.graph_update = self._snap = None

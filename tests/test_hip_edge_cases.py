@@ -163,3 +163,26 @@ def test_randomised_shapes_match_oracle(kind, d, M, nbase, xdiv, branch):
     if kind == 1:
         _close(fg.grad, f.grad, 1e-6, "g_f")
         _close(zfg.grad, zf.grad, 1e-6, "g_zf")
+
+
+def test_fused_adam_matches_torch_adam():
+    """mobocmf_adam_multi (one launch for all parameter tensors, step count on the device) vs torch.optim.Adam: 45 tensors
+    (more than one 40-tensor table), one without gradient, several steps."""
+    from mobocmf_amd.functional import FusedAdam
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(1,), (), (7, 5), (130,), (64, 64)] * 9
+    ps = [torch.randn(s, dtype=torch.float64, device=DEV, generator=g) for s in shapes]
+    a = [p.clone().requires_grad_(True) for p in ps]
+    b = [p.clone().requires_grad_(True) for p in ps]
+    oa, ob = FusedAdam(a, lr=3e-3), torch.optim.Adam(b, lr=3e-3)
+    for it in range(6):
+        grads = [torch.randn(s, dtype=torch.float64, device=DEV, generator=g) for s in shapes]
+        for k, (pa, pb, gr) in enumerate(zip(a, b, grads)):
+            pa.grad = None if k == 3 else gr.clone()
+            pb.grad = None if k == 3 else gr.clone()
+        oa.step()
+        ob.step()
+    assert int(oa.steps_done) == 6
+    for pa, pb in zip(a, b):
+        assert float((pa - pb).abs().max()) <= 1e-13 * max(1.0, float(pb.abs().max()))
+    assert torch.equal(a[3], ps[3])
