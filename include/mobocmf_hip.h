@@ -134,6 +134,15 @@ int mobocmf_elbo_data_backward(const double* mean, const double* var, const doub
                                double* g_mean, double* g_var, double* g_tau, void* scratch, size_t scratch_bytes,
                                mobocmf_stream_t stream);
 
+/* ELBO tail (variational_elbo_mf.py:37-51): out2[0] = sum data_terms - scale * sum kls, out2[1] = scale * sum kls
+ * (scale = batch / num_data).  Arrays of device-scalar pointers are HOST arrays, at most 8 entries each.
+ * Backward: g2[0] = gradient w.r.t. every data term = g_elbo; g2[1] = w.r.t. every KL = scale * (g_skl - g_elbo);
+ * g_elbo / g_skl are device scalars, either may be NULL (= 0). */
+int mobocmf_elbo_combine_forward(int32_t n_data, const double* const* data_terms, int32_t n_kl, const double* const* kls,
+                                 double scale, double* out2, mobocmf_stream_t stream);
+int mobocmf_elbo_combine_backward(const double* g_elbo, const double* g_skl, double scale, double* g2,
+                                  mobocmf_stream_t stream);
+
 /* mus[t] = mean_s mu~[t*S+s];  vars[t] = mean_s(var~ + mu~^2) - mus^2   (mfdgp.py:258-260). */
 int mobocmf_acq_moments_forward(const double* mu_t, const double* var_t, double* mus, double* vars, int64_t T,
                                 int32_t S, mobocmf_stream_t stream);

@@ -498,7 +498,44 @@ __global__ void adam_multi_kernel(AdamTable t, double lr, double b1, double b2, 
 }
 __global__ void adam_count_kernel(int64_t* steps_done) { steps_done[0] += 1; }
 
+// ELBO tail: out[0] = sum_i a_i - scale * sum_j b_j,  out[1] = scale * sum_j b_j  (data terms a, layer KLs b): one launch
+// instead of a chain of scalar adds / muls / subs, each of which is a ~4 us launch (and as many again in backward).
+#define COMBINE_MAX 8
+struct CombineTable { const double* a[COMBINE_MAX]; const double* b[COMBINE_MAX]; };
+__global__ void elbo_combine_fwd_kernel(CombineTable t, int na, int nb, double scale, double* out) {
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < na; ++i) sa += t.a[i][0];
+    for (int j = 0; j < nb; ++j) sb += t.b[j][0];
+    out[0] = sa - scale * sb;
+    out[1] = scale * sb;
+}
+// g[0] = d/da_i = g_elbo ;  g[1] = d/db_j = scale * (g_skl - g_elbo)     (either upstream gradient may be NULL = 0)
+__global__ void elbo_combine_bwd_kernel(const double* g_elbo, const double* g_skl, double scale, double* g) {
+    const double ge = g_elbo ? g_elbo[0] : 0.0, gs = g_skl ? g_skl[0] : 0.0;
+    g[0] = ge;
+    g[1] = scale * (gs - ge);
+}
+
 extern "C" {
+
+int mobocmf_elbo_combine_forward(int32_t n_data, const double* const* data_terms, int32_t n_kl, const double* const* kls,
+                                 double scale, double* out2, mobocmf_stream_t stream) {
+    if (n_data < 0 || n_kl < 0 || n_data > COMBINE_MAX || n_kl > COMBINE_MAX || !out2 || (n_data && !data_terms) ||
+        (n_kl && !kls))
+        return MOBOCMF_BAD_ARG;
+    CombineTable t = {};
+    for (int i = 0; i < n_data; ++i) { if (!data_terms[i]) return MOBOCMF_BAD_ARG; t.a[i] = data_terms[i]; }
+    for (int j = 0; j < n_kl; ++j) { if (!kls[j]) return MOBOCMF_BAD_ARG; t.b[j] = kls[j]; }
+    hipLaunchKernelGGL(elbo_combine_fwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t, n_data, n_kl, scale, out2);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_elbo_combine_backward(const double* g_elbo, const double* g_skl, double scale, double* g2,
+                                  mobocmf_stream_t stream) {
+    if (!g2) return MOBOCMF_BAD_ARG;
+    hipLaunchKernelGGL(elbo_combine_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g_elbo, g_skl, scale, g2);
+    return CHECK_LAUNCH();
+}
 
 int mobocmf_adam_multi(int32_t n_tensors, double* const* params, const double* const* grads, double* const* exp_avg,
                        double* const* exp_avg_sq, const int64_t* sizes, double lr, double beta1, double beta2, double eps,

@@ -464,6 +464,42 @@ def elbo_data(mean, var, y, fid, tau, level, div=1):
     return _ElboDataFn.apply(mean, var, y, fid, tau, level, div)
 
 
+class _ElboCombineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale, n_data, *terms):
+        lib = _lib.require_device()
+        terms = [_prep(t.reshape(())) for t in terms]
+        data, kls = terms[:n_data], terms[n_data:]
+        out = _empty(2, device=terms[0].device)
+        A = (ctypes.c_void_p * max(len(data), 1))(*[t.data_ptr() for t in data])
+        B = (ctypes.c_void_p * max(len(kls), 1))(*[t.data_ptr() for t in kls])
+        _lib.check(lib.mobocmf_elbo_combine_forward(len(data), A, len(kls), B, float(scale), _ptr(out), _stream()),
+                   "mobocmf_elbo_combine_forward")
+        ctx.scale, ctx.n_data, ctx.n = float(scale), n_data, len(terms)
+        ctx.keep = terms               # the table holds raw pointers: keep the scalars alive until the launch is enqueued
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_elbo, g_skl):
+        lib = _lib.require_device()
+        ref = g_elbo if g_elbo is not None else g_skl
+        g = _empty(2, device=ref.device)
+        ge = None if g_elbo is None else _prep(g_elbo)
+        gs = None if g_skl is None else _prep(g_skl)
+        _lib.check(lib.mobocmf_elbo_combine_backward(_ptr(ge), _ptr(gs), ctx.scale, _ptr(g), _stream()),
+                   "mobocmf_elbo_combine_backward")
+        return (None, None) + (g[0],) * ctx.n_data + (g[1],) * (ctx.n - ctx.n_data)
+
+
+def elbo_combine(data_terms, kls, scale):
+    """(sum data - scale * sum kl, scale * sum kl) in one launch (and one in backward)."""
+    if len(data_terms) > 8 or len(kls) > 8:
+        d = sum(data_terms) if data_terms else 0.0
+        k = sum(kls) * scale if kls else 0.0
+        return d - k, k
+    return _ElboCombineFn.apply(scale, len(data_terms), *data_terms, *kls)
+
+
 class _AcqMomentsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu_t, var_t, S):

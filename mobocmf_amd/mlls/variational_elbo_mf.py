@@ -21,7 +21,7 @@ class VariationalELBOMF(nn.Module):
         num_batch = target.shape[1]
         y = target.reshape(-1)
         fid = fidelities.reshape(-1).to(y.dtype)
-        data_term = 0.0
+        data_terms = []
         for i in range(min(self.num_fidelities, len(l_approximate_dist_f))):
             dist = l_approximate_dist_f[i]
             if dist is None:
@@ -29,10 +29,9 @@ class VariationalELBOMF(nn.Module):
             likelihood = getattr(self.model, self.model.name_hidden_layer_likelihood + str(i))
             mean, var = dist.mean.reshape(-1), dist.variance.reshape(-1)
             # rows with fid != i contribute nothing (an empty mask gives 0, as the reference's skip at :33)
-            data_term = data_term + F.elbo_data(mean, var, y, fid, likelihood.noise, float(i),
-                                                div=mean.numel() // num_batch)
+            data_terms.append(F.elbo_data(mean, var, y, fid, likelihood.noise, float(i), div=mean.numel() // num_batch))
+        # the tail -- sum of the data terms, sum of the layer KLs, batch/num_data scaling, the difference -- is one launch
         if not include_kl_term:
-            return data_term
-        kl_divergence = self.model.variational_strategy.kl_divergence()
-        scaled = kl_divergence * (num_batch / self.num_data)
-        return data_term - scaled, scaled
+            return F.elbo_combine(data_terms, [], 0.0)[0] if data_terms else 0.0
+        kls = self.model.variational_strategy.kl_terms()
+        return F.elbo_combine(data_terms, kls, num_batch / self.num_data)

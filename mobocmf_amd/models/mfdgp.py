@@ -31,10 +31,13 @@ class _DeepGPVariationalStrategy:
     def __init__(self, model):
         self.model = model
 
+    def kl_terms(self):
+        """The per-layer KLs (every ApproximateGP sub-module counted once)."""
+        return [getattr(self.model, self.model.name_hidden_layer + str(i)).variational_strategy.kl_divergence()
+                for i in range(self.model.num_hidden_layers)]
+
     def kl_divergence(self):
-        """Sum over all layers (every ApproximateGP sub-module counted once)."""
-        return sum(getattr(self.model, self.model.name_hidden_layer + str(i)).variational_strategy.kl_divergence()
-                   for i in range(self.model.num_hidden_layers))
+        return sum(self.kl_terms())
 
 
 class MFDGP(nn.Module):

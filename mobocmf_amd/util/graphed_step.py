@@ -49,8 +49,9 @@ class GraphedELBOStep:
             [None] + [torch.randn(n, dtype=torch.float64, device=self.x.device) for _ in range(1, self.L)]
         out = self.model(self.x, eps=eps)
         res = self.elbo(out, self.y.T, self.fid)
-        (-res[0]).backward()
-        self.loss.copy_(-res[0].detach())
+        neg = -res[0]
+        neg.backward()
+        self.loss.copy_(neg.detach())
         self.kl.copy_(res[1].detach())
         self.model.clear_kl_cache()
 
