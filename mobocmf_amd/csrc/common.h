@@ -85,6 +85,7 @@ struct GramArgs {
     double* knn;          // [Np] or null
     double jitter;
     int is_kmm;           // add jitter on the diagonal, identity on the padded diagonal
+    int gm;               // inducing rows per workgroup (set by the launchers: gram_grid's rule)
     // backward
     const double* G;      // dL/dK [Mp x Np], ld = ldk
     const double* gknn;   // [Np] or null

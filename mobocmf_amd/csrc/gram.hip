@@ -25,7 +25,8 @@ __global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
     __shared__ double il1[DB], il2[DB];
     const int d = g.d;
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * GM;
+    const int gm = g.gm;            // inducing rows of this block (<= GM; fewer for small grids: more, shorter workgroups)
+    const int m0 = blockIdx.y * gm;
     const double* hyp = g.hyp;
     double a1, af = 0, nu = 0, a2 = 0, ilf = 0;
     if (KIND == 0) {
@@ -35,12 +36,12 @@ __global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
         a1 = hyp[0]; af = hyp[1]; nu = hyp[2]; a2 = hyp[3]; ilf = 1.0 / hyp[4];
         if (tid < d) { il1[tid] = 1.0 / hyp[5 + tid]; il2[tid] = 1.0 / hyp[5 + d + tid]; }
     }
-    for (int e = tid; e < GM * d; e += GT) {
+    for (int e = tid; e < gm * d; e += GT) {
         int mm = e / d, k = e % d;
         int m = m0 + mm;
         zs[mm][k] = (m < g.M) ? g.Zx[(int64_t)(m / g.zdiv) * d + k] : 0.0;
     }
-    if (KIND == 1 && tid < GM) zfs[tid] = (m0 + tid < g.M) ? g.zf[m0 + tid] : 0.0;
+    if (KIND == 1 && tid < gm) zfs[tid] = (m0 + tid < g.M) ? g.zf[m0 + tid] : 0.0;
     __syncthreads();
 
     const int64_t n0 = (int64_t)blockIdx.x * GT + tid;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
             g.knn[n] = v;
         }
     }
-    for (int mm = 0; mm < GM; ++mm) {
+    for (int mm = 0; mm < gm; ++mm) {
         const int m = m0 + mm;
         double* krow = g.K + (int64_t)m * g.ldk;
         if (!real || m >= g.M) {
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
     extern __shared__ double dfs[];   // [xdiv][GT] per-thread private df accumulators (kind 1)
     const int d = g.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * GM;
+    const int gm = g.gm;            // inducing rows of this block (<= GM; fewer for small grids: more, shorter workgroups)
+    const int m0 = blockIdx.y * gm;
     const double* hyp = g.hyp;
     double a1, af = 0, nu = 0, a2 = 0, ilf = 0;
     if (KIND == 0) {
@@ -164,12 +166,12 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
         a1 = hyp[0]; af = hyp[1]; nu = hyp[2]; a2 = hyp[3]; ilf = 1.0 / hyp[4];
         if (tid < d) { il1[tid] = 1.0 / hyp[5 + tid]; il2[tid] = 1.0 / hyp[5 + d + tid]; }
     }
-    for (int e = tid; e < GM * d; e += GT) {
+    for (int e = tid; e < gm * d; e += GT) {
         int mm = e / d, k = e % d;
         int m = m0 + mm;
         zs[mm][k] = (m < g.M) ? g.Zx[(int64_t)(m / g.zdiv) * d + k] : 0.0;
     }
-    if (tid < GM) {
+    if (tid < gm) {
         dzf_s[tid] = 0.0;
         if (KIND == 1) zfs[tid] = (m0 + tid < g.M) ? g.zf[m0 + tid] : 0.0;
     }
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
         }
     }
 
-    for (int mm = 0; mm < GM; ++mm) {
+    for (int mm = 0; mm < gm; ++mm) {
         const int m = m0 + mm;
         if (m >= g.M) break;   // uniform across the block
         double dzf_loc = 0.0;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
     __syncthreads();
     double* hp = g.hyp_part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * H;
     if (tid < H) hp[tid] = red[0][tid] + red[1][tid];
-    if (KIND == 1 && tid < GM) g.dzf_part[(int64_t)blockIdx.x * g.Mp + m0 + tid] = dzf_s[tid];
+    if (KIND == 1 && tid < gm) g.dzf_part[(int64_t)blockIdx.x * g.Mp + m0 + tid] = dzf_s[tid];
 }
 
 // out[j] (+)= scale * sum_p part[p*stride + j]
@@ -395,12 +397,21 @@ int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* o
 
 static inline int d_bucket(int d) { return d <= 2 ? 2 : (d <= 8 ? 8 : 32); }
 
+// Inducing rows per workgroup: GM, or GM / 4 when that still leaves fewer workgroups than CUs (M x M Gram matrices, small
+// problems: a 64-workgroup launch looping over 32 rows each was a 70 us latency-bound kernel)
+static int gram_rows_per_block(const GramArgs& g) {
+    int64_t nb_cols = (g.Np + g.xdiv - 1) / g.xdiv;
+    int64_t gx = (nb_cols + GT - 1) / GT;
+    return gx * (g.Mp / GM) < 256 ? GM / 4 : GM;
+}
 void gram_grid(const GramArgs& g, dim3* grid) {
     int64_t nb_cols = (g.Np + g.xdiv - 1) / g.xdiv;   // base rows incl. the ones that only own padded columns
-    *grid = dim3((unsigned)((nb_cols + GT - 1) / GT), (unsigned)(g.Mp / GM), 1);
+    *grid = dim3((unsigned)((nb_cols + GT - 1) / GT), (unsigned)(g.Mp / gram_rows_per_block(g)), 1);
 }
 
-int launch_gram_fwd(const GramArgs& g, hipStream_t s) {
+int launch_gram_fwd(const GramArgs& g0, hipStream_t s) {
+    GramArgs g = g0;
+    g.gm = gram_rows_per_block(g0);
     if (g.d < 1 || g.d > 32) return MOBOCMF_BAD_ARG;
     dim3 grid;
     gram_grid(g, &grid);
@@ -416,7 +427,9 @@ int launch_gram_fwd(const GramArgs& g, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
-int launch_gram_bwd(const GramArgs& g, bool want_dx, hipStream_t s) {
+int launch_gram_bwd(const GramArgs& g0, bool want_dx, hipStream_t s) {
+    GramArgs g = g0;
+    g.gm = gram_rows_per_block(g0);
     if (g.d < 1 || g.d > 32) return MOBOCMF_BAD_ARG;
     dim3 grid;
     gram_grid(g, &grid);
