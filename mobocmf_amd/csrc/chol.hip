@@ -26,51 +26,67 @@ typedef double v2f64c __attribute__((ext_vector_type(2)));
 
 // a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c]; LT[j][i] = L[i][j] (0 above the
 // diagonal), rd[j] = 1 / L[j][j].  Returns the first failed pivot (1-based) or 0.
-__device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd) {
+__device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd, double& myrd) {
+    // The reciprocal pivot of step j+1 is started inside step j, right after column j+1 (alone) has received step j's
+    // update: its sqrt + divide (~200 cycles of dependent latency) then run under the remaining updates of step j
+    // instead of in front of step j+1 (measured: the 64 steps were ~750 cycles each, 20 us of the 45 us panel kernel).
     int fail = 0;
+    double rinv;
+    {
+        const double a00 = bcast(a[0], 0);
+        if (!(a00 > 0.0)) fail = 1;
+        rinv = 1.0 / sqrt(a00);
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const double ajj = bcast(a[j], j);
-        if (!(ajj > 0.0) && fail == 0) fail = j + 1;
-        const double rinv = 1.0 / sqrt(ajj);
         const double lij = a[j] * rinv;          // lanes >= j: L[lane][j]  (lane j: sqrt(ajj))
         a[j] = lij;
         LT[j][lane] = lane >= j ? lij : 0.0;
         if (lane == 0) rd[j] = rinv;
-        // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
-        if ((j + 1) & 1) {
-            if (j + 1 < NB) a[j + 1] -= lij * LT[j][j + 1];
+        if (lane == j) myrd = rinv;            // lane k keeps 1 / L[k][k] for the solves (a multiply instead of a divide)
+        double rinv_next = 0.0;
+        if (j + 1 < NB) {
+            a[j + 1] -= lij * LT[j][j + 1];       // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
+            const double an = bcast(a[j + 1], j + 1);
+            if (!(an > 0.0) && fail == 0) fail = j + 2;
+            rinv_next = 1.0 / sqrt(an);
+        }
+        if ((j + 2) & 1) {
+            if (j + 2 < NB) a[j + 2] -= lij * LT[j][j + 2];
         }
 #pragma unroll
-        for (int k = (j + 2) & ~1; k < NB; k += 2) {
+        for (int k = (j + 3) & ~1; k < NB; k += 2) {
             const v2f64c c = *(const v2f64c*)&LT[j][k];
             a[k] -= lij * c[0];
             a[k + 1] -= lij * c[1];
         }
+        rinv = rinv_next;
         __builtin_amdgcn_sched_barrier(0);
     }
     return fail;
 }
 
 // x[] = row `lane` of L^-1 given L rows in a[] (both lower triangular)
-__device__ __forceinline__ void trinv64_rows(const double (&a)[NB], double (&x)[NB], int lane) {
+// (myrd = 1 / L[lane][lane], kept in a register by the factorisation: a multiplication instead of a divide per step;
+//  reading the reciprocals back from LDS made hipcc hoist the loads and spill 7 KB per lane)
+__device__ __forceinline__ void trinv64_rows(const double (&a)[NB], double (&x)[NB], int lane, double myrd) {
 #pragma unroll
     for (int k = NB - 1; k >= 0; --k) {
         double s = (lane == k) ? 1.0 : 0.0;
 #pragma unroll
         for (int t = k + 1; t < NB; ++t) s -= x[t] * bcast(a[k], t);
-        x[k] = s / bcast(a[k], k);
+        x[k] = s * bcast(myrd, k);
     }
 }
 
 // row `lane` of B <- B L^-T  (forward substitution along the row)
-__device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[NB]) {
+__device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[NB], double myrd) {
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         double s = b[k];
 #pragma unroll
         for (int t = 0; t < k; ++t) s -= b[t] * bcast(a[t], k);
-        b[k] = s / bcast(a[k], k);
+        b[k] = s * bcast(myrd, k);
     }
 }
 
@@ -89,14 +105,15 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
     const double* drow = A + (j0 + lane) * ld + j0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = drow[c];
-    int fail = chol64_rows(a, lane, LT, rd);
+    double myrd = 0.0;
+    int fail = chol64_rows(a, lane, LT, rd, myrd);
     if (bi == 0) {
         double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
         if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
         double x[NB];
-        trinv64_rows(a, x, lane);
+        trinv64_rows(a, x, lane, myrd);
         double* irow = Dinv + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) irow[c] = (c <= lane) ? x[c] : 0.0;
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
         double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;
 #pragma unroll
         for (int c = 0; c < NB; ++c) b[c] = prow[c];
-        trsm64_rows(a, b);
+        trsm64_rows(a, b, myrd);
 #pragma unroll
         for (int c = 0; c < NB; ++c) prow[c] = b[c];
     }
@@ -119,26 +136,39 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
 // NACT (multiple of 16): rows/columns >= NACT of the block are padding (identity) and are left alone.
 template <int NACT>
 __device__ __forceinline__ int chol64_pad_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd) {
+    // The reciprocal pivot of step j+1 is started inside step j, right after column j+1 (alone) has received step j's
+    // update: its sqrt + divide (~200 cycles of dependent latency) then run under the remaining updates of step j
+    // instead of in front of step j+1 (measured: the 64 steps were ~750 cycles each, 20 us of the 45 us panel kernel).
     int fail = 0;
+    double rinv;
+    {
+        const double a00 = bcast(a[0], 0);
+        if (!(a00 > 0.0)) fail = 1;
+        rinv = 1.0 / sqrt(a00);
+    }
 #pragma unroll
     for (int j = 0; j < NACT; ++j) {
-        const double ajj = bcast(a[j], j);
-        if (!(ajj > 0.0) && fail == 0) fail = j + 1;
-        const double rinv = 1.0 / sqrt(ajj);
         const double lij = a[j] * rinv;          // lanes >= j: L[lane][j]  (lane j: sqrt(ajj))
         a[j] = lij;
         LT[j][lane] = lane >= j ? lij : 0.0;
         if (lane == 0) rd[j] = rinv;
-        // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
-        if ((j + 1) & 1) {
-            if (j + 1 < NACT) a[j + 1] -= lij * LT[j][j + 1];
+        double rinv_next = 0.0;
+        if (j + 1 < NACT) {
+            a[j + 1] -= lij * LT[j][j + 1];       // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
+            const double an = bcast(a[j + 1], j + 1);
+            if (!(an > 0.0) && fail == 0) fail = j + 2;
+            rinv_next = 1.0 / sqrt(an);
+        }
+        if ((j + 2) & 1) {
+            if (j + 2 < NACT) a[j + 2] -= lij * LT[j][j + 2];
         }
 #pragma unroll
-        for (int k = (j + 2) & ~1; k < NACT; k += 2) {
+        for (int k = (j + 3) & ~1; k < NACT; k += 2) {
             const v2f64c c = *(const v2f64c*)&LT[j][k];
             a[k] -= lij * c[0];
             a[k + 1] -= lij * c[1];
         }
+        rinv = rinv_next;
         __builtin_amdgcn_sched_barrier(0);
     }
     return fail;
