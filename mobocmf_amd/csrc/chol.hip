@@ -66,27 +66,52 @@ __device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*L
     return fail;
 }
 
-// x[] = row `lane` of L^-1 given L rows in a[] (both lower triangular)
-// (myrd = 1 / L[lane][lane], kept in a register by the factorisation: a multiplication instead of a divide per step;
-//  reading the reciprocals back from LDS made hipcc hoist the loads and spill 7 KB per lane)
-__device__ __forceinline__ void trinv64_rows(const double (&a)[NB], double (&x)[NB], int lane, double myrd) {
+// x[] = row `lane` of L^-1 (lower triangular).  Multipliers come from the LDS image the factorisation left:
+// LT[k][t] = L[t][k], contiguous in t, read as wave-uniform 16-byte broadcasts (two multipliers per ds_read_b128 instead
+// of two v_readlane per multiplier); four partial sums break the dependent FMA chain; sched_barrier per step keeps the
+// loads of one step together (without it hipcc hoists ~1000 loads and spills).
+__device__ __forceinline__ void trinv64_rows(double (&x)[NB], int lane, const double (*LT)[NB], double myrd) {
 #pragma unroll
     for (int k = NB - 1; k >= 0; --k) {
-        double s = (lane == k) ? 1.0 : 0.0;
+        double s0 = (lane == k) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if ((k + 1) & 1) {
+            if (k + 1 < NB) s0 -= x[k + 1] * LT[k][k + 1];
+        }
 #pragma unroll
-        for (int t = k + 1; t < NB; ++t) s -= x[t] * bcast(a[k], t);
-        x[k] = s * bcast(myrd, k);
+        for (int t = (k + 2) & ~1; t + 3 < NB; t += 4) {
+            const v2f64c c0 = *(const v2f64c*)&LT[k][t], c1 = *(const v2f64c*)&LT[k][t + 2];
+            s0 -= x[t] * c0[0];
+            s1 -= x[t + 1] * c0[1];
+            s2 -= x[t + 2] * c1[0];
+            s3 -= x[t + 3] * c1[1];
+        }
+        if ((NB - ((k + 2) & ~1)) & 2) {          // a last pair when the span is not a multiple of four
+            const v2f64c c = *(const v2f64c*)&LT[k][NB - 2];
+            s0 -= x[NB - 2] * c[0];
+            s1 -= x[NB - 1] * c[1];
+        }
+        x[k] = ((s0 + s1) + (s2 + s3)) * bcast(myrd, k);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// row `lane` of B <- B L^-T  (forward substitution along the row)
-__device__ __forceinline__ void trsm64_rows(const double (&a)[NB], double (&b)[NB], double myrd) {
+// row `lane` of B <- B L^-T, right-looking: once b[t] is final it is eliminated from all later columns with the
+// multipliers L[k][t] = LT[t][k] (contiguous in k: 16-byte broadcasts, independent FMAs -- the factorisation's own loop)
+__device__ __forceinline__ void trsm64_rows(double (&b)[NB], const double (*LT)[NB], double myrd) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        double s = b[k];
+    for (int t = 0; t < NB; ++t) {
+        const double bt = b[t] * bcast(myrd, t);
+        b[t] = bt;
+        if ((t + 1) & 1) {
+            if (t + 1 < NB) b[t + 1] -= bt * LT[t][t + 1];
+        }
 #pragma unroll
-        for (int t = 0; t < k; ++t) s -= b[t] * bcast(a[t], k);
-        b[k] = s * bcast(myrd, k);
+        for (int k = (t + 2) & ~1; k < NB; k += 2) {
+            const v2f64c c = *(const v2f64c*)&LT[t][k];
+            b[k] -= bt * c[0];
+            b[k + 1] -= bt * c[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -113,7 +138,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
         for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
         if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
         double x[NB];
-        trinv64_rows(a, x, lane, myrd);
+        trinv64_rows(x, lane, LT, myrd);
         double* irow = Dinv + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) irow[c] = (c <= lane) ? x[c] : 0.0;
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
         double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;
 #pragma unroll
         for (int c = 0; c < NB; ++c) b[c] = prow[c];
-        trsm64_rows(a, b, myrd);
+        trsm64_rows(b, LT, myrd);
 #pragma unroll
         for (int c = 0; c < NB; ++c) prow[c] = b[c];
     }
