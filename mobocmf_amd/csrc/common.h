@@ -58,6 +58,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s);
+int gemm_nt_slabs(const GemmArgs& g, int splitk);   // k-slices (slabs) an A B^T launch will really write
 int gemm_rowdot_parts(const GemmArgs& g);   // number of column slices EPI_DA writes to rowdot_part
 int launch_gemm_auto(const GemmArgs& g, bool B_T, double* ws, int64_t ws_elems, hipStream_t s);
 // out[i][j] = scale * sum_z slabs[z][i][j]  (lower_only: zero above the diagonal), Mr x Mr

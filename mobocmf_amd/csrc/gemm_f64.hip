@@ -383,6 +383,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 
 static bool small_panel_ok(const GemmArgs& g, bool B_T, int splitk);
 template <int EPI> static int launch_small_panel(const GemmArgs& g, hipStream_t s);
+static bool small_gemm_ok(const GemmArgs& g, bool B_T);
+static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s);
 
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
     if (g.Mr % BM || g.Nc % BN || g.Kd % BK) return MOBOCMF_BAD_ARG;
@@ -391,6 +393,7 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         if (g.epi == EPI_DA) return launch_small_panel<EPI_DA>(g, s);
         return launch_small_panel<EPI_STORE>(g, s);
     }
+    if (B_T && splitk <= 1 && small_gemm_ok(g, true)) return launch_small_gemm(g, true, s);   // small weighted syrk
     int nrb = g.Mr / BM;
     int64_t ncb = g.Nc / BN;
     dim3 grid;
@@ -465,6 +468,7 @@ int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, dou
 template <bool B_T>
 __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
     __shared__ double As[16][17], Bs[16][17];
+    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int64_t r0 = (int64_t)blockIdx.y * 16, c0 = (int64_t)blockIdx.x * 16;
     if (g.lower_out && c0 / BM > r0 / BM) return;        // same contract as the tiled kernel: lower 128-tiles only
@@ -485,6 +489,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
             const int64_t j = c0 + ty, kk = k + tx;
             double v = g.B[j * g.ldb + kk];
             if (((g.tri & TRI_LOWER_B) && kk < j) || ((g.tri & TRI_UPPER_B) && kk > j)) v = 0.0;
+            if (g.bscale) v *= g.bscale[kk];             // contraction weights (the weighted syrk A diag(w) A^T)
             Bs[tx][ty] = v;
         } else {     // B[k + ty][c0 + tx]
             const int64_t kk = k + ty, j = c0 + tx;
@@ -631,20 +636,25 @@ int gemm_rowdot_parts(const GemmArgs& g) {
     return small_panel_ok(g, false, 1) ? (int)(g.Nc / 16) : (int)(2 * (g.Nc / BN));
 }
 
-static bool small_gemm_ok(const GemmArgs& g) {
-    return !g.batched && g.epi == EPI_STORE && !g.bscale && !g.skip_if_zero && g.Mr <= 256 && g.Nc <= 256 && g.Kd <= 256 &&
-           g.Mr % 16 == 0 && g.Nc % 16 == 0 && g.Kd % 16 == 0;
+static bool small_gemm_ok(const GemmArgs& g, bool B_T) {
+    return !g.batched && g.epi == EPI_STORE && (B_T || (!g.bscale && !g.skip_if_zero)) && g.Mr <= 256 && g.Nc <= 256 &&
+           g.Kd <= 256 && g.Mr % 16 == 0 && g.Nc % 16 == 0 && g.Kd % 16 == 0;
 }
+
+static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
+    const dim3 grid((unsigned)(g.Nc / 16), (unsigned)(g.Mr / 16));
+    if (B_T) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, s, g);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+// slabs a k-sliced A B^T product will write: 1 when the small-operand kernel takes it whole
+int gemm_nt_slabs(const GemmArgs& g, int splitk) { return small_gemm_ok(g, true) ? 1 : splitk; }
 
 // Small-grid GEMMs (M x M operands: a handful of 128x128 tiles on 256 CUs) are bound by one CU's MFMA rate:
 // slice k over more workgroups into slabs, then add the slabs.  ws must hold splitk * Mr * Nc doubles.
 int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems, hipStream_t s) {
-    if (small_gemm_ok(g0)) {
-        const dim3 grid((unsigned)(g0.Nc / 16), (unsigned)(g0.Mr / 16));
-        if (B_T) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, s, g0);
-        else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, s, g0);
-        return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
-    }
+    if (small_gemm_ok(g0, B_T)) return launch_small_gemm(g0, B_T, s);
     GemmArgs g = g0;
     const int nrb = g.Mr / BM;
     const int64_t ncb = g.Nc / BN;
