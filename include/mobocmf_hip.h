@@ -143,6 +143,18 @@ int mobocmf_elbo_combine_forward(int32_t n_data, const double* const* data_terms
 int mobocmf_elbo_combine_backward(const double* g_elbo, const double* g_skl, double scale, double* g2,
                                   mobocmf_stream_t stream);
 
+/* The same pair with the noise given as the RAW parameter of an Interval constraint (mfdgp.py:116):
+ * tau = lo + (hi - lo) * sigmoid(raw_noise[0]) is evaluated inside the kernels and g_tau is the gradient w.r.t. the raw
+ * parameter (hi <= lo: raw_noise is taken as tau itself, i.e. the plain functions above). */
+int mobocmf_elbo_data_interval_forward(const double* mean, const double* var, const double* y, const double* fid,
+                                       const double* raw_noise, double lo, double hi, double level, int64_t n_rows,
+                                       int32_t div, double* out, void* scratch, size_t scratch_bytes,
+                                       mobocmf_stream_t stream);
+int mobocmf_elbo_data_interval_backward(const double* mean, const double* var, const double* y, const double* fid,
+                                        const double* raw_noise, double lo, double hi, double level, int64_t n_rows,
+                                        int32_t div, const double* g_out, double* g_mean, double* g_var, double* g_tau,
+                                        void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+
 /* mus[t] = mean_s mu~[t*S+s];  vars[t] = mean_s(var~ + mu~^2) - mus^2   (mfdgp.py:258-260). */
 int mobocmf_acq_moments_forward(const double* mu_t, const double* var_t, double* mus, double* vars, int64_t T,
                                 int32_t S, mobocmf_stream_t stream);

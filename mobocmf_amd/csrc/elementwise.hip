@@ -371,9 +371,10 @@ __device__ __forceinline__ double elp_term(double y, double mu, double v, double
     return -0.5 * ((dlt * dlt + v) / tau + ltau + LOG_2PI);
 }
 __global__ void elbo_fwd_kernel(const double* mean, const double* var, const double* y, const double* fid,
-                                const double* tau_p, double level, int64_t n, int div, double* part) {
+                                const double* tau_p, double lo, double hi, double level, int64_t n, int div, double* part) {
     __shared__ double sh[4];
-    const double tau = tau_p[0], ltau = log(tau);
+    // hi > lo: tau_p holds the RAW noise parameter of an Interval constraint, tau = lo + (hi - lo) sigmoid(raw)
+    const double tau = hi > lo ? lo + (hi - lo) / (1.0 + exp(-tau_p[0])) : tau_p[0], ltau = log(tau);
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t b = i / div;
@@ -390,10 +391,10 @@ __global__ void final_sum_kernel(const double* part, int np, double scale, doubl
     if (threadIdx.x == 0) out[0] = s * scale;
 }
 __global__ void elbo_bwd_kernel(const double* mean, const double* var, const double* y, const double* fid,
-                                const double* tau_p, double level, int64_t n, int div, const double* gout, double* gmean,
-                                double* gvar, double* part) {
+                                const double* tau_p, double lo, double hi, double level, int64_t n, int div,
+                                const double* gout, double* gmean, double* gvar, double* part) {
     __shared__ double sh[4];
-    const double tau = tau_p[0];
+    const double tau = hi > lo ? lo + (hi - lo) / (1.0 + exp(-tau_p[0])) : tau_p[0];
     const double g = gout[0] / div;
     double st = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -411,12 +412,20 @@ __global__ void elbo_bwd_kernel(const double* mean, const double* var, const dou
     st = block_sum(st, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = st;
 }
-__global__ void final_sum_scaled_kernel(const double* part, int np, const double* gout, double scale, double* out) {
+__global__ void final_sum_scaled_kernel(const double* part, int np, const double* gout, double scale, double* out,
+                                        const double* raw, double lo, double hi) {
     __shared__ double sh[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < np; i += 256) s += part[i];
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) out[0] = s * scale * gout[0];
+    if (threadIdx.x == 0) {
+        double chain = 1.0;                   // d tau / d raw of the Interval transform
+        if (hi > lo) {
+            const double sg = 1.0 / (1.0 + exp(-raw[0]));
+            chain = (hi - lo) * sg * (1.0 - sg);
+        }
+        out[0] = s * scale * gout[0] * chain;
+    }
 }
 
 __global__ void acq_fwd_kernel(const double* mu_t, const double* var_t, double* mus, double* vars, int64_t T, int S) {
@@ -584,12 +593,21 @@ int mobocmf_propagate_backward(const double* var, const double* eps, const doubl
 int mobocmf_elbo_data_forward(const double* mean, const double* var, const double* y, const double* fid,
                               const double* tau, double level, int64_t n_rows, int32_t div, double* out, void* scratch,
                               size_t scratch_bytes, mobocmf_stream_t stream) {
+    return mobocmf_elbo_data_interval_forward(mean, var, y, fid, tau, 0.0, 0.0, level, n_rows, div, out, scratch,
+                                              scratch_bytes, stream);
+}
+
+int mobocmf_elbo_data_interval_forward(const double* mean, const double* var, const double* y, const double* fid,
+                                       const double* raw_noise, double lo, double hi, double level, int64_t n_rows,
+                                       int32_t div, double* out, void* scratch, size_t scratch_bytes,
+                                       mobocmf_stream_t stream) {
+    const double* tau = raw_noise;
     if (n_rows < 0 || div < 1) return MOBOCMF_BAD_ARG;
     if (scratch_bytes < ELBO_BLOCKS * sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
     int nb = (int)((n_rows + 255) / 256);
     nb = nb < 1 ? 1 : (nb > ELBO_BLOCKS ? ELBO_BLOCKS : nb);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(nb), dim3(256), 0, s, mean, var, y, fid, tau, level, n_rows, div,
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(nb), dim3(256), 0, s, mean, var, y, fid, tau, lo, hi, level, n_rows, div,
                        (double*)scratch);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, nb, 1.0 / div, out);
     return CHECK_LAUNCH();
@@ -599,15 +617,24 @@ int mobocmf_elbo_data_backward(const double* mean, const double* var, const doub
                                const double* tau, double level, int64_t n_rows, int32_t div, const double* g_out,
                                double* g_mean, double* g_var, double* g_tau, void* scratch, size_t scratch_bytes,
                                mobocmf_stream_t stream) {
+    return mobocmf_elbo_data_interval_backward(mean, var, y, fid, tau, 0.0, 0.0, level, n_rows, div, g_out, g_mean, g_var,
+                                               g_tau, scratch, scratch_bytes, stream);
+}
+
+int mobocmf_elbo_data_interval_backward(const double* mean, const double* var, const double* y, const double* fid,
+                                        const double* raw_noise, double lo, double hi, double level, int64_t n_rows,
+                                        int32_t div, const double* g_out, double* g_mean, double* g_var, double* g_tau,
+                                        void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
+    const double* tau = raw_noise;
     if (n_rows < 0 || div < 1) return MOBOCMF_BAD_ARG;
     if (scratch_bytes < ELBO_BLOCKS * sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
     int nb = (int)((n_rows + 255) / 256);
     nb = nb < 1 ? 1 : (nb > ELBO_BLOCKS ? ELBO_BLOCKS : nb);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(elbo_bwd_kernel, dim3(nb), dim3(256), 0, s, mean, var, y, fid, tau, level, n_rows, div, g_out,
-                       g_mean, g_var, (double*)scratch);
+    hipLaunchKernelGGL(elbo_bwd_kernel, dim3(nb), dim3(256), 0, s, mean, var, y, fid, tau, lo, hi, level, n_rows, div,
+                       g_out, g_mean, g_var, (double*)scratch);
     hipLaunchKernelGGL(final_sum_scaled_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, nb, g_out, 1.0 / div,
-                       g_tau);
+                       g_tau, tau, lo, hi);
     return CHECK_LAUNCH();
 }
 

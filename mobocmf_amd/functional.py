@@ -429,7 +429,7 @@ def propagate(mean, var, eps, div=1):
 
 class _ElboDataFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mean, var, y, fid, tau, level, div):
+    def forward(ctx, mean, var, y, fid, tau, level, div, lo=0.0, hi=0.0):
         lib = _lib.require_device()
         mean, var, y, fid, tau = (_prep(t.reshape(-1)) for t in (mean, var, y, fid, tau))
         n = mean.numel()
@@ -437,11 +437,12 @@ class _ElboDataFn(torch.autograd.Function):
             raise _lib.MobocmfError("elbo_data: shape mismatch")
         out = _empty((), device=mean.device)
         scratch = scratch_buffer(8192, mean.device)
-        _lib.check(lib.mobocmf_elbo_data_forward(_ptr(mean), _ptr(var), _ptr(y), _ptr(fid), _ptr(tau), float(level), n,
-                                                 div, _ptr(out), _ptr(scratch), scratch.numel(), _stream()),
+        _lib.check(lib.mobocmf_elbo_data_interval_forward(_ptr(mean), _ptr(var), _ptr(y), _ptr(fid), _ptr(tau), float(lo),
+                                                          float(hi), float(level), n, div, _ptr(out), _ptr(scratch),
+                                                          scratch.numel(), _stream()),
                    "mobocmf_elbo_data_forward")
         ctx.save_for_backward(mean, var, y, fid, tau)
-        ctx.level, ctx.div = float(level), div
+        ctx.level, ctx.div, ctx.lo, ctx.hi = float(level), div, float(lo), float(hi)
         return out
 
     @staticmethod
@@ -452,15 +453,19 @@ class _ElboDataFn(torch.autograd.Function):
         gm, gv = _empty_like(mean), _empty_like(var)
         gt = _empty_like(tau)
         scratch = scratch_buffer(8192, mean.device)
-        _lib.check(lib.mobocmf_elbo_data_backward(_ptr(mean), _ptr(var), _ptr(y), _ptr(fid), _ptr(tau), ctx.level,
-                                                  mean.numel(), ctx.div, _ptr(g), _ptr(gm), _ptr(gv), _ptr(gt),
-                                                  _ptr(scratch), scratch.numel(), _stream()),
+        _lib.check(lib.mobocmf_elbo_data_interval_backward(_ptr(mean), _ptr(var), _ptr(y), _ptr(fid), _ptr(tau), ctx.lo,
+                                                           ctx.hi, ctx.level, mean.numel(), ctx.div, _ptr(g), _ptr(gm),
+                                                           _ptr(gv), _ptr(gt), _ptr(scratch), scratch.numel(), _stream()),
                    "mobocmf_elbo_data_backward")
-        return gm, gv, None, None, gt.reshape(ctx.saved_tensors[4].shape), None, None
+        return gm, gv, None, None, gt.reshape(ctx.saved_tensors[4].shape), None, None, None, None
 
 
-def elbo_data(mean, var, y, fid, tau, level, div=1):
-    """(1/div) sum_{fid==level} E_q[log N(y | f, tau)]   (variational_elbo_mf.py:31-35)."""
+def elbo_data(mean, var, y, fid, tau, level, div=1, interval=None):
+    """(1/div) sum_{fid==level} E_q[log N(y | f, tau)]   (variational_elbo_mf.py:31-35).
+    ``interval=(lo, hi)``: ``tau`` is the RAW noise parameter of an Interval constraint; the sigmoid transform and its
+    chain rule run inside the kernels (six element-wise launches less per fidelity and step)."""
+    if interval is not None:
+        return _ElboDataFn.apply(mean, var, y, fid, tau, level, div, float(interval[0]), float(interval[1]))
     return _ElboDataFn.apply(mean, var, y, fid, tau, level, div)
 
 

@@ -1,8 +1,11 @@
 """ELBO of the multi-fidelity DGP -- host mirror of mobocmf/mlls/variational_elbo_mf.py:15-51."""
+import math
+
 import torch
 from torch import nn
 
 from .. import functional as F
+from .. import gp
 
 
 class VariationalELBOMF(nn.Module):
@@ -29,7 +32,12 @@ class VariationalELBOMF(nn.Module):
             likelihood = getattr(self.model, self.model.name_hidden_layer_likelihood + str(i))
             mean, var = dist.mean.reshape(-1), dist.variance.reshape(-1)
             # rows with fid != i contribute nothing (an empty mask gives 0, as the reference's skip at :33)
-            data_terms.append(F.elbo_data(mean, var, y, fid, likelihood.noise, float(i), div=mean.numel() // num_batch))
+            c = likelihood.raw_noise_constraint
+            if type(c) is gp.Interval and math.isfinite(c.upper_bound) and c.upper_bound > c.lower_bound:
+                data_terms.append(F.elbo_data(mean, var, y, fid, likelihood.raw_noise, float(i),
+                                              div=mean.numel() // num_batch, interval=(c.lower_bound, c.upper_bound)))
+            else:
+                data_terms.append(F.elbo_data(mean, var, y, fid, likelihood.noise, float(i), div=mean.numel() // num_batch))
         # the tail -- sum of the data terms, sum of the layer KLs, batch/num_data scaling, the difference -- is one launch
         if not include_kl_term:
             return F.elbo_combine(data_terms, [], 0.0)[0] if data_terms else 0.0
