@@ -134,6 +134,13 @@ int mobocmf_elbo_data_backward(const double* mean, const double* var, const doub
                                double* g_mean, double* g_var, double* g_tau, void* scratch, size_t scratch_bytes,
                                mobocmf_stream_t stream);
 
+/* GPyTorch's shortcut branch (inputs identical to the inducing inputs: q(u) itself): the marginal
+ * variances var[i] = max(sum_{j<=i} L_S[i][j]^2, min_var) of S = L_S L_S^T (L_S M x M row-major, lower triangle read), and
+ * the gradient g_LS[i][j] = 2 L_S[i][j] g_var[i] (j <= i, var[i] above the floor; 0 elsewhere). */
+int mobocmf_shortcut_var_forward(const double* L_S, int32_t M, double min_var, double* var, mobocmf_stream_t stream);
+int mobocmf_shortcut_var_backward(const double* L_S, const double* var, const double* g_var, int32_t M, double min_var,
+                                  double* g_LS, mobocmf_stream_t stream);
+
 /* ELBO tail (variational_elbo_mf.py:37-51): out2[0] = sum data_terms - scale * sum kls, out2[1] = scale * sum kls
  * (scale = batch / num_data).  Arrays of device-scalar pointers are HOST arrays, at most 8 entries each.
  * Backward: g2[0] = gradient w.r.t. every data term = g_elbo; g2[1] = w.r.t. every KL = scale * (g_skl - g_elbo);

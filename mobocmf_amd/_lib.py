@@ -49,6 +49,8 @@ SYMBOLS = {
     "mobocmf_acq_moments_forward": [_P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_acq_moments_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_jes_forward": [_P, _P, _P, _I64, _P],
+    "mobocmf_shortcut_var_forward": [_P, _I32, _D, _P, _P],
+    "mobocmf_shortcut_var_backward": [_P, _P, _P, _I32, _D, _P, _P],
     "mobocmf_elbo_combine_forward": [_I32, _P, _I32, _P, _D, _P, _P],
     "mobocmf_elbo_combine_backward": [_P, _P, _D, _P, _P],
     "mobocmf_adam_multi": [_I32, _P, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P],

@@ -507,6 +507,27 @@ __global__ void adam_multi_kernel(AdamTable t, double lr, double b1, double b2, 
 }
 __global__ void adam_count_kernel(int64_t* steps_done) { steps_done[0] += 1; }
 
+// GPyTorch's shortcut (inputs identical to the inducing inputs -> q(u) itself): marginal variances of
+// S = L_S L_S^T, var[i] = max(sum_{j<=i} L[i][j]^2, min_var), one row per 64 threads; and its gradient w.r.t. L_S.
+__global__ void shortcut_var_fwd_kernel(const double* L, int M, double min_var, double* var) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    double s = 0.0;
+    for (int j = lane; j <= row; j += 64) {
+        const double v = L[(int64_t)row * M + j];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) var[row] = s > min_var ? s : min_var;
+}
+__global__ void shortcut_var_bwd_kernel(const double* L, const double* var, const double* g, int M, double min_var,
+                                        double* gL) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * M) return;
+    const int i = (int)(idx / M), j = (int)(idx % M);
+    gL[idx] = (j <= i && var[i] > min_var) ? 2.0 * L[idx] * g[i] : 0.0;
+}
+
 // ELBO tail: out[0] = sum_i a_i - scale * sum_j b_j,  out[1] = scale * sum_j b_j  (data terms a, layer KLs b): one launch
 // instead of a chain of scalar adds / muls / subs, each of which is a ~4 us launch (and as many again in backward).
 #define COMBINE_MAX 8
@@ -526,6 +547,21 @@ __global__ void elbo_combine_bwd_kernel(const double* g_elbo, const double* g_sk
 }
 
 extern "C" {
+
+int mobocmf_shortcut_var_forward(const double* L_S, int32_t M, double min_var, double* var, mobocmf_stream_t stream) {
+    if (!L_S || !var || M < 1) return MOBOCMF_BAD_ARG;
+    hipLaunchKernelGGL(shortcut_var_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, L_S, M,
+                       min_var, var);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_shortcut_var_backward(const double* L_S, const double* var, const double* g_var, int32_t M, double min_var,
+                                  double* g_LS, mobocmf_stream_t stream) {
+    if (!L_S || !var || !g_var || !g_LS || M < 1) return MOBOCMF_BAD_ARG;
+    hipLaunchKernelGGL(shortcut_var_bwd_kernel, GRID1((int64_t)M * M), 0, (hipStream_t)stream, L_S, var, g_var, M, min_var,
+                       g_LS);
+    return CHECK_LAUNCH();
+}
 
 int mobocmf_elbo_combine_forward(int32_t n_data, const double* const* data_terms, int32_t n_kl, const double* const* kls,
                                  double scale, double* out2, mobocmf_stream_t stream) {

@@ -469,6 +469,35 @@ def elbo_data(mean, var, y, fid, tau, level, div=1, interval=None):
     return _ElboDataFn.apply(mean, var, y, fid, tau, level, div)
 
 
+class _ShortcutVarFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, L_S, min_var):
+        lib = _lib.require_device()
+        L_S = _prep(L_S)
+        M = L_S.shape[0]
+        var = _empty(M, device=L_S.device)
+        _lib.check(lib.mobocmf_shortcut_var_forward(_ptr(L_S), M, float(min_var), _ptr(var), _stream()),
+                   "mobocmf_shortcut_var_forward")
+        ctx.save_for_backward(L_S, var)
+        ctx.min_var = float(min_var)
+        return var
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.require_device()
+        L_S, var = ctx.saved_tensors
+        g = _prep(g)
+        gL = _empty_like(L_S)
+        _lib.check(lib.mobocmf_shortcut_var_backward(_ptr(L_S), _ptr(var), _ptr(g), L_S.shape[0], ctx.min_var, _ptr(gL),
+                                                     _stream()), "mobocmf_shortcut_var_backward")
+        return gL, None
+
+
+def shortcut_var(L_S, min_var=MIN_VARIANCE):
+    """diag(L_S L_S^T) floored at min_var: the marginal variances of q(u) (GPyTorch's equal-inputs shortcut)."""
+    return _ShortcutVarFn.apply(L_S, min_var)
+
+
 class _ElboCombineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scale, n_data, *terms):

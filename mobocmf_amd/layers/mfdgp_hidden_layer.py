@@ -301,8 +301,7 @@ class MFDGPHiddenLayer(nn.Module):
             hit = bool(torch.equal(x, vs.Zx) and (f is None or torch.equal(f, vs.zf)))
             self._shortcut_last = hit
         if hit:
-            L = torch.tril(vd.chol_variational_covar)
-            return vd.variational_mean, (L * L).sum(1).clamp_min(F.MIN_VARIANCE)
+            return vd.variational_mean, F.shortcut_var(vd.chol_variational_covar)
         if isinstance(chain, F.FrozenChain):
             return F.layer_panel_frozen(chain, x, f, xdiv=xdiv, want_dx=want_dx)
         if chain is not None:

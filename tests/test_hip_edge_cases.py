@@ -186,3 +186,21 @@ def test_fused_adam_matches_torch_adam():
     for pa, pb in zip(a, b):
         assert float((pa - pb).abs().max()) <= 1e-13 * max(1.0, float(pb.abs().max()))
     assert torch.equal(a[3], ps[3])
+
+
+def test_shortcut_variance_matches_torch():
+    from mobocmf_amd import functional as F
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M in (1, 7, 64, 130):
+        L = torch.randn(M, M, dtype=torch.float64, device=DEV, generator=g)
+        L[0, 0] = 1e-7                                        # a row under the floor
+        w = torch.randn(M, dtype=torch.float64, device=DEV, generator=g)
+        a = L.clone().requires_grad_(True)
+        b = L.clone().requires_grad_(True)
+        va = F.shortcut_var(a)
+        Lt = torch.tril(b)
+        vb = (Lt * Lt).sum(1).clamp_min(F.MIN_VARIANCE)
+        assert torch.allclose(va, vb, rtol=1e-14, atol=0)
+        (va * w).sum().backward()
+        (vb * w).sum().backward()
+        assert torch.allclose(a.grad, b.grad, rtol=1e-14, atol=0)
