@@ -355,13 +355,18 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
         g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
         g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
         TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
-        TRY(launch_sum_partials(B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, g_hyp, D.H, 1.0, 0, s));
-        if (desc->kind == 1) {
-            TRY(launch_sum_partials(B.df_part, D.ggrid_mn.y, Np, g_f, D.N, 1.0, 0, s));
-            TRY(launch_sum_partials(B.dzf_part, D.ggrid_mn.x, Mp, g_zf, D.M, 1.0, 0, s));
+        {
+            SumTask tk[4];
+            int nt = 0;
+            tk[nt++] = {B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, nullptr, 0, 0, g_hyp, D.H, 0};
+            if (desc->kind == 1) {
+                tk[nt++] = {B.df_part, D.ggrid_mn.y, Np, nullptr, 0, 0, g_f, D.N, 0};
+                tk[nt++] = {B.dzf_part, D.ggrid_mn.x, Mp, nullptr, 0, 0, g_zf, D.M, 0};
+            }
+            if (desc->want_dx)
+                tk[nt++] = {B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, nullptr, 0, 0, g_x, D.nbase * desc->d, 0};
+            TRY(launch_sum_partials_multi(tk, nt, s));
         }
-        if (desc->want_dx)
-            TRY(launch_sum_partials(B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, g_x, D.nbase * desc->d, 1.0, 0, s));
     }
     if (!do_chain) return MOBOCMF_OK;
     if (desc->phase == MOBOCMF_PHASE_CHAIN_ONLY) {      // no upstream mean/var gradient: H = Hc = 0, da = 0
@@ -417,10 +422,13 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     g.xdiv = 1; g.x = Zx; g.f = zf; g.nbase = D.M; g.ldk = Mp; g.Np = Mp; g.G = Gm; g.gknn = nullptr;
     g.hyp_part = B.hyp_part2; g.df_part = B.df_part2; g.dzf_part = B.dzf_part2; g.dx_part = nullptr;
     TRY(launch_gram_bwd(g, false, s));
-    TRY(launch_sum_partials(B.hyp_part2, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, D.H, g_hyp, D.H, 1.0, acc, s));
-    if (desc->kind == 1) {
-        TRY(launch_sum_partials(B.df_part2, D.ggrid_mm.y, Mp, g_zf, D.M, 1.0, acc, s));
-        TRY(launch_sum_partials(B.dzf_part2, D.ggrid_mm.x, Mp, g_zf, D.M, 1.0, 1, s));
+    {
+        SumTask tk[2];
+        int nt = 0;
+        tk[nt++] = {B.hyp_part2, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, D.H, nullptr, 0, 0, g_hyp, D.H, acc};
+        if (desc->kind == 1)      // both arguments of K_mm are Z~: the row-side and the column-side partials land in g_zf
+            tk[nt++] = {B.df_part2, D.ggrid_mm.y, Mp, B.dzf_part2, D.ggrid_mm.x, Mp, g_zf, D.M, acc};
+        TRY(launch_sum_partials_multi(tk, nt, s));
     }
     return MOBOCMF_OK;
 }

@@ -58,6 +58,14 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s);
+// out[j] (+)= sum_p part[p*stride + j] (+ sum_p part2[p*stride2 + j]); several such reductions in ONE launch when every
+// partial count is small (small problems: each separate launch is ~4.5 us of pure latency)
+struct SumTask {
+    const double* part; int64_t P, stride;
+    const double* part2; int64_t P2, stride2;      // optional second source (part2 == nullptr: none)
+    double* out; int64_t len; int accumulate;
+};
+int launch_sum_partials_multi(const SumTask* tasks, int n, hipStream_t s);
 int gemm_nt_slabs(const GemmArgs& g, int splitk);   // k-slices (slabs) an A B^T launch will really write
 int gemm_rowdot_parts(const GemmArgs& g);   // number of column slices EPI_DA writes to rowdot_part
 int launch_gemm_auto(const GemmArgs& g, bool B_T, double* ws, int64_t ws_elems, hipStream_t s);

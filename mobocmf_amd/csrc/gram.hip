@@ -382,6 +382,55 @@ __global__ void group_sum_kernel(const double* in, double* out, int64_t nout, in
     out[j] = accumulate ? out[j] + v : v;
 }
 
+#define SUM_MULTI_MAX 4
+struct SumTasksArg { SumTask t[SUM_MULTI_MAX]; int blk0[SUM_MULTI_MAX + 1]; int n; };
+__global__ void sum_partials_multi_kernel(SumTasksArg T) {
+    int k = 0;
+    while (k + 1 < T.n && (int)blockIdx.x >= T.blk0[k + 1]) ++k;
+    const SumTask& t = T.t[k];
+    const int64_t j = (int64_t)(blockIdx.x - T.blk0[k]) * blockDim.x + threadIdx.x;
+    if (j >= t.len) return;
+    double v = 0.0;
+    for (int64_t p = 0; p < t.P; ++p) v += t.part[p * t.stride + j];
+    if (t.part2)
+        for (int64_t p = 0; p < t.P2; ++p) v += t.part2[p * t.stride2 + j];
+    t.out[j] = t.accumulate ? t.out[j] + v : v;
+}
+
+int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* out, int64_t len, double scale,
+                        int accumulate, hipStream_t s);
+
+int launch_sum_partials_multi(const SumTask* tasks, int n, hipStream_t s) {
+    bool small = n <= SUM_MULTI_MAX;
+    for (int i = 0; i < n; ++i) small = small && tasks[i].P <= 64 && (!tasks[i].part2 || tasks[i].P2 <= 64);
+    if (!small) {     // many partials per output: the separate launches pick the wide (one block per output) reduction
+        for (int i = 0; i < n; ++i) {
+            int rc = launch_sum_partials(tasks[i].part, tasks[i].P, tasks[i].stride, tasks[i].out, tasks[i].len, 1.0,
+                                         tasks[i].accumulate, s);
+            if (rc) return rc;
+            if (tasks[i].part2) {
+                rc = launch_sum_partials(tasks[i].part2, tasks[i].P2, tasks[i].stride2, tasks[i].out, tasks[i].len, 1.0, 1, s);
+                if (rc) return rc;
+            }
+        }
+        return MOBOCMF_OK;
+    }
+    SumTasksArg T = {};
+    int nb = 0, m = 0;
+    for (int i = 0; i < n; ++i) {
+        if (tasks[i].len <= 0) continue;
+        T.t[m] = tasks[i];
+        T.blk0[m] = nb;
+        nb += (int)((tasks[i].len + 255) / 256);
+        ++m;
+    }
+    T.blk0[m] = nb;
+    T.n = m;
+    if (m == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(sum_partials_multi_kernel, dim3((unsigned)nb), dim3(256), 0, s, T);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
 int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* out, int64_t len, double scale,
                         int accumulate, hipStream_t s) {
     if (len <= 0) return MOBOCMF_OK;
