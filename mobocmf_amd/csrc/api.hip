@@ -276,9 +276,11 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     {
         GemmArgs ga = gemm_args(S.Linv, Mp, S.K, Np, S.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
         ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = S.a;
+        ga.Kreal = D.M;      // rows >= M of K_mn (and of A, C, dA below) are zero padding
         TRY(launch_gemm(ga, false, 1, s));
         GemmArgs gc = gemm_args(S.UT, Mp, S.A, Np, S.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
         gc.epi = EPI_COLSTATS; gc.colsq_part = F.rpart; gc.coldot_part = nullptr; gc.avec = S.a;
+        gc.Kreal = D.M;
         gc.stream_out = (desc->branch == 0 && Np * Mp * 8 >= ((int64_t)64 << 20)) ? 1 : 0;   // C is next read in backward
         TRY(launch_gemm(gc, false, 1, s));
     }
@@ -325,6 +327,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
         {
             GemmArgs ga = gemm_args(S.U, Mp, S.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
             ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = S.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = S.A;
+            ga.Kreal = D.M;
             ga.rowdot_part = inputs_only ? nullptr : B.dapart;      // da = A gmu rides in the epilogue (it reads A anyway)
             TRY(launch_gemm(ga, false, 1, s));
             if (!inputs_only) TRY(launch_sum_partials(B.dapart, gemm_rowdot_parts(ga), Mp, B.da, Mp, 1.0, 0, s));
@@ -348,6 +351,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
         // dK = L^-T dA
         {
             GemmArgs ga = gemm_args(S.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
+            ga.Kreal = D.M;
             TRY(launch_gemm(ga, false, 1, s));
         }
         // Gram backward of K_mn and k_nn

@@ -40,6 +40,8 @@ struct GemmArgs {
     int batched;
     // B_T=1: weights of the contraction index, sum_k A[i][k] bscale[k] B[j][k];  EPI_DA: column scale of the product
     const double* bscale;
+    int64_t Kreal;                 // > 0: rows >= Kreal of B are zero padding (the real inner dimension, e.g. M of an
+                                   // Mp-padded operand): kernels that honour it stop the contraction there
     double* rowdot_part;           // EPI_DA (optional): partial row sums of Aaux[row][col] * gmu[col], [slice][Mr] with
                                    // gemm_rowdot_parts(g) column slices -- da = A g_mean without another pass over A
     int stream_out;                // write C with non-temporal stores: for a panel whose next reader is far away (it

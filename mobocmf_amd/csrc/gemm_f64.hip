@@ -547,17 +547,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int64_t k0 = 0, k1 = g.Kd;               // multiples of 128 (Mr, Kd are)
     if (g.tri & TRI_LOWER_A) k1 = k1 < r0 + BM ? k1 : r0 + BM;
     if (g.tri & TRI_UPPER_A) k0 = r0;
+    // B's rows >= Kreal are zero padding (a 16-point problem padded to 128): the contraction stops at the real size
+    const int64_t kend = g.Kreal > 0 ? ((g.Kreal + 15) & ~(int64_t)15) : g.Kd;
+    if (k1 > kend) k1 = kend;
     double acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0;
     for (int64_t kc = k0; kc < k1; kc += BM) {
+        const int kn = (int)(k1 - kc < BM ? k1 - kc : BM);      // multiple of 16: K steps of this chunk that matter
         double va[8][8], vb[8];               // every load of the block in flight before the first use
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t row = r0 + ty + 16 * i;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) va[i][c] = g.A[row * g.lda + kc + c * 16 + tx];
-            vb[i] = g.B[(kc + ty + 16 * i) * g.ldb + c0 + tx];
+            for (int c = 0; c < 8; ++c) va[i][c] = c * 16 < kn ? g.A[row * g.lda + kc + c * 16 + tx] : 0.0;
+            vb[i] = 16 * i < kn ? g.B[(kc + ty + 16 * i) * g.ldb + c0 + tx] : 0.0;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __syncthreads();
 #pragma unroll 8
-        for (int q = 0; q < BM; ++q) {
+        for (int q = 0; q < kn; ++q) {
             const double b = Bs[q * SP_LDB + tx];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += As[(ty + 16 * i) * SP_LDA + q] * b;
