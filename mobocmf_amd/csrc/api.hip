@@ -260,6 +260,7 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
         {
             GemmArgs ga = gemm_args(S.Linv, Mp, S.LSp, Mp, S.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
             ga.lower_out = 1;
+            ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
             TRY(launch_gemm_auto(ga, false, F.ws, F.ws_elems, s));
         }
         TRY(launch_transpose(S.U, Mp, S.UT, Mp, Mp, Mp, s));
@@ -382,16 +383,20 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     // ---- M x M chain:  dL = -tril(L^-T [dA A^T + dU_tot U^T + da_tot a^T]) + gkl diag(1/L_ii)
     {
         GemmArgs g1 = gemm_args(S.UT, Mp, H, Mp, G1, Mp, Mp, Mp, Mp, TRI_UPPER_A, 1.0);          // G1 = U^T H
+        g1.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(g1, false, B.slabs, slab_elems, s));
         GemmArgs g2 = gemm_args(S.U, Mp, G1, Mp, G2, Mp, Mp, Mp, Mp, TRI_LOWER_A, 1.0);          // G2 = U U^T H
+        g2.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(g2, false, B.slabs, slab_elems, s));
         GemmArgs g3 = gemm_args(H, Mp, S.U, Mp, X, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);            // X = H U (lower tiles)
         g3.lower_out = 1;
+        g3.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(g3, false, B.slabs, slab_elems, s));
         TRY(launch_dutot(X, S.U, B.da, S.a, g_kl, Mp, dU, B.da_tot, s));
         TRY(launch_y_combine(G2, Hc, S.a, B.da, B.da_tot, Mp, Y, s));
         GemmArgs g4 = gemm_args(dU, Mp, S.U, Mp, Y, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);   // Y += dU_tot U^T
         g4.accumulate = 1;
+        g4.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(g4, true, B.slabs, slab_elems, s));
     }
     // g_m = L^-T da_tot
@@ -400,6 +405,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     {
         GemmArgs ga = gemm_args(S.LinvT, Mp, dU, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
         ga.lower_out = 1;
+        ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
         TRY(launch_gls_out(T1, S.LSp, g_kl, D.M, Mp, g_LS, s));
     }
@@ -407,6 +413,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     {
         GemmArgs ga = gemm_args(S.LinvT, Mp, Y, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A, 1.0);
         ga.lower_out = 1;
+        ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
         TRY(launch_dl_from_t2(T2, S.L, g_kl, D.M, Mp, dL, s));
     }
@@ -414,11 +421,14 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     {
         TRY(launch_transpose(S.L, Mp, LT, Mp, Mp, Mp, s));
         GemmArgs ga = gemm_args(LT, Mp, dL, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
         TRY(launch_phi(T2, Mp, T1, s));
         GemmArgs gb = gemm_args(S.LinvT, Mp, T1, Mp, T4, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        gb.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(gb, false, B.slabs, slab_elems, s));
         GemmArgs gc = gemm_args(T4, Mp, S.Linv, Mp, T2, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);
+        gc.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
         TRY(launch_gemm_auto(gc, false, B.slabs, slab_elems, s));
         TRY(launch_symmetrize(T2, Mp, Gm, s));
     }

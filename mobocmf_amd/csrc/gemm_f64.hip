@@ -480,6 +480,10 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
     if (g.tri & TRI_UPPER_A) k0 = k0 > r0 ? k0 : r0;
     if (g.tri & TRI_LOWER_B) k0 = k0 > c0 ? k0 : c0;
     if (g.tri & TRI_UPPER_B) k1 = k1 < c0 + 16 ? k1 : c0 + 16;
+    if (g.Kreal > 0) {       // the contraction index >= Kreal only meets zero padding of one of the operands
+        const int64_t kend = (g.Kreal + 15) & ~(int64_t)15;
+        if (k1 > kend) k1 = kend;
+    }
     double acc = 0.0;
     for (int64_t kc = k0; kc < k1; kc += KC) {
         const int kn = (int)(k1 - kc < KC ? k1 - kc : KC);       // multiple of 16
