@@ -21,6 +21,7 @@
 // Within a K step lane group kk handles k = 4*kk + ks (ks = 0..3), so that per-k weights are contiguous.
 // Triangular operands only visit the non-zero k range of their tile.  blockIdx -> tile mapping is XCD-aware.
 #include "common.h"
+#include <cstdlib>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
@@ -459,6 +460,17 @@ int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, dou
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
+// Hand-over to the tiled MFMA kernels (largest dimension), from tools/size_sweep.py + the C3 bench: the 16x16-block
+// product wins up to 384 (a 512^3 product is LDS-bound at ~27 us and costs C3 3 %), the whole-block panel kernel up to
+// K = 512 when the launch stays within 512 workgroups (M = N = 300: 1.98 -> 1.54 ms per step, 450: 2.47 -> 2.2).
+static int small_gemm_limit() {
+    static const int lim = getenv("MOBOCMF_SMALL_GEMM_MAX") ? atoi(getenv("MOBOCMF_SMALL_GEMM_MAX")) : 384;
+    return lim;
+}
+static int small_panel_limit() {
+    static const int lim = getenv("MOBOCMF_SMALL_PANEL_MAX") ? atoi(getenv("MOBOCMF_SMALL_PANEL_MAX")) : 512;
+    return lim;
+}
 // ---------------------------------------------------------------------------------- small operands
 // All dimensions <= 256 (the M x M chain of a surrogate with M <= 256 -- the sizes the reference's own BO runs live at):
 // the 128x128x16 MFMA pipeline is pure latency there (one to four workgroups walking 8-16 dependent K steps, ~20 us a
@@ -655,7 +667,7 @@ static int launch_small_panel(const GemmArgs& g, hipStream_t s) {
 
 static bool small_panel_ok(const GemmArgs& g, bool B_T, int splitk) {
     return !B_T && splitk <= 1 && !g.batched && !g.skip_if_zero && !g.lower_out && !(g.tri & (TRI_LOWER_B | TRI_UPPER_B)) &&
-           g.Kd <= 256 && g.Mr <= 256 && g.Mr % BM == 0 && g.Nc % 16 == 0 && g.Kd % BM == 0 &&
+           g.Kd <= small_panel_limit() && g.Mr <= small_panel_limit() && g.Mr % BM == 0 && g.Nc % 16 == 0 && g.Kd % BM == 0 &&
            (g.Nc / 16) * (g.Mr / BM) <= 512 && (g.epi == EPI_DA || !g.bscale);
 }
 
@@ -664,8 +676,10 @@ int gemm_rowdot_parts(const GemmArgs& g) {
 }
 
 static bool small_gemm_ok(const GemmArgs& g, bool B_T) {
-    return !g.batched && g.epi == EPI_STORE && (B_T || (!g.bscale && !g.skip_if_zero)) && g.Mr <= 256 && g.Nc <= 256 &&
-           g.Kd <= 256 && g.Mr % 16 == 0 && g.Nc % 16 == 0 && g.Kd % 16 == 0;
+    const int L = small_gemm_limit();
+    if (g.Mr > L || g.Nc > L || g.Kd > L) return false;
+    return !g.batched && g.epi == EPI_STORE && (B_T || (!g.bscale && !g.skip_if_zero)) && g.Mr <= 512 && g.Nc <= 512 &&
+           g.Kd <= 512 && g.Mr % 16 == 0 && g.Nc % 16 == 0 && g.Kd % 16 == 0;
 }
 
 static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
