@@ -18,4 +18,5 @@ done > $O/other_configs.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rk -- python3 tools/gemm_bench.py > $O/gemm_bench.txt 2>&1   # roofline kernel in isolation: stats must agree with the HIP-event time
 python tools/acq_bench.py 50 > $O/acq_bench.txt 2>&1
 python tools/cond_bench.py 400 > $O/cond_bench.txt 2>&1
+python tools/size_sweep.py > $O/size_sweep.txt 2>&1
 du -sh $O
