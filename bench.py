@@ -9,7 +9,12 @@ SURVEY 8(e)); the single RCCL all-gather of posterior moments for the joint acqu
 the timed region and is reported as `exchange_ms`.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...            (starts the N ranks itself, one fresh process per GPU, RCCL)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+The line's `value` is the median of --repeats (default 3) timed regions of exactly K steps each (all listed in
+`repeat_values`); `roofline` times the GEMM instantiations the layer really launches (column-statistics and dA
+epilogues included), each on its own; `cpu_baseline` is 3 warm-up + 10 timed oracle steps on the box's host cores.
 """
 import argparse
 import json
@@ -89,38 +94,98 @@ def one_step(sur, cfg, gens, streams):
     return losses
 
 
-def measure_dominant_kernel(cfg, device, iters=20):
-    """Average duration of the dominant kernel (gemm_f64_kernel<false>, lower-triangular left operand: A = L^-1 K_mn
-    at the top layer's shape), HIP events on the stream it is launched on."""
+def executed_gemm_flops(cfg):
+    """Flops the step really executes in its N'-sized contractions: per layer 4 triangular products (A = L^-1 K, C = U^T A,
+    dA, dK: M^2 N' each) + the weighted syrk H = A diag(gv) A^T (M^2 N') = 5 M^2 N' (DESIGN.md section 1)."""
+    return sum(5.0 * cfg["M"] ** 2 * (cfg["N"] if l == 0 else cfg["N"] * cfg["S"]) for l in range(cfg["L"]))
+
+
+def _file_sha16(path):
+    import hashlib
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
+def measure_gemm_variants(cfg, device, iters=20):
+    """Average duration (HIP events on the launch stream, each variant alone on an idle chip) of the four triangular
+    M x N' products of the top layer, launched exactly as mobocmf_layer_forward / _backward launch them:
+      A = L^-1 K  (lower-triangular, column-statistics epilogue: q and mean partials)
+      C = U^T A   (upper-triangular, column-statistics epilogue: r partials, non-temporal stores)
+      dA          (lower-triangular, dA epilogue: column scale + rank-1 + axpy, row-dot partials for da)
+      dK = L^-T dA (upper-triangular, plain store)
+    Algorithmic flops per launch: M^2 N' (triangular product)."""
     from mobocmf_amd import functional as F
     Mp = (cfg["M"] + 127) // 128 * 128
     Np = (cfg["N"] * cfg["S"] + 127) // 128 * 128
-    A = torch.tril(torch.randn(Mp, Mp, dtype=torch.float64, device=device))
-    B = torch.randn(Mp, Np, dtype=torch.float64, device=device)
+    nrb = Mp // 128
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    rnd = lambda *sh: torch.randn(*sh, dtype=torch.float64, device=device, generator=g)
+    Lw = torch.tril(rnd(Mp, Mp))
+    Up = torch.triu(rnd(Mp, Mp))
+    B = rnd(Mp, Np)
+    A2 = rnd(Mp, Np)
     C = torch.empty(Mp, Np, dtype=torch.float64, device=device)
-    for _ in range(3):
-        F.gemm_f64(A, B, C, tri=1)
-    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    st.record()
-    for _ in range(iters):
-        F.gemm_f64(A, B, C, tri=1)
-    en.record()
-    torch.cuda.synchronize()
-    sec = st.elapsed_time(en) * 1e-3 / iters
-    flops = float(cfg["M"]) ** 2 * cfg["N"] * cfg["S"]          # algorithmic: M^2 N' (triangular product)
-    traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same shape)
+    avec, gmu, cgv, gv = rnd(Mp), rnd(Np), rnd(Np), rnd(Np)
+    p1 = torch.empty(nrb, Np, dtype=torch.float64, device=device)
+    p2 = torch.empty(nrb, Np, dtype=torch.float64, device=device)
+    rdp = torch.empty(2 * (Np // 128), Mp, dtype=torch.float64, device=device)
+    stream_out = Np * Mp * 8 >= (64 << 20)
+    variants = [
+        ("A = L^-1 K (lower, colstats q+mean)", lambda: F.gemm_f64_epilogue(Lw, B, C, 1, 1, colsq_part=p1, coldot_part=p2, avec=avec)),
+        ("C = U^T A (upper, colstats r, stream-out)", lambda: F.gemm_f64_epilogue(Up, B, C, 2, 1, stream_out=stream_out, colsq_part=p1, avec=avec)),
+        ("dA (lower, dA epilogue + row dots)", lambda: F.gemm_f64_epilogue(Lw, B, C, 1, 2, alpha=2.0, avec=avec, bscale=gv, gmu=gmu, cgv=cgv, Aaux=A2, rowdot_part=rdp)),
+        ("dK = L^-T dA (upper, plain store)", lambda: F.gemm_f64_epilogue(Up, B, C, 2, 0)),
+    ]
+    flops = float(cfg["M"]) ** 2 * cfg["N"] * cfg["S"]
+    out = []
+    for name, fn in variants:
+        for _ in range(3):
+            fn()
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        st.record()
+        for _ in range(iters):
+            fn()
+        en.record()
+        torch.cuda.synchronize()
+        sec = st.elapsed_time(en) * 1e-3 / iters
+        out.append({"kernel": name, "kernel_ms": sec * 1e3, "achieved": flops / sec / 1e12,
+                    "frac": flops / sec / 1e12 / FP64_PEAK_TFLOPS})
+    return out, flops, (Mp, Np)
+
+
+def measure_dominant_kernel(cfg, device, iters=20):
+    """`roofline` of the bench line: the dominant kernel of the step is the triangular f64 MFMA GEMM; the record carries
+    the instantiation with the largest share of the step (A = L^-1 K with the column-statistics epilogue) and, under
+    `variants`, all four top-layer launches with their own times, plus their flop-weighted (= time-weighted, equal flops)
+    fraction."""
+    var, flops, (Mp, Np) = measure_gemm_variants(cfg, device, iters)
+    head = var[0]
+    traffic, traffic_src = None, None
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/): static, valid only for the kernel source
+    # they were collected on
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")) as fh:
-            pm = json.load(fh)
-        if Mp == 512 and Np == 65536:
-            traffic = pm["traffic_bytes_per_launch"]
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if name.endswith("_pmc_gemm.json"):
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    pm = json.load(fh)
+                same = pm.get("kernel_source_sha16") == _file_sha16(os.path.join(ROOT, "mobocmf_amd", "csrc", "gemm_f64.hip"))
+                if pm.get("shape") == [Mp, Np, Mp] and same:
+                    traffic = pm["traffic_bytes_per_launch"]
+                    traffic_src = "profiles/%s (static: separate rocprofv3 --pmc passes on this kernel source)" % name
+                else:
+                    traffic_src = "profiles/%s is for another kernel source or shape: not quoted" % name
+                break
     except Exception:
         pass
-    return {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / sec / 1e12 / FP64_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": "gemm_f64_kernel<false> (A = L^-1 K_mn, %dx%dx%d lower-triangular)" % (Mp, Np, Mp),
-            "kernel_ms": sec * 1e3, "flops_per_launch": flops}
+    tot = sum(v["kernel_ms"] for v in var)
+    return {"bound": "mfma", "achieved": head["achieved"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": head["frac"], "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "gemm_f64_kernel<NN, triangular, colstats> -- %s, %dx%dx%d" % (head["kernel"], Mp, Np, Mp),
+            "kernel_ms": head["kernel_ms"], "flops_per_launch": flops, "variants": var,
+            "weighted_frac": len(var) * flops / (tot * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "timing": "HIP events on the launch stream, %d launches per variant, each variant alone on an idle chip" % iters}
 
 
 def usable_cores():
@@ -146,9 +211,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, steps=2, device=None):
+def cpu_baseline(cfg, steps=10, warmup=3, device=None, budget_s=75.0):
     """Reference-equivalent float64 torch-CPU restatement (gpytorch unavailable): the oracle executing GPyTorch's
-    op sequence + autograd + torch.optim.Adam, ONE surrogate at the full C3 size, 1 warm-up + `steps` timed steps."""
+    op sequence + autograd + torch.optim.Adam, ONE surrogate at the full size, `warmup` warm-up + `steps` timed steps
+    (>= 3 + >= 10), median / min / max reported; never more than ~budget_s of CPU work."""
     import numpy as np
 
     from oracle import mfdgp_oracle as O
@@ -177,14 +243,16 @@ def cpu_baseline(cfg, steps=2, device=None):
     eps = [None] + [t(e) for e in prob["eps"][1:]]
     parity = parity_vs_oracle(O, cfg, prob, raw, x, y, fid, eps, device) if device is not None else None
     times = []
-    for k in range(steps + 1):
+    t_all = time.perf_counter()
+    for k in range(warmup + steps):
         t0 = time.perf_counter()
         O.elbo_step(raw, opt, x, y, fid, eps, cfg["S"], ref_equiv=True)
         times.append(time.perf_counter() - t0)
-        if sum(times) > 40.0 and len(times) >= 2:      # bounded sample: never more than ~1 minute of CPU work
+        if time.perf_counter() - t_all > budget_s and len(times) > warmup + 2:      # bounded sample (slow / small hosts)
             break
-    med = sorted(times[1:])[len(times[1:]) // 2]
-    steps = len(times) - 1
+    timed = sorted(times[warmup:])
+    med = timed[len(timed) // 2]
+    steps = len(timed)
     model = ""
     try:
         with open("/proc/cpuinfo") as fh:
@@ -192,9 +260,11 @@ def cpu_baseline(cfg, steps=2, device=None):
     except Exception:
         pass
     return {"value": 1.0 / med, "unit": "ELBO steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 surrogate of C3 at full size (d=8 M=512 N=8192 S=8), 1 warm-up + %d timed steps, median; "
-                      "reference-equivalent CPU restatement (gpytorch unavailable)" % steps,
-            "os_cpu_count": os.cpu_count(), "cpu_model": model, "sec_per_step": med}, parity
+            "sample": "1 surrogate at full size (d=%d M=%d N=%d S=%d), %d warm-up + %d timed steps, median; "
+                      "reference-equivalent CPU restatement (gpytorch unavailable)" %
+                      (cfg["d"], cfg["M"], cfg["N"], cfg["S"], warmup, steps),
+            "os_cpu_count": os.cpu_count(), "cpu_model": model, "sec_per_step": med,
+            "sec_per_step_min": timed[0], "sec_per_step_max": timed[-1], "timed_steps": steps, "warmup_steps": warmup}, parity
 
 
 def parity_vs_oracle(O, cfg, prob, raw, x, y, fid, eps, device, T=256):
@@ -245,16 +315,31 @@ def main():
                          "the same surrogates on 1/W of the batch rows + one gradient all-reduce per step (strong scaling)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="serialise each surrogate's layers on one stream (no chain/panel split across streams)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; value = median")
+    ap.add_argument("--launch", action="store_true", help="go through the rank launcher even for --gpus 1")
     args = ap.parse_args()
     if args.no_overlap:
         from mobocmf_amd.models import MFDGP
         MFDGP.overlap_chains = False
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.launch):
+        # plain `python bench.py --gpus N`: start the N ranks here -- one fresh process per GPU, RCCL -- before anything
+        # in this process touches the GPU (device_count() does not initialise it); rank 0 prints the single JSON line
+        have = torch.cuda.device_count()
+        if args.force_device < 0 and have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (args.gpus, have))
+            raise SystemExit(3)
+        from mobocmf_amd import parallel
+        os.dup2(json_fd, 1)
+        codes = parallel.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        raise SystemExit(max(abs(c) for c in codes))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE != --gpus")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
+        raise SystemExit(2)
     if args.force_device >= 0:
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
@@ -304,16 +389,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = one_step(sur, cfg, gens, streams)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed_all = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            losses = one_step(sur, cfg, gens, streams)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        elapsed_all.append(el)
+    elapsed = sorted(elapsed_all)[len(elapsed_all) // 2]       # median repeat; every repeat is listed in the line
     finite = all(bool(torch.isfinite(l)) for l in losses)
 
     # the path's single exchange: all-gather of the posterior moments on a shared test grid (JES)
@@ -349,9 +438,18 @@ def main():
                                    (args.config, cfg["d"], cfg["L"], cfg["M"], cfg["N"], cfg["S"], n_out),
                        "surrogates_per_gpu": n_out, "parallelism": ("row-sharded x%d + grad all-reduce" if rows else "surrogate-per-rank x%d") % world},
             "per_surrogate_steps_per_s": value / n_sur,
+            "repeat_values": [n_sur * args.steps / e for e in elapsed_all],
+            "repeat_spread": (max(elapsed_all) - min(elapsed_all)) / elapsed,
             "step_flops_algorithmic": algorithmic_flops(cfg),
-            "step_fp64_frac": algorithmic_flops(cfg) * value / world / (FP64_PEAK_TFLOPS * 1e12),
-            "exchange_ms": exchange_ms, "finite": finite, "step_issue": "eager" if args.eager else "hip-graph replay",
+            "step_flops_executed_gemm": executed_gemm_flops(cfg),
+            # executed GEMM flops per second over the FP64 peak: what the chip really sustains over the whole step
+            "step_executed_fp64_frac": executed_gemm_flops(cfg) * value / world / (FP64_PEAK_TFLOPS * 1e12),
+            # SURVEY 8(d)'s F_step prices the reference's solve-based op sequence (~1.9x the flops executed here): a
+            # speed-up-adjusted figure, NOT a roofline fraction
+            "step_algorithmic_fp64_frac": algorithmic_flops(cfg) * value / world / (FP64_PEAK_TFLOPS * 1e12),
+            "exchange_ms": exchange_ms, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+            "backend": (args.backend if dist is not None else None),
+            "finite": finite, "step_issue": "eager" if args.eager else "hip-graph replay",
         }
         if not args.no_roofline:
             line["roofline"] = measure_dominant_kernel(cfg, device)

@@ -17,8 +17,9 @@
  *   mobocmf_adam_step                   torch.optim.Adam.step at blackbox_mfdgp_fitter.py:169
  *
  * Conventions: all pointers are DEVICE pointers to row-major float64 unless stated; sizes are explicit;
- * every function enqueues work on `stream` and returns immediately (no allocation, no free, no host sync,
- * no global mutable state -> re-entrant, one process per GPU).  Return value: MOBOCMF_OK or an error
+ * every function enqueues work on `stream` and returns immediately (no allocation, no free, no host sync;
+ * re-entrant, one process per GPU).  The only process-wide state is the pair of kernel-selection thresholds of
+ * mobocmf_set_tuning (atomic words with compiled-in defaults) and a per-device "attribute set" bit mask.  Return value: MOBOCMF_OK or an error
  * code; a non-positive-definite K_mm is reported through the device word `info` (0 = OK, k>0 = pivot k
  * failed), mirroring LAPACK potrf / torch.linalg.cholesky_ex, so the caller may retry with more jitter
  * (gpytorch psd_safe_cholesky semantics) without a sync on the fast path.
@@ -34,6 +35,9 @@ extern "C" {
 #endif
 
 typedef void* mobocmf_stream_t; /* hipStream_t */
+
+#define MOBOCMF_MAX_D 32    /* input dimensions a layer accepts (x columns; the Gram kernels keep a row in registers) */
+#define MOBOCMF_MAX_XDIV 48 /* sample replicas per base row (num_samples_for_acquisition / _for_training) */
 
 enum {
     MOBOCMF_OK = 0,
@@ -53,9 +57,9 @@ enum {
  */
 typedef struct {
     int32_t kind;    /* 0 | 1 */
-    int32_t d;       /* columns of x and Zx, 1..32 */
+    int32_t d;       /* columns of x and Zx, 1..MOBOCMF_MAX_D */
     int32_t M;       /* inducing points */
-    int32_t xdiv;    /* >= 1 */
+    int32_t xdiv;    /* 1..MOBOCMF_MAX_XDIV */
     int64_t Np;      /* rows through the layer (N'), Np % xdiv == 0 */
     int32_t branch;  /* 0: training branch (clamp(k_nn - q, 0)); 1: eval branch (no clamp) */
     int32_t want_dx; /* backward also returns d/dx (acquisition optimisation) */
@@ -115,6 +119,12 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
 int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f,
                                   const double* hyp, double* cov, int64_t ldcov, void* saved, size_t saved_bytes,
                                   void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+
+/* Dense prior covariance K[i][j] = k([x1[i], f1[i]], [x2[j], f2[j]]) of one layer's kernel (the lazy prior of
+ * MFDGPHiddenLayer.forward, mfdgp_hidden_layer.py:232-243, evaluated): x1 [n1 x d], x2 [n2 x d], f1 [n1] / f2 [n2] (kind 1,
+ * else NULL).  K is row-major with ldk >= n2 and must hold round_up(n1, 32) rows (rows >= n1 are written as zeros). */
+int mobocmf_gram_forward(int32_t kind, int32_t d, const double* x1, const double* f1, int64_t n1, const double* x2,
+                         const double* f2, int64_t n2, const double* hyp, double* K, int64_t ldk, mobocmf_stream_t stream);
 
 /* f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n],  n < n_out  (mfdgp_hidden_layer.py:263-274). */
 int mobocmf_propagate_forward(const double* mean, const double* var, const double* eps, double* f_out, int64_t n_out,
@@ -192,6 +202,26 @@ int mobocmf_adam_multi(int32_t n_tensors, double* const* params, const double* c
 int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
                      const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t accumulate,
                      mobocmf_stream_t stream);
+
+/* The same kernel with the epilogues the layer launches it with (tests, and bench.py's per-variant roofline):
+ *   epi 0  plain store (dK = L^-T dA);
+ *   epi 1  store + partial column statistics per 128-row block: colsq_part[rb][n] = sum_i C[i][n]^2 and (coldot_part
+ *          non-NULL) coldot_part[rb][n] = sum_i avec[i] C[i][n]  over the rows i of block rb   (A = L^-1 K -> q, mean;
+ *          C = U^T A -> r);
+ *   epi 2  C[i][n] = alpha bscale[n] (A B)[i][n] + avec[i] gmu[n] - 2 Aaux[i][n] cgv[n]   (dA), and (rowdot_part
+ *          non-NULL) rowdot_part[slice][i] = partial sums over 64-column slices of Aaux[i][n] gmu[n]   (da).
+ * B is [Kd x Nc] (no transposed form).  stream_out: non-temporal stores of C.  Pointers an epilogue does not use: NULL. */
+int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
+                              const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t stream_out,
+                              double* colsq_part, double* coldot_part, const double* avec, const double* bscale,
+                              const double* gmu, const double* cgv, const double* Aaux, double* rowdot_part,
+                              mobocmf_stream_t stream);
+
+/* Kernel-selection thresholds (largest operand dimension up to which the small-operand kernels are used instead of the
+ * tiled MFMA pipeline): small_gemm_max for M x M products (default 384), small_panel_max for M x N' panel products
+ * (default 512).  A value <= 0 leaves that threshold unchanged.  Process-wide; meant for size sweeps, set it before
+ * the work it should affect is enqueued. */
+int mobocmf_set_tuning(int32_t small_gemm_max, int32_t small_panel_max);
 
 /* Host-side, synchronising: copies the device word and returns MOBOCMF_OK or MOBOCMF_NOT_PD (pivot in *pivot). */
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream);

@@ -56,8 +56,12 @@ SYMBOLS = {
     "mobocmf_adam_multi": [_I32, _P, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P],
     "mobocmf_adam_step": [_P, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P],
     "mobocmf_gemm_f64": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32, _P],
+    "mobocmf_gemm_f64_epilogue": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32] + [_P] * 8 + [_P],
+    "mobocmf_set_tuning": [_I32, _I32],
+    "mobocmf_gram_forward": [_I32, _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P],
     "mobocmf_check_info": [_P, ctypes.POINTER(_I32), _P],
 }
+MAX_D, MAX_XDIV = 32, 48        # MOBOCMF_MAX_D / MOBOCMF_MAX_XDIV of include/mobocmf_hip.h
 
 _lib = None
 

@@ -53,6 +53,7 @@ def optimize_acqf_multistart(acq_function, bounds, num_restarts=5, raw_samples=2
     dev, dt = lo.device, lo.dtype
     with torch.no_grad():
         Xraw = lo + (hi - lo) * torch.rand(raw_samples, d, dtype=dt, device=dev, generator=generator)
+        parallel.broadcast_(Xraw)     # sharded surrogates: every rank scores (and all-gathers values of) the same points
         vals = acq_function(Xraw)
         X = Xraw[torch.topk(vals, min(num_restarts, raw_samples)).indices].clone()
     X.requires_grad_(True)
@@ -65,6 +66,7 @@ def optimize_acqf_multistart(acq_function, bounds, num_restarts=5, raw_samples=2
         opt.step()
         with torch.no_grad():
             X.clamp_(min=lo, max=hi)
+            parallel.broadcast_(X)    # (no-op on one rank) summation order may differ by an ulp between ranks
             v = acq_function(X)
             better = v > best_v
             best_v = torch.where(better, v, best_v)
@@ -119,7 +121,7 @@ class JESMOC_MFDGP:
             local = [torch.zeros(X.shape[0], dtype=X.dtype, device=X.device)]
         acq = torch.stack(local).sum(0)
         _, w = parallel.world()
-        if w > 1:
+        if w > 1:       # every rank enters the exchange, also one that holds no black-box of this fidelity
             acq = acq + (parallel.coupled_acquisition(acq.detach()[None]) - acq.detach())
         return acq
 

@@ -70,8 +70,8 @@ struct Dims {
 };
 
 bool valid_desc(const mobocmf_layer_desc* d) {
-    return d && (d->kind == 0 || d->kind == 1) && d->d >= 1 && d->d <= 32 && d->M >= 1 && d->xdiv >= 1 &&
-           d->xdiv <= 48 && d->Np >= 1 && d->Np % d->xdiv == 0 && (d->branch == 0 || d->branch == 1) && d->phase >= 0 &&
+    return d && (d->kind == 0 || d->kind == 1) && d->d >= 1 && d->d <= MOBOCMF_MAX_D && d->M >= 1 && d->xdiv >= 1 &&
+           d->xdiv <= MOBOCMF_MAX_XDIV && d->Np >= 1 && d->Np % d->xdiv == 0 && (d->branch == 0 || d->branch == 1) && d->phase >= 0 &&
            d->phase <= MOBOCMF_PHASE_PANEL_INPUTS;
 }
 
@@ -181,7 +181,7 @@ GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb, d
 
 extern "C" {
 
-int mobocmf_version(void) { return 100; }
+int mobocmf_version(void) { return 200; }
 
 int mobocmf_device_arch_ok(void) {
     int dev = 0;
@@ -489,6 +489,34 @@ int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64
     GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, Mr, Nc, Kd, tri, alpha);
     g.accumulate = accumulate;
     return launch_gemm(g, trans_b != 0, 1, (hipStream_t)stream);
+}
+
+int mobocmf_gram_forward(int32_t kind, int32_t d, const double* x1, const double* f1, int64_t n1, const double* x2,
+                         const double* f2, int64_t n2, const double* hyp, double* K, int64_t ldk, mobocmf_stream_t stream) {
+    if ((kind != 0 && kind != 1) || d < 1 || d > MOBOCMF_MAX_D || !x1 || !x2 || !hyp || !K || n1 < 1 || n2 < 1 ||
+        n1 > 0x7fffffff || ldk < n2 || (kind == 1 && (!f1 || !f2)))
+        return MOBOCMF_BAD_ARG;
+    GramArgs g = {};
+    g.kind = kind; g.d = d; g.xdiv = 1; g.zdiv = 1;
+    g.x = x2; g.f = f2; g.nbase = n2; g.Zx = x1; g.zf = f1; g.M = (int)n1; g.hyp = hyp;
+    g.K = K; g.ldk = ldk; g.Mp = (int)round_up(n1, 32); g.Np = n2; g.knn = nullptr; g.jitter = 0.0; g.is_kmm = 0;
+    return launch_gram_fwd(g, (hipStream_t)stream);
+}
+
+int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
+                              const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t stream_out,
+                              double* colsq_part, double* coldot_part, const double* avec, const double* bscale,
+                              const double* gmu, const double* cgv, const double* Aaux, double* rowdot_part,
+                              mobocmf_stream_t stream) {
+    if (!A || !B || !C || Mr <= 0 || Nc <= 0 || Kd <= 0 || (lda & 1) || (ldb & 1)) return MOBOCMF_BAD_ARG;
+    if (epi < EPI_STORE || epi > EPI_DA) return MOBOCMF_BAD_ARG;
+    if (epi == EPI_COLSTATS && (!colsq_part || !avec)) return MOBOCMF_BAD_ARG;
+    if (epi == EPI_DA && (!avec || !gmu || !cgv || !Aaux)) return MOBOCMF_BAD_ARG;
+    GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, Mr, Nc, Kd, tri, alpha);
+    g.epi = epi; g.stream_out = stream_out;
+    g.colsq_part = colsq_part; g.coldot_part = coldot_part; g.avec = avec;
+    g.bscale = epi == EPI_DA ? bscale : nullptr; g.gmu = gmu; g.cgv = cgv; g.Aaux = Aaux; g.rowdot_part = rowdot_part;
+    return launch_gemm(g, false, 1, (hipStream_t)stream);
 }
 
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream) {

@@ -110,4 +110,4 @@ struct GramArgs {
 // kind 0: [alpha, ls[0..d)]                                   (1 + d doubles)
 // kind 1: [a1, af, nu, a2, lsf, ls1[0..d), ls2[0..d)]         (5 + 2d doubles)
 static inline int hyp_len(int kind, int d) { return kind == 0 ? 1 + d : 5 + 2 * d; }
-#define MAX_D 64
+#define MAX_D MOBOCMF_MAX_D

@@ -21,7 +21,7 @@
 // Within a K step lane group kk handles k = 4*kk + ks (ks = 0..3), so that per-k weights are contiguous.
 // Triangular operands only visit the non-zero k range of their tile.  blockIdx -> tile mapping is XCD-aware.
 #include "common.h"
-#include <cstdlib>
+#include <atomic>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
@@ -37,10 +37,37 @@ __device__ __forceinline__ void glds16(const double* gsrc, double* lds_wave_base
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Diagnostic build only (-DGEMM_STAMPS, tools/gemm_stamps.py): wall-clock stamps (100 MHz s_memrealtime) of one lane per
+// workgroup at the phase boundaries, written to a debug buffer that nothing else reads.  Compiled out of the product.
+#ifdef GEMM_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+extern "C" int mobocmf_debug_set_stamps(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : 3;
+}
+#define STAMP(i)                                                                                            \
+    do {                                                                                                    \
+        if (g_stamp_buf && threadIdx.x == 0) g_stamp_buf[(int64_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define STAMP_ID()                                                                                          \
+    do {                                                                                                    \
+        if (g_stamp_buf && threadIdx.x == 0) {                                                              \
+            unsigned hw, xcc;                                                                               \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                             \
+            g_stamp_buf[(int64_t)blockIdx.x * 16 + 15] = ((unsigned long long)xcc << 32) | hw;              \
+        }                                                                                                   \
+    } while (0)
+#else
+#define STAMP(i)
+#define STAMP_ID()
+#endif
+
 template <bool B_T, bool TRI, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_ELEMS];   // [buf][A | B]
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
+    STAMP(0);
+    STAMP_ID();
     // ---- block id -> (tile, k-slice).  Blocks b, b+8, ... share an XCD (and its L2):
     //  * no split-K: the row blocks that re-read the same 128-column panel of B run back to back on one XCD;
     //  * split-K: all tiles of one k-slice (they share the slice's rows of A and B) run back to back on one XCD.
@@ -191,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // a barrier; the waits are written out (hipcc adds them only when it sees the DMA in the same scheduling scope)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAMP(1 + 4 * part);      // first stage landed
     v4f64 w_nxt = (v4f64){1.0, 1.0, 1.0, 1.0};
     if (B_T && g.bscale && nk > 0) w_nxt = *(const v4f64*)(g.bscale + k0 + 4 * lk);
     // Software pipeline of one K step over 8 groups g = (kpair p, row tile mt): the A fragments of group g+1
@@ -276,7 +304,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         const int64_t d0 = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && diag_first) ? nd : 0;
         const int64_t d1 = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !diag_first) ? nk - nd : nk;
         STAGE_LOOP(0, d0, 1, MMA_IF)
+        STAMP(2 + 4 * part);
         STAGE_LOOP(d0, d1, 0, MMA_ALL)
+        STAMP(3 + 4 * part);
         STAGE_LOOP(d1, nk, 1, MMA_IF)
     } else {
         STAGE_LOOP(0, nk, 0, MMA_ALL)
@@ -290,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #undef LOAD_B
 
     // ------------------------------------------------------------------ epilogue
+    STAMP(4 + 4 * part);      // main loop done
     const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;     // + mt*32 + 4*r
     const int64_t col0 = cb * BN + wc * 64 + li;               // + nt*16
     if (EPI == EPI_DA) {
@@ -330,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
                     if (li == 0) out[row0 + mt * 32 + 4 * r] = v;
                 }
         }
+        STAMP(9 + part);
         continue;   // LDS was not touched after the main loop's last barrier
     }
 #define STORE_TILE(ST)                                                                                      \
@@ -379,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }
         __syncthreads();   // `red` aliases the staging buffers of the next part
     }
+    STAMP(9 + part);          // epilogue issued
   }   // parts
 }
 
@@ -463,13 +496,14 @@ int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, dou
 // Hand-over to the tiled MFMA kernels (largest dimension), from tools/size_sweep.py + the C3 bench: the 16x16-block
 // product wins up to 384 (a 512^3 product is LDS-bound at ~27 us and costs C3 3 %), the whole-block panel kernel up to
 // K = 512 when the launch stays within 512 workgroups (M = N = 300: 1.98 -> 1.54 ms per step, 450: 2.47 -> 2.2).
-static int small_gemm_limit() {
-    static const int lim = getenv("MOBOCMF_SMALL_GEMM_MAX") ? atoi(getenv("MOBOCMF_SMALL_GEMM_MAX")) : 384;
-    return lim;
-}
-static int small_panel_limit() {
-    static const int lim = getenv("MOBOCMF_SMALL_PANEL_MAX") ? atoi(getenv("MOBOCMF_SMALL_PANEL_MAX")) : 512;
-    return lim;
+static std::atomic<int> g_small_gemm_max{384}, g_small_panel_max{512};
+static int small_gemm_limit() { return g_small_gemm_max.load(std::memory_order_relaxed); }
+static int small_panel_limit() { return g_small_panel_max.load(std::memory_order_relaxed); }
+extern "C" int mobocmf_set_tuning(int32_t small_gemm_max, int32_t small_panel_max) {
+    if (small_gemm_max > 512 || small_panel_max > 512) return MOBOCMF_BAD_ARG;   // the small kernels' own size limits
+    if (small_gemm_max > 0) g_small_gemm_max.store(small_gemm_max, std::memory_order_relaxed);
+    if (small_panel_max > 0) g_small_panel_max.store(small_panel_max, std::memory_order_relaxed);
+    return MOBOCMF_OK;
 }
 // ---------------------------------------------------------------------------------- small operands
 // All dimensions <= 256 (the M x M chain of a surrogate with M <= 256 -- the sizes the reference's own BO runs live at):
@@ -653,12 +687,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 template <int EPI>
 static int launch_small_panel(const GemmArgs& g, hipStream_t s) {
-    static bool configured = false;          // first call happens in an eager warm-up, never under stream capture
-    if (!configured) {
+    // the dynamic-LDS attribute is per device: one bit per device ordinal (first call per device happens in an eager
+    // warm-up, never under stream capture); setting it twice from two threads is harmless, so a relaxed fetch_or is enough
+    static std::atomic<uint64_t> configured{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MOBOCMF_HIP_ERROR;
+    if (!(configured.load(std::memory_order_acquire) & (1ull << dev))) {
         if (hipFuncSetAttribute((const void*)small_panel_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SP_LDS_BYTES) != hipSuccess)
             return MOBOCMF_HIP_ERROR;
-        configured = true;
+        configured.fetch_or(1ull << dev, std::memory_order_release);
     }
     const dim3 grid((unsigned)(g.Nc / 16), (unsigned)(g.Mr / BM));
     hipLaunchKernelGGL(small_panel_kernel<EPI>, grid, dim3(256), SP_LDS_BYTES, s, g);

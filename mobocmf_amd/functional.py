@@ -61,13 +61,42 @@ def _empty_like(t):
 
 
 def scratch_buffer(nbytes, device):
-    """Per (device, stream) scratch, grown on demand; dead after each C call."""
+    """Per (device, stream) scratch, grown on demand; dead after each C call.  A buffer handed out while the stream is
+    being captured is baked into the graph: it is also recorded in ``_capture_pins`` so that the object owning the graph
+    can keep it alive (``take_capture_pins``) -- growing the arena later must not free memory a live graph replays on."""
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
         _scratch[key] = buf
+    if torch.cuda.is_current_stream_capturing() and not any(b is buf for b in _capture_pins):
+        _capture_pins.append(buf)
     return _poison(buf)
+
+
+_capture_pins = []
+
+
+def take_capture_pins():
+    """The scratch buffers handed out under capture since the last call (the caller -- a graphed step -- holds them for as
+    long as its graph lives)."""
+    out = list(_capture_pins)
+    _capture_pins.clear()
+    return out
+
+
+def release_scratch(stream=None):
+    """Drop the arena's entry of ``stream`` (all entries without an argument): the memory returns to the allocator once
+    no graph pins it.  Fitters call this when a training phase's streams retire (torch hands stream handles out of a
+    small pool, so a stale entry would otherwise pin up to ~1 GB per handle for ever)."""
+    if stream is None:
+        _scratch.clear()
+        _side_streams.clear()
+        return
+    for key in [k for k in _scratch if k[1] == stream.cuda_stream]:
+        del _scratch[key]
+    for key in [k for k in _side_streams if k[1] == stream.cuda_stream]:
+        del _side_streams[key]
 
 
 def hyp_len(kind, d):
@@ -78,6 +107,12 @@ PHASE_ALL, PHASE_CHAIN, PHASE_PANEL, PHASE_CHAIN_ONLY, PHASE_PANEL_INPUTS = 0, 1
 
 
 def make_desc(kind, d, M, Np, xdiv=1, branch=0, want_dx=False, jitter=JITTER, min_var=MIN_VARIANCE, phase=PHASE_ALL):
+    if not 1 <= d <= _lib.MAX_D:
+        raise _lib.MobocmfError("mobocmf_amd: a layer takes 1..%d input dimensions (got %d): the Gram kernels keep one "
+                                "input row in registers" % (_lib.MAX_D, d))
+    if not 1 <= xdiv <= _lib.MAX_XDIV:
+        raise _lib.MobocmfError("mobocmf_amd: at most %d samples per input row (num_samples_for_acquisition / "
+                                "num_samples_for_training), got %d" % (_lib.MAX_XDIV, xdiv))
     return LayerDesc(kind=kind, d=d, M=M, xdiv=xdiv, Np=Np, branch=branch, want_dx=int(want_dx), jitter=jitter,
                      min_var=min_var, phase=phase, reserved=0)
 
@@ -648,6 +683,40 @@ def check_info(info):
         return piv.value
     _lib.check(rc, "mobocmf_check_info")
     return 0
+
+
+def gemm_f64_epilogue(A, B, C, tri, epi, alpha=1.0, stream_out=False, colsq_part=None, coldot_part=None, avec=None,
+                      bscale=None, gmu=None, cgv=None, Aaux=None, rowdot_part=None):
+    """The GEMM with the epilogue the layer launches it with (mobocmf_gemm_f64_epilogue): tests and per-variant timing."""
+    lib = _lib.require_device()
+    A, B = _prep(A), _prep(B)
+    Mr, Kd = A.shape
+    Nc = B.shape[1]
+    _lib.check(lib.mobocmf_gemm_f64_epilogue(tri, epi, Mr, Nc, Kd, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C),
+                                             C.stride(0), alpha, int(stream_out), _ptr(colsq_part), _ptr(coldot_part),
+                                             _ptr(avec), _ptr(bscale), _ptr(gmu), _ptr(cgv), _ptr(Aaux), _ptr(rowdot_part),
+                                             _stream()), "mobocmf_gemm_f64_epilogue")
+    return C
+
+
+def gram(kind, x1, f1, x2, f2, hyp):
+    """Dense k([x1, f1], [x2, f2]) of a layer's kernel (n1 x n2), no autograd: the evaluated prior of
+    MFDGPHiddenLayer.forward."""
+    lib = _lib.require_device()
+    with torch.no_grad():
+        x1, f1, x2, f2, hyp = (_prep(None if t is None else t.detach()) for t in (x1, f1, x2, f2, hyp))
+        n1, n2, d = x1.shape[0], x2.shape[0], x1.shape[1]
+        if x2.shape[1] != d or hyp.numel() != hyp_len(kind, d) or not 1 <= d <= _lib.MAX_D:
+            raise _lib.MobocmfError("gram: shape mismatch")
+        K = _empty((n1 + 31) // 32 * 32, n2, device=x1.device)
+        _lib.check(lib.mobocmf_gram_forward(kind, d, _ptr(x1), _ptr(f1), n1, _ptr(x2), _ptr(f2), n2, _ptr(hyp), _ptr(K),
+                                            K.stride(0), _stream()), "mobocmf_gram_forward")
+    return K[:n1]
+
+
+def set_tuning(small_gemm_max=0, small_panel_max=0):
+    """Kernel-selection thresholds of the library (size sweeps); 0 leaves a threshold unchanged."""
+    _lib.check(_lib.load().mobocmf_set_tuning(int(small_gemm_max), int(small_panel_max)), "mobocmf_set_tuning")
 
 
 def gemm_f64(A, B, C=None, tri=0, trans_b=False, alpha=1.0, accumulate=False):

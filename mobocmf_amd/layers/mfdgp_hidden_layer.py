@@ -314,9 +314,18 @@ class MFDGPHiddenLayer(nn.Module):
         return mean, var
 
     def forward(self, x):
-        """Reference signature (:232-243): x = cat[Z~, X~] -> prior N(0, k(x, x)).  The lazy prior is never
-        materialised on this path; kept for API compatibility."""
-        raise NotImplementedError("the lazy prior over cat[Z, X] is consumed inside the HIP layer call")
+        """Reference signature (:232-243): the layer's prior N(0, k(x, x)) at rows x = [x, f] (``input_dims`` columns).
+        The reference returns it lazily and GPyTorch's strategy only ever evaluates blocks of it; the variational layer
+        call (``__call__``) never comes through here -- its Gram blocks are produced inside the HIP layer call.  A direct
+        call gets the dense prior from the same Gram kernel (no gradient)."""
+        assert x.shape[-1] == self.input_dims
+        hyp = gp.pack_hypers(self.covar_module, self.kind)
+        if self.kind == 0:
+            K = F.gram(0, x, None, x, None, hyp)
+        else:
+            xs, fs = x[:, :-1].contiguous(), x[:, -1].contiguous()
+            K = F.gram(1, xs, fs, xs, fs, hyp)
+        return gp.MultivariateNormal(torch.zeros(x.shape[0], dtype=x.dtype, device=x.device), covariance_matrix=K)
 
     def __call__(self, x, *other_inputs, eps=None, xdiv=1, want_dx=False, chain=None, **kwargs):
         """Layer 0: ``layer(x)``.  Layers >= 1: ``layer(x, previous_output)`` (mfdgp_hidden_layer.py:245-286).

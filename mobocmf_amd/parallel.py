@@ -15,9 +15,56 @@ def world():
     return 0, 1
 
 
+def launch_ranks(argv, n, port=None, extra_env=None, timeout=None):
+    """One fresh process per rank (= per GPU) of ``argv`` (e.g. [sys.executable, "bench.py", ...]), with the
+    torch.distributed.run environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT).  The caller
+    must not have touched the GPU (children are started with fork+exec).  Rank 0 inherits stdout, the other ranks'
+    stdout goes to stderr, so a program whose rank 0 prints one record still prints exactly one.  Returns the list of
+    exit codes; if a rank fails, the others are terminated (a rank blocked in a collective would wait for ever)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    if port is None:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    t0 = time.time()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+        failed = any(c not in (None, 0) for c in codes)
+        if failed or (timeout is not None and time.time() - t0 > timeout):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    pr.terminate()
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    return codes
+
+
 def shard_blackboxes(names, rank=None, world_size=None):
     """Round-robin assignment of black-box (objective / constraint) names to ranks; every rank derives the
-    same table.  Returns (my_names, owner_of) with owner_of[name] = rank."""
+    same table.  Returns (my_names, owner_of) with owner_of[name] = rank.  Counts per rank may differ (5 names on 2
+    ranks) and a rank may end up without any constraint: the exchanges below are written for ragged and empty shards."""
     r, w = world()
     rank = r if rank is None else rank
     world_size = w if world_size is None else world_size
@@ -26,46 +73,102 @@ def shard_blackboxes(names, rank=None, world_size=None):
     return [n for n in names if owner[n] == rank], owner
 
 
+def _collective_device(t):
+    """gloo rehearsals of a GPU path hop through the host; RCCL takes HBM buffers."""
+    import torch.distributed as dist
+    return torch.device("cpu") if (t.device.type == "cuda" and dist.get_backend() == "gloo") else t.device
+
+
 def all_gather_moments(local):
-    """local: (k, ...) tensor of this rank's k surrogates -> (world*k, ...) in rank order.  World size 1
-    degenerates to the identity (no communicator needed)."""
+    """local: (k, ...) tensor of this rank's k surrogates (the SAME k on every rank) -> (world*k, ...) in rank order.
+    World size 1 degenerates to the identity (no communicator needed)."""
     import torch.distributed as dist
     _, w = world()
     if w == 1:
         return local
-    local = local.contiguous()
     dev = local.device
-    if dev.type == "cuda" and dist.get_backend() == "gloo":
-        local = local.cpu()                       # CPU rehearsal of the multi-rank path (tests); RCCL takes HBM buffers
+    local = local.contiguous().to(_collective_device(local))
     out = torch.empty((w * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)      # concatenation along dim 0, rank order
     return out.to(dev)
 
 
-def coupled_acquisition(local_acq):
-    """Sum over ALL black-boxes of the per-black-box acquisition (JESMOC_MFDGP.py:125-135): each rank holds
-    the (k_local, T) values of its own surrogates; one all-gather, then a local sum."""
-    return all_gather_moments(local_acq).sum(0)
-
-
-def gather_with_local_grad(fm, fv, cm, cv):
-    """omega-factor coupling of the conditioned training (blackbox_mfdgp_fitter.py:317-341) when the surrogates are
-    sharded over ranks: every rank needs ALL models' (mean, var) at the 10 x~ points; its own rows keep their autograd
-    history, the other ranks' rows arrive as constants (one all-gather of 2 x 10 doubles per model).  Ranks must hold
-    the same number of objectives and of constraints.  World size 1: identity."""
+def all_gather_ragged(local):
+    """local: (k_r, ...) with k_r free per rank (0 allowed; the trailing shape must agree) -> list of the W per-rank
+    tensors.  EVERY rank enters both collectives (row counts, then rows padded to the largest count) whatever its own
+    count is -- a rank that skipped the call because it holds no rows would leave the others waiting."""
+    import torch.distributed as dist
     _, w = world()
     if w == 1:
+        return [local]
+    dev = local.device
+    cdev = _collective_device(local)
+    counts = torch.empty(w, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=cdev))
+    counts = counts.tolist()
+    kmax = max(counts)
+    if kmax == 0:
+        return [local.new_zeros((0,) + tuple(local.shape[1:])) for _ in range(w)]
+    pad = torch.zeros((kmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
+    pad[:local.shape[0]] = local.detach().to(cdev)
+    out = torch.empty((w * kmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
+    dist.all_gather_into_tensor(out, pad)
+    return [out[r * kmax:r * kmax + counts[r]].to(dev) for r in range(w)]
+
+
+def broadcast_(t, src=0):
+    """In-place broadcast from ``src`` (points every rank must agree on: x~ of the conditioned training, acquisition
+    candidates).  World size 1: no-op."""
+    import torch.distributed as dist
+    _, w = world()
+    if w == 1:
+        return t
+    cdev = _collective_device(t)
+    if cdev != t.device:
+        host = t.detach().to(cdev)
+        dist.broadcast(host, src)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src)
+    return t
+
+
+def coupled_acquisition(local_acq):
+    """Sum over ALL black-boxes of the per-black-box acquisition (JESMOC_MFDGP.py:125-135): each rank holds
+    the (k_local, T) values of its own surrogates (any k_local, 0 included); one ragged all-gather, then a local sum."""
+    return torch.cat(all_gather_ragged(local_acq), 0).sum(0)
+
+
+def gather_with_local_grad(fm, fv, cm, cv, obj_index=None, con_index=None):
+    """omega-factor coupling of the conditioned training (blackbox_mfdgp_fitter.py:317-341) when the surrogates are
+    sharded over ranks: every rank needs ALL models' (mean, var) at the 10 x~ points; its own rows keep their autograd
+    history, the other ranks' rows arrive as constants (one ragged all-gather per kind).  Ranks may hold different numbers
+    of objectives / constraints, none included.  ``obj_index`` / ``con_index``: the GLOBAL position of each local row
+    (the column of the Pareto front / the entry of the threshold vector it belongs to); the result is ordered by it.
+    Without them the rows come back in rank order.  World size 1: identity."""
+    r, w = world()
+    if w == 1:
         return fm, fv, cm, cv
-    r, _ = world()
 
-    def mix(local):
-        if local.shape[0] == 0:
-            return local
-        allv = all_gather_moments(local.detach())
-        k = local.shape[0]
-        return torch.cat([allv[:r * k], local, allv[(r + 1) * k:]], 0)
+    def mix(mean, var, index):
+        local = torch.stack([mean, var], 1)                       # (k, 2, T)
+        parts = all_gather_ragged(local)
+        parts[r] = local                                          # own rows: with gradient
+        allv = torch.cat(parts, 0)
+        if index is not None:
+            idx = torch.as_tensor(list(index), dtype=torch.int64, device=mean.device).reshape(-1)
+            if idx.numel() != mean.shape[0]:
+                raise ValueError("gather_with_local_grad: one global index per local row")
+            order = torch.cat(all_gather_ragged(idx), 0)
+            if sorted(order.tolist()) != list(range(order.numel())):
+                raise ValueError("gather_with_local_grad: global indices of all ranks must be a permutation of "
+                                 "0..n-1, got %s" % order.tolist())
+            allv = allv.index_select(0, torch.argsort(order))
+        return allv[:, 0], allv[:, 1]
 
-    return mix(fm), mix(fv), mix(cm), mix(cv)
+    fm, fv = mix(fm, fv, obj_index)
+    cm, cv = mix(cm, cv, con_index)
+    return fm, fv, cm, cv
 
 
 # ---------------------------------------------------------------------------------------------------------------

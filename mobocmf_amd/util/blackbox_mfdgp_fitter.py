@@ -2,9 +2,17 @@
 ``MFDGPHandler`` :22-39, ``BlackBoxMFDGPFitter.__init__`` :43-81, ``initialize_mfdgp`` :84-115,
 ``_train_mfdgp`` :117-152, ``train_mfdgps`` :154-178; the ELBO step is :161-171).
 
+Conditioned training (:245-354) and Pareto sampling of posterior function samples (:181-225, row N2)
+are mirrored below over the same HIP path.
+
 MI355X additions: ``device`` (models and data live on the GPU), ``num_inducing`` / ``num_samples_for_training``
 pass-through, and surrogate sharding over ranks (one process per GPU, see mobocmf_amd.parallel).
-Conditioned training (:245-354) and Pareto sampling (:181-225) are SURVEY rows N1/N2 (not built yet).
+
+Which GPyTorch branch the training batch takes: the reference trains on ``DataLoader(..., shuffle=True)`` (:35), so with
+its default Z = x_train the full batch is a random PERMUTATION of Z and ``torch.equal(x, Z)`` is false: layer 0 goes through
+the general path (mu = K_nm (K_mm + eps I)^-1 m, not m itself).  Both trainers here do the same: the eager one iterates the
+shuffling loader, the HIP-graph one captures the step on a fixed non-identity permutation of the rows (the full-batch
+loss does not depend on the row order).
 """
 import sys
 import warnings
@@ -57,6 +65,7 @@ class MFDGPHandler:
         self.iter_train_loader = None
         self.num_data = x_train.shape[0]
         self.num_fidelities = num_fidelities
+        self.global_index = None       # position among ALL objectives (or constraints) when surrogates are sharded over ranks
 
 
 class BlackBoxMFDGPFitter:
@@ -86,10 +95,20 @@ class BlackBoxMFDGPFitter:
         self.device = device
         self.model_kwargs = model_kwargs
         self.verbose = True
+        self.thresholds_cons_global = None      # sharded surrogates: thresholds of ALL constraints, global order
+
+    def set_global_constraint_thresholds(self, thresholds):
+        """Surrogates sharded over ranks (mobocmf_amd.parallel): the omega factors (:235-243) see every constraint of the
+        problem, so each rank needs the whole threshold vector in global constraint order (``global_index`` of
+        ``initialize_mfdgp``).  Single process: not needed (the local vector is the whole one)."""
+        self.thresholds_cons_global = torch.as_tensor(thresholds, dtype=torch.double).reshape(-1)
+        self._thr_cache = None
 
     def initialize_mfdgp(self, x_train, y_train, fidelities, blackbox_name, threshold_constraint=0.0,
                          is_constraint=False, previously_trained_model=None,
-                         init_params_to_prior_and_fix_them=False, use_only_highest_fidelity=False):
+                         init_params_to_prior_and_fix_them=False, use_only_highest_fidelity=False, global_index=None):
+        """``global_index`` (sharded surrogates only): this black-box's position among ALL objectives -- the column of the
+        Pareto front it is conditioned on -- or among ALL constraints; default: its position on this rank."""
         if self.x_train is None:
             self.x_train = x_train
         else:
@@ -101,6 +120,7 @@ class BlackBoxMFDGPFitter:
                                init_params_to_prior_and_fix_them=init_params_to_prior_and_fix_them,
                                use_only_highest_fidelity=use_only_highest_fidelity, device=self.device,
                                **self.model_kwargs)
+        handler.global_index = global_index
         if is_constraint:
             self.cons_train = torch.cat((self.cons_train, y_train.cpu().double()), 1)
             self.mfdgp_handlers_cons[blackbox_name] = handler
@@ -149,19 +169,34 @@ class BlackBoxMFDGPFitter:
             kl_iter += kl.detach()
         return loss_iter, kl_iter
 
+    @staticmethod
+    def shuffled_rows(n, device):
+        """One draw of the loader's shuffle (:35), never the identity for n > 1: the row order the captured step keeps.
+        (An identity draw -- probability 1/n! in the reference -- would send layer 0 through GPyTorch's equal-inputs
+        shortcut; the general branch is what the reference's training executes.)"""
+        perm = torch.randperm(n)
+        if n > 1 and bool((perm == torch.arange(n)).all()):
+            perm = torch.roll(perm, 1)
+        return perm.to(device)
+
     def _train_mfdgp_graphed(self, fix_variational_hypers, num_epochs, lr):
         """Full-batch fast path: every surrogate's ELBO step is captured into a HIP graph (mobocmf_amd.util.graphed_step)
         and the independent surrogates advance in lockstep on separate streams (the reference loops over them one
-        after the other, :134-152; they share nothing, so the result only differs in which N(0,1) draws each gets)."""
+        after the other, :134-152; they share nothing, so the result only differs in which N(0,1) draws each gets).
+        The rows are shuffled once (see the module docstring): the step runs GPyTorch's general branch, as the
+        reference's shuffled batches do."""
         from .graphed_step import GraphedELBOStep
         steps = []
         for tag, n, h in self._handlers():
             h.mfdgp.fix_variational_hypers(fix_variational_hypers)
             x, y, fid = h.train_dataset.tensors
-            steps.append((tag, n, GraphedELBOStep(h.mfdgp, h.elbo, x, y, fid, lr=lr)))
+            perm = self.shuffled_rows(x.shape[0], x.device)
+            steps.append((tag, n, GraphedELBOStep(h.mfdgp, h.elbo, x[perm].contiguous(), y[perm].contiguous(),
+                                                  fid[perm].contiguous(), lr=lr)))
         from ..layers.mfdgp_hidden_layer import NotPSDError
         for _, _, g in steps:
             g.snapshot()
+            g.last_good = -1                # last epoch whose state was verified
         for i in range(num_epochs):
             for _, _, g in steps:
                 g.step()
@@ -170,12 +205,19 @@ class BlackBoxMFDGPFitter:
                     try:
                         g.check()
                         g.snapshot()
+                        g.last_good = i
                     except (NotPSDError, FloatingPointError) as err:
-                        # a replayed graph cannot retry with more jitter: roll back to the last verified state and
-                        # finish this surrogate's phase eagerly (per-step jitter ladder, as the reference)
-                        warnings.warn("%s %d: %s -- rolling back %d epochs and continuing eagerly" %
-                                      (tag, n, err, ITER_PRINT))
+                        # a replayed graph cannot retry with more jitter: roll back to the last verified state and redo
+                        # the epochs since then eagerly (per-step jitter ladder, as the reference); the surrogate then
+                        # stays eager for the rest of the phase
+                        redo = i - g.last_good
+                        warnings.warn("%s %d: %s -- rolling back %d epochs and redoing them eagerly" % (tag, n, err, redo))
                         g.restore_and_go_eager()
+                        for _ in range(redo):
+                            g.step()
+                        g.check()
+                        g.snapshot()
+                        g.last_good = i
                     if self.verbose:
                         print("[%s: " % tag, n, "] Epoch:", i, "/", num_epochs, ". Avg. Neg. ELBO per epoch:",
                               g.loss.item(), "\t KL per epoch:", g.kl.item())
@@ -183,6 +225,7 @@ class BlackBoxMFDGPFitter:
         for _, _, g in steps:
             g.stream.synchronize()
             g.model.set_check_pd(True)
+            g.retire()
 
     def train_mfdgps(self, use_graphs=None):
         """2-phase Adam schedule of the reference (:175-176).  ``use_graphs`` (default: automatically when every
@@ -245,13 +288,22 @@ class BlackBoxMFDGPFitter:
         self.pareto_set = pareto_set.double().to(dev)
         self.pareto_front = pareto_front.double().to(dev)
 
-    def _thresholds_on(self, device):
-        """Device copy of the constraint thresholds (uploaded once: a host->device copy is not capturable)."""
-        c = getattr(self, "_thr_cache", None)
-        if c is None or c[0] is not self.thresholds_cons or c[1].device != torch.device(device):
-            c = (self.thresholds_cons, self.thresholds_cons.to(device))
+    def _thresholds_on(self, device, all_constraints=False):
+        """Device copy of the constraint thresholds (uploaded once: a host->device copy is not capturable).
+        ``all_constraints``: the vector over the constraints of every rank (omega factors), else this rank's own."""
+        src = self.thresholds_cons_global if (all_constraints and self.thresholds_cons_global is not None) \
+            else self.thresholds_cons
+        c = getattr(self, "_thr_cache", None) or {}
+        hit = c.get(all_constraints)
+        if hit is None or hit[0] is not src or hit[1].device != torch.device(device):
+            hit = (src, src.to(device))
+            c[all_constraints] = hit
             self._thr_cache = c
-        return c[1]
+        return hit[1]
+
+    @staticmethod
+    def _global_index(h, local_index):
+        return local_index if getattr(h, "global_index", None) is None else h.global_index
 
     def loss_theta_factors(self, cs_mean, cs_var, threshold):
         """:227-233."""
@@ -260,15 +312,31 @@ class BlackBoxMFDGPFitter:
 
     def loss_omega_factors(self, fs_mean, fs_var, cs_mean, cs_var, pareto_front):
         """:235-243.  fs_* (n_obj, T), cs_* (n_con, T)."""
-        thr = self._thresholds_on(fs_mean.device)
+        thr = self._thresholds_on(fs_mean.device, all_constraints=True)
+        if thr.numel() != cs_mean.shape[0]:
+            raise ValueError("omega factors: %d constraint rows but %d thresholds (sharded surrogates need "
+                             "set_global_constraint_thresholds)" % (cs_mean.shape[0], thr.numel()))
         c = torch.ones(fs_mean.shape[-1], dtype=fs_mean.dtype, device=fs_mean.device)
         if cs_mean.numel():
             c = _prod(_ncdf((cs_mean - thr[:, None]) / torch.sqrt(cs_var)), 0)
         c = c * _prod(_ncdf((pareto_front[:, :, None] - fs_mean) / torch.sqrt(fs_var)), 1)
         return torch.sum(np.log(self.eps) * c + np.log(1 - self.eps) * (1.0 - c))
 
-    def conditioned_loss(self, x_tilde, eps=None):
-        """The joint loss of one conditioned-training iteration (:270-343).
+    def next_conditioned_batch(self, h):
+        """The training batch of one model for one conditioned iteration (:281-285, :296-300): the whole data set when the
+        handler trains full-batch (every example of the reference: batch_size = N; the loss does not depend on the row
+        order), otherwise the next batch of the model's own shuffling loader, re-armed when it runs out."""
+        if h.batch_size >= h.num_data:
+            return h.train_dataset.tensors
+        try:
+            return next(h.iter_train_loader)
+        except (TypeError, StopIteration):
+            h.iter_train_loader = iter(h.train_loader)
+            return next(h.iter_train_loader)
+
+    def conditioned_loss(self, x_tilde, eps=None, batches=None):
+        """The joint loss of one conditioned-training iteration (:270-343).  ``batches``: optional {(tag, i): (x, y, fid)}
+        replacing the loader draw (tests).
 
         The reference runs three forwards per model (training batch, Pareto set, x_tilde); the layer is separable over
         rows, so here they are ONE forward on the concatenated rows: one Cholesky chain and one set of GEMMs per layer
@@ -281,7 +349,7 @@ class BlackBoxMFDGPFitter:
         tilde = {}
         k = 0
         for tag, i, h in self._handlers():
-            xb, yb, fb = h.train_dataset.tensors
+            xb, yb, fb = batches[(tag, i)] if batches is not None else self.next_conditioned_batch(h)
             B = xb.shape[0]
             S = h.mfdgp.num_samples_for_training
             top = h.num_fidelities - 1
@@ -297,7 +365,8 @@ class BlackBoxMFDGPFitter:
             if tag == "OBJ":
                 pf = torch.full((P, 1), float(top), dtype=xb.dtype, device=xb.device)
                 pl = [None] * top + [MVN(mu_p, var_p)]
-                loss = loss - h.elbo(pl, self.pareto_front[:, i:i + 1].T, pf, include_kl_term=False)
+                gi = self._global_index(h, i)                 # the front's columns follow the GLOBAL objective order
+                loss = loss - h.elbo(pl, self.pareto_front[:, gi:gi + 1].T, pf, include_kl_term=False)
             else:
                 if S > 1:
                     raise NotImplementedError("theta factors are defined for one sample per row (reference: S = 1)")
@@ -309,7 +378,10 @@ class BlackBoxMFDGPFitter:
         cons = [(tilde[(t, i)][0], tilde[(t, i)][1]) for t, i, _ in self._handlers() if t == "CON"]
         cm = torch.stack([c[0] for c in cons]) if cons else fm.new_zeros((0, T))
         cv = torch.stack([c[1] for c in cons]) if cons else fm.new_zeros((0, T))
-        fm, fv, cm, cv = parallel.gather_with_local_grad(fm, fv, cm, cv)
+        if parallel.world()[1] > 1:
+            oi = [self._global_index(h, i) for t, i, h in self._handlers() if t == "OBJ"]
+            ci = [self._global_index(h, i) for t, i, h in self._handlers() if t == "CON"]
+            fm, fv, cm, cv = parallel.gather_with_local_grad(fm, fv, cm, cv, oi, ci)
         return loss - self.loss_omega_factors(fm, fv, cm, cv, self.pareto_front)
 
     def train_conditioned_mfdgps(self, num_iters=None, use_graphs=None):
@@ -322,10 +394,15 @@ class BlackBoxMFDGPFitter:
         for _, _, h in self._handlers():
             h.mfdgp.fix_variational_hypers_cond(True)
         num_iters = self.num_epochs_2 if num_iters is None else num_iters
+        full_batch = all(h.batch_size >= h.num_data for _, _, h in self._handlers())
         if use_graphs is None:
-            use_graphs = self.pareto_set.is_cuda and parallel.world()[1] == 1
+            use_graphs = self.pareto_set.is_cuda and parallel.world()[1] == 1 and full_batch
+        if use_graphs and not full_batch:
+            raise ValueError("a captured conditioned step needs batch_size >= number of training points (mini-batches come "
+                             "from a host-side loader)")
         step = GraphedConditionedStep(self, lr=self.lr_2, use_graph=use_graphs)
         step.snapshot()
+        last_good = -1
         for i in range(num_iters):
             step.step()
             if (i % ITER_PRINT) == 0 or (i + 1) == num_iters:
@@ -333,14 +410,20 @@ class BlackBoxMFDGPFitter:
                     step.check()
                     step.snapshot()
                 except (NotPSDError, FloatingPointError) as err:
-                    warnings.warn("conditioned training: %s -- rolling back %d iterations and continuing eagerly" %
-                                  (err, ITER_PRINT))
+                    warnings.warn("conditioned training: %s -- rolling back %d iterations and redoing them eagerly" %
+                                  (err, i - last_good))
                     step.restore_and_go_eager()
+                    for _ in range(i - last_good):
+                        step.step()
+                    step.check()
+                    step.snapshot()
+                last_good = i
                 if self.verbose:
                     print("Iter:", i, "/", num_iters, ". Neg. ELBO per iter:", step.loss.item())
                     sys.stdout.flush()
         step.stream.synchronize()
         torch.cuda.current_stream(self.pareto_set.device).wait_stream(step.stream)
+        step.retire()
         for _, _, h in self._handlers():
             h.iter_train_loader = None
             h.mfdgp.set_check_pd(True)

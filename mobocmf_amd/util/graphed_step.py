@@ -88,6 +88,8 @@ class GraphedELBOStep:
                 with torch.cuda.graph(self.graph_update, stream=self.stream, capture_error_mode="thread_local"):
                     self._update()
                 self._reset_after_warmup(snapshot)     # the capture pass above ran the exchange + nothing else for real
+        from .. import functional as F
+        self._pinned_scratch = F.take_capture_pins()      # the graph replays on these buffers: they live as long as it does
         cur.wait_stream(self.stream)
 
     def _reset_after_warmup(self, snapshot):
@@ -100,6 +102,14 @@ class GraphedELBOStep:
                         v.zero_()
         if not self.exchanges:
             self.optimizer.zero_grad(set_to_none=True)
+
+    def retire(self):
+        """Drop the graph and this step's entry in the scratch arena (the fitter calls it when a training phase ends)."""
+        from .. import functional as F
+        self.stream.synchronize()
+        self.graph = self.graph_update = None
+        self._pinned_scratch = None
+        F.release_scratch(self.stream)
 
     def step(self):
         """Enqueues one step on ``self.stream``; ``self.loss`` / ``self.kl`` hold the step's -ELBO and scaled KL."""
@@ -202,6 +212,9 @@ class GraphedConditionedStep(GraphedELBOStep):
         self.optimizer.zero_grad(set_to_none=True)
         x_tilde = self.fixed_x_tilde if self.fixed_x_tilde is not None else \
             torch.rand(self.n_tilde, self.d, dtype=torch.float64, device=self.device)
+        from .. import parallel
+        if self.fixed_x_tilde is None and parallel.world()[1] > 1:
+            parallel.broadcast_(x_tilde)      # sharded surrogates: the gathered moments must refer to the SAME points
         loss = self.fitter.conditioned_loss(x_tilde)
         loss.backward()
         self.loss.copy_(loss.detach())

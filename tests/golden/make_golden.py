@@ -103,18 +103,29 @@ def ref_moop():
     np.savez(os.path.join(HERE, "ref_moop.npz"), **out)
 
 
-def oracle_case(name, prob, S, T=6):
+def permuted_problem(prob, seed=5):
+    """The same problem with its DATA rows shuffled (Z_x keeps the original order): what one batch of the reference's
+    DataLoader(shuffle=True) looks like at M = N (blackbox_mfdgp_fitter.py:35) -- the general branch, not torch.equal's."""
+    perm = np.random.default_rng(seed).permutation(prob["x"].shape[0])
+    if (perm == np.arange(perm.size)).all():
+        perm = np.roll(perm, 1)
+    out = dict(prob)
+    out.update(x=prob["x"][perm], y=prob["y"][perm], fid=prob["fid"][perm], perm=perm)
+    return out
+
+
+def oracle_case(name, prob, S, T=6, shortcut=True):
     st = oracle_state(prob, requires_grad=True)
     x, y, fid = to_t(prob["x"]), to_t(prob["y"]), to_t(prob["fid"])
     eps = [None] + [to_t(e) for e in prob["eps"][1:]]
-    e, skl = O.elbo(st, x, y, fid, eps=eps, S=S)
+    e, skl = O.elbo(st, x, y, fid, eps=eps, S=S, shortcut=shortcut)
     leaves = state_leaves(st)
     grads = torch.autograd.grad(e, leaves)
     out = {"elbo": e.detach().numpy(), "scaled_kl": skl.detach().numpy()}
     for i, g in enumerate(grads):
         out[f"grad_{i}"] = g.numpy()
     with torch.no_grad():
-        outs = O.model_forward(st, x, eps=eps, S=S)
+        outs = O.model_forward(st, x, eps=eps, S=S, shortcut=shortcut)
         for l, (mu, v) in enumerate(outs):
             out[f"mean_{l}"], out[f"var_{l}"] = mu.numpy(), v.numpy()
         X = to_t(np.random.default_rng(123).random((T, prob["d"])))
@@ -157,6 +168,8 @@ if __name__ == "__main__":
         ref_moop()
     for o in range(3):
         oracle_case(f"C1_forrester_out{o}", forrester_state_problem(o), S=4)
+        # the branch the reference's training executes: shuffled batch rows, no equal-inputs shortcut
+        oracle_case(f"C1_forrester_out{o}_general", permuted_problem(forrester_state_problem(o)), S=4, shortcut=False)
     for seed in range(3):
         oracle_case(f"small2d_seed{seed}", synthetic.make_problem(d=2, L=2, M=8, N=12, S=3, seed=seed), S=3)
     oracle_case("small3layer", synthetic.make_problem(d=3, L=3, M=10, N=16, S=2, seed=7), S=2)

@@ -150,3 +150,55 @@ def test_jesmoc_next_point_flow():
     assert float((parts[0].detach().cpu() - ref).abs().max()) < 1e-6 * max(1.0, float(ref.abs().max()))
     x_next, fid = acq.get_nextpoint_coupled(maxiter=15)
     assert x_next.shape == (2,) and 0 <= fid < 2 and bool(((x_next >= 0) & (x_next <= 1)).all())
+
+
+def test_minibatch_conditioned_loss_follows_the_loader_iterators():
+    """batch_size < N: every model draws the next batch of ITS OWN shuffling loader per iteration, re-armed when it runs
+    out (blackbox_mfdgp_fitter.py:281-285, :296-300), and the batch ELBO is rescaled by num_data / batch
+    (:288, :303; KL inside scaled by batch / num_data).  Loss and gradients vs the oracle on the very batches drawn."""
+    from torch.utils.data import DataLoader
+    n_obj, n_con, N, B, P, T, d = 2, 1, 12, 5, 4, 10, 2
+    fitter, probs = _fitter(n_obj, n_con, N)
+    for _, _, h in fitter._handlers():
+        h.batch_size = B
+        h.train_loader = DataLoader(h.train_dataset, batch_size=B, shuffle=True)
+    g = torch.Generator().manual_seed(7)
+    pareto_set = torch.rand(P, d, dtype=torch.float64, generator=g)
+    pareto_front = torch.randn(P, n_obj, dtype=torch.float64, generator=g) * 0.5
+    fitter.set_pareto_solution(pareto_set, pareto_front)
+    seen = {k: [] for k in range(n_obj + n_con)}
+    for it in range(4):                   # 12 rows in batches of 5, 5, 2: the 4th draw re-arms the loader
+        x_tilde = torch.rand(T, d, dtype=torch.float64, generator=g)
+        torch.manual_seed(100 + it)
+        batches = {(tag, i): fitter.next_conditioned_batch(h) for tag, i, h in fitter._handlers()}
+        eps_all, objs, cons = {}, [], []
+        for idx, (tag, i, h) in enumerate(fitter._handlers()):
+            xb, yb, fb = batches[(tag, i)]
+            nb = xb.shape[0]
+            seen[idx].append(nb)
+            e = torch.randn(nb + P + T, dtype=torch.float64, generator=g)
+            eps_all[(tag, i)] = [None, e.to(DEV)]
+            st = oracle_state(probs[idx], requires_grad=True)
+            rec = {"state": st, "x": xb.cpu(), "y": yb.cpu()[:, 0], "fid": fb.cpu()[:, 0], "num_data": N,
+                   "eps_batch": [None, e[:nb]], "eps_pareto": [None, e[nb:nb + P]], "eps_tilde": [None, e[nb + P:]]}
+            (objs if tag == "OBJ" else cons).append(rec)
+        loss_o = O.conditioned_loss(objs, cons, pareto_set, pareto_front, x_tilde, fitter.thresholds_cons, fitter.eps)
+        loss_o.backward()
+        for _, _, h in fitter._handlers():
+            for p in h.mfdgp.parameters():
+                p.grad = None
+        loss = fitter.conditioned_loss(x_tilde.to(DEV), eps=eps_all, batches=batches)
+        loss.backward()
+        assert abs(float(loss) - float(loss_o)) / abs(float(loss_o)) < 1e-8, it
+        for rec, (tag, i, h) in zip(objs + cons, fitter._handlers()):
+            for l in range(2):
+                vd = getattr(h.mfdgp, f"hidden_layer_{l}").variational_strategy._variational_distribution
+                ref = rec["state"]["layers"][l]["m"].grad
+                assert float((vd.variational_mean.grad.cpu() - ref).abs().max() / ref.abs().max()) < 1e-6, (it, tag, i, l)
+    assert all(v == [5, 5, 2, 5] for v in seen.values()), seen
+    # the training driver: mini-batches run eagerly (a host-side loader cannot be captured), a request for graphs is refused
+    with pytest.raises(ValueError):
+        fitter.train_conditioned_mfdgps(num_iters=2, use_graphs=True)
+    fitter.lr_2 = 5e-3
+    fitter.train_conditioned_mfdgps(num_iters=5)
+    assert all(h.iter_train_loader is None for _, _, h in fitter._handlers())

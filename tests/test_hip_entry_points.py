@@ -1,0 +1,103 @@
+"""C-ABI entry points added in round 2: the GEMM with the layer's epilogues (what bench.py's per-variant roofline times),
+the dense prior Gram behind MFDGPHiddenLayer.forward, the tuning thresholds."""
+import numpy as np
+import pytest
+import torch
+
+from mobocmf_amd.util import synthetic
+from oracle import mfdgp_oracle as O
+from tests.helpers import oracle_state, to_t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("Mp,Np", [(128, 256), (256, 2048), (512, 8192), (640, 1024), (512, 32768), (384, 65536)])
+def test_gemm_epilogue_variants_match_torch(Mp, Np):
+    """The four launches of a layer's panel work through mobocmf_gemm_f64_epilogue vs float64 torch ops: small-panel
+    kernel (Mp <= 512, few workgroups), tiled kernel without and with row-block pairing."""
+    from mobocmf_amd import functional as F
+    g = torch.Generator(device=DEV)
+    g.manual_seed(Mp + Np)
+    rnd = lambda *s: torch.randn(*s, dtype=torch.float64, device=DEV, generator=g)
+    Lw, Up = torch.tril(rnd(Mp, Mp)), torch.triu(rnd(Mp, Mp))
+    B, Aaux = rnd(Mp, Np), rnd(Mp, Np)
+    avec, gmu, cgv, gv = rnd(Mp), rnd(Np), rnd(Np), rnd(Np)
+    nrb = Mp // 128
+    for tri, T in ((1, Lw), (2, Up)):
+        ref = T @ B
+        # plain store
+        C = torch.full((Mp, Np), float("nan"), dtype=torch.float64, device=DEV)
+        F.gemm_f64_epilogue(T, B, C, tri, 0)
+        assert rel(C, ref) < 1e-12
+        # column statistics (+ non-temporal stores)
+        for so in (False, True):
+            C.fill_(float("nan"))
+            p1 = torch.full((nrb, Np), float("nan"), dtype=torch.float64, device=DEV)
+            p2 = torch.full((nrb, Np), float("nan"), dtype=torch.float64, device=DEV)
+            F.gemm_f64_epilogue(T, B, C, tri, 1, stream_out=so, colsq_part=p1, coldot_part=p2, avec=avec)
+            assert rel(C, ref) < 1e-12
+            assert rel(p1.sum(0), (ref * ref).sum(0)) < 1e-12
+            assert rel(p2.sum(0), avec @ ref) < 1e-11
+        # dA epilogue + row dots
+        C.fill_(float("nan"))
+        rdp = torch.zeros(2 * max(Np // 128, Np // 16), Mp, dtype=torch.float64, device=DEV)
+        F.gemm_f64_epilogue(T, B, C, tri, 2, alpha=2.0, avec=avec, bscale=gv, gmu=gmu, cgv=cgv, Aaux=Aaux, rowdot_part=rdp)
+        want = 2.0 * ref * gv[None, :] + avec[:, None] * gmu[None, :] - 2.0 * Aaux * cgv[None, :]
+        assert rel(C, want) < 1e-12
+        assert rel(rdp.sum(0), Aaux @ gmu) < 1e-11
+
+
+def test_layer_forward_is_the_dense_prior():
+    """MFDGPHiddenLayer.forward (mfdgp_hidden_layer.py:232-243): N(0, k(x, x)) of the layer's kernel, both kinds."""
+    prob = synthetic.make_problem(d=3, L=2, M=10, N=40, S=1, seed=3)
+    model = synthetic.model_from_problem(prob, device=DEV)
+    st = oracle_state(prob)
+    x = to_t(prob["x"])
+    f = torch.randn(40, 1, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    p0 = model.hidden_layer_0.forward(x.to(DEV))
+    assert rel(p0.covariance_matrix, O.gram(st["layers"][0]["hyp"], x, x)) < 1e-13
+    assert float(p0.mean.abs().max()) == 0.0 and p0.variance.shape == (40,)
+    X1 = torch.cat([x, f], 1)
+    p1 = model.hidden_layer_1.forward(X1.to(DEV))
+    assert rel(p1.covariance_matrix, O.gram(st["layers"][1]["hyp"], X1, X1)) < 1e-13
+
+
+def test_set_tuning_switches_kernels_not_results():
+    """mobocmf_set_tuning moves the hand-over between the small-operand kernels and the tiled MFMA pipeline: results agree
+    to rounding on either side; bad values are refused."""
+    from mobocmf_amd import _lib
+    from mobocmf_amd import functional as F
+    from mobocmf_amd.mlls import VariationalELBOMF
+    prob = synthetic.make_problem(d=2, L=2, M=100, N=300, S=2, seed=1)
+    t = lambda a: to_t(a).to(DEV)
+    vals = []
+    try:
+        for lim in ((16, 16), (384, 512)):
+            F.set_tuning(*lim)
+            model = synthetic.model_from_problem(prob, num_samples_for_training=2, device=DEV)
+            out = model(t(prob["x"]), eps=[None, t(prob["eps"][1])])
+            e, _ = VariationalELBOMF(model, 300, 2)(out, t(prob["y"])[None, :], t(prob["fid"])[:, None])
+            (-e).backward()
+            vals.append((float(e), model.hidden_layer_1.variational_strategy._variational_distribution
+                         .variational_mean.grad.clone()))
+    finally:
+        F.set_tuning(384, 512)
+    assert abs(vals[0][0] - vals[1][0]) < 1e-9 * abs(vals[1][0])
+    assert rel(vals[0][1], vals[1][1]) < 1e-6
+    with pytest.raises(_lib.MobocmfError):
+        F.set_tuning(4096, 0)
+
+
+def test_limits_are_reported_with_a_message():
+    from mobocmf_amd import _lib
+    from mobocmf_amd import functional as F
+    with pytest.raises(_lib.MobocmfError, match="input dimensions"):
+        F.make_desc(0, 33, 8, 16)
+    with pytest.raises(_lib.MobocmfError, match="samples per input row"):
+        F.make_desc(1, 4, 8, 49 * 2, xdiv=49)

@@ -60,6 +60,59 @@ def test_world_size_2_gloo_exchange():
     assert t0 == t1 == [6.0] * 7                                                     # 2*1 + 2*2
 
 
+def _ragged_worker(rank, world, port, q):
+    """Unequal shards, one rank without any constraint (2 objectives + 1 constraint... on 2 ranks: the layout round-robin
+    sharding produces): every rank must still enter every collective, and rows must come back in GLOBAL order."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobocmf_amd import parallel
+    T = 3
+    # objectives: rank 0 holds global 0 and 2, rank 1 holds global 1; the only constraint lives on rank 1
+    obj_idx = [0, 2] if rank == 0 else [1]
+    con_idx = [] if rank == 0 else [0]
+    fm = torch.stack([torch.full((T,), float(10 + g), dtype=torch.float64) for g in obj_idx]).requires_grad_(True)
+    cm = torch.stack([torch.full((T,), float(50 + g), dtype=torch.float64) for g in con_idx]).requires_grad_(True) \
+        if con_idx else torch.zeros((0, T), dtype=torch.float64, requires_grad=True)
+    afm, afv, acm, acv = parallel.gather_with_local_grad(fm, fm * 2, cm, cm * 3, obj_idx, con_idx)
+    (afm.prod(0).sum() + acm.sum()).backward()
+    parts = parallel.all_gather_ragged(torch.full((rank, 2), float(rank)))          # 0 rows on rank 0, 1 row on rank 1
+    acq = parallel.coupled_acquisition(torch.full((len(obj_idx) + len(con_idx), T), 1.0, dtype=torch.float64))
+    x = torch.full((2,), float(rank + 5))
+    parallel.broadcast_(x)
+    bad = None
+    try:
+        parallel.gather_with_local_grad(fm, fm, cm, cm, [0] * len(obj_idx), con_idx)   # not a permutation
+    except ValueError as err:
+        bad = str(err)
+    q.put((rank, afm[:, 0].tolist(), afv[:, 0].tolist(), acm[:, 0].tolist(), acv[:, 0].tolist(), fm.grad[:, 0].tolist(),
+           None if cm.grad is None else cm.grad.reshape(-1).tolist(), [tuple(p.shape) for p in parts], acq.tolist(),
+           x.tolist(), bad is not None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_ragged_and_empty_shards_do_not_deadlock():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, afm, afv, acm, acv, gfm, gcm, shapes, acq, x, bad in res:
+        assert afm == [10.0, 11.0, 12.0] and afv == [20.0, 22.0, 24.0]          # global objective order on every rank
+        assert acm == [50.0] and acv == [150.0]
+        assert shapes == [(0, 2), (1, 2)] and acq == [4.0] * 3 and x == [5.0, 5.0] and bad
+    assert res[0][5] == [11.0 * 12.0, 10.0 * 11.0] and res[1][5] == [10.0 * 12.0]      # d prod / d own rows only
+    assert res[0][6] in (None, []) and res[1][6] == [1.0] * 3
+
+
 def test_world_size_1_degenerates_to_identity():
     from mobocmf_amd import parallel
     x = torch.arange(6, dtype=torch.float64).reshape(1, 2, 3)

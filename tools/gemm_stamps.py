@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Where a workgroup of the triangular GEMM spends its time (diagnostic build -DGEMM_STAMPS, 100 MHz wall-clock stamps):
+    bash tools/build_variant.sh stamps -DGEMM_STAMPS          (build container)
+    MOBOCMF_HIP_LIB=$PWD/abtest/libstamps.so python tools/gemm_stamps.py      (GPU box)
+Prints per-phase durations (median over workgroups), how the phases of all workgroups line up on the wall clock (the
+number of workgroups inside a main loop in each 5 us bin), and which workgroups share a CU."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mobocmf_amd import _lib  # noqa: E402
+from mobocmf_amd import functional as F  # noqa: E402
+
+dev = torch.device("cuda")
+lib = _lib.load()
+raw = ctypes.CDLL(_lib.LIB_PATH)
+M, N = 512, 65536
+A = torch.tril(torch.randn(M, M, dtype=torch.float64, device=dev))
+B = torch.randn(M, N, dtype=torch.float64, device=dev)
+C = torch.empty(M, N, dtype=torch.float64, device=dev)
+avec = torch.randn(M, dtype=torch.float64, device=dev)
+p1 = torch.empty(M // 128, N, dtype=torch.float64, device=dev)
+p2 = torch.empty(M // 128, N, dtype=torch.float64, device=dev)
+nwg = 4096
+stamps = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
+for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("dense store", 0, 0)):
+    fn = lambda: F.gemm_f64_epilogue(A, B, C, tri, epi, colsq_part=p1, coldot_part=p2, avec=avec)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    raw.mobocmf_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+    stamps.zero_()
+    fn()
+    torch.cuda.synchronize()
+    raw.mobocmf_debug_set_stamps(ctypes.c_void_p(0))
+    s = stamps.cpu().numpy().reshape(nwg, 16)
+    used = s[:, 0] > 0
+    s = s[used]
+    t0 = s[:, 0].min()
+    us = lambda a: (a - t0) / 100.0
+    print("== %s: %d workgroups, kernel span %.1f us" % (name, len(s), us(s[:, [9, 10]].max())))
+    start = us(s[:, 0])
+    print("   start: first %.1f, median %.1f, p90 %.1f, last %.1f us" %
+          (start.min(), np.median(start), np.percentile(start, 90), start.max()))
+    for part in (0, 1):
+        sel = s[:, 1 + 4 * part] > 0
+        if not sel.any():
+            continue
+        prev = s[sel, 0] if part == 0 else s[sel, 9]
+        pro = (s[sel, 1 + 4 * part] - prev) / 100.0
+        loop = (s[sel, 4 + 4 * part] - s[sel, 1 + 4 * part]) / 100.0
+        epi_t = (s[sel, 9 + part] - s[sel, 4 + 4 * part]) / 100.0
+        print("   part %d: prologue %.2f | main loop %.2f (min %.2f max %.2f) | epilogue issue %.2f  [us, median]" %
+              (part, np.median(pro), np.median(loop), loop.min(), loop.max(), np.median(epi_t)))
+        if (s[sel, 2 + 4 * part] > 0).any():
+            d0 = (s[sel, 2 + 4 * part] - s[sel, 1 + 4 * part]) / 100.0
+            d1 = (s[sel, 3 + 4 * part] - s[sel, 2 + 4 * part]) / 100.0
+            d2 = (s[sel, 4 + 4 * part] - s[sel, 3 + 4 * part]) / 100.0
+            print("           diag-first %.2f | dense %.2f | diag-last %.2f" % (np.median(d0), np.median(d1), np.median(d2)))
+    end = us(np.maximum(s[:, 9], s[:, 10]))
+    print("   end: first %.1f, median %.1f, last %.1f us" % (end.min(), np.median(end), end.max()))
+    span = end.max()
+    bins = np.arange(0, span + 5, 5.0)
+    inloop = np.zeros(len(bins))
+    for part in (0, 1):
+        sel = s[:, 1 + 4 * part] > 0
+        a, b = us(s[sel, 1 + 4 * part]), us(s[sel, 4 + 4 * part])
+        for i, tb in enumerate(bins):
+            inloop[i] += ((a <= tb) & (b > tb)).sum()
+    print("   workgroups inside a main loop at t = 0, 5, 10 ... us:", " ".join("%d" % v for v in inloop))
+    hw = s[:, 15]
+    lo = hw & 0xffffffff
+    cu_key = (hw >> 32) * 100000 + ((lo >> 8) & 0xf) * 64 + ((lo >> 12) & 0x1) * 16 + ((lo >> 13) & 0xf)   # xcc, cu, sh, se
+    order = np.nonzero(used)[0]
+    groups = {}
+    for b, k, st in zip(order, cu_key, start):
+        groups.setdefault(int(k), []).append((int(b), round(float(st), 1)))
+    ex = list(groups.items())[:4]
+    print("   distinct (xcc, cu, sh, se) keys: %d; examples (block id, start us) per key: %s" % (len(groups), [v[:6] for _, v in ex]))

@@ -7,13 +7,15 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // mode 0: v_mfma_f64_16x16x4_f64   mode 1: v_mfma_f64_4x4x4_4b_f64   mode 2: v_fma_f64
 // mode 3: waves 0,1 MFMA 16x16x4, waves 2,3 v_fma_f64 (co-issue test, one wave per SIMD)
+// mode 4: half of the waves 4x4x4 MFMA, half v_fma_f64, chosen by (wave + blockIdx) parity: with two workgroups per CU every
+//         SIMD hosts one wave of each kind -- do the matrix and the vector FP64 pipes add up, or are they one datapath?
 template <int MODE>
 __global__ __launch_bounds__(256) void loop_kernel(double* out, int iters, double a0, double b0) {
     double a = a0 + threadIdx.x * 1e-3, b = b0 - threadIdx.x * 1e-3;
     double s = 0;
     const int wave = threadIdx.x >> 6;
     bool do_mfma = MODE == 0 || (MODE == 3 && wave < 2);
-    if (MODE == 1) {
+    if (MODE == 1 || (MODE == 4 && ((wave + blockIdx.x) & 1))) {
         double acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0;
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void loop_kernel(double* out, int iters, doubl
         for (int i = 0; i < 32; ++i) acc[i] = i;
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < (MODE == 4 ? 2 : 8); ++r)
 #pragma unroll
                 for (int i = 0; i < 32; ++i) acc[i] = __builtin_fma(a, b, acc[i]);
             asm volatile("" ::: "memory");
@@ -68,7 +70,7 @@ void run(const char* name, double flops_per_wave_iter_mfma, double flops_per_wav
             if (ms < best) best = ms;
         }
         double fl;
-        if (MODE == 3) fl = 10.0 * grid * iters * (2 * flops_per_wave_iter_mfma + 2 * flops_per_wave_iter_valu);
+        if (MODE == 3 || MODE == 4) fl = 10.0 * grid * iters * (2 * flops_per_wave_iter_mfma + 2 * flops_per_wave_iter_valu);
         else fl = 10.0 * grid * 4 * iters * (MODE == 2 ? flops_per_wave_iter_valu : flops_per_wave_iter_mfma);
         printf("%-34s waves/SIMD=%d: %.1f TFLOP/s (%.2f ms)\n", name, wgs_per_cu, fl / best / 1e9, best);
     }
@@ -81,5 +83,6 @@ int main() {
     run<1>("v_mfma_f64_4x4x4_4b_f64", 16.0 * 512, 0, out);
     run<2>("v_fma_f64", 0, 8.0 * 32 * 128, out);
     run<3>("2 waves MFMA + 2 waves v_fma_f64", 16.0 * 2048, 8.0 * 32 * 128, out);
+    run<4>("4x4x4 MFMA waves + v_fma_f64 waves mixed", 16.0 * 512, 2.0 * 32 * 128, out);
     return 0;
 }
