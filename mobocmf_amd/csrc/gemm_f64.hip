@@ -65,9 +65,18 @@ extern "C" int mobocmf_debug_set_stamps(unsigned long long* p) {
 template <bool B_T, bool TRI, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_ELEMS];   // [buf][A | B]
+    __shared__ double avs[EPI == EPI_STORE ? 1 : BM];          // avec of the row block (epilogues)
+    __shared__ double red[EPI == EPI_COLSTATS ? 4 * BN : 1];   // [2 stats][2 wr][128 cols]
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     STAMP(0);
     STAMP_ID();
+#ifdef GEMM_STAGGER_US
+    // experiment: the second resident workgroup of every CU starts late, so that the two streams of a CU stay out of phase
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + 100ull * GEMM_STAGGER_US;
+        while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     // ---- block id -> (tile, k-slice).  Blocks b, b+8, ... share an XCD (and its L2):
     //  * no split-K: the row blocks that re-read the same 128-column panel of B run back to back on one XCD;
     //  * split-K: all tiles of one k-slice (they share the slice's rows of A and B) run back to back on one XCD.
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 
     const int64_t nk = (k1 > k0) ? (k1 - k0) / BK : 0;
 #define KSTEP(KT) (rev ? nk - 1 - (KT) : (KT))   /* iteration -> K step of the tile */
+    if (EPI != EPI_STORE && tid < BM) avs[tid] = g.avec[(int64_t)rb * BM + tid];   // visible after the barrier below
     if (nk > 0) stage(Ag, k0 + KSTEP(0) * BK, 0);
     // LDS-DMA data is ordered for other wavefronts' ds_reads only by the issuing wavefront's vmcnt wait followed by
     // a barrier; the waits are written out (hipcc adds them only when it sees the DMA in the same scheduling scope)
@@ -320,87 +330,97 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #undef LOAD_B
 
     // ------------------------------------------------------------------ epilogue
+    // Every operand of an epilogue is fetched up front in batches (the row vector `avec` through LDS, staged at the top
+    // of the part; column vectors and the Aaux tile by unconditional loads): a conditional load inside the unrolled
+    // element loop compiles to one branch + load + s_waitcnt vmcnt(0) PER ELEMENT (64 dependent round trips, ~24 us per
+    // epilogue -- the round-1 column-statistics epilogue did exactly that).
     STAMP(4 + 4 * part);      // main loop done
     const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;     // + mt*32 + 4*r
     const int64_t col0 = cb * BN + wc * 64 + li;               // + nt*16
+    const int arow = wr * 16 + lk;                             // row inside the block: + mt*32 + 4*r
     if (EPI == EPI_DA) {
         // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n];   optionally rd[row] = sum_n Aaux[row][n] * gmu[n]
-        double rd[4][4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rd[mt][r] = 0.0;
+        double gm[4], cg[4], cs[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int64_t col = col0 + nt * 16;
-            const double gm = g.gmu[col], cg = g.cgv[col];
-            const double cs = g.alpha * (g.bscale ? g.bscale[col] : 1.0);   // column scaling commutes with A*
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = row0 + mt * 32 + 4 * r;
-                    const double av = g.Aaux[row * g.ldc + col];
-                    C[row * g.ldc + col] = cs * acc[mt][nt][r] + g.avec[row] * gm - 2.0 * av * cg;
-                    rd[mt][r] += av * gm;
-                }
+            gm[nt] = g.gmu[col0 + nt * 16];
+            cg[nt] = g.cgv[col0 + nt * 16];
+            cs[nt] = 1.0;
         }
-        if (g.rowdot_part) {
-            // the 16 lanes li of a lane group hold the same rows, different columns: butterfly over li, then one lane
-            // per lane group writes this wavefront's 64-column slice
-            double* out = g.rowdot_part + ((int64_t)cb * 2 + wc) * g.Mr;
+        if (g.bscale) {      // column scaling commutes with A*
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int nt = 0; nt < 4; ++nt) cs[nt] = g.bscale[col0 + nt * 16];
+        }
+        double* rdout = g.rowdot_part ? g.rowdot_part + ((int64_t)cb * 2 + wc) * g.Mr : nullptr;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double v = rd[mt][r];
-                    v += __shfl_xor(v, 1);
-                    v += __shfl_xor(v, 2);
-                    v += __shfl_xor(v, 4);
-                    v += __shfl_xor(v, 8);
-                    if (li == 0) out[row0 + mt * 32 + 4 * r] = v;
+        for (int mt = 0; mt < 4; ++mt) {
+            double av[4][4], ar[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ar[r] = avs[arow + mt * 32 + 4 * r];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) av[nt][r] = g.Aaux[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + nt * 16];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double rd = 0.0;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const double a = av[nt][r];
+                    C[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + nt * 16] =
+                        g.alpha * cs[nt] * acc[mt][nt][r] + ar[r] * gm[nt] - 2.0 * a * cg[nt];
+                    rd += a * gm[nt];
                 }
+                // the 16 lanes li of a lane group hold the same row, different columns: butterfly over li, then one lane
+                // per lane group writes this wavefront's 64-column slice
+                rd += __shfl_xor(rd, 1);
+                rd += __shfl_xor(rd, 2);
+                rd += __shfl_xor(rd, 4);
+                rd += __shfl_xor(rd, 8);
+                if (rdout && li == 0) rdout[row0 + mt * 32 + 4 * r] = rd;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one 16-row group at a time: bounded live ranges, no spills
         }
         STAMP(9 + part);
-        continue;   // LDS was not touched after the main loop's last barrier
+        if (nparts == 2) __syncthreads();   // `avs` is rewritten at the top of the next part
+        continue;
     }
-#define STORE_TILE(ST)                                                                                      \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                       \
+    double sq[4] = {0.0, 0.0, 0.0, 0.0}, dt[4] = {0.0, 0.0, 0.0, 0.0};
+#define STORE_TILE(ST, ACCUM)                                                                               \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                     \
+        double ar[4];                                                                                       \
+        if (EPI == EPI_COLSTATS) { _Pragma("unroll") for (int r = 0; r < 4; ++r) ar[r] = avs[arow + mt * 32 + 4 * r]; } \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                   \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
-                const int64_t row = row0 + mt * 32 + 4 * r;                                                 \
-                const int64_t col = col0 + nt * 16;                                                         \
+                double* cp = &C[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + nt * 16];                         \
                 double v = g.alpha * acc[mt][nt][r];                                                        \
-                if (g.accumulate) v += C[row * g.ldc + col];                                                \
-                acc[mt][nt][r] = v;                                                                         \
-                ST(v, &C[row * g.ldc + col]);                                                               \
-            }
+                if (ACCUM) v += *cp;                                                                        \
+                ST(v, cp);                                                                                  \
+                if (EPI == EPI_COLSTATS) {                                                                  \
+                    sq[nt] += v * v;                                                                        \
+                    dt[nt] += ar[r] * v;                                                                    \
+                }                                                                                           \
+            }                                                                                               \
+    }
 #define ST_PLAIN(v, p) (*(p) = (v))
 #define ST_STREAM(v, p) __builtin_nontemporal_store((v), (p))
-    if (g.stream_out) { STORE_TILE(ST_STREAM) } else { STORE_TILE(ST_PLAIN) }
+    if (g.accumulate) { STORE_TILE(ST_PLAIN, 1) }
+    else if (g.stream_out) { STORE_TILE(ST_STREAM, 0) }
+    else { STORE_TILE(ST_PLAIN, 0) }
 #undef STORE_TILE
     if (EPI == EPI_COLSTATS) {
-        // partial column sums over this tile's 128 rows: per lane over its 16 rows, then across the
-        // 4 lane groups of the wavefront (shuffles), then across the two row-wavefronts (LDS).
-        double* red = lds;   // [2 stats][2 wr][128 cols]   (main-loop LDS is dead after the last barrier)
+        // partial column sums over this tile's 128 rows: per lane over its 16 rows (above), then across the 4 lane groups
+        // of the wavefront (shuffles), then across the two row-wavefronts (LDS).
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            double sq = 0.0, dt = 0.0;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double v = acc[mt][nt][r];
-                    sq += v * v;
-                    if (g.coldot_part) dt += g.avec[row0 + mt * 32 + 4 * r] * v;
-                }
-            sq += __shfl_xor(sq, 16);
-            sq += __shfl_xor(sq, 32);
-            dt += __shfl_xor(dt, 16);
-            dt += __shfl_xor(dt, 32);
+            double s1 = sq[nt], s2 = dt[nt];
+            s1 += __shfl_xor(s1, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16);
+            s2 += __shfl_xor(s2, 32);
             if (lk == 0) {
-                red[(0 * 2 + wr) * BN + wc * 64 + nt * 16 + li] = sq;
-                red[(1 * 2 + wr) * BN + wc * 64 + nt * 16 + li] = dt;
+                red[(0 * 2 + wr) * BN + wc * 64 + nt * 16 + li] = s1;
+                red[(1 * 2 + wr) * BN + wc * 64 + nt * 16 + li] = s2;
             }
         }
         __syncthreads();
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
             if (g.coldot_part)
                 g.coldot_part[(int64_t)rb * g.Nc + cb * BN + tid] = red[2 * BN + tid] + red[3 * BN + tid];
         }
-        __syncthreads();   // `red` aliases the staging buffers of the next part
+        if (nparts == 2) __syncthreads();   // `red` / `avs` are rewritten by the next part
     }
     STAMP(9 + part);          // epilogue issued
   }   // parts
