@@ -339,7 +339,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
         // (skip_if_zero) when no column is clamped.
         if (!inputs_only) {
             GemmArgs ga = gemm_args(S.A, Np, S.A, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
-            ga.bscale = B.gv; ga.lower_out = 1; ga.slab_stride = mm;
+            ga.bscale = B.gv; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm;
             const int nsl = gemm_nt_slabs(ga, D.splitk);      // 1: a small problem goes through whole, no k-slicing
             TRY(launch_gemm(ga, true, nsl, s));
             TRY(launch_reduce_slabs_sym(B.slabs, mm, nsl, H, Mp, nullptr, nullptr, s));

@@ -31,6 +31,9 @@ struct GemmArgs {
     int64_t Kd;        // contraction length (multiple of 16)
     int tri;           // TRI_*: restricts the k range per row block (A triangular, square A: Kd == Mr)
     int lower_out;     // 1: skip tiles strictly above the diagonal (square outputs)
+    int sym_out;       // 1 (with lower_out, A B^T with B = A: a syrk): the result is symmetric, so the 64 x 64 quadrant
+                       // strictly above the diagonal of every DIAGONAL tile is not computed either (left as zeros; the
+                       // slab reduction mirrors it from the lower quadrant)
     double alpha;
     int accumulate;    // 1: C += alpha*A*B  (else C = ...)
     // split-K: gridDim.z slices of the contraction, slice z writes C + z*slab_stride (reduced by reduce_slabs)

@@ -206,7 +206,9 @@ __global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride
         return;
     }
     if (j / TILE > i / TILE) return;
-    const double* p = slabs + (int64_t)i * Mp + j;
+    // diagonal tiles: the quadrant strictly above the diagonal is not computed by the syrk (GemmArgs.sym_out) -- every
+    // element above the diagonal takes its mirror image, which also makes the result exactly symmetric
+    const double* p = j > i ? slabs + (int64_t)j * Mp + i : slabs + (int64_t)i * Mp + j;
     double v = 0.0;
     for (int z = 0; z < nslab; ++z) v += p[z * slab_stride];
     out[idx] = v;

@@ -17,7 +17,11 @@
 // reads are removed by an XOR swizzle of the 16-byte chunk applied on the SOURCE address of the DMA and on
 // the fragment read (same involution on both sides):
 //   A / B_T image [128 rows][16 k]   : chunk ^= ((row >> 1) & 1) << 2
-//   B image       [16 k][128 cols]   : chunk ^= ((k >> 2) & 1) << 3
+//   B image       [16 k][128 cols]   : none -- every lane owns ADJACENT column pairs (columns 2*li, 2*li+1 and 32 + 2*li,
+//                                      33 + 2*li of its wavefront's 64), so a B fragment is one ds_read_b128 per k and
+//                                      column pair, and the lane groups the LDS services a b128 read in ({0-3,12-15,
+//                                      20-27}, ...) already hit 16 different 16-byte bank groups; the epilogues move 16
+//                                      bytes per lane (half the store / load instructions of one column per lane)
 // Within a K step lane group kk handles k = 4*kk + ks (ks = 0..3), so that per-k weights are contiguous.
 // Triangular operands only visit the non-zero k range of their tile.  blockIdx -> tile mapping is XCD-aware.
 #include "common.h"
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     const int a_row = tid >> 3;
     const int a_lchk = (tid & 7) ^ (((a_row >> 1) & 1) << 2);
     const double* Ag0 = A + (int64_t)a_row * g.lda + a_lchk * 2;
-    // B image: lane -> (k = wave (+4 per round), physical chunk l); source chunk ^ 8 on odd rounds
+    // B image: lane -> (k = wave (+4 per round), chunk l)
     const double* Bg = B_T ? B + (cb * BN + a_row) * g.ldb + a_lchk * 2
                            : B + (int64_t)wave * g.ldb + cb * BN;
     auto stage = [&](const double* Ag, int64_t k, int buf) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                glds16(Bg + (k + 4 * r) * g.ldb + ((lane ^ ((r & 1) << 3)) * 2), Bs + (r * 4 + wave) * 128);
+                glds16(Bg + (k + 4 * r) * g.ldb + lane * 2, Bs + (r * 4 + wave) * 128);
         }
     };
 
@@ -175,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // then skip a similar share of structurally-zero groups (critical path 20/32 of a dense block instead of 26/32)
     const int a_base = (wr * 16 + (lane & 3)) * BK;                 // + (mt*32 + 4r)*BK + colP
     const int bt_base = (wc * 64 + li) * BK;                        // B_T: + nt*16*BK + colP
-    // B: k row = 4*lk + ks, 16-col group nt stored at group nt ^ (lk&1)
-    const int bn_base = (4 * lk) * BN + wc * 64 + li;               // + ks*BN + (nt ^ (lk&1))*16
+    // B: k row = 4*lk + ks; accumulator column nt of a lane = wc*64 + (nt>>1)*32 + 2*li + (nt&1)
+    const int bn_base = (4 * lk) * BN + wc * 64 + 2 * li;           // + ks*BN + (nt>>1)*32
 
   for (int part = 0; part < nparts; ++part) {
     // Paired row blocks: the LONG one first, and the two workgroups that share a column block of B -- pairs (0, nrb-1)
@@ -255,8 +259,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }                                                                                                   \
     } else {                                                                                                \
         _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                      \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                  \
-                dst[e][t] = Bs[bn_base + (2 * (P) + e) * BN + ((t ^ (lk & 1)) << 4)];                       \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                \
+                const v2f64 v = *(const v2f64*)(Bs + bn_base + (2 * (P) + e) * BN + h * 32);                \
+                dst[e][2 * h] = v[0];                                                                       \
+                dst[e][2 * h + 1] = v[1];                                                                   \
+            }                                                                                               \
     }
 #define MMA_DO(asrc, bsrc, MT)                                                                              \
     _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                          \
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     if (act & (1 << (MT))) { MMA_DO(asrc, bsrc, MT) }                                                       \
     __builtin_amdgcn_sched_barrier(0);
 // K steps [KT0, KT1) of the pipeline.  COND = 1: inside a triangular diagonal block, 16-row groups that are structurally
-// zero for the step are skipped (bit mt of `act`); COND = 0: branch-free body.
+// zero for the step are skipped (bit mt of `act`); COND = 2: a fixed set of row groups; COND = 0: branch-free body.
 #define STAGE_LOOP(KT0, KT1, COND, MMA)                                                                     \
     for (int64_t kt = (KT0); kt < (KT1); ++kt) {                                                            \
         const int buf = (int)(kt & 1);                                                                      \
@@ -280,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }                                                                                                   \
         const double* As = lds + buf * 2 * TILE_ELEMS;                                                      \
         const double* Bs = As + TILE_ELEMS;                                                                 \
-        int act = 15;                                                                                       \
-        if (COND) {                                                                                         \
+        int act = (COND) == 2 ? 12 : 15;                                                                    \
+        if ((COND) == 1) {                                                                                  \
             const int64_t kk = k0 + KSTEP(kt) * BK;                                                         \
             const int64_t r0 = (int64_t)rb * BM + wr * 16;                                                  \
             act = 0;                                                                                        \
@@ -318,6 +325,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         STAGE_LOOP(d0, d1, 0, MMA_ALL)
         STAMP(3 + 4 * part);
         STAGE_LOOP(d1, nk, 1, MMA_IF)
+    } else if (B_T && g.sym_out && g.lower_out && rb == cb && wc == 1) {
+        // symmetric output, diagonal tile: rows 0..63 x columns 64..127 lie strictly above the diagonal.  The two
+        // row-wavefronts own interleaved 16-row groups, so both column-1 wavefronts skip their row groups mt = 0, 1
+        // (10 % of a syrk's MFMA work at four row blocks); the slab reduction mirrors those elements
+        STAGE_LOOP(0, nk, 2, MMA_IF)
     } else {
         STAGE_LOOP(0, nk, 0, MMA_ALL)
     }
@@ -335,41 +347,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // element loop compiles to one branch + load + s_waitcnt vmcnt(0) PER ELEMENT (64 dependent round trips, ~24 us per
     // epilogue -- the round-1 column-statistics epilogue did exactly that).
     STAMP(4 + 4 * part);      // main loop done
-    const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;     // + mt*32 + 4*r
-    const int64_t col0 = cb * BN + wc * 64 + li;               // + nt*16
+    // accumulator acc[mt][nt][r] of a lane: row = row0 + mt*32 + 4*r; column = col0 + COLOFF(nt).  NN: the lane's columns
+    // come in adjacent pairs (nt = 2h, 2h+1 -> col0 + 32h, +1): 16-byte accesses; A B^T keeps one column per 16-lane group.
+    const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;
+    const int64_t col0 = cb * BN + wc * 64 + (B_T ? li : 2 * li);
+    const int ccol = wc * 64 + (B_T ? li : 2 * li);            // the same inside the tile
+#define COLOFF(nt) (B_T ? (nt) * 16 : ((nt) >> 1) * 32 + ((nt) & 1))
     const int arow = wr * 16 + lk;                             // row inside the block: + mt*32 + 4*r
-    if (EPI == EPI_DA) {
+    if (EPI == EPI_DA && !B_T) {
         // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n];   optionally rd[row] = sum_n Aaux[row][n] * gmu[n]
-        double gm[4], cg[4], cs[4];
+        v2f64 gm[2], cg[2], cs[2];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            gm[nt] = g.gmu[col0 + nt * 16];
-            cg[nt] = g.cgv[col0 + nt * 16];
-            cs[nt] = 1.0;
+        for (int h = 0; h < 2; ++h) {
+            gm[h] = *(const v2f64*)(g.gmu + col0 + 32 * h);
+            cg[h] = *(const v2f64*)(g.cgv + col0 + 32 * h);
+            cs[h] = (v2f64){1.0, 1.0};
         }
         if (g.bscale) {      // column scaling commutes with A*
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) cs[nt] = g.bscale[col0 + nt * 16];
+            for (int h = 0; h < 2; ++h) cs[h] = *(const v2f64*)(g.bscale + col0 + 32 * h);
         }
         double* rdout = g.rowdot_part ? g.rowdot_part + ((int64_t)cb * 2 + wc) * g.Mr : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            double av[4][4], ar[4];
+            v2f64 av[2][4];
+            double ar[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ar[r] = avs[arow + mt * 32 + 4 * r];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) av[nt][r] = g.Aaux[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + nt * 16];
+                for (int h = 0; h < 2; ++h)
+                    av[h][r] = *(const v2f64*)(g.Aaux + (row0 + mt * 32 + 4 * r) * g.ldc + col0 + 32 * h);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double rd = 0.0;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const double a = av[nt][r];
-                    C[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + nt * 16] =
-                        g.alpha * cs[nt] * acc[mt][nt][r] + ar[r] * gm[nt] - 2.0 * a * cg[nt];
-                    rd += a * gm[nt];
+                for (int h = 0; h < 2; ++h) {
+                    const v2f64 a = av[h][r];
+                    v2f64 o;
+                    o[0] = g.alpha * cs[h][0] * acc[mt][2 * h][r] + ar[r] * gm[h][0] - 2.0 * a[0] * cg[h][0];
+                    o[1] = g.alpha * cs[h][1] * acc[mt][2 * h + 1][r] + ar[r] * gm[h][1] - 2.0 * a[1] * cg[h][1];
+                    *(v2f64*)(C + (row0 + mt * 32 + 4 * r) * g.ldc + col0 + 32 * h) = o;
+                    rd += a[0] * gm[h][0] + a[1] * gm[h][1];
                 }
                 // the 16 lanes li of a lane group hold the same row, different columns: butterfly over li, then one lane
                 // per lane group writes this wavefront's 64-column slice
@@ -386,28 +406,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         continue;
     }
     double sq[4] = {0.0, 0.0, 0.0, 0.0}, dt[4] = {0.0, 0.0, 0.0, 0.0};
-#define STORE_TILE(ST, ACCUM)                                                                               \
+#define STAT(v, nt, r)                                                                                      \
+    if (EPI == EPI_COLSTATS) {                                                                              \
+        sq[nt] += (v) * (v);                                                                                \
+        dt[nt] += ar[r] * (v);                                                                              \
+    }
+#define STORE_TILE(ST, ST2, ACCUM)                                                                          \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                     \
-        double ar[4];                                                                                       \
+        double ar[4] = {0.0, 0.0, 0.0, 0.0};                                                                \
         if (EPI == EPI_COLSTATS) { _Pragma("unroll") for (int r = 0; r < 4; ++r) ar[r] = avs[arow + mt * 32 + 4 * r]; } \
-        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                   \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
-                double* cp = &C[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + nt * 16];                         \
-                double v = g.alpha * acc[mt][nt][r];                                                        \
-                if (ACCUM) v += *cp;                                                                        \
-                ST(v, cp);                                                                                  \
-                if (EPI == EPI_COLSTATS) {                                                                  \
-                    sq[nt] += v * v;                                                                        \
-                    dt[nt] += ar[r] * v;                                                                    \
+        if (B_T) {                                                                                          \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                               \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+                    double* cp = &C[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + COLOFF(nt)];                  \
+                    double v = g.alpha * acc[mt][nt][r];                                                    \
+                    if (ACCUM) v += *cp;                                                                    \
+                    ST(v, cp);                                                                              \
+                    STAT(v, nt, r)                                                                          \
                 }                                                                                           \
-            }                                                                                               \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                  \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+                    v2f64* cp = (v2f64*)&C[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + 32 * h];               \
+                    v2f64 v;                                                                                \
+                    v[0] = g.alpha * acc[mt][2 * h][r];                                                     \
+                    v[1] = g.alpha * acc[mt][2 * h + 1][r];                                                 \
+                    if (ACCUM) v += *cp;                                                                    \
+                    ST2(v, cp);                                                                             \
+                    STAT(v[0], 2 * h, r)                                                                    \
+                    STAT(v[1], 2 * h + 1, r)                                                                \
+                }                                                                                           \
+        }                                                                                                   \
     }
 #define ST_PLAIN(v, p) (*(p) = (v))
 #define ST_STREAM(v, p) __builtin_nontemporal_store((v), (p))
-    if (g.accumulate) { STORE_TILE(ST_PLAIN, 1) }
-    else if (g.stream_out) { STORE_TILE(ST_STREAM, 0) }
-    else { STORE_TILE(ST_PLAIN, 0) }
+    if (g.accumulate) { STORE_TILE(ST_PLAIN, ST_PLAIN, 1) }
+    else if (g.stream_out) { STORE_TILE(ST_STREAM, ST_STREAM, 0) }
+    else { STORE_TILE(ST_PLAIN, ST_PLAIN, 0) }
 #undef STORE_TILE
+#undef STAT
     if (EPI == EPI_COLSTATS) {
         // partial column sums over this tile's 128 rows: per lane over its 16 rows (above), then across the 4 lane groups
         // of the wavefront (shuffles), then across the two row-wavefronts (LDS).
@@ -419,8 +456,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
             s2 += __shfl_xor(s2, 16);
             s2 += __shfl_xor(s2, 32);
             if (lk == 0) {
-                red[(0 * 2 + wr) * BN + wc * 64 + nt * 16 + li] = s1;
-                red[(1 * 2 + wr) * BN + wc * 64 + nt * 16 + li] = s2;
+                red[(0 * 2 + wr) * BN + ccol + COLOFF(nt)] = s1;
+                red[(1 * 2 + wr) * BN + ccol + COLOFF(nt)] = s2;
             }
         }
         __syncthreads();
@@ -431,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }
         if (nparts == 2) __syncthreads();   // `red` / `avs` are rewritten by the next part
     }
+#undef COLOFF
     STAMP(9 + part);          // epilogue issued
   }   // parts
 }
@@ -442,6 +480,7 @@ static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s);
 
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
     if (g.Mr % BM || g.Nc % BN || g.Kd % BK) return MOBOCMF_BAD_ARG;
+    if (!B_T && ((g.ldc & 1) || ((uintptr_t)g.C & 15))) return MOBOCMF_BAD_ARG;   // 16-byte epilogue accesses (A B form)
     if (small_panel_ok(g, B_T, splitk)) {
         if (g.epi == EPI_COLSTATS) return launch_small_panel<EPI_COLSTATS>(g, s);
         if (g.epi == EPI_DA) return launch_small_panel<EPI_DA>(g, s);

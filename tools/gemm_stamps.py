@@ -72,7 +72,17 @@ for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("dense 
         for i, tb in enumerate(bins):
             inloop[i] += ((a <= tb) & (b > tb)).sum()
     print("   workgroups inside a main loop at t = 0, 5, 10 ... us:", " ".join("%d" % v for v in inloop))
+    # who is slow?  total busy time (first stamp -> last stamp) per workgroup, grouped by XCD and by dispatch round
     hw = s[:, 15]
+    xcc = (hw >> 32) & 0xf
+    dur = (np.maximum(s[:, 9], s[:, 10]) - s[:, 0]) / 100.0
+    rnd = (start > np.median(start)).astype(int)
+    print("   workgroup duration by XCD (median us, round 1 | round 2):",
+          " ".join("%d:%.0f|%.0f" % (x, np.median(dur[(xcc == x) & (rnd == 0)]) if ((xcc == x) & (rnd == 0)).any() else 0,
+                                     np.median(dur[(xcc == x) & (rnd == 1)]) if ((xcc == x) & (rnd == 1)).any() else 0)
+                   for x in range(8)))
+    print("   duration percentiles (us): p5 %.0f p25 %.0f p50 %.0f p75 %.0f p95 %.0f; XCD of block 0..7: %s" %
+          (tuple(np.percentile(dur, [5, 25, 50, 75, 95])) + (xcc[:8].tolist(),)))
     lo = hw & 0xffffffff
     cu_key = (hw >> 32) * 100000 + ((lo >> 8) & 0xf) * 64 + ((lo >> 12) & 0x1) * 16 + ((lo >> 13) & 0xf)   # xcc, cu, sh, se
     order = np.nonzero(used)[0]
