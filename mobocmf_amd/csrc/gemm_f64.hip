@@ -226,7 +226,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 
     const int64_t nk = (k1 > k0) ? (k1 - k0) / BK : 0;
 #define KSTEP(KT) (rev ? nk - 1 - (KT) : (KT))   /* iteration -> K step of the tile */
-    if (EPI != EPI_STORE && tid < BM) avs[tid] = g.avec[(int64_t)rb * BM + tid];   // visible after the barrier below
+    // avec of this row block -> LDS (visible after the barrier below); the column-statistics epilogue only needs it for
+    // the a^T C partials
+    if ((EPI == EPI_DA || (EPI == EPI_COLSTATS && g.coldot_part)) && tid < BM) avs[tid] = g.avec[(int64_t)rb * BM + tid];
     if (nk > 0) stage(Ag, k0 + KSTEP(0) * BK, 0);
     // LDS-DMA data is ordered for other wavefronts' ds_reads only by the issuing wavefront's vmcnt wait followed by
     // a barrier; the waits are written out (hipcc adds them only when it sees the DMA in the same scheduling scope)
@@ -414,7 +416,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #define STORE_TILE(ST, ST2, ACCUM)                                                                          \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                     \
         double ar[4] = {0.0, 0.0, 0.0, 0.0};                                                                \
-        if (EPI == EPI_COLSTATS) { _Pragma("unroll") for (int r = 0; r < 4; ++r) ar[r] = avs[arow + mt * 32 + 4 * r]; } \
+        if (EPI == EPI_COLSTATS && g.coldot_part) {                                                         \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) ar[r] = avs[arow + mt * 32 + 4 * r];              \
+        }                                                                                                   \
         if (B_T) {                                                                                          \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                               \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
