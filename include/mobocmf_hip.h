@@ -114,6 +114,39 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
                            double* g_hyp, double* g_m, double* g_LS, double* g_x, void* saved, size_t saved_bytes,
                            void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
 
+/* ---- The same layer call for SEVERAL layers of one model (n <= 4, equal M): the CHAIN halves of all layers run as ONE
+ * z-batched sequence of launches.  A chain is a serial string of latency-bound M x M kernels (Cholesky panels, triangular
+ * inverse, a dozen M x M products); the layers' chains are independent of each other (Z~_l = [Z_x, m_{l-1}] depends on
+ * parameters only), so batching them divides the length of that string by the number of layers.
+ * Memory: one CHAIN BLOCK per layer (mobocmf_chain_block_bytes; all M x M-sized: the chain state L, L^-1, U, ... that the
+ * PANEL halves read, H / Hc / da that the PANEL backward leaves for the chain backward, and the chain's scratch), the n
+ * blocks `block_stride` bytes apart (a multiple of 256, >= the block size) starting at `blocks`; per layer a PANEL `saved`
+ * and `scratch` (mobocmf_panel_workspace_bytes).  Call order of a step: layers_chain_forward; layer_panel_forward per layer
+ * (bottom up); layer_panel_backward per layer (top down); layers_chain_backward.  Arrays of pointers are HOST arrays of n
+ * entries (device pointers inside).  The PANEL backward OVERWRITES g_hyp / g_zf with the K_mn share, the chain backward
+ * OVERWRITES its own g_hyp / g_zf arguments with the K_mm share (the caller adds the two).  had_panel[l] = 0: layer l got no
+ * upstream mean / var gradient (only its KL was differentiated). */
+int mobocmf_chain_block_bytes(const mobocmf_layer_desc* desc, size_t* block_bytes, size_t* state_bytes);
+int mobocmf_panel_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes);
+int mobocmf_layers_chain_forward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
+                                 const double* const* zf, const double* const* hyp, const double* const* m,
+                                 const double* const* L_S, double* const* kl, int32_t* const* info, void* blocks,
+                                 size_t block_stride, mobocmf_stream_t stream);
+int mobocmf_layers_chain_backward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
+                                  const double* const* zf, const double* const* hyp, const double* const* g_kl,
+                                  const int32_t* had_panel, double* const* g_zf, double* const* g_hyp, double* const* g_m,
+                                  double* const* g_LS, void* blocks, size_t block_stride, mobocmf_stream_t stream);
+int mobocmf_layer_panel_forward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                                const double* zf, const double* hyp, double* mean, double* var, void* chain_block,
+                                size_t block_bytes, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                                mobocmf_stream_t stream);
+/* desc->phase == MOBOCMF_PHASE_PANEL_INPUTS: parameters held constant (no H / Hc / da for a chain backward). */
+int mobocmf_layer_panel_backward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                                 const double* zf, const double* hyp, const double* g_mean, const double* g_var,
+                                 double* g_f, double* g_zf, double* g_hyp, double* g_x, void* chain_block,
+                                 size_t block_bytes, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                                 mobocmf_stream_t stream);
+
 /* cov[Np x Np] = K_nn - A^T A + C^T C from the state a forward call left in `saved` (eval branch, full
  * predictive covariance; MFMA contraction).  Np must be <= 16384. */
 int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f,

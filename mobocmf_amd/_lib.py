@@ -39,6 +39,12 @@ SYMBOLS = {
     "mobocmf_layer_chain_state_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ)],
     "mobocmf_layer_forward": [ctypes.POINTER(LayerDesc)] + [_P] * 11 + [_P, _SZ, _P, _SZ, _P],
     "mobocmf_layer_backward": [ctypes.POINTER(LayerDesc)] + [_P] * 16 + [_P, _SZ, _P, _SZ, _P],
+    "mobocmf_chain_block_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
+    "mobocmf_panel_workspace_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
+    "mobocmf_layers_chain_forward": [_I32] + [_P] * 8 + [_P, _SZ, _P],
+    "mobocmf_layers_chain_backward": [_I32] + [_P] * 10 + [_P, _SZ, _P],
+    "mobocmf_layer_panel_forward": [ctypes.POINTER(LayerDesc)] + [_P] * 7 + [_P, _SZ, _P, _SZ, _P, _SZ, _P],
+    "mobocmf_layer_panel_backward": [ctypes.POINTER(LayerDesc)] + [_P] * 11 + [_P, _SZ, _P, _SZ, _P, _SZ, _P],
     "mobocmf_predictive_covariance": [ctypes.POINTER(LayerDesc), _P, _P, _P, _P, _I64, _P, _SZ, _P, _SZ, _P],
     "mobocmf_propagate_forward": [_P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_propagate_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],

@@ -39,6 +39,25 @@ int launch_symmetrize(const double* S, int Mp, double* G, hipStream_t s);
 int launch_gls_out(const double* X, const double* LSp, const double* gkl, int M, int Mp, double* gLS, hipStream_t s);
 int launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
 int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s);
+// layer-batched forms (blockIdx.z = layer, workspace pointers + z*zs doubles, user tensors as tables)
+int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
+                   hipStream_t s);
+int launch_trtri_z(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
+                   int64_t ws_elems, int nz, int64_t zs, hipStream_t s);
+int launch_transpose_z(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, int nz,
+                       int64_t zs, hipStream_t s);
+int launch_gemv_rows_z(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double scale,
+                       int accumulate, int nz, int64_t zs, hipStream_t s);
+int launch_kl_z(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* const* kl,
+                double* part, int nz, int64_t zs, hipStream_t s);
+int launch_dutot_z(const double* X, const double* U, const double* da, const double* a, const double* const* gkl, int Mp,
+                   double* dU, double* da_tot, int nz, int64_t zs, hipStream_t s);
+int launch_y_combine_z(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
+                       double* Y, int nz, int64_t zs, hipStream_t s);
+int launch_dl_from_t2_z(const double* T2, const double* L, const double* const* gkl, int M, int Mp, double* dL, int nz,
+                        int64_t zs, hipStream_t s);
+int launch_phi_z(const double* T3, int Mp, double* P, int nz, int64_t zs, hipStream_t s);
+int launch_symmetrize_z(const double* S, int Mp, double* G, int nz, int64_t zs, hipStream_t s);
 
 #define TRY(x)              \
     do {                    \
@@ -105,67 +124,124 @@ Dims dims_of(const mobocmf_layer_desc* d) {
     return D;
 }
 
-struct Saved {
-    double *L, *Linv, *LinvT, *U, *UT, *LSp, *a, *mp, *K, *A, *C, *knn, *q, *r, *varraw;
+// ---------------------------------------------------------------------------------------------------------------
+// Workspaces.  A layer call has a CHAIN half (the M x M work that depends on the parameters alone) and a PANEL half (the
+// M x N' work).  Everything the chain half owns is M x M-sized and lives in ChainWs; with several layers of equal M the
+// chain blocks lie a constant stride apart and ONE z-batched sequence of launches runs all their chains (the chain is a
+// serial string of latency-bound kernels: batching the layers cuts its length by the number of layers).
+//   * single-layer entry points (mobocmf_layer_forward / _backward): ChainWs is carved out of `saved` and `scratch`;
+//   * multi-layer entry points (mobocmf_layers_chain_*, mobocmf_layer_panel_*): out of the caller's chain blocks.
+// ---------------------------------------------------------------------------------------------------------------
+struct ChainWs {
+    // state: forward chain -> panel halves and backward chain
+    double *L, *Linv, *LinvT, *U, *UT, *LSp, *a, *mp;
+    // forward scratch
+    double *Dinv, *Ld, *T, *ws, *klpart;
+    int64_t ws_elems;
+    // panel backward -> chain backward
+    double *H, *Hc, *da, *flag;
+    // backward scratch
+    double *W[8], *da_tot, *slabs, *hyp_part2, *df_part2, *dzf_part2;
+    int64_t slab_elems;
 };
 
-// The CHAIN half's state comes first and does not depend on N': its leading bytes may be copied between the `saved`
-// buffers of calls that share the parameters (mobocmf_layer_chain_state_bytes).
-void carve_chain_state(Bump& b, const Dims& D, Saved& S) {
+struct PanelSaved { double *K, *A, *C, *knn, *q, *r, *varraw; };
+struct PanelFwd { double *qpart, *mupart, *rpart; };
+struct PanelBwd { double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *dapart, *hyp_part, *df_part, *dzf_part, *dx_part; int64_t slab_elems; };
+
+void carve_chain_state(Bump& b, const Dims& D, ChainWs& S) {
     int64_t mm = (int64_t)D.Mp * D.Mp;
     S.L = b.take(mm); S.Linv = b.take(mm); S.LinvT = b.take(mm); S.U = b.take(mm); S.UT = b.take(mm); S.LSp = b.take(mm);
     S.a = b.take(D.Mp); S.mp = b.take(D.Mp);
 }
-
-bool carve_saved(Bump& b, const Dims& D, Saved& S) {
+void carve_panel_saved(Bump& b, const Dims& D, PanelSaved& S) {
     int64_t mn = (int64_t)D.Mp * D.Np;
-    carve_chain_state(b, D, S);
     S.K = b.take(mn); S.A = b.take(mn); S.C = b.take(mn);
     S.knn = b.take(D.Np); S.q = b.take(D.Np); S.r = b.take(D.Np); S.varraw = b.take(D.Np);
-    return b.ok;
 }
-
-struct ScratchF {
-    double *Dinv, *Ld, *T, *qpart, *mupart, *rpart, *ws;
-    int64_t ws_elems;
-};
-bool carve_scratch_fwd(Bump& b, const Dims& D, ScratchF& S) {
+void carve_chain_fwd(Bump& b, const Dims& D, ChainWs& S) {
     S.Dinv = b.take((int64_t)(D.Mp / NB) * NB * NB);
     S.Ld = b.take((int64_t)(D.Mp / NB) * NB * NB);
     S.T = b.take((int64_t)D.Mp * D.Mp);
+    S.ws_elems = (int64_t)16 * D.Mp * D.Mp;
+    S.ws = b.take(S.ws_elems);
+    S.klpart = b.take(D.Mp);
+}
+void carve_panel_fwd(Bump& b, const Dims& D, PanelFwd& S) {
     S.qpart = b.take((int64_t)D.nrb * D.Np);
     S.mupart = b.take((int64_t)D.nrb * D.Np);
     S.rpart = b.take((int64_t)D.nrb * D.Np);
-    S.ws_elems = (int64_t)16 * D.Mp * D.Mp;
-    S.ws = b.take(S.ws_elems);
-    return b.ok;
 }
-
-struct ScratchB {
-    double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *W[10], *da, *da_tot, *flag, *hyp_part, *df_part, *dzf_part, *dx_part,
-        *hyp_part2, *df_part2, *dzf_part2, *gzf_tmp, *dapart;
-};
-bool carve_scratch_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, ScratchB& S) {
+void carve_chain_bwd_in(Bump& b, const Dims& D, ChainWs& S) {
+    int64_t mm = (int64_t)D.Mp * D.Mp;
+    S.H = b.take(mm); S.Hc = b.take(mm); S.da = b.take(D.Mp); S.flag = b.take(4);
+}
+// kind-independent sizes (hyp_part2 for the largest hyper-parameter vector, the f-column partials always): the chain
+// blocks of all layers of a model have ONE size
+void carve_chain_bwd(Bump& b, const Dims& D, ChainWs& S) {
+    int64_t mm = (int64_t)D.Mp * D.Mp;
+    for (int i = 0; i < 8; ++i) S.W[i] = b.take(mm);
+    S.da_tot = b.take(D.Mp);
+    S.hyp_part2 = b.take((int64_t)D.ggrid_mm.x * D.ggrid_mm.y * hyp_len(1, MOBOCMF_MAX_D));
+    S.df_part2 = b.take((int64_t)D.ggrid_mm.y * D.Mp);
+    S.dzf_part2 = b.take((int64_t)D.ggrid_mm.x * D.Mp);
+}
+void carve_panel_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, PanelBwd& S) {
     int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
     S.gmu = b.take(D.Np); S.gv = b.take(D.Np); S.gv2 = b.take(D.Np); S.cgv = b.take(D.Np);
     S.dA = b.take(mn); S.dK = b.take(mn);
-    S.slabs = b.take((int64_t)(D.splitk > 16 ? D.splitk : 16) * mm);
-    for (int i = 0; i < 10; ++i) S.W[i] = b.take(mm);
-    S.da = b.take(D.Mp);
-    S.da_tot = b.take(D.Mp);
-    S.flag = b.take(4);
+    S.slab_elems = (int64_t)(D.splitk > 16 ? D.splitk : 16) * mm;
+    S.slabs = b.take(S.slab_elems);
     S.dapart = b.take((D.Np <= 8192 ? D.Np / 16 : D.Np / 64) * (int64_t)D.Mp);   // row-dot partials of the dA epilogue (gemm_rowdot_parts)
     S.hyp_part = b.take((int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H);
-    S.hyp_part2 = b.take((int64_t)D.ggrid_mm.x * D.ggrid_mm.y * D.H);
-    S.df_part = S.dzf_part = S.df_part2 = S.dzf_part2 = S.gzf_tmp = nullptr;
+    S.df_part = S.dzf_part = nullptr;
     if (d->kind == 1) {
         S.df_part = b.take((int64_t)D.ggrid_mn.y * D.Np);
         S.dzf_part = b.take((int64_t)D.ggrid_mn.x * D.Mp);
-        S.df_part2 = b.take((int64_t)D.ggrid_mm.y * D.Mp);
-        S.dzf_part2 = b.take((int64_t)D.ggrid_mm.x * D.Mp);
-        S.gzf_tmp = b.take(D.Mp);
     }
     S.dx_part = d->want_dx ? b.take((int64_t)D.ggrid_mn.y * D.nbase * d->d) : nullptr;
+}
+
+// single-layer layout: saved = [chain state | panel saved]; scratch (forward) = [chain fwd | panel fwd];
+// scratch (backward) = [panel bwd | chain bwd in | chain bwd] (the chain's k-slice slabs alias the panel's)
+bool carve_single_saved(void* saved, size_t bytes, const Dims& D, ChainWs& c, PanelSaved& p, size_t* used = nullptr) {
+    Bump b(saved, bytes);
+    carve_chain_state(b, D, c);
+    carve_panel_saved(b, D, p);
+    if (used) *used = b.off;
+    return b.ok;
+}
+bool carve_single_fwd(void* scratch, size_t bytes, const Dims& D, ChainWs& c, PanelFwd& p, size_t* used = nullptr) {
+    Bump b(scratch, bytes);
+    carve_chain_fwd(b, D, c);
+    carve_panel_fwd(b, D, p);
+    if (used) *used = b.off;
+    return b.ok;
+}
+bool carve_single_bwd(void* scratch, size_t bytes, const Dims& D, const mobocmf_layer_desc* d, ChainWs& c, PanelBwd& p,
+                      size_t* used = nullptr) {
+    Bump b(scratch, bytes);
+    carve_panel_bwd(b, D, d, p);
+    carve_chain_bwd_in(b, D, c);
+    carve_chain_bwd(b, D, c);
+    c.slabs = p.slabs;
+    c.slab_elems = p.slab_elems;
+    if (used) *used = b.off;
+    return b.ok;
+}
+// multi-layer layout: one chain block per layer = [state | fwd scratch | bwd in | bwd scratch]; the k-slice slabs of the
+// backward chain alias the forward scratch `ws` (dead by then)
+bool carve_chain_block(void* block, size_t bytes, const Dims& D, ChainWs& c, size_t* state_bytes = nullptr,
+                       size_t* used = nullptr) {
+    Bump b(block, bytes);
+    carve_chain_state(b, D, c);
+    if (state_bytes) *state_bytes = b.off;
+    carve_chain_fwd(b, D, c);
+    carve_chain_bwd_in(b, D, c);
+    carve_chain_bwd(b, D, c);
+    c.slabs = c.ws;
+    c.slab_elems = c.ws_elems;
+    if (used) *used = b.off;
     return b.ok;
 }
 
@@ -175,6 +251,252 @@ GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb, d
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.Mr = Mr; g.Nc = Nc; g.Kd = Kd; g.tri = tri; g.alpha = alpha;
     return g;
+}
+
+// per-layer user tensors of a chain call (tables of n entries)
+struct ChainIO {
+    const mobocmf_layer_desc* const* desc;
+    const double* const* Zx; const double* const* zf; const double* const* hyp;
+    const double* const* m; const double* const* L_S;
+    double* const* kl; int32_t* const* info;                                   // forward
+    const double* const* g_kl; double* const* g_zf; double* const* g_hyp;       // backward
+    double* const* g_m; double* const* g_LS;
+};
+
+GramArgs kmm_gram(const mobocmf_layer_desc* d, const Dims& D, const double* Zx, const double* zf, const double* hyp) {
+    GramArgs g = {};
+    g.kind = d->kind; g.d = d->d; g.xdiv = 1; g.zdiv = 1;
+    g.x = Zx; g.f = zf; g.nbase = D.M; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp;
+    g.ldk = D.Mp; g.Mp = D.Mp; g.Np = D.Mp; g.knn = nullptr; g.jitter = d->jitter; g.is_kmm = 1;
+    return g;
+}
+
+// M x M product of every layer of the batch (operands in the chain blocks)
+int chain_gemm(GemmArgs g, bool B_T, const ChainWs& c, int n, int64_t zs, hipStream_t s) {
+    if (n > 1) { g.zlayers = n; g.zsA = g.zsB = g.zsC = zs; }
+    return launch_gemm_auto(g, B_T, c.slabs, c.slab_elems, s);
+}
+
+// CHAIN half, forward, of n layers with the same M: K_mm + jitter, its Cholesky and inverse, U = L^-1 L_S, a = L^-1 m, KL.
+// c = workspace of layer 0; layer z works on every pointer + z*zs.
+int chain_forward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const Dims& D, hipStream_t s) {
+    const int Mp = D.Mp;
+    const int64_t mm = (int64_t)Mp * Mp;
+    for (int z = 0; z < n; ++z) {      // the Gram kernels differ per layer (kernel kind, user tensors): one launch each
+        GramArgs g = kmm_gram(io.desc[z], D, io.Zx[z], io.zf[z], io.hyp[z]);
+        g.K = c.L + z * zs;
+        TRY(launch_gram_fwd(g, s));
+    }
+    TRY(launch_potrf_z(c.L, Mp, Mp, D.M, c.Dinv, c.Ld, io.info, n, zs, s));
+    TRY(launch_zero32_z(c.Linv, mm * 2, n, zs * 8, s));
+    TRY(launch_trtri_z(c.L, Mp, Mp, c.Dinv, c.Linv, c.T, c.ws, c.ws_elems, n, zs, s));
+    TRY(launch_transpose_z(c.Linv, Mp, c.LinvT, Mp, Mp, Mp, n, zs, s));
+    for (int z = 0; z < n; ++z) {      // user tensors -> padded copies
+        TRY(launch_pad_tril(io.L_S[z], D.M, D.M, c.LSp + z * zs, Mp, s));
+        TRY(launch_pad_vec(io.m[z], D.M, c.mp + z * zs, Mp, s));
+    }
+    // U = L^-1 L_S (lower x lower), a = L^-1 m
+    TRY(launch_zero32_z(c.U, mm * 2, n, zs * 8, s));
+    {
+        GemmArgs ga = gemm_args(c.Linv, Mp, c.LSp, Mp, c.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
+        ga.lower_out = 1;
+        ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (DESIGN 3.1, small problems)
+        GemmArgs gz = ga;
+        if (n > 1) { gz.zlayers = n; gz.zsA = gz.zsB = gz.zsC = zs; }
+        TRY(launch_gemm_auto(gz, false, c.ws, c.ws_elems, s));
+    }
+    TRY(launch_transpose_z(c.U, Mp, c.UT, Mp, Mp, Mp, n, zs, s));
+    TRY(launch_gemv_rows_z(c.Linv, Mp, c.mp, c.a, Mp, Mp, 1.0, 0, n, zs, s));
+    TRY(launch_kl_z(c.L, c.LSp, c.U, c.a, D.M, Mp, io.kl, c.klpart, n, zs, s));
+    return MOBOCMF_OK;
+}
+
+// PANEL half, forward: K_mn, A = L^-1 K (+ q, mean partials), C = U^T A (+ r partials), moments
+int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& c, const PanelSaved& P, const PanelFwd& F,
+                  const double* x, const double* f, const double* Zx, const double* zf, const double* hyp, double* mean,
+                  double* var, hipStream_t s) {
+    const int Mp = D.Mp;
+    const int64_t Np = D.Np;
+    GramArgs g = {};
+    g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
+    g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase; g.jitter = desc->jitter;
+    g.K = P.K; g.ldk = Np; g.Np = Np; g.knn = P.knn; g.is_kmm = 0;
+    TRY(launch_gram_fwd(g, s));
+    GemmArgs ga = gemm_args(c.Linv, Mp, P.K, Np, P.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
+    ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = c.a;
+    ga.Kreal = D.M;      // rows >= M of K_mn (and of A, C, dA below) are zero padding
+    TRY(launch_gemm(ga, false, 1, s));
+    GemmArgs gc = gemm_args(c.UT, Mp, P.A, Np, P.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
+    gc.epi = EPI_COLSTATS; gc.colsq_part = F.rpart; gc.coldot_part = nullptr; gc.avec = c.a;
+    gc.Kreal = D.M;
+    gc.stream_out = (desc->branch == 0 && Np * Mp * 8 >= ((int64_t)64 << 20)) ? 1 : 0;   // C is next read in backward
+    TRY(launch_gemm(gc, false, 1, s));
+    TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, D.nrb, Np, D.N, P.knn, desc->branch, desc->min_var, P.q, P.r,
+                              P.varraw, mean, var, s));
+    return MOBOCMF_OK;
+}
+
+// PANEL half, backward: dA, the weighted syrk(s) H / Hc and da (unless the parameters are constants), dK, Gram backward of
+// K_mn and k_nn.  Writes g_f, g_x and -- overwriting -- the K_mn share of g_hyp / g_zf.
+int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& c, const PanelSaved& P, const PanelBwd& B,
+                   bool inputs_only, const double* x, const double* f, const double* Zx, const double* zf,
+                   const double* hyp, const double* g_mean, const double* g_var, double* g_f, double* g_zf, double* g_hyp,
+                   double* g_x, hipStream_t s) {
+    const int Mp = D.Mp;
+    const int64_t Np = D.Np, mm = (int64_t)Mp * Mp;
+    int32_t* nclamped = (int32_t*)c.flag;
+    double* Hc = desc->branch != 0 ? c.H : c.Hc;
+    TRY(launch_moments_bwd_prep(g_mean, g_var, P.knn, P.q, P.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
+                                B.gv2, B.cgv, nclamped, s));
+    // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
+    {
+        GemmArgs ga = gemm_args(c.U, Mp, P.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
+        ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = c.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = P.A;
+        ga.Kreal = D.M;
+        ga.rowdot_part = inputs_only ? nullptr : B.dapart;      // da = A gmu rides in the epilogue (it reads A anyway)
+        TRY(launch_gemm(ga, false, 1, s));
+        if (!inputs_only) TRY(launch_sum_partials(B.dapart, gemm_rowdot_parts(ga), Mp, c.da, Mp, 1.0, 0, s));
+    }
+    // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
+    //   dU = 2 tril(A diag(gv) C^T) = 2 tril(H U),   dA A^T = 2 U U^T H + a da^T - 2 Hc,  Hc = A diag(cgv) A^T.
+    // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
+    // (skip_if_zero) when no column is clamped.
+    if (!inputs_only) {
+        GemmArgs ga = gemm_args(P.A, Np, P.A, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
+        ga.bscale = B.gv; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm;
+        const int nsl = gemm_nt_slabs(ga, D.splitk);      // 1: a small problem goes through whole, no k-slicing
+        TRY(launch_gemm(ga, true, nsl, s));
+        TRY(launch_reduce_slabs_sym(B.slabs, mm, nsl, c.H, Mp, nullptr, nullptr, s));
+        if (desc->branch == 0) {
+            ga.bscale = B.cgv; ga.skip_if_zero = nclamped;
+            TRY(launch_gemm(ga, true, nsl, s));
+            TRY(launch_reduce_slabs_sym(B.slabs, mm, nsl, Hc, Mp, nclamped, c.H, s));
+        }
+    }
+    // dK = L^-T dA
+    {
+        GemmArgs ga = gemm_args(c.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
+        ga.Kreal = D.M;
+        TRY(launch_gemm(ga, false, 1, s));
+    }
+    // Gram backward of K_mn and k_nn
+    GramArgs g = {};
+    g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
+    g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
+    g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
+    g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
+    TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
+    SumTask tk[4];
+    int nt = 0;
+    tk[nt++] = {B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, nullptr, 0, 0, g_hyp, D.H, 0};
+    if (desc->kind == 1) {
+        tk[nt++] = {B.df_part, D.ggrid_mn.y, Np, nullptr, 0, 0, g_f, D.N, 0};
+        tk[nt++] = {B.dzf_part, D.ggrid_mn.x, Mp, nullptr, 0, 0, g_zf, D.M, 0};
+    }
+    if (desc->want_dx)
+        tk[nt++] = {B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, nullptr, 0, 0, g_x, D.nbase * desc->d, 0};
+    return launch_sum_partials_multi(tk, nt, s);
+}
+
+// CHAIN half, backward, of n layers:  dL = -tril(L^-T [dA A^T + dU_tot U^T + da_tot a^T]) + gkl diag(1/L_ii), g_m, g_LS,
+// Cholesky backward, Gram backward of K_mm.  H, Hc, da come from the PANEL halves (zero[z]: layer z had none -- no
+// upstream mean / var gradient).  acc[z]: add to g_hyp / g_zf (the PANEL half wrote its share there) instead of overwriting.
+int chain_backward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const Dims& D, const bool* zero, const int* acc,
+                   hipStream_t s) {
+    const int Mp = D.Mp;
+    const int64_t mm = (int64_t)Mp * Mp;
+    double *G1 = c.W[0], *G2 = c.W[1], *X = c.W[2], *dU = c.W[3], *Y = c.W[4], *T1 = c.W[5], *T2 = c.W[6], *LT = c.W[7];
+    double *dL = G1, *T4 = G2, *Gm = X;   // reused once their first content is dead
+    bool any_clamp_branch = false;
+    for (int z = 0; z < n; ++z) {
+        if (zero[z]) {
+            TRY(launch_zero32(c.H + z * zs, mm * 2, s));
+            TRY(launch_zero32(c.Hc + z * zs, mm * 2, s));
+            TRY(launch_zero32(c.da + z * zs, (int64_t)Mp * 2, s));
+        }
+        any_clamp_branch = any_clamp_branch || io.desc[z]->branch == 0;
+    }
+    // layers on the eval branch keep Hc == H: the batched launches read Hc, so copy it there
+    for (int z = 0; z < n; ++z)
+        if (io.desc[z]->branch != 0 && !zero[z] && (n > 1 || any_clamp_branch))
+            TRY(launch_copy_block(c.H + z * zs, Mp, c.Hc + z * zs, Mp, Mp, Mp, s));
+    const double* Hc = (n == 1 && io.desc[0]->branch != 0) ? c.H : c.Hc;
+    {
+        GemmArgs g1 = gemm_args(c.UT, Mp, c.H, Mp, G1, Mp, Mp, Mp, Mp, TRI_UPPER_A, 1.0);          // G1 = U^T H
+        g1.Kreal = D.M;      // the contraction's padded tail multiplies zeros (DESIGN 3.1, small problems)
+        TRY(chain_gemm(g1, false, c, n, zs, s));
+        GemmArgs g2 = gemm_args(c.U, Mp, G1, Mp, G2, Mp, Mp, Mp, Mp, TRI_LOWER_A, 1.0);            // G2 = U U^T H
+        g2.Kreal = D.M;
+        TRY(chain_gemm(g2, false, c, n, zs, s));
+        GemmArgs g3 = gemm_args(c.H, Mp, c.U, Mp, X, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);            // X = H U (lower tiles)
+        g3.lower_out = 1;
+        g3.Kreal = D.M;
+        TRY(chain_gemm(g3, false, c, n, zs, s));
+        TRY(launch_dutot_z(X, c.U, c.da, c.a, io.g_kl, Mp, dU, c.da_tot, n, zs, s));
+        TRY(launch_y_combine_z(G2, Hc, c.a, c.da, c.da_tot, Mp, Y, n, zs, s));
+        GemmArgs g4 = gemm_args(dU, Mp, c.U, Mp, Y, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);   // Y += dU_tot U^T
+        g4.accumulate = 1;
+        g4.Kreal = D.M;
+        TRY(chain_gemm(g4, true, c, n, zs, s));
+    }
+    // g_m = L^-T da_tot  (user tensors: one launch per layer)
+    for (int z = 0; z < n; ++z)
+        TRY(launch_gemv_rows(c.LinvT + z * zs, Mp, c.da_tot + z * zs, io.g_m[z], D.M, Mp, 1.0, 0, s));
+    // g_LS = tril(L^-T dU_tot) - gkl diag(1/LS_ii)
+    {
+        GemmArgs ga = gemm_args(c.LinvT, Mp, dU, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        ga.lower_out = 1;
+        ga.Kreal = D.M;
+        TRY(chain_gemm(ga, false, c, n, zs, s));
+        for (int z = 0; z < n; ++z)
+            TRY(launch_gls_out(T1 + z * zs, c.LSp + z * zs, io.g_kl[z], D.M, Mp, io.g_LS[z], s));
+    }
+    // dL
+    {
+        GemmArgs ga = gemm_args(c.LinvT, Mp, Y, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A, 1.0);
+        ga.lower_out = 1;
+        ga.Kreal = D.M;
+        TRY(chain_gemm(ga, false, c, n, zs, s));
+        TRY(launch_dl_from_t2_z(T2, c.L, io.g_kl, D.M, Mp, dL, n, zs, s));
+    }
+    // Cholesky backward: dKmm = sym(L^-T Phi(L^T dL) L^-1)
+    {
+        TRY(launch_transpose_z(c.L, Mp, LT, Mp, Mp, Mp, n, zs, s));
+        GemmArgs ga = gemm_args(LT, Mp, dL, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        ga.Kreal = D.M;
+        TRY(chain_gemm(ga, false, c, n, zs, s));
+        TRY(launch_phi_z(T2, Mp, T1, n, zs, s));
+        GemmArgs gb = gemm_args(c.LinvT, Mp, T1, Mp, T4, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
+        gb.Kreal = D.M;
+        TRY(chain_gemm(gb, false, c, n, zs, s));
+        GemmArgs gc = gemm_args(T4, Mp, c.Linv, Mp, T2, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);
+        gc.Kreal = D.M;
+        TRY(chain_gemm(gc, false, c, n, zs, s));
+        TRY(launch_symmetrize_z(T2, Mp, Gm, n, zs, s));
+    }
+    // Gram backward of K_mm (both arguments are Z~): per layer
+    for (int z = 0; z < n; ++z) {
+        const mobocmf_layer_desc* d = io.desc[z];
+        GramArgs g = kmm_gram(d, D, io.Zx[z], io.zf[z], io.hyp[z]);
+        g.G = Gm + z * zs; g.gknn = nullptr;
+        g.hyp_part = c.hyp_part2 + z * zs; g.df_part = c.df_part2 + z * zs; g.dzf_part = c.dzf_part2 + z * zs;
+        g.dx_part = nullptr;
+        TRY(launch_gram_bwd(g, false, s));
+        const int H = hyp_len(d->kind, d->d);
+        SumTask tk[2];
+        int nt = 0;
+        tk[nt++] = {g.hyp_part, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, H, nullptr, 0, 0, io.g_hyp[z], H, acc[z]};
+        if (d->kind == 1)      // both arguments of K_mm are Z~: the row-side and the column-side partials land in g_zf
+            tk[nt++] = {g.df_part, D.ggrid_mm.y, Mp, g.dzf_part, D.ggrid_mm.x, Mp, io.g_zf[z], D.M, acc[z]};
+        TRY(launch_sum_partials_multi(tk, nt, s));
+    }
+    return MOBOCMF_OK;
+}
+
+bool same_chain_shape(int n, const mobocmf_layer_desc* const* d) {
+    for (int z = 0; z < n; ++z)
+        if (!valid_desc(d[z]) || d[z]->M != d[0]->M) return false;
+    return true;
 }
 
 }  // namespace
@@ -195,19 +517,20 @@ int mobocmf_device_arch_ok(void) {
 int mobocmf_layer_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes) {
     if (!valid_desc(desc) || !saved_bytes || !scratch_bytes) return MOBOCMF_BAD_ARG;
     Dims D = dims_of(desc);
-    Bump bs(nullptr, ~(size_t)0 >> 1);
-    Saved S;
-    carve_saved(bs, D, S);
-    *saved_bytes = bs.off;
-    Bump bf(nullptr, ~(size_t)0 >> 1), bb(nullptr, ~(size_t)0 >> 1);
-    ScratchF F;
-    ScratchB B;
-    carve_scratch_fwd(bf, D, F);
-    carve_scratch_bwd(bb, D, desc, B);
+    const size_t big = ~(size_t)0 >> 1;
+    ChainWs c;
+    PanelSaved P;
+    PanelFwd F;
+    PanelBwd B;
+    size_t sv = 0, sf = 0, sb = 0;
+    carve_single_saved(nullptr, big, D, c, P, &sv);
+    carve_single_fwd(nullptr, big, D, c, F, &sf);
+    carve_single_bwd(nullptr, big, D, desc, c, B, &sb);
+    *saved_bytes = sv;
     // predictive covariance scratch: A^T, C^T (Np x Mp) + padded cov (Np x Np), only sized for Np <= 16384
     size_t cov = 0;
     if (D.Np <= 16384) cov = (size_t)(2 * D.Np * D.Mp + D.Np * D.Np) * sizeof(double) + 1024;
-    size_t m = bf.off > bb.off ? bf.off : bb.off;
+    size_t m = sf > sb ? sf : sb;
     *scratch_bytes = m > cov ? m : cov;
     return MOBOCMF_OK;
 }
@@ -216,8 +539,8 @@ int mobocmf_layer_chain_state_bytes(const mobocmf_layer_desc* desc, size_t* byte
     if (!valid_desc(desc) || !bytes) return MOBOCMF_BAD_ARG;
     Dims D = dims_of(desc);
     Bump b(nullptr, ~(size_t)0 >> 1);
-    Saved S;
-    carve_chain_state(b, D, S);
+    ChainWs c;
+    carve_chain_state(b, D, c);
     *bytes = b.off;
     return MOBOCMF_OK;
 }
@@ -235,59 +558,18 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
     if (desc->kind == 1 && (!zf || (do_panel && !f))) return MOBOCMF_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     Dims D = dims_of(desc);
-    Bump bs(saved, saved_bytes), bf(scratch, scratch_bytes);
-    Saved S;
-    ScratchF F;
-    if (!carve_saved(bs, D, S) || !carve_scratch_fwd(bf, D, F)) return MOBOCMF_WORKSPACE_TOO_SMALL;
-    const int Mp = D.Mp;
-    const int64_t Np = D.Np, mm = (int64_t)Mp * Mp;
-
-    GramArgs g = {};
-    g.kind = desc->kind; g.d = desc->d; g.xdiv = 1; g.zdiv = 1;
-    g.x = Zx; g.f = zf; g.nbase = D.M; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp;
-    g.K = S.L; g.ldk = Mp; g.Mp = Mp; g.Np = Mp; g.knn = nullptr; g.jitter = desc->jitter; g.is_kmm = 1;
+    ChainWs c = {};
+    PanelSaved P;
+    PanelFwd F;
+    if (!carve_single_saved(saved, saved_bytes, D, c, P) || !carve_single_fwd(scratch, scratch_bytes, D, c, F))
+        return MOBOCMF_WORKSPACE_TOO_SMALL;
     if (do_chain) {
-        // K_mm + jitter -> L (in place Cholesky)
-        TRY(launch_gram_fwd(g, s));
-        TRY(launch_potrf(S.L, Mp, Mp, D.M, F.Dinv, F.Ld, info, s));
-        TRY(launch_zero32(S.Linv, mm * 2, s));
-        TRY(launch_trtri(S.L, Mp, Mp, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
-        TRY(launch_transpose(S.Linv, Mp, S.LinvT, Mp, Mp, Mp, s));
-        TRY(launch_pad_tril(L_S, D.M, D.M, S.LSp, Mp, s));
-        TRY(launch_pad_vec(m, D.M, S.mp, Mp, s));
-        // U = L^-1 L_S (lower x lower), a = L^-1 m
-        TRY(launch_zero32(S.U, mm * 2, s));
-        {
-            GemmArgs ga = gemm_args(S.Linv, Mp, S.LSp, Mp, S.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
-            ga.lower_out = 1;
-            ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
-            TRY(launch_gemm_auto(ga, false, F.ws, F.ws_elems, s));
-        }
-        TRY(launch_transpose(S.U, Mp, S.UT, Mp, Mp, Mp, s));
-        TRY(launch_gemv_rows(S.Linv, Mp, S.mp, S.a, Mp, Mp, 1.0, 0, s));
-        TRY(launch_kl(S.L, S.LSp, S.U, S.a, D.M, Mp, kl, F.qpart, s));
+        ChainIO io = {};
+        io.desc = &desc; io.Zx = &Zx; io.zf = &zf; io.hyp = &hyp; io.m = &m; io.L_S = &L_S; io.kl = &kl; io.info = &info;
+        TRY(chain_forward(1, c, 0, io, D, s));
     }
     if (!do_panel) return MOBOCMF_OK;
-
-    // K_mn, k_nn
-    g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
-    g.K = S.K; g.ldk = Np; g.Np = Np; g.knn = S.knn; g.is_kmm = 0;
-    TRY(launch_gram_fwd(g, s));
-    // A = L^-1 K_mn  (+ q, mean partials);  C = U^T A (+ r partials)
-    {
-        GemmArgs ga = gemm_args(S.Linv, Mp, S.K, Np, S.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
-        ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = S.a;
-        ga.Kreal = D.M;      // rows >= M of K_mn (and of A, C, dA below) are zero padding
-        TRY(launch_gemm(ga, false, 1, s));
-        GemmArgs gc = gemm_args(S.UT, Mp, S.A, Np, S.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
-        gc.epi = EPI_COLSTATS; gc.colsq_part = F.rpart; gc.coldot_part = nullptr; gc.avec = S.a;
-        gc.Kreal = D.M;
-        gc.stream_out = (desc->branch == 0 && Np * Mp * 8 >= ((int64_t)64 << 20)) ? 1 : 0;   // C is next read in backward
-        TRY(launch_gemm(gc, false, 1, s));
-    }
-    TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, D.nrb, Np, D.N, S.knn, desc->branch, desc->min_var, S.q, S.r,
-                              S.varraw, mean, var, s));
-    return MOBOCMF_OK;
+    return panel_forward(desc, D, c, P, F, x, f, Zx, zf, hyp, mean, var, s);
 }
 
 int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
@@ -300,151 +582,135 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     const bool do_panel = desc->phase == MOBOCMF_PHASE_ALL || desc->phase == MOBOCMF_PHASE_PANEL || inputs_only;
     const bool do_chain = desc->phase == MOBOCMF_PHASE_ALL || desc->phase == MOBOCMF_PHASE_CHAIN ||
                           desc->phase == MOBOCMF_PHASE_CHAIN_ONLY;
-    const int acc = desc->phase == MOBOCMF_PHASE_ALL ? 1 : 0;   // split: the chain half reports its own g_hyp / g_zf
     if (do_panel && (!x || !g_mean || !g_var || (desc->want_dx && !g_x))) return MOBOCMF_BAD_ARG;
     if (do_chain && (!g_kl || !g_m || !g_LS)) return MOBOCMF_BAD_ARG;
     if (desc->kind == 1 && (!zf || !g_zf || (do_panel && (!f || !g_f)))) return MOBOCMF_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     Dims D = dims_of(desc);
-    Bump bs(saved, saved_bytes), bb(scratch, scratch_bytes);
-    Saved S;
-    ScratchB B;
-    if (!carve_saved(bs, D, S) || !carve_scratch_bwd(bb, D, desc, B)) return MOBOCMF_WORKSPACE_TOO_SMALL;
-    const int Mp = D.Mp;
-    const int64_t Np = D.Np, mm = (int64_t)Mp * Mp;
-    double *H = B.W[0], *Hc = B.W[1], *G1 = B.W[2], *G2 = B.W[3], *X = B.W[4], *dU = B.W[5], *Y = B.W[6], *T1 = B.W[7],
-           *T2 = B.W[8], *LT = B.W[9];
-    double *dL = G1, *T4 = G2, *Gm = X;   // reused once their first content is dead
-    int32_t* nclamped = (int32_t*)B.flag;
-    const int64_t slab_elems = (int64_t)(D.splitk > 16 ? D.splitk : 16) * mm;
-
-    if (desc->branch != 0) Hc = H;
-    GramArgs g = {};
-    g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
-    if (do_panel) {
-        TRY(launch_moments_bwd_prep(g_mean, g_var, S.knn, S.q, S.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
-                                    B.gv2, B.cgv, nclamped, s));
-        // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
-        {
-            GemmArgs ga = gemm_args(S.U, Mp, S.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
-            ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = S.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = S.A;
-            ga.Kreal = D.M;
-            ga.rowdot_part = inputs_only ? nullptr : B.dapart;      // da = A gmu rides in the epilogue (it reads A anyway)
-            TRY(launch_gemm(ga, false, 1, s));
-            if (!inputs_only) TRY(launch_sum_partials(B.dapart, gemm_rowdot_parts(ga), Mp, B.da, Mp, 1.0, 0, s));
-        }
-        // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
-        //   dU = 2 tril(A diag(gv) C^T) = 2 tril(H U),   dA A^T = 2 U U^T H + a da^T - 2 Hc,  Hc = A diag(cgv) A^T.
-        // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
-        // (skip_if_zero) when no column is clamped.
-        if (!inputs_only) {
-            GemmArgs ga = gemm_args(S.A, Np, S.A, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
-            ga.bscale = B.gv; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm;
-            const int nsl = gemm_nt_slabs(ga, D.splitk);      // 1: a small problem goes through whole, no k-slicing
-            TRY(launch_gemm(ga, true, nsl, s));
-            TRY(launch_reduce_slabs_sym(B.slabs, mm, nsl, H, Mp, nullptr, nullptr, s));
-            if (desc->branch == 0) {
-                ga.bscale = B.cgv; ga.skip_if_zero = nclamped;
-                TRY(launch_gemm(ga, true, nsl, s));
-                TRY(launch_reduce_slabs_sym(B.slabs, mm, nsl, Hc, Mp, nclamped, H, s));
-            }
-        }
-        // dK = L^-T dA
-        {
-            GemmArgs ga = gemm_args(S.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
-            ga.Kreal = D.M;
-            TRY(launch_gemm(ga, false, 1, s));
-        }
-        // Gram backward of K_mn and k_nn
-        g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
-        g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
-        g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
-        TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
-        {
-            SumTask tk[4];
-            int nt = 0;
-            tk[nt++] = {B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, nullptr, 0, 0, g_hyp, D.H, 0};
-            if (desc->kind == 1) {
-                tk[nt++] = {B.df_part, D.ggrid_mn.y, Np, nullptr, 0, 0, g_f, D.N, 0};
-                tk[nt++] = {B.dzf_part, D.ggrid_mn.x, Mp, nullptr, 0, 0, g_zf, D.M, 0};
-            }
-            if (desc->want_dx)
-                tk[nt++] = {B.dx_part, D.ggrid_mn.y, D.nbase * desc->d, nullptr, 0, 0, g_x, D.nbase * desc->d, 0};
-            TRY(launch_sum_partials_multi(tk, nt, s));
-        }
-    }
+    ChainWs c = {};
+    PanelSaved P;
+    PanelBwd B;
+    if (!carve_single_saved(saved, saved_bytes, D, c, P) || !carve_single_bwd(scratch, scratch_bytes, D, desc, c, B))
+        return MOBOCMF_WORKSPACE_TOO_SMALL;
+    if (do_panel)
+        TRY(panel_backward(desc, D, c, P, B, inputs_only, x, f, Zx, zf, hyp, g_mean, g_var, g_f, g_zf, g_hyp, g_x, s));
     if (!do_chain) return MOBOCMF_OK;
-    if (desc->phase == MOBOCMF_PHASE_CHAIN_ONLY) {      // no upstream mean/var gradient: H = Hc = 0, da = 0
-        TRY(launch_zero32(H, mm * 2, s));
-        if (Hc != H) TRY(launch_zero32(Hc, mm * 2, s));
-        TRY(launch_zero32(B.da, (int64_t)Mp * 2, s));
-    }
+    ChainIO io = {};
+    io.desc = &desc; io.Zx = &Zx; io.zf = &zf; io.hyp = &hyp; io.m = &m; io.L_S = &L_S;
+    io.g_kl = &g_kl; io.g_zf = &g_zf; io.g_hyp = &g_hyp; io.g_m = &g_m; io.g_LS = &g_LS;
+    const bool zero = desc->phase == MOBOCMF_PHASE_CHAIN_ONLY;     // no upstream mean/var gradient: H = Hc = 0, da = 0
+    const int acc = desc->phase == MOBOCMF_PHASE_ALL ? 1 : 0;       // split: the chain half reports its own g_hyp / g_zf
+    return chain_backward(1, c, 0, io, D, &zero, &acc, s);
+}
 
-    // ---- M x M chain:  dL = -tril(L^-T [dA A^T + dU_tot U^T + da_tot a^T]) + gkl diag(1/L_ii)
-    {
-        GemmArgs g1 = gemm_args(S.UT, Mp, H, Mp, G1, Mp, Mp, Mp, Mp, TRI_UPPER_A, 1.0);          // G1 = U^T H
-        g1.Kreal = D.M;      // the contraction's padded tail multiplies zeros (DESIGN 3.1, small problems)
-        TRY(launch_gemm_auto(g1, false, B.slabs, slab_elems, s));
-        GemmArgs g2 = gemm_args(S.U, Mp, G1, Mp, G2, Mp, Mp, Mp, Mp, TRI_LOWER_A, 1.0);          // G2 = U U^T H
-        g2.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
-        TRY(launch_gemm_auto(g2, false, B.slabs, slab_elems, s));
-        GemmArgs g3 = gemm_args(H, Mp, S.U, Mp, X, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);            // X = H U (lower tiles)
-        g3.lower_out = 1;
-        g3.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
-        TRY(launch_gemm_auto(g3, false, B.slabs, slab_elems, s));
-        TRY(launch_dutot(X, S.U, B.da, S.a, g_kl, Mp, dU, B.da_tot, s));
-        TRY(launch_y_combine(G2, Hc, S.a, B.da, B.da_tot, Mp, Y, s));
-        GemmArgs g4 = gemm_args(dU, Mp, S.U, Mp, Y, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);   // Y += dU_tot U^T
-        g4.accumulate = 1;
-        g4.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
-        TRY(launch_gemm_auto(g4, true, B.slabs, slab_elems, s));
-    }
-    // g_m = L^-T da_tot
-    TRY(launch_gemv_rows(S.LinvT, Mp, B.da_tot, g_m, D.M, Mp, 1.0, 0, s));
-    // g_LS = tril(L^-T dU_tot) - gkl diag(1/LS_ii)
-    {
-        GemmArgs ga = gemm_args(S.LinvT, Mp, dU, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
-        ga.lower_out = 1;
-        ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (DESIGN 3.1, small problems)
-        TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
-        TRY(launch_gls_out(T1, S.LSp, g_kl, D.M, Mp, g_LS, s));
-    }
-    // dL
-    {
-        GemmArgs ga = gemm_args(S.LinvT, Mp, Y, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A, 1.0);
-        ga.lower_out = 1;
-        ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (DESIGN 3.1, small problems)
-        TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
-        TRY(launch_dl_from_t2(T2, S.L, g_kl, D.M, Mp, dL, s));
-    }
-    // Cholesky backward: dKmm = sym(L^-T Phi(L^T dL) L^-1)
-    {
-        TRY(launch_transpose(S.L, Mp, LT, Mp, Mp, Mp, s));
-        GemmArgs ga = gemm_args(LT, Mp, dL, Mp, T2, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
-        ga.Kreal = D.M;      // the contraction's padded tail multiplies zeros (DESIGN 3.1, small problems)
-        TRY(launch_gemm_auto(ga, false, B.slabs, slab_elems, s));
-        TRY(launch_phi(T2, Mp, T1, s));
-        GemmArgs gb = gemm_args(S.LinvT, Mp, T1, Mp, T4, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
-        gb.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
-        TRY(launch_gemm_auto(gb, false, B.slabs, slab_elems, s));
-        GemmArgs gc = gemm_args(T4, Mp, S.Linv, Mp, T2, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);
-        gc.Kreal = D.M;      // the contraction's padded tail multiplies zeros (small problems)
-        TRY(launch_gemm_auto(gc, false, B.slabs, slab_elems, s));
-        TRY(launch_symmetrize(T2, Mp, Gm, s));
-    }
-    // Gram backward of K_mm (both arguments are Z~)
-    g.xdiv = 1; g.x = Zx; g.f = zf; g.nbase = D.M; g.ldk = Mp; g.Np = Mp; g.G = Gm; g.gknn = nullptr;
-    g.hyp_part = B.hyp_part2; g.df_part = B.df_part2; g.dzf_part = B.dzf_part2; g.dx_part = nullptr;
-    TRY(launch_gram_bwd(g, false, s));
-    {
-        SumTask tk[2];
-        int nt = 0;
-        tk[nt++] = {B.hyp_part2, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, D.H, nullptr, 0, 0, g_hyp, D.H, acc};
-        if (desc->kind == 1)      // both arguments of K_mm are Z~: the row-side and the column-side partials land in g_zf
-            tk[nt++] = {B.df_part2, D.ggrid_mm.y, Mp, B.dzf_part2, D.ggrid_mm.x, Mp, g_zf, D.M, acc};
-        TRY(launch_sum_partials_multi(tk, nt, s));
-    }
+// ------------------------------------------------------------------------------------------------- multi-layer forms
+int mobocmf_chain_block_bytes(const mobocmf_layer_desc* desc, size_t* block_bytes, size_t* state_bytes) {
+    if (!valid_desc(desc) || !block_bytes) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc);
+    ChainWs c;
+    size_t st = 0, used = 0;
+    carve_chain_block(nullptr, ~(size_t)0 >> 1, D, c, &st, &used);
+    *block_bytes = used;
+    if (state_bytes) *state_bytes = st;
     return MOBOCMF_OK;
+}
+
+int mobocmf_panel_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes) {
+    if (!valid_desc(desc) || !saved_bytes || !scratch_bytes) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc);
+    const size_t big = ~(size_t)0 >> 1;
+    Bump bs(nullptr, big), bf(nullptr, big), bb(nullptr, big);
+    PanelSaved P;
+    PanelFwd F;
+    PanelBwd B;
+    carve_panel_saved(bs, D, P);
+    carve_panel_fwd(bf, D, F);
+    carve_panel_bwd(bb, D, desc, B);
+    *saved_bytes = bs.off;
+    *scratch_bytes = bf.off > bb.off ? bf.off : bb.off;
+    return MOBOCMF_OK;
+}
+
+int mobocmf_layers_chain_forward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
+                                 const double* const* zf, const double* const* hyp, const double* const* m,
+                                 const double* const* L_S, double* const* kl, int32_t* const* info, void* blocks,
+                                 size_t block_stride, mobocmf_stream_t stream) {
+    if (n < 1 || n > MAX_ZL || !desc || !Zx || !zf || !hyp || !m || !L_S || !kl || !info || !blocks || (block_stride & 255))
+        return MOBOCMF_BAD_ARG;
+    if (!same_chain_shape(n, desc)) return MOBOCMF_BAD_ARG;
+    for (int z = 0; z < n; ++z)
+        if (!Zx[z] || !hyp[z] || !m[z] || !L_S[z] || !kl[z] || !info[z] || (desc[z]->kind == 1 && !zf[z])) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc[0]);
+    ChainWs c = {};
+    if (!carve_chain_block(blocks, block_stride, D, c)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    ChainIO io = {};
+    io.desc = desc; io.Zx = Zx; io.zf = zf; io.hyp = hyp; io.m = m; io.L_S = L_S; io.kl = kl; io.info = info;
+    return chain_forward(n, c, (int64_t)(block_stride / sizeof(double)), io, D, (hipStream_t)stream);
+}
+
+int mobocmf_layers_chain_backward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
+                                  const double* const* zf, const double* const* hyp, const double* const* g_kl,
+                                  const int32_t* had_panel, double* const* g_zf, double* const* g_hyp, double* const* g_m,
+                                  double* const* g_LS, void* blocks, size_t block_stride, mobocmf_stream_t stream) {
+    if (n < 1 || n > MAX_ZL || !desc || !Zx || !zf || !hyp || !g_kl || !had_panel || !g_zf || !g_hyp || !g_m || !g_LS ||
+        !blocks || (block_stride & 255))
+        return MOBOCMF_BAD_ARG;
+    if (!same_chain_shape(n, desc)) return MOBOCMF_BAD_ARG;
+    bool zero[MAX_ZL];
+    int acc[MAX_ZL];
+    for (int z = 0; z < n; ++z) {
+        if (!Zx[z] || !hyp[z] || !g_kl[z] || !g_hyp[z] || !g_m[z] || !g_LS[z] || (desc[z]->kind == 1 && (!zf[z] || !g_zf[z])))
+            return MOBOCMF_BAD_ARG;
+        zero[z] = had_panel[z] == 0;
+        acc[z] = 0;          // the chain halves report their own g_hyp / g_zf (the caller adds the panel halves')
+    }
+    Dims D = dims_of(desc[0]);
+    ChainWs c = {};
+    if (!carve_chain_block(blocks, block_stride, D, c)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    ChainIO io = {};
+    io.desc = desc; io.Zx = Zx; io.zf = zf; io.hyp = hyp;
+    io.g_kl = g_kl; io.g_zf = g_zf; io.g_hyp = g_hyp; io.g_m = g_m; io.g_LS = g_LS;
+    return chain_backward(n, c, (int64_t)(block_stride / sizeof(double)), io, D, zero, acc, (hipStream_t)stream);
+}
+
+int mobocmf_layer_panel_forward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                                const double* zf, const double* hyp, double* mean, double* var, void* chain_block,
+                                size_t block_bytes, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                                mobocmf_stream_t stream) {
+    if (!valid_desc(desc) || !x || !Zx || !hyp || !mean || !var || !chain_block || !saved || !scratch) return MOBOCMF_BAD_ARG;
+    if (desc->kind == 1 && (!zf || !f)) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc);
+    ChainWs c = {};
+    if (!carve_chain_block(chain_block, block_bytes, D, c)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    Bump bs(saved, saved_bytes), bf(scratch, scratch_bytes);
+    PanelSaved P;
+    PanelFwd F;
+    carve_panel_saved(bs, D, P);
+    carve_panel_fwd(bf, D, F);
+    if (!bs.ok || !bf.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    return panel_forward(desc, D, c, P, F, x, f, Zx, zf, hyp, mean, var, (hipStream_t)stream);
+}
+
+int mobocmf_layer_panel_backward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                                 const double* zf, const double* hyp, const double* g_mean, const double* g_var,
+                                 double* g_f, double* g_zf, double* g_hyp, double* g_x, void* chain_block,
+                                 size_t block_bytes, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                                 mobocmf_stream_t stream) {
+    if (!valid_desc(desc) || !x || !Zx || !hyp || !g_mean || !g_var || !g_hyp || !chain_block || !saved || !scratch ||
+        (desc->want_dx && !g_x))
+        return MOBOCMF_BAD_ARG;
+    if (desc->kind == 1 && (!zf || !f || !g_f || !g_zf)) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc);
+    ChainWs c = {};
+    if (!carve_chain_block(chain_block, block_bytes, D, c)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    Bump bs(saved, saved_bytes), bb(scratch, scratch_bytes);
+    PanelSaved P;
+    PanelBwd B;
+    carve_panel_saved(bs, D, P);
+    carve_panel_bwd(bb, D, desc, B);
+    if (!bs.ok || !bb.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    return panel_backward(desc, D, c, P, B, desc->phase == MOBOCMF_PHASE_PANEL_INPUTS, x, f, Zx, zf, hyp, g_mean, g_var, g_f,
+                          g_zf, g_hyp, g_x, (hipStream_t)stream);
 }
 
 int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* hyp,
@@ -455,9 +721,10 @@ int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* 
     hipStream_t s = (hipStream_t)stream;
     Dims D = dims_of(desc);
     if (D.Np > 16384) return MOBOCMF_BAD_ARG;
-    Bump bs(saved, saved_bytes), bc(scratch, scratch_bytes);
-    Saved S;
-    if (!carve_saved(bs, D, S)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    Bump bc(scratch, scratch_bytes);
+    ChainWs cw = {};
+    PanelSaved S;
+    if (!carve_single_saved(saved, saved_bytes, D, cw, S)) return MOBOCMF_WORKSPACE_TOO_SMALL;
     const int Mp = D.Mp;
     const int64_t Np = D.Np;
     double* AT = bc.take(Np * Mp);

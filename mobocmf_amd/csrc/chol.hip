@@ -119,12 +119,16 @@ __device__ __forceinline__ void trsm64_rows(double (&b)[NB], const double (*LT)[
 // NOTE: every workgroup re-factorises the diagonal block from A, so block 0 must NOT overwrite it in place
 // (a workgroup that is scheduled late -- e.g. when other streams occupy the CUs -- would read L_jj instead of
 // A_jj).  The factor goes to the side buffer Ld; finish_l_kernel copies it into the diagonal at the end.
+struct InfoZ { int32_t* p[MAX_ZL]; };      // per-layer status words (user tensors: not strided)
+
 __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
-                                                         int32_t* info) {
+                                                         InfoZ infoz, int64_t zs) {
     __shared__ __attribute__((aligned(16))) double LT[NB][NB];
     __shared__ double rd[NB];
     const int lane = threadIdx.x;
     const int bi = blockIdx.x;
+    A += blockIdx.y * zs; Dinv += blockIdx.y * zs; Ld += blockIdx.y * zs;      // layer batching
+    int32_t* info = infoz.p[blockIdx.y];
     const int64_t j0 = (int64_t)jb * NB;
     double a[NB];
     const double* drow = A + (j0 + lane) * ld + j0;
@@ -231,11 +235,13 @@ __device__ __forceinline__ void trsm64_pad_rows(const double (&a)[NB], double (&
 // A_jj).  The factor goes to the side buffer Ld; finish_l_kernel copies it into the diagonal at the end.
 template <int NACT>
 __global__ __launch_bounds__(64) void potrf_panel_pad_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
-                                                         int32_t* info) {
+                                                         InfoZ infoz, int64_t zs) {
     __shared__ __attribute__((aligned(16))) double LT[NB][NB];
     __shared__ double rd[NB];
     const int lane = threadIdx.x;
     const int bi = blockIdx.x;
+    A += blockIdx.y * zs; Dinv += blockIdx.y * zs; Ld += blockIdx.y * zs;      // layer batching
+    int32_t* info = infoz.p[blockIdx.y];
     const int64_t j0 = (int64_t)jb * NB;
     double a[NB];
     const double* drow = A + (j0 + lane) * ld + j0;
@@ -292,9 +298,10 @@ __device__ __forceinline__ void load64(double* dst, const double* src, int64_t l
 }
 
 // trailing update of panel jb: A[ti][tj] -= P_ti * P_tj^T for 64-blocks ti >= tj > jb (P = panel columns)
-__global__ __launch_bounds__(256) void syrk64_update_kernel(double* A, int64_t ld, int jb) {
+__global__ __launch_bounds__(256) void syrk64_update_kernel(double* A, int64_t ld, int jb, int64_t zs) {
     const int ti = jb + 1 + blockIdx.x, tj = jb + 1 + blockIdx.y;
     if (tj > ti) return;
+    A += blockIdx.z * zs;
     __shared__ double Pi[NB * LD64], Pj[NB * LD64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int64_t j0 = (int64_t)jb * NB;
@@ -335,18 +342,20 @@ int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s) {
 }
 
 // strict upper triangle <- 0, diagonal 64x64 blocks <- the factors kept in Ld
-__global__ void finish_l_kernel(double* A, int64_t ld, int n, const double* Ld) {
+__global__ void finish_l_kernel(double* A, int64_t ld, int n, const double* Ld, int64_t zs) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)n * n) return;
+    A += blockIdx.z * zs; Ld += blockIdx.z * zs;
     int i = (int)(idx / n), j = (int)(idx % n);
     if (j > i) A[(int64_t)i * ld + j] = 0.0;
     else if (i / NB == j / NB) A[(int64_t)i * ld + j] = Ld[(int64_t)(i / NB) * NB * NB + (i % NB) * NB + (j % NB)];
 }
 
 // Ld / Dinv blocks [b0, b1) <- identity (panels that lie entirely in the identity padding of K_mm)
-__global__ void identity_blocks_kernel(double* Dinv, double* Ld, int b0, int b1) {
+__global__ void identity_blocks_kernel(double* Dinv, double* Ld, int b0, int b1, int64_t zs) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)(b1 - b0) * NB * NB) return;
+    Dinv += blockIdx.z * zs; Ld += blockIdx.z * zs;
     const int e = (int)(idx % (NB * NB));
     const double v = (e / NB == e % NB) ? 1.0 : 0.0;
     Dinv[(int64_t)b0 * NB * NB + idx] = v;
@@ -355,33 +364,47 @@ __global__ void identity_blocks_kernel(double* Dinv, double* Ld, int b0, int b1)
 
 // Dinv and Ld: (Mp/64) x 64 x 64 doubles each.  M = real order: rows/columns >= M of A are identity padding, which the
 // factorisation leaves alone -- a 16-point problem padded to 128 costs 16 elimination steps, not 128.
-int launch_potrf(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* info, hipStream_t s) {
+int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
+                   hipStream_t s) {
+    // nz layers (same M): layer z works on A + z*zs, Dinv + z*zs, Ld + z*zs (doubles) and reports through info[z]
     const int nblk = Mp / NB;
     const int nreal = (M + NB - 1) / NB;          // 64-blocks that hold real rows
-    if (launch_zero32(info, 1, s)) return MOBOCMF_HIP_ERROR;
+    InfoZ iz = {};
+    for (int z = 0; z < nz; ++z) {
+        iz.p[z] = info[z];
+        if (launch_zero32(info[z], 1, s)) return MOBOCMF_HIP_ERROR;
+    }
     for (int jb = 0; jb < nreal; ++jb) {
         int nact = M - jb * NB;
         nact = nact >= NB ? NB : (nact + 15) & ~15;
-        const dim3 grid(nreal - jb);              // blocks below the real rows are zero in these columns and stay zero
-        if (nact == 16) hipLaunchKernelGGL(potrf_panel_pad_kernel<16>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, info);
-        else hipLaunchKernelGGL(potrf_panel_kernel, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, info);
+        const dim3 grid(nreal - jb, nz);          // blocks below the real rows are zero in these columns and stay zero
+        if (nact == 16) hipLaunchKernelGGL(potrf_panel_pad_kernel<16>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
+        else hipLaunchKernelGGL(potrf_panel_kernel, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
         int nt = nreal - jb - 1;
-        if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, ld, jb);
+        if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt, nz), dim3(256), 0, s, A, ld, jb, zs);
     }
     if (nreal < nblk) {
         int64_t n = (int64_t)(nblk - nreal) * NB * NB;
-        hipLaunchKernelGGL(identity_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Dinv, Ld, nreal, nblk);
+        hipLaunchKernelGGL(identity_blocks_kernel, dim3((unsigned)((n + 255) / 256), 1, nz), dim3(256), 0, s, Dinv, Ld, nreal,
+                           nblk, zs);
     }
     int64_t n2 = (int64_t)Mp * Mp;
-    hipLaunchKernelGGL(finish_l_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, A, ld, Mp, (const double*)Ld);
+    hipLaunchKernelGGL(finish_l_kernel, dim3((unsigned)((n2 + 255) / 256), 1, nz), dim3(256), 0, s, A, ld, Mp,
+                       (const double*)Ld, zs);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+int launch_potrf(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* info, hipStream_t s) {
+    int32_t* one[1] = {info};
+    return launch_potrf_z(A, ld, Mp, M, Dinv, Ld, one, 1, 0, s);
 }
 
 // ---------------------------------------------------------------------------------- triangular inverse
 // level 0: the 128x128 diagonal blocks of L^-1 from the 64x64 inverses:  [[D0,0],[-D1 L10 D0, D1]]
 __global__ __launch_bounds__(256) void trtri_level0_kernel(const double* L, int64_t ld, const double* Dinv, double* Linv,
-                                                           int64_t ldi) {
+                                                           int64_t ldi, int64_t zs) {
     const int b = blockIdx.x;
+    L += blockIdx.y * zs; Dinv += blockIdx.y * zs; Linv += blockIdx.y * zs;      // layer batching
     __shared__ double S0[NB * LD64], S1[NB * LD64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
@@ -438,10 +461,13 @@ __global__ __launch_bounds__(256) void trtri_level0_kernel(const double* L, int6
 // Linv (Mp x Mp, pre-zeroed above the block diagonal by the caller) = L^-1.  T = scratch Mp x Mp.
 // Power-of-two block counts: recursive doubling, [[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]], every level
 // is two (batched) MFMA GEMMs; otherwise block row by block row.
-int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
-                 int64_t ws_elems, hipStream_t s) {
+int launch_trtri_z(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
+                   int64_t ws_elems, int nz, int64_t zs, hipStream_t s) {
+    // nz layers: every operand of layer z is the layer-0 pointer + z*zs (doubles)
     const int nb = Mp / TILE;
-    hipLaunchKernelGGL(trtri_level0_kernel, dim3(nb), dim3(256), 0, s, L, ld, Dinv, Linv, (int64_t)Mp);
+    const int zl = nz > 1 ? nz : 0;
+    auto layered = [&](GemmArgs& g) { g.zlayers = zl; g.zsA = g.zsB = g.zsC = zs; };
+    hipLaunchKernelGGL(trtri_level0_kernel, dim3(nb, nz), dim3(256), 0, s, L, ld, Dinv, Linv, (int64_t)Mp, zs);
     if ((nb & (nb - 1)) == 0) {
         for (int sz = TILE; sz < Mp; sz *= 2) {
             const int nmerge = Mp / (2 * sz);
@@ -456,6 +482,8 @@ int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double
             h.B = T + (int64_t)sz * Mp;         h.ldb = Mp;
             h.C = Linv + (int64_t)sz * Mp;      h.ldc = Mp;
             h.Mr = sz; h.Nc = sz; h.Kd = sz; h.tri = TRI_LOWER_A; h.alpha = -1.0;
+            layered(g);
+            layered(h);
             int rc;
             if (nmerge > 1) {
                 g.batched = h.batched = nmerge;
@@ -487,6 +515,7 @@ int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double
         g.Kd = (int64_t)i * TILE;
         g.tri = TRI_LOWER_B;
         g.alpha = 1.0;
+        layered(g);
         int rc = launch_gemm_auto(g, false, ws, ws_elems, s);
         if (rc) return rc;
         // Linv[i, 0:i] = -Linv[i,i] * T
@@ -501,8 +530,14 @@ int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double
         h.Nc = (int64_t)i * TILE;
         h.Kd = TILE;
         h.alpha = -1.0;
-        rc = launch_gemm(h, false, 1, s);
+        layered(h);
+        rc = zl ? launch_gemm_auto(h, false, ws, ws_elems, s) : launch_gemm(h, false, 1, s);
         if (rc) return rc;
     }
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+int launch_trtri(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
+                 int64_t ws_elems, hipStream_t s) {
+    return launch_trtri_z(L, ld, Mp, Dinv, Linv, T, ws, ws_elems, 1, 0, s);
 }

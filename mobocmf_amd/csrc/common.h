@@ -41,6 +41,10 @@ struct GemmArgs {
     // batching (only without split-K): blockIdx.z selects the batch
     int64_t strideA, strideB, strideC;
     int batched;
+    // layer batching (chains of several layers in one launch): blockIdx.z = batch * zlayers + layer; layer l works on
+    // A + l*zsA, B + l*zsB, C + l*zsC (0 / 1 layers: off).  Not with split-K.
+    int zlayers;
+    int64_t zsA, zsB, zsC;
     // B_T=1: weights of the contraction index, sum_k A[i][k] bscale[k] B[j][k];  EPI_DA: column scale of the product
     const double* bscale;
     int64_t Kreal;                 // > 0: rows >= Kreal of B are zero padding (the real inner dimension, e.g. M of an
@@ -81,6 +85,8 @@ int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, dou
 // zero-fill by a kernel (32-bit words); used instead of hipMemsetAsync so that a captured step contains only
 // kernel nodes (a replayed memset node was observed to leave 0xFE bytes in a 4-byte word on ROCm 7.2)
 int launch_zero32(void* ptr, int64_t nwords, hipStream_t s);
+int launch_zero32_z(void* ptr, int64_t nwords, int nz, int64_t zs_bytes, hipStream_t s);   // nz regions, zs_bytes apart
+#define MAX_ZL 4   // layers whose chains one batched call may carry
 
 // ------------------------------------------------------------------ Gram (gram.hip)
 struct GramArgs {

@@ -40,6 +40,20 @@ int launch_zero32(void* ptr, int64_t nwords, hipStream_t s) {
     hipLaunchKernelGGL(zero32_kernel, GRID1(nwords), 0, s, (uint32_t*)ptr, nwords);
     return CHECK_LAUNCH();
 }
+// Layer batching of the M x M chain (several layers' chains in one launch): blockIdx.z = layer, every workspace pointer of
+// layer z is the layer-0 pointer + z*zs (the layers' chain blocks lie a constant stride apart); per-layer USER tensors
+// (g_kl, info, ...) travel as small pointer tables.
+#define GRIDZ(n, nz) dim3((unsigned)(((n) + 255) / 256), 1, (unsigned)(nz)), dim3(256)
+struct ScalZ { const double* p[MAX_ZL]; };
+__global__ void zero32_z_kernel(uint32_t* p, int64_t n, int64_t zs_words) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[blockIdx.z * zs_words + i] = 0u;
+}
+int launch_zero32_z(void* ptr, int64_t nwords, int nz, int64_t zs_bytes, hipStream_t s) {
+    if (nwords <= 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(zero32_z_kernel, GRIDZ(nwords, nz), 0, s, (uint32_t*)ptr, nwords, zs_bytes / 4);
+    return CHECK_LAUNCH();
+}
 
 // ------------------------------------------------------------------ M x M helpers
 // dst (Mp x Mp) = tril(src (M x M, ld lds)) zero padded
@@ -64,8 +78,11 @@ int launch_pad_vec(const double* src, int64_t n, double* dst, int64_t np, hipStr
 }
 
 // out[c][r] = in[r][c]   (rows x cols -> cols x rows), 32x32 LDS tiles
-__global__ void transpose_kernel(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols) {
+__global__ void transpose_kernel(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols,
+                                 int64_t zs) {
     __shared__ double t[32][33];
+    in += blockIdx.z * zs;
+    out += blockIdx.z * zs;
     int64_t c = (int64_t)blockIdx.x * 32 + threadIdx.x, r0 = (int64_t)blockIdx.y * 32;
     for (int k = threadIdx.y; k < 32; k += 8)
         if (r0 + k < rows && c < cols) t[k][threadIdx.x] = in[(r0 + k) * ldi + c];
@@ -74,38 +91,48 @@ __global__ void transpose_kernel(const double* in, int64_t ldi, double* out, int
     for (int k = threadIdx.y; k < 32; k += 8)
         if (c0 + k < cols && r < rows) out[(c0 + k) * ldo + r] = t[threadIdx.x][k];
 }
-int launch_transpose(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s) {
-    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, ldi, out, ldo, rows, cols);
+int launch_transpose_z(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, int nz,
+                       int64_t zs, hipStream_t s) {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)nz);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, ldi, out, ldo, rows, cols, zs);
     return CHECK_LAUNCH();
+}
+int launch_transpose(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s) {
+    return launch_transpose_z(in, ldi, out, ldo, rows, cols, 1, 0, s);
 }
 
 // out[i] = sum_j Mat[i][j] * vec[j]   (one wavefront per row), optional accumulate
 __global__ void gemv_rows_kernel(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols,
-                                 double scale, int accumulate) {
+                                 double scale, int accumulate, int64_t zs) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= rows) return;
+    Mat += blockIdx.z * zs; vec += blockIdx.z * zs; out += blockIdx.z * zs;
     const double* p = Mat + (int64_t)row * ld;
     double s = 0.0;
     for (int64_t j = lane; j < cols; j += 64) s += p[j] * vec[j];
     s = wave_sum(s) * scale;
     if (lane == 0) out[row] = accumulate ? out[row] + s : s;
 }
+int launch_gemv_rows_z(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double scale,
+                       int accumulate, int nz, int64_t zs, hipStream_t s) {
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((rows + 3) / 4, 1, nz), dim3(256), 0, s, Mat, ld, vec, out, rows, cols, scale,
+                       accumulate, zs);
+    return CHECK_LAUNCH();
+}
 int launch_gemv_rows(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double scale,
                      int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(gemv_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, Mat, ld, vec, out, rows, cols, scale,
-                       accumulate);
-    return CHECK_LAUNCH();
+    return launch_gemv_rows_z(Mat, ld, vec, out, rows, cols, scale, accumulate, 1, 0, s);
 }
 
 // KL = 0.5 * (2 sum log L_ii - sum log LS_ii^2 + |U|_F^2 + |a|^2 - M)      
 // stage 1: one block per 4 rows of U (lower triangle) -> partial sums; stage 2: one block adds them
 __global__ void kl_part_kernel(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp,
-                               double* part) {
+                               double* part, int64_t zs) {
     __shared__ double sh[4];
     double s = 0.0;
     const int r0 = blockIdx.x * 4;
+    L += blockIdx.z * zs; LSp += blockIdx.z * zs; U += blockIdx.z * zs; a += blockIdx.z * zs; part += blockIdx.z * zs;
     for (int rr = 0; rr < 4; ++rr) {
         const int i = r0 + rr;
         if (i >= M) break;
@@ -126,12 +153,18 @@ __global__ void kl_final_kernel(const double* part, int np, int M, double* kl) {
     s = block_sum(s, sh);
     if (threadIdx.x == 0) kl[0] = 0.5 * (s - (double)M);
 }
+int launch_kl_z(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* const* kl,
+                double* part, int nz, int64_t zs, hipStream_t s) {
+    const int nb = (M + 3) / 4;
+    hipLaunchKernelGGL(kl_part_kernel, dim3(nb, 1, nz), dim3(256), 0, s, L, LSp, U, a, M, Mp, part, zs);
+    for (int z = 0; z < nz; ++z)      // kl[z] is a user tensor
+        hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(256), 0, s, (const double*)(part + z * zs), nb, M, kl[z]);
+    return CHECK_LAUNCH();
+}
 int launch_kl(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* kl,
               double* part, hipStream_t s) {
-    const int nb = (M + 3) / 4;
-    hipLaunchKernelGGL(kl_part_kernel, dim3(nb), dim3(256), 0, s, L, LSp, U, a, M, Mp, part);
-    hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nb, M, kl);
-    return CHECK_LAUNCH();
+    double* one[1] = {kl};
+    return launch_kl_z(L, LSp, U, a, M, Mp, one, part, 1, 0, s);
 }
 
 // ------------------------------------------------------------------ predictive moments
@@ -222,34 +255,50 @@ int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab,
 }
 
 // dU_tot = 2 tril(X) + gkl U  (X = H U, lower tiles valid);  da_tot = da + gkl a
-__global__ void dutot_kernel(const double* X, const double* U, const double* da, const double* a, const double* gkl,
-                             int Mp, double* dU, double* da_tot) {
+__global__ void dutot_kernel(const double* X, const double* U, const double* da, const double* a, ScalZ gklz,
+                             int Mp, double* dU, double* da_tot, int64_t zs) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double* gkl = gklz.p[blockIdx.z];
     const double g = gkl ? gkl[0] : 0.0;
+    X += blockIdx.z * zs; U += blockIdx.z * zs; da += blockIdx.z * zs; a += blockIdx.z * zs;
+    dU += blockIdx.z * zs; da_tot += blockIdx.z * zs;
     if (idx < (int64_t)Mp * Mp) {
         int i = (int)(idx / Mp), j = (int)(idx % Mp);
         dU[idx] = j <= i ? 2.0 * X[idx] + g * U[idx] : 0.0;
     }
     if (idx < Mp) da_tot[idx] = da[idx] + g * a[idx];
 }
+int launch_dutot_z(const double* X, const double* U, const double* da, const double* a, const double* const* gkl, int Mp,
+                   double* dU, double* da_tot, int nz, int64_t zs, hipStream_t s) {
+    ScalZ t = {};
+    for (int z = 0; z < nz; ++z) t.p[z] = gkl[z];
+    hipLaunchKernelGGL(dutot_kernel, GRIDZ((int64_t)Mp * Mp, nz), 0, s, X, U, da, a, t, Mp, dU, da_tot, zs);
+    return CHECK_LAUNCH();
+}
 int launch_dutot(const double* X, const double* U, const double* da, const double* a, const double* gkl, int Mp,
                  double* dU, double* da_tot, hipStream_t s) {
-    hipLaunchKernelGGL(dutot_kernel, GRID1((int64_t)Mp * Mp), 0, s, X, U, da, a, gkl, Mp, dU, da_tot);
-    return CHECK_LAUNCH();
+    const double* one[1] = {gkl};
+    return launch_dutot_z(X, U, da, a, one, Mp, dU, da_tot, 1, 0, s);
 }
 
 // Y = 2 G2 - 2 Hc + a da^T + da_tot a^T
 __global__ void y_combine_kernel(const double* G2, const double* Hc, const double* a, const double* da,
-                                 const double* da_tot, int Mp, double* Y) {
+                                 const double* da_tot, int Mp, double* Y, int64_t zs) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Mp * Mp) return;
+    G2 += blockIdx.z * zs; Hc += blockIdx.z * zs; a += blockIdx.z * zs; da += blockIdx.z * zs;
+    da_tot += blockIdx.z * zs; Y += blockIdx.z * zs;
     int i = (int)(idx / Mp), j = (int)(idx % Mp);
     Y[idx] = 2.0 * (G2[idx] - Hc[idx]) + a[i] * da[j] + da_tot[i] * a[j];
 }
+int launch_y_combine_z(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
+                       double* Y, int nz, int64_t zs, hipStream_t s) {
+    hipLaunchKernelGGL(y_combine_kernel, GRIDZ((int64_t)Mp * Mp, nz), 0, s, G2, Hc, a, da, da_tot, Mp, Y, zs);
+    return CHECK_LAUNCH();
+}
 int launch_y_combine(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
                      double* Y, hipStream_t s) {
-    hipLaunchKernelGGL(y_combine_kernel, GRID1((int64_t)Mp * Mp), 0, s, G2, Hc, a, da, da_tot, Mp, Y);
-    return CHECK_LAUNCH();
+    return launch_y_combine_z(G2, Hc, a, da, da_tot, Mp, Y, 1, 0, s);
 }
 
 // ------------------------------------------------------------------ Cholesky-chain backward glue (Mp x Mp)
@@ -278,9 +327,11 @@ int launch_rank1_add(double* X, const double* u, const double* v, int Mp, hipStr
 }
 
 // dL = -tril(T2) + gkl * diag(1/L_ii)  (rows/cols < M only; zero elsewhere)
-__global__ void dl_from_t2_kernel(const double* T2, const double* L, const double* gkl, int M, int Mp, double* dL) {
+__global__ void dl_from_t2_kernel(const double* T2, const double* L, ScalZ gklz, int M, int Mp, double* dL, int64_t zs) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Mp * Mp) return;
+    const double* gkl = gklz.p[blockIdx.z];
+    T2 += blockIdx.z * zs; L += blockIdx.z * zs; dL += blockIdx.z * zs;
     int i = (int)(idx / Mp), j = (int)(idx % Mp);
     double v = 0.0;
     if (i < M && j <= i) {
@@ -289,34 +340,45 @@ __global__ void dl_from_t2_kernel(const double* T2, const double* L, const doubl
     }
     dL[idx] = v;
 }
-int launch_dl_from_t2(const double* T2, const double* L, const double* gkl, int M, int Mp, double* dL, hipStream_t s) {
-    hipLaunchKernelGGL(dl_from_t2_kernel, GRID1((int64_t)Mp * Mp), 0, s, T2, L, gkl, M, Mp, dL);
+int launch_dl_from_t2_z(const double* T2, const double* L, const double* const* gkl, int M, int Mp, double* dL, int nz,
+                        int64_t zs, hipStream_t s) {
+    ScalZ t = {};
+    for (int z = 0; z < nz; ++z) t.p[z] = gkl[z];
+    hipLaunchKernelGGL(dl_from_t2_kernel, GRIDZ((int64_t)Mp * Mp, nz), 0, s, T2, L, t, M, Mp, dL, zs);
     return CHECK_LAUNCH();
+}
+int launch_dl_from_t2(const double* T2, const double* L, const double* gkl, int M, int Mp, double* dL, hipStream_t s) {
+    const double* one[1] = {gkl};
+    return launch_dl_from_t2_z(T2, L, one, M, Mp, dL, 1, 0, s);
 }
 
 // P = Phi(T3): lower triangle with halved diagonal
-__global__ void phi_kernel(const double* T3, int Mp, double* P) {
+__global__ void phi_kernel(const double* T3, int Mp, double* P, int64_t zs) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Mp * Mp) return;
+    T3 += blockIdx.z * zs; P += blockIdx.z * zs;
     int i = (int)(idx / Mp), j = (int)(idx % Mp);
     P[idx] = j < i ? T3[idx] : (j == i ? 0.5 * T3[idx] : 0.0);
 }
-int launch_phi(const double* T3, int Mp, double* P, hipStream_t s) {
-    hipLaunchKernelGGL(phi_kernel, GRID1((int64_t)Mp * Mp), 0, s, T3, Mp, P);
+int launch_phi_z(const double* T3, int Mp, double* P, int nz, int64_t zs, hipStream_t s) {
+    hipLaunchKernelGGL(phi_kernel, GRIDZ((int64_t)Mp * Mp, nz), 0, s, T3, Mp, P, zs);
     return CHECK_LAUNCH();
 }
+int launch_phi(const double* T3, int Mp, double* P, hipStream_t s) { return launch_phi_z(T3, Mp, P, 1, 0, s); }
 
 // G = (S + S^T)/2
-__global__ void symmetrize_kernel(const double* S, int Mp, double* G) {
+__global__ void symmetrize_kernel(const double* S, int Mp, double* G, int64_t zs) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Mp * Mp) return;
+    S += blockIdx.z * zs; G += blockIdx.z * zs;
     int i = (int)(idx / Mp), j = (int)(idx % Mp);
     G[idx] = 0.5 * (S[idx] + S[(int64_t)j * Mp + i]);
 }
-int launch_symmetrize(const double* S, int Mp, double* G, hipStream_t s) {
-    hipLaunchKernelGGL(symmetrize_kernel, GRID1((int64_t)Mp * Mp), 0, s, S, Mp, G);
+int launch_symmetrize_z(const double* S, int Mp, double* G, int nz, int64_t zs, hipStream_t s) {
+    hipLaunchKernelGGL(symmetrize_kernel, GRIDZ((int64_t)Mp * Mp, nz), 0, s, S, Mp, G, zs);
     return CHECK_LAUNCH();
 }
+int launch_symmetrize(const double* S, int Mp, double* G, hipStream_t s) { return launch_symmetrize_z(S, Mp, G, 1, 0, s); }
 
 // g_LS (M x M, ld M) = tril(X (Mp x Mp)) - gkl * diag(1/LS_ii)
 __global__ void gls_out_kernel(const double* X, const double* LSp, const double* gkl, int M, int Mp, double* gLS) {

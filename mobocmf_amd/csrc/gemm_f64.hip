@@ -134,9 +134,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     const double* B = g.B;
     double* C = g.C;
     if (g.batched) {
-        A += z * g.strideA;
-        B += z * g.strideB;
-        C += z * g.strideC;
+        const int zl = g.zlayers > 1 ? z % g.zlayers : 0;      // layer, batch index inside the layer
+        const int zb = g.zlayers > 1 ? z / g.zlayers : z;
+        A += zb * g.strideA + zl * g.zsA;
+        B += zb * g.strideB + zl * g.zsB;
+        C += zb * g.strideC + zl * g.zsC;
     }
     if (!g.batched && splitk > 1) C += z * g.slab_stride;
     const int nparts = (pair && rb != nrb - 1 - rb) ? 2 : 1;
@@ -496,7 +498,7 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
     dim3 grid;
     int pair = 0;
     if (g.batched) {
-        grid = dim3((unsigned)(nrb * ncb), 1, (unsigned)g.batched);
+        grid = dim3((unsigned)(nrb * ncb), 1, (unsigned)(g.batched * (g.zlayers > 1 ? g.zlayers : 1)));
         splitk = 1;
     } else if (splitk > 1) {
         int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
@@ -584,6 +586,9 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int64_t r0 = (int64_t)blockIdx.y * 16, c0 = (int64_t)blockIdx.x * 16;
     if (g.lower_out && c0 / BM > r0 / BM) return;        // same contract as the tiled kernel: lower 128-tiles only
+    g.A += blockIdx.z * g.zsA;                            // layer batching (blockIdx.z = layer)
+    g.B += blockIdx.z * g.zsB;
+    g.C += blockIdx.z * g.zsC;
     int64_t k0 = 0, k1 = g.Kd;
     if (g.tri & TRI_LOWER_A) k1 = k1 < r0 + 16 ? k1 : r0 + 16;
     if (g.tri & TRI_UPPER_A) k0 = k0 > r0 ? k0 : r0;
@@ -779,12 +784,12 @@ int gemm_rowdot_parts(const GemmArgs& g) {
 static bool small_gemm_ok(const GemmArgs& g, bool B_T) {
     const int L = small_gemm_limit();
     if (g.Mr > L || g.Nc > L || g.Kd > L) return false;
-    return !g.batched && g.epi == EPI_STORE && (B_T || (!g.bscale && !g.skip_if_zero)) && g.Mr <= 512 && g.Nc <= 512 &&
+    return (!g.batched || (g.batched == 1 && g.zlayers > 1)) && g.epi == EPI_STORE && (B_T || (!g.bscale && !g.skip_if_zero)) && g.Mr <= 512 && g.Nc <= 512 &&
            g.Kd <= 512 && g.Mr % 16 == 0 && g.Nc % 16 == 0 && g.Kd % 16 == 0;
 }
 
 static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
-    const dim3 grid((unsigned)(g.Nc / 16), (unsigned)(g.Mr / 16));
+    const dim3 grid((unsigned)(g.Nc / 16), (unsigned)(g.Mr / 16), (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
     if (B_T) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, s, g);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
@@ -796,6 +801,12 @@ int gemm_nt_slabs(const GemmArgs& g, int splitk) { return small_gemm_ok(g, true)
 // Small-grid GEMMs (M x M operands: a handful of 128x128 tiles on 256 CUs) are bound by one CU's MFMA rate:
 // slice k over more workgroups into slabs, then add the slabs.  ws must hold splitk * Mr * Nc doubles.
 int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems, hipStream_t s) {
+    if (g0.zlayers > 1) {       // chains of several layers in one launch: z-batched, no k-slicing
+        GemmArgs g = g0;
+        if (!g.batched) g.batched = 1;
+        if (small_gemm_ok(g, B_T)) return launch_small_gemm(g, B_T, s);
+        return launch_gemm(g, B_T, 1, s);
+    }
     if (small_gemm_ok(g0, B_T)) return launch_small_gemm(g0, B_T, s);
     GemmArgs g = g0;
     const int nrb = g.Mr / BM;

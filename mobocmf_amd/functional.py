@@ -355,6 +355,164 @@ def layer_panel(P, token, x, f, Zx, zf, hyp):
     return _PanelFn.apply(x, f, Zx, zf, hyp, token, P)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# All layers of a model in one batch of CHAIN launches (include/mobocmf_hip.h, mobocmf_layers_chain_*): the chain is a
+# serial string of latency-bound M x M kernels, the layers' chains do not depend on each other, so one z-batched
+# sequence divides its length by the number of layers.  One autograd node carries every layer's chain; the per-layer
+# PANEL nodes hang off its ``token``, so autograd runs the batched chain backward after all PANEL backwards.
+# ------------------------------------------------------------------------------------------------------------
+class ChainBatch:
+    """Workspace + bookkeeping shared by ``layers_chain`` and the per-layer ``layer_panel_batched`` calls of one forward."""
+    __slots__ = ("n", "kinds", "ds", "M", "branch", "jitters", "min_var", "blocks", "stride", "block_bytes", "infos",
+                 "kls", "had_panel", "token")
+
+    def chain_desc(self, z):
+        return make_desc(self.kinds[z], self.ds[z], self.M, 1, 1, self.branch, False, self.jitters[z], self.min_var,
+                         PHASE_CHAIN)
+
+    def block(self, z):
+        return self.blocks[z * self.stride:z * self.stride + self.block_bytes]
+
+
+def _table(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def _desc_table(descs):
+    return (ctypes.POINTER(LayerDesc) * len(descs))(*[ctypes.pointer(d) for d in descs])
+
+
+class _ChainsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, CB, *flat):
+        lib = _lib.require_device()
+        n = CB.n
+        per = [[_prep(t) for t in flat[5 * z:5 * z + 5]] for z in range(n)]      # Zx, zf, hyp, m, L_S per layer
+        dev = per[0][0].device
+        descs = [CB.chain_desc(z) for z in range(n)]
+        bb, st = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(lib.mobocmf_chain_block_bytes(ctypes.byref(descs[0]), ctypes.byref(bb), ctypes.byref(st)),
+                   "mobocmf_chain_block_bytes")
+        CB.block_bytes = bb.value
+        CB.stride = (bb.value + 255) // 256 * 256
+        CB.blocks = _poison(torch.empty(n * CB.stride, dtype=torch.uint8, device=dev))
+        CB.kls = [_empty((), device=dev) for _ in range(n)]
+        CB.had_panel = [0] * n
+        token = torch.zeros(1, dtype=torch.float64, device=dev)
+        P = lambda i, none_ok=False: _table([0 if per[z][i] is None else per[z][i].data_ptr() for z in range(n)])
+        rc = lib.mobocmf_layers_chain_forward(n, _desc_table(descs), P(0), P(1), P(2), P(3), P(4),
+                                              _table([k.data_ptr() for k in CB.kls]),
+                                              _table([t.data_ptr() for t in CB.infos]), _ptr(CB.blocks), CB.stride,
+                                              _stream())
+        _lib.check(rc, "mobocmf_layers_chain_forward")
+        ctx.CB = CB
+        ctx.descs = descs
+        ctx.has = [[t is not None for t in per[z]] for z in range(n)]
+        ctx.save_for_backward(*[t for z in range(n) for t in per[z] if t is not None])
+        return (token,) + tuple(CB.kls)
+
+    @staticmethod
+    def backward(ctx, g_token, *g_kls):
+        lib = _lib.require_device()
+        CB = ctx.CB
+        n = CB.n
+        it = iter(ctx.saved_tensors)
+        per = [[next(it) if h else None for h in ctx.has[z]] for z in range(n)]
+        dev = per[0][0].device
+        gk = [_prep(g) if g is not None else torch.zeros((), dtype=torch.float64, device=dev) for g in g_kls]
+        new = lambda *s: _empty(*s, device=dev)
+        g_zf = [new(CB.M) if per[z][1] is not None else None for z in range(n)]
+        g_hyp = [new(per[z][2].numel()) for z in range(n)]
+        g_m = [new(CB.M) for _ in range(n)]
+        g_LS = [new(CB.M, CB.M) for _ in range(n)]
+        T = lambda ts: _table([0 if t is None else t.data_ptr() for t in ts])
+        rc = lib.mobocmf_layers_chain_backward(n, _desc_table(ctx.descs), T([p[0] for p in per]), T([p[1] for p in per]),
+                                               T([p[2] for p in per]), T(gk), (ctypes.c_int32 * n)(*CB.had_panel),
+                                               T(g_zf), T(g_hyp), T(g_m), T(g_LS), _ptr(CB.blocks), CB.stride, _stream())
+        _lib.check(rc, "mobocmf_layers_chain_backward")
+        out = [None]
+        for z in range(n):
+            out += [None, g_zf[z], g_hyp[z], g_m[z], g_LS[z]]
+        return tuple(out)
+
+
+def layers_chain(layers_params, kinds, branch, jitters, infos, min_var=MIN_VARIANCE):
+    """CHAIN halves of all layers in one batch.  ``layers_params``: per layer (Zx, zf or None, hyp, m, L_S), equal M.
+    Returns the ChainBatch (``.kls`` = per-layer KL tensors with gradient, ``.token`` for the PANEL calls)."""
+    CB = ChainBatch()
+    CB.n = len(layers_params)
+    if not 1 <= CB.n <= 4:
+        raise _lib.MobocmfError("layers_chain: 1..4 layers per batch")
+    CB.kinds, CB.ds = list(kinds), [p[0].shape[1] for p in layers_params]
+    CB.M = layers_params[0][0].shape[0]
+    if any(p[0].shape[0] != CB.M for p in layers_params):
+        raise _lib.MobocmfError("layers_chain: the layers must share the number of inducing points")
+    CB.branch, CB.jitters, CB.min_var, CB.infos = branch, list(jitters), min_var, list(infos)
+    out = _ChainsFn.apply(CB, *[t for p in layers_params for t in p])
+    CB.token, CB.kls = out[0], list(out[1:])
+    return CB
+
+
+class _PanelBatchedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f, Zx, zf, hyp, token, CB, z, xdiv, want_dx):
+        lib = _lib.require_device()
+        x, f, Zx, zf, hyp = (_prep(t) for t in (x, f, Zx, zf, hyp))
+        Np = x.shape[0] * xdiv
+        kind = CB.kinds[z]
+        if x.shape[1] != CB.ds[z] or (kind == 1 and (f is None or f.numel() != Np)):
+            raise _lib.MobocmfError("shape mismatch between the chain batch and a panel call")
+        dev = x.device
+        desc = make_desc(kind, CB.ds[z], CB.M, Np, xdiv, CB.branch, want_dx, CB.jitters[z], CB.min_var, PHASE_PANEL)
+        sb, cb = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(lib.mobocmf_panel_workspace_bytes(ctypes.byref(desc), ctypes.byref(sb), ctypes.byref(cb)),
+                   "mobocmf_panel_workspace_bytes")
+        saved = _poison(torch.empty(sb.value, dtype=torch.uint8, device=dev))
+        scratch = scratch_buffer(cb.value, dev)
+        mean, var = _empty(Np, device=dev), _empty(Np, device=dev)
+        blk = CB.block(z)
+        rc = lib.mobocmf_layer_panel_forward(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp),
+                                             _ptr(mean), _ptr(var), _ptr(blk), blk.numel(), _ptr(saved), sb.value,
+                                             _ptr(scratch), scratch.numel(), _stream())
+        _lib.check(rc, "mobocmf_layer_panel_forward")
+        ctx.CB, ctx.z, ctx.desc, ctx.saved_ws, ctx.sb, ctx.cb = CB, z, desc, saved, sb.value, cb.value
+        ctx.save_for_backward(*[t for t in (x, f, Zx, zf, hyp) if t is not None])
+        ctx.has_f = f is not None
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, g_mean, g_var):
+        lib = _lib.require_device()
+        CB, z, desc = ctx.CB, ctx.z, ctx.desc
+        ts = list(ctx.saved_tensors)
+        if ctx.has_f:
+            x, f, Zx, zf, hyp = ts
+        else:
+            x, Zx, hyp = ts
+            f = zf = None
+        dev = x.device
+        g_mean, g_var = _prep(g_mean), _prep(g_var)
+        scratch = scratch_buffer(ctx.cb, dev)      # H / Hc / da go to the chain block, nothing of the scratch is kept
+        new = lambda *s: _empty(*s, device=dev)
+        g_f = new(desc.Np) if ctx.has_f else None
+        g_zf = new(CB.M) if ctx.has_f else None
+        g_hyp = new(hyp.numel())
+        g_x = new(x.shape[0], desc.d) if desc.want_dx else None
+        blk = CB.block(z)
+        rc = lib.mobocmf_layer_panel_backward(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp),
+                                              _ptr(g_mean), _ptr(g_var), _ptr(g_f), _ptr(g_zf), _ptr(g_hyp), _ptr(g_x),
+                                              _ptr(blk), blk.numel(), _ptr(ctx.saved_ws), ctx.sb, _ptr(scratch),
+                                              scratch.numel(), _stream())
+        _lib.check(rc, "mobocmf_layer_panel_backward")
+        CB.had_panel[z] = 1
+        return g_x, g_f, None, g_zf, g_hyp, torch.zeros(1, dtype=torch.float64, device=dev), None, None, None, None
+
+
+def layer_panel_batched(CB, z, x, f, Zx, zf, hyp, xdiv=1, want_dx=False):
+    """PANEL half of layer ``z`` of a chain batch: mean (N'), var (N')."""
+    return _PanelBatchedFn.apply(x, f, Zx, zf, hyp, CB.token, CB, z, xdiv, want_dx)
+
+
 class FrozenChain:
     """CHAIN state of one layer for FIXED parameters (acquisition optimisation): computed once, then copied to the
     front of the ``saved`` buffer of every PANEL call; gradients flow to the layer inputs only."""

@@ -301,9 +301,16 @@ class MFDGPHiddenLayer(nn.Module):
             hit = bool(torch.equal(x, vs.Zx) and (f is None or torch.equal(f, vs.zf)))
             self._shortcut_last = hit
         if hit:
+            if isinstance(chain, tuple) and isinstance(chain[0], F.ChainBatch):
+                vs._kl_cache = chain[0].kls[chain[1]]      # the batch has this layer's KL already
             return vd.variational_mean, F.shortcut_var(vd.chol_variational_covar)
         if isinstance(chain, F.FrozenChain):
             return F.layer_panel_frozen(chain, x, f, xdiv=xdiv, want_dx=want_dx)
+        if isinstance(chain, tuple) and isinstance(chain[0], F.ChainBatch):      # all layers' chains in one batch
+            CB, z, hyp = chain
+            mean, var = F.layer_panel_batched(CB, z, x, f, vs.Zx, vs.zf, hyp, xdiv=xdiv, want_dx=want_dx)
+            vs._kl_cache = CB.kls[z]
+            return mean, var
         if chain is not None:
             P, token, hyp = chain
             mean, var = F.layer_panel(P, token, x, f, vs.Zx, vs.zf, hyp)

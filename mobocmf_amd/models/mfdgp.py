@@ -175,7 +175,7 @@ class MFDGP(nn.Module):
         if self._frozen is not None:
             chains = self._frozen_chains(num_layers)
         else:
-            chains = self._launch_chains(inputs, num_layers, S, want_dx)
+            chains = self._batched_chains(inputs, num_layers) or self._launch_chains(inputs, num_layers, S, want_dx)
         for i in range(num_layers):
             hidden_layer = getattr(self, self.name_hidden_layer + str(i))
             if i == 0:
@@ -212,6 +212,35 @@ class MFDGP(nn.Module):
                 self._frozen[key] = layer.freeze_chain()
             out.append(self._frozen[key])
         return out
+    batch_chains = True                   # all layers' CHAIN halves as one z-batched sequence of launches (fast path)
+
+    def _batched_chains(self, inputs, num_layers):
+        """The parameter-only (CHAIN) halves of all layers in ONE batch of launches (functional.layers_chain): the layers'
+        chains are independent -- Z~_l = [Z_x, m_{l-1}] is made of parameters -- and each is a serial string of
+        latency-bound M x M kernels, so batching divides that string's length by the number of layers.  Only without
+        per-call host checks (``set_check_pd(False)``: graphed step / bench / fitter fast path) and with one M for all
+        layers; otherwise None (the layers then run one by one)."""
+        layers = [getattr(self, self.name_hidden_layer + str(i)) for i in range(num_layers)]
+        if not (self.batch_chains and not self.overlap_chains and inputs.is_cuda and 2 <= num_layers <= 4
+                and not any(l.check_pd for l in layers)):
+            return None
+        params, kinds, jit, infos, hyps = [], [], [], [], []
+        for layer in layers:
+            vs = layer.variational_strategy
+            vd = vs._variational_distribution
+            if vs.Zx.shape[0] != layers[0].variational_strategy.Zx.shape[0] or (layer.kind == 1 and vs.zf is None):
+                return None
+            if layer._info is None or layer._info.device != inputs.device:
+                layer._info = torch.zeros((), dtype=torch.int32, device=inputs.device)
+            hyp = gp.pack_hypers(layer.covar_module, layer.kind)
+            hyps.append(hyp)
+            params.append((vs.Zx, vs.zf if layer.kind == 1 else None, hyp, vd.variational_mean, vd.chol_variational_covar))
+            kinds.append(layer.kind)
+            jit.append(vs.jitter_val)
+            infos.append(layer._info)
+        CB = F.layers_chain(params, kinds, 0 if self.training else 1, jit, infos)
+        return [(CB, z, hyps[z]) for z in range(num_layers)]
+
     overlap_chains = False                # opt-in (see DESIGN.md: HIP-graph replay of forked captures is slower on ROCm 7.2)
     OVERLAP_MAX_ROWS = 1 << 21            # above this the private backward scratch per layer is not worth its memory
 

@@ -147,3 +147,60 @@ def test_frozen_chains_reproduce_acquisition_and_its_gradient():
         m1, v1 = mu.predict_for_acquisition(X, 0)
         assert torch.equal(m0, m1) and torch.equal(v0, v1)
     assert mu._frozen is None and mc._frozen is None
+
+
+@pytest.mark.parametrize("cfg", [dict(d=3, L=2, M=20, N=60, S=2, seed=9), dict(d=2, L=3, M=130, N=200, S=2, seed=3),
+                                 dict(d=4, L=2, M=300, N=700, S=1, seed=5)],
+                         ids=["2layers_small", "3layers_M130", "2layers_M300"])
+def test_batched_chains_match_the_layer_by_layer_path(cfg):
+    """All layers' CHAIN halves in one z-batched sequence of launches (mobocmf_layers_chain_*, the fast path of the graphed
+    step) vs one fused call per layer: ELBO, KL and every parameter gradient agree to rounding (the batched M x M products
+    are not k-sliced, so the summation order differs)."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.models import MFDGP
+    prob = synthetic.make_problem(**cfg)
+    t = lambda a: to_t(a).to(DEV)
+    eps = [None] + [t(e) for e in prob["eps"][1:]]
+    res = []
+    for batched in (False, True):
+        model = build_model(prob, S_train=cfg["S"])
+        model.set_check_pd(False)
+        keep, MFDGP.batch_chains = MFDGP.batch_chains, batched
+        try:
+            out = model(t(prob["x"]), eps=eps)
+            e, skl = VariationalELBOMF(model, cfg["N"], cfg["L"])(out, t(prob["y"])[None, :], t(prob["fid"])[:, None])
+            (-e).backward()
+        finally:
+            MFDGP.batch_chains = keep
+        res.append((float(e), float(skl), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (e0, k0, g0), (e1, k1, g1) = res
+    assert abs(e0 - e1) < 1e-11 * abs(e0) and abs(k0 - k1) < 1e-11 * abs(k0)
+    assert g0.keys() == g1.keys() and len(g0) >= 4 * cfg["L"]
+    for n in g0:
+        err = float((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-300))
+        assert err < 1e-7, (n, err)
+
+
+def test_batched_chains_kl_only_and_truncated_forward():
+    """(i) only the KL is differentiated (no panel backward ran: the chain backward must treat H, da as zero);
+    (ii) a forward truncated at max_fidelity batches the layers it runs."""
+    from mobocmf_amd.models import MFDGP
+    prob = synthetic.make_problem(d=2, L=3, M=12, N=30, S=1, seed=2)
+    t = lambda a: to_t(a).to(DEV)
+    grads = []
+    for batched in (False, True):
+        model = build_model(prob, S_train=1)
+        model.set_check_pd(False)
+        keep, MFDGP.batch_chains = MFDGP.batch_chains, batched
+        try:
+            out = model(t(prob["x"]), max_fidelity=1, eps=[None, t(prob["eps"][1]), None])
+            assert len(out) == 2
+            kl = model.variational_strategy.kl_terms()
+            (kl[0] + 2.0 * kl[1] + out[1].mean.sum()).backward()
+        finally:
+            MFDGP.batch_chains = keep
+        grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        err = float((grads[0][n] - grads[1][n]).abs().max() / grads[0][n].abs().max().clamp_min(1e-300))
+        assert err < 1e-7, (n, err)
