@@ -56,8 +56,14 @@ def build_graphed(cfg, outputs, device, use_graph, shard_rows=False):
         model = synthetic.model_from_problem(prob, device=device)
         elbo = VariationalELBOMF(model, cfg["N"], cfg["L"])
         t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=device)
-        steps.append(GraphedELBOStep(model, elbo, t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], lr=1e-3,
-                                     use_graph=use_graph))
+        x, y, fid = t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None]
+        if cfg["M"] == cfg["N"] and not shard_rows:
+            # Z = the training inputs (the reference's default, C1): its shuffling loader feeds a PERMUTATION of Z, i.e.
+            # GPyTorch's general branch, never the equal-inputs shortcut (blackbox_mfdgp_fitter.py:35) -- same here
+            from mobocmf_amd.util.blackbox_mfdgp_fitter import BlackBoxMFDGPFitter
+            perm = BlackBoxMFDGPFitter.shuffled_rows(cfg["N"], device)
+            x, y, fid = x[perm].contiguous(), y[perm].contiguous(), fid[perm].contiguous()
+        steps.append(GraphedELBOStep(model, elbo, x, y, fid, lr=1e-3, use_graph=use_graph))
     return steps
 
 

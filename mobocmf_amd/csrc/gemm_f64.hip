@@ -140,7 +140,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         B += zb * g.strideB + zl * g.zsB;
         C += zb * g.strideC + zl * g.zsC;
     }
-    if (!g.batched && splitk > 1) C += z * g.slab_stride;
+    if (!g.batched && splitk > 1) {
+        C += z * g.slab_stride;
+        if (g.zlayers > 1) {      // k-sliced AND layer-batched: blockIdx.z = layer (slabs of layer l at C + l*zsC)
+            A += blockIdx.z * g.zsA;
+            B += blockIdx.z * g.zsB;
+            C += blockIdx.z * g.zsC;
+        }
+    }
     const int nparts = (pair && rb != nrb - 1 - rb) ? 2 : 1;
     const int rb_first = rb;
 
@@ -502,7 +509,7 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         splitk = 1;
     } else if (splitk > 1) {
         int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
-        grid = dim3((unsigned)(ntile * splitk), 1, 1);
+        grid = dim3((unsigned)(ntile * splitk), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
     } else {
         // pairing balances the work per workgroup; it only pays when there are more tiles than resident workgroup
         // slots (2 per CU), otherwise the longest single tile is the critical path and pairing lengthens it
@@ -532,9 +539,12 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
 // out[i][j] (+)= sum_z slabs[z][i][j]   (rows x cols, slabs dense with ld = cols); lower_only: tiles above the
 // diagonal are neither read nor written, elements above the diagonal inside diagonal tiles are zeroed if `tril`
 __global__ void reduce_slabs_kernel(const double* slabs, int64_t slab_stride, int nslab, double* out, int64_t ld,
-                                    int rows, int64_t cols, double scale, int lower_only, int tril, int accumulate) {
+                                    int rows, int64_t cols, double scale, int lower_only, int tril, int accumulate,
+                                    int64_t zs_slabs, int64_t zs_out) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)rows * cols) return;
+    slabs += blockIdx.z * zs_slabs;      // layer batching
+    out += blockIdx.z * zs_out;
     int i = (int)(idx / cols);
     int64_t j = idx % cols;
     if (lower_only && (j / TILE) > (i / TILE)) {
@@ -554,7 +564,7 @@ int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, dou
                         double scale, int lower_only, int accumulate, hipStream_t s) {
     int64_t n = (int64_t)Mr * Mr;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, slab_stride,
-                       nslab, out, ld, Mr, (int64_t)Mr, scale, lower_only, lower_only, accumulate);
+                       nslab, out, ld, Mr, (int64_t)Mr, scale, lower_only, lower_only, accumulate, (int64_t)0, (int64_t)0);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
@@ -801,13 +811,15 @@ int gemm_nt_slabs(const GemmArgs& g, int splitk) { return small_gemm_ok(g, true)
 // Small-grid GEMMs (M x M operands: a handful of 128x128 tiles on 256 CUs) are bound by one CU's MFMA rate:
 // slice k over more workgroups into slabs, then add the slabs.  ws must hold splitk * Mr * Nc doubles.
 int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems, hipStream_t s) {
-    if (g0.zlayers > 1) {       // chains of several layers in one launch: z-batched, no k-slicing
-        GemmArgs g = g0;
-        if (!g.batched) g.batched = 1;
-        if (small_gemm_ok(g, B_T)) return launch_small_gemm(g, B_T, s);
-        return launch_gemm(g, B_T, 1, s);
-    }
-    if (small_gemm_ok(g0, B_T)) return launch_small_gemm(g0, B_T, s);
+    // zlayers > 1: the same product for several layers (operands + l*zs*), blockIdx.z = layer; ws = the slab buffer of
+    // layer 0, the other layers' slab buffers lie zsC apart like every other chain operand
+    const int nz = g0.zlayers > 1 ? g0.zlayers : 1;
+    if (nz > 1 && g0.batched > 1) return launch_gemm(g0, B_T, 1, s);      // batch x layers: plain z-batched launch
+    if (nz > 1) {
+        GemmArgs g1 = g0;
+        g1.batched = 1;
+        if (small_gemm_ok(g1, B_T)) return launch_small_gemm(g1, B_T, s);
+    } else if (small_gemm_ok(g0, B_T)) return launch_small_gemm(g0, B_T, s);
     GemmArgs g = g0;
     const int nrb = g.Mr / BM;
     const int64_t ncb = g.Nc / BN;
@@ -815,23 +827,27 @@ int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems,
     int64_t nk = g.Kd / BK;
     if (g.tri) nk = (nk + 1) / 2;
     int sk = 1;
-    if (!g.batched && g.epi == EPI_STORE && ntile < 96 && nk >= 8) {
-        sk = (int)(512 / ntile);      // up to one round of resident workgroups (the nk / 4 floor below keeps slices >= 4 steps)
+    if (!g.batched && g.epi == EPI_STORE && ntile * nz < 96 * nz && ntile < 96 && nk >= 8) {
+        sk = (int)(512 / (ntile * nz));      // up to one round of resident workgroups
         if (sk > nk / 2) sk = (int)(nk / 2);
         if (sk >= 8) sk &= ~7;
         if ((int64_t)sk * g.Mr * g.Nc > ws_elems) sk = (int)(ws_elems / ((int64_t)g.Mr * g.Nc));
         if (sk >= 8) sk &= ~7;
     }
-    if (sk < 2) return launch_gemm(g0, B_T, 1, s);
+    if (sk < 2) {
+        if (nz > 1) { g.batched = 1; return launch_gemm(g, B_T, 1, s); }
+        return launch_gemm(g0, B_T, 1, s);
+    }
     g.C = ws;
     g.ldc = g.Nc;
     g.slab_stride = (int64_t)g.Mr * g.Nc;
     g.accumulate = 0;
+    // (layer l: slabs at ws + l*zsC -- zsC is the chain-block stride, the slab buffer sits inside the block)
     int rc = launch_gemm(g, B_T, sk, s);
     if (rc) return rc;
     int64_t n = (int64_t)g.Mr * g.Nc;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double*)ws,
-                       g.slab_stride, sk, g0.C, g0.ldc, g.Mr, g.Nc, 1.0, g0.lower_out, 0, g0.accumulate);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256), 1, (unsigned)nz), dim3(256), 0, s,
+                       (const double*)ws, g.slab_stride, sk, g0.C, g0.ldc, g.Mr, g.Nc, 1.0, g0.lower_out, 0, g0.accumulate,
+                       nz > 1 ? g0.zsC : (int64_t)0, nz > 1 ? g0.zsC : (int64_t)0);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
-

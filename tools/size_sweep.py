@@ -19,7 +19,10 @@ for n in sizes:
     model = synthetic.model_from_problem(prob, device=dev)
     elbo = VariationalELBOMF(model, n, 2)
     t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)
-    g = GraphedELBOStep(model, elbo, t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], lr=1e-3)
+    # Z = x (M = N): the rows are shuffled once, as the reference's loader does -- the general branch, not the shortcut
+    perm = torch.roll(torch.arange(n, device=dev), 1) if n > 1 else torch.arange(n, device=dev)
+    g = GraphedELBOStep(model, elbo, t(prob["x"])[perm].contiguous(), t(prob["y"])[:, None][perm].contiguous(),
+                        t(prob["fid"])[:, None][perm].contiguous(), lr=1e-3)
     for _ in range(20):
         g.step()
     g.stream.synchronize()
