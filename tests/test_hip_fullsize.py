@@ -58,6 +58,46 @@ def test_full_size_elbo_and_gradients(name):
             assert rel(p.grad.reshape(gref.shape), gref) < 1e-4, (l, key, rel(p.grad.reshape(gref.shape), gref))
 
 
+@pytest.mark.parametrize("batched", [False, True], ids=["layer_by_layer", "batched_chains"])
+def test_C4_shaped_three_layer_gradients(batched):
+    """C4's shape at a size the oracle can differentiate on the GPU: d = 32, 3 fidelities, M = 1024, S = 16 with N = 4096
+    base rows (65 536 rows through layers 1 and 2): ELBO, per-layer moments and EVERY raw-parameter gradient of the
+    three-layer backward vs the oracle, through both the fused per-layer calls and the z-batched chains."""
+    from mobocmf_amd.models import MFDGP
+    cfg = dict(d=32, L=3, M=1024, N=4096, S=16)
+    prob = synthetic.make_problem(**cfg, seed=4)
+    S, L = cfg["S"], cfg["L"]
+    model = build_model(prob, S_train=S)
+    model.set_check_pd(not batched)
+    raw = _to_dev(_raw_from_model(model, L))
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device=DEV)
+    x, y, fid = t(prob["x"]), t(prob["y"]), t(prob["fid"])
+    eps = [None] + [t(e) for e in prob["eps"][1:]]
+    st = O.state_from_raw(raw)
+    e_o, skl_o = O.elbo(st, x, y, fid, eps=eps, S=S, ref_equiv=True)     # matmul distances: (M, N', d) would not fit
+    (-e_o).backward()
+    with torch.no_grad():
+        outs_o = O.model_forward(st, x, eps=eps, S=S, ref_equiv=True)
+    keep, MFDGP.batch_chains = MFDGP.batch_chains, batched
+    try:
+        (e, skl), out = hip_elbo(model, prob, S)
+        (-e).backward()
+    finally:
+        MFDGP.batch_chains = keep
+    assert rel(e, e_o) < 1e-7 and rel(skl, skl_o) < 1e-7
+    for l in range(L):
+        assert rel(out[l].mean.reshape(-1), outs_o[l][0]) < 1e-6
+        assert rel(out[l].variance.reshape(-1), outs_o[l][1]) < 1e-5
+    for l in range(L):
+        for key, tt in raw["layers"][l].items():
+            p = _model_param_for(model, l, key)
+            gref = tt.grad if key != "L_S" else torch.tril(tt.grad)
+            assert rel(p.grad.reshape(gref.shape), gref) < 1e-4, (l, key, rel(p.grad.reshape(gref.shape), gref))
+        assert rel(getattr(model, f"hidden_layer_likelihood_{l}").raw_noise.grad.reshape(()), raw["raw_noise"][l].grad) < 1e-4
+    del out, model, st, raw
+    torch.cuda.empty_cache()
+
+
 def test_C4_three_layers_million_rows_properties():
     """C4: d=32, 3 fidelities, M=1024, N=65536, S=16 -> 1,048,576 rows through layers 1 and 2 (8.6 GB per M x N'
     matrix).  Checks: finite ELBO; KL of every layer vs the oracle (M-sized); a 4096-row slice of every layer's

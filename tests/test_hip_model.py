@@ -69,7 +69,9 @@ def rel(a, b):
 
 CASES = [(f"C1_forrester_out{o}", lambda o=o: forrester_state_problem(o), 4) for o in range(3)] + \
         [(f"small2d_seed{s}", lambda s=s: synthetic.make_problem(d=2, L=2, M=8, N=12, S=3, seed=s), 3) for s in range(3)] + \
-        [("small3layer", lambda: synthetic.make_problem(d=3, L=3, M=10, N=16, S=2, seed=7), 2)]
+        [("small3layer", lambda: synthetic.make_problem(d=3, L=3, M=10, N=16, S=2, seed=7), 2)] + \
+        [("C2_seed0", lambda: synthetic.make_problem(**{k: v for k, v in synthetic.CONFIGS["C2"].items() if k != "outputs"},
+                                                     seed=0), 8)]
 
 
 @pytest.mark.parametrize("name,mk,S", CASES, ids=[c[0] for c in CASES])
@@ -79,18 +81,20 @@ def test_elbo_grads_and_acquisition_match_golden(name, mk, S):
     prob = mk()
     model = build_model(prob, S_train=S, S_acq=S)
     (e, skl), out = hip_elbo(model, prob, S)
-    assert rel(e, g["elbo"]) < 1e-8 and rel(skl, g["scaled_kl"]) < 1e-8
+    # C2: 128 inducing points in 2-D, cond(K_mm + 1e-6 I) ~ 1e9 -- either implementation carries ~cond * eps
+    k = 1e3 if name.startswith("C2") else 1.0
+    assert rel(e, g["elbo"]) < 1e-8 * k and rel(skl, g["scaled_kl"]) < 1e-8 * k
     for l in range(prob["L"]):
-        assert rel(out[l].mean.reshape(-1), g[f"mean_{l}"]) < 1e-7
-        assert rel(out[l].variance.reshape(-1), g[f"var_{l}"]) < 1e-6
+        assert rel(out[l].mean.reshape(-1), g[f"mean_{l}"]) < 1e-7 * k
+        assert rel(out[l].variance.reshape(-1), g[f"var_{l}"]) < 1e-6 * min(k, 50.0)
     # gradients w.r.t. the constrained values: compare through the oracle chain rule on raw parameters
     X = to_t(g["acq_X"]).to(DEV)
     for f in range(prob["L"]):
         for flag, tag in ((True, "train"), (False, "eval")):
             model.train(flag)
             mus, vs = model.predict_for_acquisition(X, f)
-            assert rel(mus, g[f"acq_mu_{f}_{tag}"]) < 1e-6, (f, tag)
-            assert rel(vs, g[f"acq_var_{f}_{tag}"]) < 1e-5, (f, tag)
+            assert rel(mus, g[f"acq_mu_{f}_{tag}"]) < 1e-6 * min(k, 50.0), (f, tag)
+            assert rel(vs, g[f"acq_var_{f}_{tag}"]) < 1e-5 * min(k, 10.0), (f, tag)
     model.train()
 
 
