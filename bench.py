@@ -133,8 +133,8 @@ def measure_gemm_variants(cfg, device, iters=20):
     A2 = rnd(Mp, Np)
     C = torch.empty(Mp, Np, dtype=torch.float64, device=device)
     avec, gmu, cgv, gv = rnd(Mp), rnd(Np), rnd(Np), rnd(Np)
-    p1 = torch.empty(nrb, Np, dtype=torch.float64, device=device)
-    p2 = torch.empty(nrb, Np, dtype=torch.float64, device=device)
+    p1 = torch.empty(2 * nrb, Np, dtype=torch.float64, device=device)
+    p2 = torch.empty(2 * nrb, Np, dtype=torch.float64, device=device)
     rdp = torch.empty(2 * (Np // 128), Mp, dtype=torch.float64, device=device)
     stream_out = Np * Mp * 8 >= (64 << 20)
     variants = [

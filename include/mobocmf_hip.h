@@ -238,9 +238,9 @@ int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64
 
 /* The same kernel with the epilogues the layer launches it with (tests, and bench.py's per-variant roofline):
  *   epi 0  plain store (dK = L^-T dA);
- *   epi 1  store + partial column statistics per 128-row block: colsq_part[rb][n] = sum_i C[i][n]^2 and (coldot_part
- *          non-NULL) coldot_part[rb][n] = sum_i avec[i] C[i][n]  over the rows i of block rb   (A = L^-1 K -> q, mean;
- *          C = U^T A -> r);
+ *   epi 1  store + partial column statistics, 2 * Mr / 128 partial rows of Nc entries each: sum_p colsq_part[p][n] =
+ *          sum_i C[i][n]^2 and (coldot_part non-NULL) sum_p coldot_part[p][n] = sum_i avec[i] C[i][n]   (A = L^-1 K -> q,
+ *          mean; C = U^T A -> r);
  *   epi 2  C[i][n] = alpha bscale[n] (A B)[i][n] + avec[i] gmu[n] - 2 Aaux[i][n] cgv[n]   (dA), and (rowdot_part
  *          non-NULL) rowdot_part[slice][i] = partial sums over 64-column slices of Aaux[i][n] gmu[n]   (da).
  * B is [Kd x Nc] (no transposed form).  stream_out: non-temporal stores of C.  Pointers an epilogue does not use: NULL. */

@@ -168,9 +168,9 @@ void carve_chain_fwd(Bump& b, const Dims& D, ChainWs& S) {
     S.klpart = b.take(D.Mp);
 }
 void carve_panel_fwd(Bump& b, const Dims& D, PanelFwd& S) {
-    S.qpart = b.take((int64_t)D.nrb * D.Np);
-    S.mupart = b.take((int64_t)D.nrb * D.Np);
-    S.rpart = b.take((int64_t)D.nrb * D.Np);
+    S.qpart = b.take((int64_t)2 * D.nrb * D.Np);      // two partial rows per 128-row block (gemm_f64.hip, EPI_COLSTATS)
+    S.mupart = b.take((int64_t)2 * D.nrb * D.Np);
+    S.rpart = b.take((int64_t)2 * D.nrb * D.Np);
 }
 void carve_chain_bwd_in(Bump& b, const Dims& D, ChainWs& S) {
     int64_t mm = (int64_t)D.Mp * D.Mp;
@@ -331,7 +331,7 @@ int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& 
     gc.Kreal = D.M;
     gc.stream_out = (desc->branch == 0 && Np * Mp * 8 >= ((int64_t)64 << 20)) ? 1 : 0;   // C is next read in backward
     TRY(launch_gemm(gc, false, 1, s));
-    TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, D.nrb, Np, D.N, P.knn, desc->branch, desc->min_var, P.q, P.r,
+    TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, 2 * D.nrb, Np, D.N, P.knn, desc->branch, desc->min_var, P.q, P.r,
                               P.varraw, mean, var, s));
     return MOBOCMF_OK;
 }

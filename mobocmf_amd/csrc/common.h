@@ -58,8 +58,8 @@ struct GemmArgs {
     const int32_t* skip_if_zero;   // device word: the whole launch is a no-op when it is 0 (rarely needed passes)
     // epilogues
     int epi;
-    double* colsq_part;    // EPI_COLSTATS: [Mr/TILE][Nc] partial column sums of C^2
-    double* coldot_part;   // EPI_COLSTATS: [Mr/TILE][Nc] partial column sums of avec[i]*C[i][n]   (may be null)
+    double* colsq_part;    // EPI_COLSTATS: [2*Mr/TILE][Nc] partial column sums of C^2 (two wavefront rows per row block)
+    double* coldot_part;   // EPI_COLSTATS: [2*Mr/TILE][Nc] partial column sums of avec[i]*C[i][n]   (may be null)
     const double* avec;    // EPI_COLSTATS / EPI_DA: length Mr
     const double* gmu;     // EPI_DA: length Nc
     const double* cgv;     // EPI_DA: length Nc

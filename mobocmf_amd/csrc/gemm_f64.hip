@@ -69,8 +69,6 @@ extern "C" int mobocmf_debug_set_stamps(unsigned long long* p) {
 template <bool B_T, bool TRI, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_ELEMS];   // [buf][A | B]
-    __shared__ double avs[EPI == EPI_STORE ? 1 : BM];          // avec of the row block (epilogues)
-    __shared__ double red[EPI == EPI_COLSTATS ? 4 * BN : 1];   // [2 stats][2 wr][128 cols]
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     STAMP(0);
     STAMP_ID();
@@ -235,10 +233,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 
     const int64_t nk = (k1 > k0) ? (k1 - k0) / BK : 0;
 #define KSTEP(KT) (rev ? nk - 1 - (KT) : (KT))   /* iteration -> K step of the tile */
-    // avec of this row block -> LDS (visible after the barrier below); the column-statistics epilogue only needs it for
-    // the a^T C partials
-    if ((EPI == EPI_DA || (EPI == EPI_COLSTATS && g.coldot_part)) && tid < BM) avs[tid] = g.avec[(int64_t)rb * BM + tid];
     if (nk > 0) stage(Ag, k0 + KSTEP(0) * BK, 0);
+
     // LDS-DMA data is ordered for other wavefronts' ds_reads only by the issuing wavefront's vmcnt wait followed by
     // a barrier; the waits are written out (hipcc adds them only when it sees the DMA in the same scheduling scope)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,15 +354,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // element loop compiles to one branch + load + s_waitcnt vmcnt(0) PER ELEMENT (64 dependent round trips, ~24 us per
     // epilogue -- the round-1 column-statistics epilogue did exactly that).
     STAMP(4 + 4 * part);      // main loop done
+
     // accumulator acc[mt][nt][r] of a lane: row = row0 + mt*32 + 4*r; column = col0 + COLOFF(nt).  NN: the lane's columns
     // come in adjacent pairs (nt = 2h, 2h+1 -> col0 + 32h, +1): 16-byte accesses; A B^T keeps one column per 16-lane group.
     const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;
     const int64_t col0 = cb * BN + wc * 64 + (B_T ? li : 2 * li);
     const int ccol = wc * 64 + (B_T ? li : 2 * li);            // the same inside the tile
 #define COLOFF(nt) (B_T ? (nt) * 16 : ((nt) >> 1) * 32 + ((nt) & 1))
-    const int arow = wr * 16 + lk;                             // row inside the block: + mt*32 + 4*r
     if (EPI == EPI_DA && !B_T) {
-        // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n];   optionally rd[row] = sum_n Aaux[row][n] * gmu[n]
+        // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n];   optionally rd[row] = sum_n Aaux[row][n] * gmu[n].
+        // No LDS, no workgroup barrier (see the column-statistics epilogue): avec comes by broadcast loads.  The Aaux tile
+        // is fetched one 16-row group at a time (all four at once would need 128 VGPRs next to the 128 accumulators).
         v2f64 gm[2], cg[2], cs[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -378,14 +376,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #pragma unroll
             for (int h = 0; h < 2; ++h) cs[h] = *(const v2f64*)(g.bscale + col0 + 32 * h);
         }
-        double* rdout = g.rowdot_part ? g.rowdot_part + ((int64_t)cb * 2 + wc) * g.Mr : nullptr;
+        // row dots: after the butterfly over li all 16 lanes of a lane group hold the sum of row (mt, r); lane li keeps the
+        // one with 4*mt + r == li -- one register for the wavefront's 16 x 4 row sums
+        double rdkeep = 0.0;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             v2f64 av[2][4];
             double ar[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ar[r] = avs[arow + mt * 32 + 4 * r];
+                ar[r] = g.avec[row0 + mt * 32 + 4 * r];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                     av[h][r] = *(const v2f64*)(g.Aaux + (row0 + mt * 32 + 4 * r) * g.ldc + col0 + 32 * h);
@@ -402,53 +402,108 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
                     *(v2f64*)(C + (row0 + mt * 32 + 4 * r) * g.ldc + col0 + 32 * h) = o;
                     rd += a[0] * gm[h][0] + a[1] * gm[h][1];
                 }
-                // the 16 lanes li of a lane group hold the same row, different columns: butterfly over li, then one lane
-                // per lane group writes this wavefront's 64-column slice
-                rd += __shfl_xor(rd, 1);
-                rd += __shfl_xor(rd, 2);
-                rd += __shfl_xor(rd, 4);
-                rd += __shfl_xor(rd, 8);
-                if (rdout && li == 0) rdout[row0 + mt * 32 + 4 * r] = rd;
+                if (g.rowdot_part) {
+                    rd += __shfl_xor(rd, 1);
+                    rd += __shfl_xor(rd, 2);
+                    rd += __shfl_xor(rd, 4);
+                    rd += __shfl_xor(rd, 8);
+                    if (li == 4 * mt + r) rdkeep = rd;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);      // one 16-row group at a time: bounded live ranges, no spills
         }
+        if (g.rowdot_part)      // lane li: row (mt, r) = (li >> 2, li & 3) of this wavefront's 64-column slice
+            g.rowdot_part[((int64_t)cb * 2 + wc) * g.Mr + row0 + (li >> 2) * 32 + 4 * (li & 3)] = rdkeep;
         STAMP(9 + part);
-        if (nparts == 2) __syncthreads();   // `avs` is rewritten at the top of the next part
         continue;
     }
-    double sq[4] = {0.0, 0.0, 0.0, 0.0}, dt[4] = {0.0, 0.0, 0.0, 0.0};
-#define STAT(v, nt, r)                                                                                      \
-    if (EPI == EPI_COLSTATS) {                                                                              \
-        sq[nt] += (v) * (v);                                                                                \
-        dt[nt] += ar[r] * (v);                                                                              \
+    if (EPI == EPI_COLSTATS) {
+        // Column statistics FIRST, the C stores last: a register reload from scratch (the epilogue's address arithmetic
+        // may spill a value) is a vector-memory operation, and its s_waitcnt vmcnt(0) would wait for every C store issued
+        // before it (measured: 17 us per tile at M = 1024 with the stores in front).
+        // Partial sums stay PER WAVEFRONT: per lane over its 16 rows, then across the wavefront's 4 lane groups (two
+        // shuffles); partial row 2*rb + wr of colsq_part / coldot_part.  No workgroup barrier: right after the main loop a
+        // wavefront may sit behind an MFMA burst of the co-resident workgroup, and a barrier here made all four wait for
+        // the unluckiest one (3.6 us of a 7 us epilogue, in-kernel stamps).
+        double sq[4] = {0.0, 0.0, 0.0, 0.0}, dt[4] = {0.0, 0.0, 0.0, 0.0};
+        const bool want_dot = g.coldot_part != nullptr;
+        double ar[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[mt][r] = 0.0;
+        if (want_dot) {      // 16 broadcast loads (L2 hits), all in flight together; no store is outstanding here
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ar[mt][r] = g.avec[row0 + mt * 32 + 4 * r];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = g.alpha * acc[mt][nt][r];
+                    sq[nt] += v * v;
+                    dt[nt] += ar[mt][r] * v;
+                }
+        if (part == 0) STAMP(11);      // sums done
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            sq[nt] += __shfl_xor(sq[nt], 16);
+            sq[nt] += __shfl_xor(sq[nt], 32);
+            if (want_dot) {
+                dt[nt] += __shfl_xor(dt[nt], 16);
+                dt[nt] += __shfl_xor(dt[nt], 32);
+            }
+        }
+        if (lk == 0) {
+            const int64_t prow = ((int64_t)rb * 2 + wr) * g.Nc + col0;
+            if (B_T) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    g.colsq_part[prow + COLOFF(nt)] = sq[nt];
+                    if (want_dot) g.coldot_part[prow + COLOFF(nt)] = dt[nt];
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    *(v2f64*)(g.colsq_part + prow + 32 * h) = (v2f64){sq[2 * h], sq[2 * h + 1]};
+                    if (want_dot) *(v2f64*)(g.coldot_part + prow + 32 * h) = (v2f64){dt[2 * h], dt[2 * h + 1]};
+                }
+            }
+        }
+        if (part == 0) STAMP(12);      // partials written
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // One running per-lane pointer walks the tile's rows (stride 4 rows inside a 16-row group, 32 rows between groups):
+    // precomputed row addresses cost 32 VGPRs on top of the 128 accumulators and spill -- and every reload from scratch
+    // between two stores is an s_waitcnt vmcnt(0), i.e. a full drain of the stores issued so far (~10 us per tile).
 #define STORE_TILE(ST, ST2, ACCUM)                                                                          \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                     \
-        double ar[4] = {0.0, 0.0, 0.0, 0.0};                                                                \
-        if (EPI == EPI_COLSTATS && g.coldot_part) {                                                         \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) ar[r] = avs[arow + mt * 32 + 4 * r];              \
-        }                                                                                                   \
-        if (B_T) {                                                                                          \
-            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                               \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
-                    double* cp = &C[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + COLOFF(nt)];                  \
-                    double v = g.alpha * acc[mt][nt][r];                                                    \
-                    if (ACCUM) v += *cp;                                                                    \
-                    ST(v, cp);                                                                              \
-                    STAT(v, nt, r)                                                                          \
+    {                                                                                                       \
+        double* cp = C + row0 * g.ldc + col0;                                                               \
+        const int64_t step4 = 4 * g.ldc, step_mt = 32 * g.ldc - 16 * g.ldc;                                 \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                 \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
+                if (B_T) {                                                                                  \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                     \
+                        double v = g.alpha * acc[mt][nt][r];                                                \
+                        if (ACCUM) v += cp[COLOFF(nt)];                                                     \
+                        ST(v, cp + COLOFF(nt));                                                             \
+                    }                                                                                       \
+                } else {                                                                                    \
+                    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                        \
+                        v2f64 v;                                                                            \
+                        v[0] = g.alpha * acc[mt][2 * h][r];                                                 \
+                        v[1] = g.alpha * acc[mt][2 * h + 1][r];                                             \
+                        if (ACCUM) v += *(const v2f64*)(cp + 32 * h);                                       \
+                        ST2(v, (v2f64*)(cp + 32 * h));                                                      \
+                    }                                                                                       \
                 }                                                                                           \
-        } else {                                                                                            \
-            _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                  \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
-                    v2f64* cp = (v2f64*)&C[(row0 + mt * 32 + 4 * r) * g.ldc + col0 + 32 * h];               \
-                    v2f64 v;                                                                                \
-                    v[0] = g.alpha * acc[mt][2 * h][r];                                                     \
-                    v[1] = g.alpha * acc[mt][2 * h + 1][r];                                                 \
-                    if (ACCUM) v += *cp;                                                                    \
-                    ST2(v, cp);                                                                             \
-                    STAT(v[0], 2 * h, r)                                                                    \
-                    STAT(v[1], 2 * h + 1, r)                                                                \
-                }                                                                                           \
+                cp += step4;                                                                                \
+            }                                                                                               \
+            cp += step_mt;                                                                                  \
         }                                                                                                   \
     }
 #define ST_PLAIN(v, p) (*(p) = (v))
@@ -457,30 +512,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     else if (g.stream_out) { STORE_TILE(ST_STREAM, ST_STREAM, 0) }
     else { STORE_TILE(ST_PLAIN, ST_PLAIN, 0) }
 #undef STORE_TILE
-#undef STAT
-    if (EPI == EPI_COLSTATS) {
-        // partial column sums over this tile's 128 rows: per lane over its 16 rows (above), then across the 4 lane groups
-        // of the wavefront (shuffles), then across the two row-wavefronts (LDS).
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            double s1 = sq[nt], s2 = dt[nt];
-            s1 += __shfl_xor(s1, 16);
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 16);
-            s2 += __shfl_xor(s2, 32);
-            if (lk == 0) {
-                red[(0 * 2 + wr) * BN + ccol + COLOFF(nt)] = s1;
-                red[(1 * 2 + wr) * BN + ccol + COLOFF(nt)] = s2;
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            g.colsq_part[(int64_t)rb * g.Nc + cb * BN + tid] = red[tid] + red[BN + tid];
-            if (g.coldot_part)
-                g.coldot_part[(int64_t)rb * g.Nc + cb * BN + tid] = red[2 * BN + tid] + red[3 * BN + tid];
-        }
-        if (nparts == 2) __syncthreads();   // `red` / `avs` are rewritten by the next part
-    }
+    if (part == 0) STAMP(13);          // C stores issued
+
 #undef COLOFF
     STAMP(9 + part);          // epilogue issued
   }   // parts
@@ -757,8 +790,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 s0 += red[(0 * 16 + q) * 17 + tx];
                 s1 += red[(1 * 16 + q) * 17 + tx];
             }
-            g.colsq_part[(int64_t)rb * g.Nc + col] = s0;
-            if (g.coldot_part) g.coldot_part[(int64_t)rb * g.Nc + col] = s1;
+            // same partial layout as the tiled kernel (two rows per 128-row block): the second one is zero here
+            g.colsq_part[(int64_t)(2 * rb) * g.Nc + col] = s0;
+            g.colsq_part[(int64_t)(2 * rb + 1) * g.Nc + col] = 0.0;
+            if (g.coldot_part) {
+                g.coldot_part[(int64_t)(2 * rb) * g.Nc + col] = s1;
+                g.coldot_part[(int64_t)(2 * rb + 1) * g.Nc + col] = 0.0;
+            }
         }
     }
 }

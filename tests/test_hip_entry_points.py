@@ -38,8 +38,8 @@ def test_gemm_epilogue_variants_match_torch(Mp, Np):
         # column statistics (+ non-temporal stores)
         for so in (False, True):
             C.fill_(float("nan"))
-            p1 = torch.full((nrb, Np), float("nan"), dtype=torch.float64, device=DEV)
-            p2 = torch.full((nrb, Np), float("nan"), dtype=torch.float64, device=DEV)
+            p1 = torch.full((2 * nrb, Np), float("nan"), dtype=torch.float64, device=DEV)      # two partial rows per block
+            p2 = torch.full((2 * nrb, Np), float("nan"), dtype=torch.float64, device=DEV)
             F.gemm_f64_epilogue(T, B, C, tri, 1, stream_out=so, colsq_part=p1, coldot_part=p2, avec=avec)
             assert rel(C, ref) < 1e-12
             assert rel(p1.sum(0), (ref * ref).sum(0)) < 1e-12

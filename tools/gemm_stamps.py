@@ -23,8 +23,8 @@ A = torch.tril(torch.randn(M, M, dtype=torch.float64, device=dev))
 B = torch.randn(M, N, dtype=torch.float64, device=dev)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)
 avec = torch.randn(M, dtype=torch.float64, device=dev)
-p1 = torch.empty(M // 128, N, dtype=torch.float64, device=dev)
-p2 = torch.empty(M // 128, N, dtype=torch.float64, device=dev)
+p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
+p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
 nwg = 4096
 stamps = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
 for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("dense store", 0, 0)):
@@ -56,6 +56,11 @@ for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("dense 
         epi_t = (s[sel, 9 + part] - s[sel, 4 + 4 * part]) / 100.0
         print("   part %d: prologue %.2f | main loop %.2f (min %.2f max %.2f) | epilogue issue %.2f  [us, median]" %
               (part, np.median(pro), np.median(loop), loop.min(), loop.max(), np.median(epi_t)))
+        if part == 0 and (s[sel, 13] > 0).any():
+            base = s[sel, 4]
+            f = lambda i: np.median((s[sel, i] - base) / 100.0) if (s[sel, i] > 0).any() else float("nan")
+            print("           epilogue of part 0 from the end of the main loop: sums %.2f | partials %.2f | C stores issued %.2f us" %
+                  (f(11), f(12), f(13)))
         if (s[sel, 2 + 4 * part] > 0).any():
             d0 = (s[sel, 2 + 4 * part] - s[sel, 1 + 4 * part]) / 100.0
             d1 = (s[sel, 3 + 4 * part] - s[sel, 2 + 4 * part]) / 100.0

@@ -20,14 +20,16 @@ Lw, Up = torch.tril(rnd(M, M)), torch.triu(rnd(M, M))
 B, A2 = rnd(M, N), rnd(M, N)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)
 avec, gmu, cgv, gv = rnd(M), rnd(N), rnd(N), rnd(N)
-p1 = torch.empty(M // 128, N, dtype=torch.float64, device=dev)
-p2 = torch.empty(M // 128, N, dtype=torch.float64, device=dev)
+p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
+p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
 rdp = torch.empty(2 * (N // 128), M, dtype=torch.float64, device=dev)
 
 
 def run(tri, epi, so):
     T = Lw if tri == 1 else Up
-    if epi == 0:
+    if epi == 3:      # column statistics without the a^T C partials (the C = U^T A launch)
+        F.gemm_f64_epilogue(T, B, C, tri, 1, stream_out=so, colsq_part=p1, avec=avec)
+    elif epi == 0:
         F.gemm_f64_epilogue(T, B, C, tri, 0, stream_out=so)
     elif epi == 1:
         F.gemm_f64_epilogue(T, B, C, tri, 1, stream_out=so, colsq_part=p1, coldot_part=p2, avec=avec)
@@ -49,7 +51,7 @@ def timeit(fn, iters=20):
 for _ in range(400):      # ~0.3 s of load: let the clock settle
     run(1, 0, False)
 torch.cuda.synchronize()
-combos = [(t, e, s) for t in (1, 2) for e in (0, 1, 2) for s in ((False, True) if e < 2 else (False,))]
+combos = [(t, e, s) for t in (1, 2) for e in (0, 1, 3, 2) for s in ((False, True) if e != 2 else (False,))]
 res = {c: [] for c in combos}
 for rnd_i in range(3):
     for c in combos:
@@ -58,7 +60,7 @@ fl = float(M) * M * N
 for (t, e, s), v in res.items():
     best = min(v)
     print("%s %-8s %-3s: %s ms  -> best %.3f ms = %.1f TFLOP/s = %.3f of 78.6" %
-          ("lower" if t == 1 else "upper", ("store", "colstats", "dA")[e], "nt" if s else "", " ".join("%.3f" % x for x in v),
+          ("lower" if t == 1 else "upper", ("store", "colstats", "dA", "colsq")[e], "nt" if s else "", " ".join("%.3f" % x for x in v),
            best, fl / best / 1e9, fl / best / 1e9 / 78.6))
 D = rnd(M, M)
 for _ in range(3):
