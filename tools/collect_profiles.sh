@@ -1,22 +1,36 @@
 #!/bin/bash
-# Round artefacts for profiles/ (run on the GPU box through gpurun): bench line, rocprofv3 kernel trace + stats of the
-# same command, PMC traffic of the dominant kernel, the other configurations.  Output: gpurun_out/final/
+# Round artefacts for profiles/ (run on the GPU box through gpurun): bench line, rocprofv3 kernel trace + stats of a
+# single-stream run of the same step (no roofline launches mixed in), the GEMM variants in isolation under rocprofv3,
+# PMC traffic of the dominant kernel, the other configurations.  Output: gpurun_out/final/
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final
 rm -rf $O && mkdir -p $O   # (also delete the LOCAL gpurun_out/final before a new call: merged files accumulate)
 python bench.py > $O/bench_C3.json 2> $O/bench_C3.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_C3_profiled_run.json 2> $O/prof.err
-echo "kernel trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 5 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline > $O/bench_C3_profiled_run.json 2> $O/prof.err
+python tools/summarize_profile.py $(ls $O/prof/*/*kernel_trace.csv | head -1) $O/bench_C3_kernel_summary.md > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- python3 bench.py --surrogates 1 --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-roofline > $O/bench_1surrogate_profiled_run.json 2> $O/prof1.err
+python tools/summarize_profile.py $(ls $O/prof1/*/*kernel_trace.csv | head -1) $O/single_stream_kernel_summary.md > /dev/null
+python tools/step_timeline.py $(ls $O/prof1/*/*kernel_trace.csv | head -1) > $O/single_stream_step_timeline.txt
+echo "kernel traces done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rk -- python3 tools/gemm_variants.py > $O/gemm_variants_under_rocprof.txt 2>&1
+python tools/summarize_profile.py $(ls $O/rk/*/*kernel_trace.csv | head -1) $O/gemm_variants_kernel_summary.md > /dev/null
+python tools/gemm_variants.py > $O/gemm_variants.txt 2>&1
+python tools/gemm_variants.py 1024 65536 > $O/gemm_variants_M1024.txt 2>&1
+python tools/gemm_variants.py 512 8192 > $O/gemm_variants_layer0.txt 2>&1
+echo "variants done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 tools/pmc_gemm.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 tools/pmc_gemm.py > /dev/null 2>&1
+python tools/pmc_summarize.py $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) $O/pmc_gemm.json > /dev/null
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python3 tools/pmc_gemm.py > /dev/null 2>&1 || true
 echo "pmc done"
-for a in "--config C1" "--config C2" "--config C5" "--config C4 --surrogates 1 --steps 3 --warmup 1" "--surrogates 1" "--config C2 --eager"; do
-  python bench.py $a --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a', '|', round(d['value'],1), 'steps/s |', round(d['ms_per_step'],3), 'ms per bench step |', d['config']['surrogates_per_gpu'], 'surrogates')"
+for a in "--config C1" "--config C2" "--config C5" "--config C4 --surrogates 1 --steps 3 --warmup 1 --repeats 1" "--surrogates 1" "--config C2 --eager" "--launch"; do
+  python bench.py $a --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a', '|', round(d['value'],1), 'steps/s |', round(d['ms_per_step'],3), 'ms per bench step |', d['config']['surrogates_per_gpu'], 'surrogates | repeats', [round(v,1) for v in d['repeat_values']])"
 done > $O/other_configs.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/rk -- python3 tools/gemm_bench.py > $O/gemm_bench.txt 2>&1   # roofline kernel in isolation: stats must agree with the HIP-event time
 python tools/acq_bench.py 50 > $O/acq_bench.txt 2>&1
 python tools/cond_bench.py 400 > $O/cond_bench.txt 2>&1
 python tools/size_sweep.py > $O/size_sweep.txt 2>&1
+./tools/mfma_peak > $O/mfma_peak.txt 2>&1 || true
+rm -rf $O/prof/*/*agent_info.csv $O/prof1/*/*agent_info.csv
 du -sh $O

@@ -1,4 +1,5 @@
-"""Runs only the dominant kernel (A = L^-1 K_mn, 512 x 65536 x 512 lower-triangular) a few times: used under
+"""Runs only the dominant kernel of the step -- A = L^-1 K_mn with the column-statistics epilogue, 512 x 65536 x 512
+lower-triangular, launched exactly as mobocmf_layer_forward launches it -- a few times: used under
 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) to measure its HBM traffic per launch."""
 import os
 import sys
@@ -13,6 +14,9 @@ M, N = 512, 65536
 A = torch.tril(torch.randn(M, M, dtype=torch.float64, device=dev))
 B = torch.randn(M, N, dtype=torch.float64, device=dev)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)
+avec = torch.randn(M, dtype=torch.float64, device=dev)
+p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
+p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
 for _ in range(5):
-    F.gemm_f64(A, B, C, tri=1)
+    F.gemm_f64_epilogue(A, B, C, 1, 1, colsq_part=p1, coldot_part=p2, avec=avec)
 torch.cuda.synchronize()
