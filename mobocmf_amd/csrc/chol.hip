@@ -24,6 +24,17 @@ __device__ __forceinline__ double bcast(double v, int src) {
 // wavefront's LDS traffic is program-ordered.
 typedef double v2f64c __attribute__((ext_vector_type(2)));
 
+// 1 / sqrt(a): v_rsq_f64 seed + two Newton steps (the IEEE sqrt + divide pair is ~60 dependent instructions on the pivot
+// chain of every elimination step); relative error ~1 ulp, a <= 0 or NaN gives inf / NaN as before (the caller tests a).
+__device__ __forceinline__ double rsqrt_nr(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    y = y * (1.5 - (0.5 * a) * y * y);
+    // last step in residual form (fused): e = 1 - a y^2 is exact to one rounding, so y + (y/2) e is within ~1 ulp
+    const double t = a * y;
+    const double e = __builtin_fma(-t, y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
+}
+
 // a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c]; LT[j][i] = L[i][j] (0 above the
 // diagonal), rd[j] = 1 / L[j][j].  Returns the first failed pivot (1-based) or 0.
 __device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd, double& myrd) {
@@ -35,7 +46,7 @@ __device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*L
     {
         const double a00 = bcast(a[0], 0);
         if (!(a00 > 0.0)) fail = 1;
-        rinv = 1.0 / sqrt(a00);
+        rinv = rsqrt_nr(a00);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -49,7 +60,7 @@ __device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*L
             a[j + 1] -= lij * LT[j][j + 1];       // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
             const double an = bcast(a[j + 1], j + 1);
             if (!(an > 0.0) && fail == 0) fail = j + 2;
-            rinv_next = 1.0 / sqrt(an);
+            rinv_next = rsqrt_nr(an);
         }
         if ((j + 2) & 1) {
             if (j + 2 < NB) a[j + 2] -= lij * LT[j][j + 2];
@@ -157,6 +168,113 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, 
     }
 }
 
+// Two wavefronts per workgroup: wavefront 0 factorises the 64 x 64 diagonal block, wavefront 1 runs the right-looking
+// triangular solve of its 64-row block TWO elimination steps behind (step t needs column t of L and 1 / L_tt only, which
+// wavefront 0 publishes in LDS in its step t; one workgroup barrier per step hands them over).  The panel's critical path
+// is then the factorisation alone instead of factorisation + solve back to back.
+// Both roles are the SAME step -- scale the pivot column entry, eliminate it from the columns to the right with the
+// multipliers L[k][j] read from LDS -- so they share one unrolled loop: wavefront 1 keeps its row shifted by two columns
+// (v[c + 2]) and reads the LDS image through a pointer shifted by two rows and two columns, which makes its step t the
+// loop's iteration t + 2 with the same register indices (and the 16-byte alignment of the multiplier pairs intact).  Two
+// role-specific unrolled loops in one kernel made hipcc spill ~2000 registers.
+// Block 0 solves against the identity: its wavefront 1 ends with row i of L^-T, i.e. column i of L^-1 (the inverse of the
+// diagonal block that the blocked triangular inverse needs), written transposed.
+// The loop body is STRAIGHT-LINE code: role differences are selects and pointer choices, never branches.  With basic blocks
+// inside the unrolled loop LLVM sinks each update v[k] -= m * L[k][j] down to the block that finally uses v[k], i.e. turns
+// the right-looking elimination into a left-looking one that keeps every multiplier ever loaded in registers (2000 spills).
+// Iterations in which a role has nothing to do (wavefront 1 in the first two, wavefront 0 in the last two) run on zero
+// padding: the LDS image and the reciprocal-pivot vector carry two extra rows / entries on either side.
+#define P2_LAG 2
+__global__ __launch_bounds__(128) void potrf_panel2_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
+                                                           InfoZ infoz, int64_t zs) {
+    __shared__ __attribute__((aligned(16))) double LTp[NB + 2 * P2_LAG + 1][NB];      // rows -2 .. NB + 2 of the image
+    __shared__ double rdp[NB + 2 * P2_LAG];
+    __shared__ double sink[NB + 2 * P2_LAG];                                           // wavefront 1's "publications"
+    __shared__ __attribute__((aligned(16))) double sinkrow[NB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar role
+    const int bi = blockIdx.x;
+    A += blockIdx.y * zs; Dinv += blockIdx.y * zs; Ld += blockIdx.y * zs;      // layer batching
+    int32_t* info = infoz.p[blockIdx.y];
+    const int64_t j0 = (int64_t)jb * NB;
+    const int lag = wave * P2_LAG;
+    double (*LT)[NB] = LTp + P2_LAG;
+    double* rd = rdp + P2_LAG;
+    // zero padding read by the idle iterations: rows -2, -1 (wavefront 1's first two) and NB .. NB + 2 (wavefront 0's last two)
+    for (int e = threadIdx.x; e < P2_LAG * NB; e += 128) (&LTp[0][0])[e] = 0.0;
+    for (int e = threadIdx.x; e < (P2_LAG + 1) * NB; e += 128) (&LT[NB][0])[e] = 0.0;
+    if (threadIdx.x < P2_LAG) rdp[threadIdx.x] = 0.0;
+    double v[NB + P2_LAG];
+    double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;      // wavefront 1: its block's row
+    {
+        const bool ident = wave == 1 && bi == 0;
+        const double* src = wave == 0 ? A + (j0 + lane) * ld + j0 : prow;
+#pragma unroll
+        for (int c = 0; c < NB + P2_LAG; ++c) v[c] = 0.0;
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) v[c] = src[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) v[c + P2_LAG] = ident ? (c == lane ? 1.0 : 0.0) : src[c];
+        }
+    }
+    const double* LTw = &LT[0][0] - lag * NB - lag;      // LTw[i*NB + k] = LT[i - lag][k - lag]
+    const double* rdw = rd - lag;
+    double* pubrow = wave == 0 ? &LT[0][0] + lane : sinkrow + lane;      // + i*NB for wavefront 0 (stride 0 for the sink)
+    const int pubstride = wave == 0 ? NB : 0;
+    double* pubrd = wave == 0 ? rd : sink + P2_LAG;
+    int fail = 0;
+    double rinv = rsqrt_nr(bcast(v[0], 0));
+    if (!(bcast(v[0], 0) > 0.0)) fail = 1;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NB + P2_LAG; ++i) {
+        // both roles take the reciprocal pivot from LDS (wavefront 0 reads back what it has just published: ~100 cycles on
+        // its pivot chain, but a role-dependent source compiles to a branch, and any branch in this loop brings the
+        // sinking described above back)
+        pubrd[i] = rinv;
+        const double r = rdw[i];
+        const double m = v[i] * r;          // factorisation: L[lane][i];  solve: X[lane][i - lag]
+        v[i] = m;
+        pubrow[i * pubstride] = lane >= i ? m : 0.0;      // column i of L (wavefront 1: into the sink)
+        if (i + 1 < NB + P2_LAG) {
+            v[i + 1] -= m * LTw[i * NB + i + 1];
+            // the next pivot's reciprocal square root starts now and runs under the updates below (wavefront 1 computes
+            // one too and never uses it: a branch here would cost more than the ~20 instructions)
+            const double an = bcast(v[i + 1], (i + 1) & 63);
+            fail = (fail == 0 && i + 1 < NB && !(an > 0.0)) ? i + 2 : fail;
+            rinv = rsqrt_nr(an);
+        }
+        if ((i + 2) & 1) {
+            if (i + 2 < NB + P2_LAG) v[i + 2] -= m * LTw[i * NB + i + 2];
+        }
+#pragma unroll
+        for (int k = (i + 3) & ~1; k + 1 < NB + P2_LAG; k += 2) {
+            const v2f64c c = *(const v2f64c*)&LTw[i * NB + k];
+            v[k] -= m * c[0];
+            v[k + 1] -= m * c[1];
+        }
+        __syncthreads();          // iteration i's column of L and reciprocal pivot are in LDS for iteration i + lag
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wave == 0) {
+        if (bi == 0) {
+            double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? v[c] : 0.0;
+            if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
+        }
+    } else if (bi == 0) {      // v[k + lag] = L^-T[lane][k] = L^-1[k][lane]: store transposed (one coalesced row per k)
+        double* inv = Dinv + (int64_t)jb * NB * NB;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) inv[k * NB + lane] = (k >= lane) ? v[k + P2_LAG] : 0.0;
+    } else {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) prow[c] = v[c + P2_LAG];
+    }
+}
+
 // ---- padded variants (NACT = 16: rows/columns >= NACT of the block are identity padding and are left alone; only
 // this small instantiation is used -- 32 and 48 made hipcc spill, and so did a templated <64>, so the full block keeps
 // the plain routines above).
@@ -173,7 +291,7 @@ __device__ __forceinline__ int chol64_pad_rows(double (&a)[NB], int lane, double
     {
         const double a00 = bcast(a[0], 0);
         if (!(a00 > 0.0)) fail = 1;
-        rinv = 1.0 / sqrt(a00);
+        rinv = rsqrt_nr(a00);
     }
 #pragma unroll
     for (int j = 0; j < NACT; ++j) {
@@ -186,7 +304,7 @@ __device__ __forceinline__ int chol64_pad_rows(double (&a)[NB], int lane, double
             a[j + 1] -= lij * LT[j][j + 1];       // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
             const double an = bcast(a[j + 1], j + 1);
             if (!(an > 0.0) && fail == 0) fail = j + 2;
-            rinv_next = 1.0 / sqrt(an);
+            rinv_next = rsqrt_nr(an);
         }
         if ((j + 2) & 1) {
             if (j + 2 < NACT) a[j + 2] -= lij * LT[j][j + 2];
@@ -379,7 +497,7 @@ int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* L
         nact = nact >= NB ? NB : (nact + 15) & ~15;
         const dim3 grid(nreal - jb, nz);          // blocks below the real rows are zero in these columns and stay zero
         if (nact == 16) hipLaunchKernelGGL(potrf_panel_pad_kernel<16>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
-        else hipLaunchKernelGGL(potrf_panel_kernel, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
+        else hipLaunchKernelGGL(potrf_panel2_kernel, grid, dim3(128), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
         int nt = nreal - jb - 1;
         if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt, nz), dim3(256), 0, s, A, ld, jb, zs);
     }
