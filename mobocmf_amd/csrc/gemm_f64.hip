@@ -35,6 +35,40 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 #define BK 16
 #define TILE_ELEMS (BM * BK)   // 2048 doubles = 16 KiB per operand tile
 
+// Cross-lane sums without the LDS crossbar (ds_bpermute round trips): DPP moves inside a 16-lane row, permlane swaps across
+// rows.  row16_sum: every lane ends with the sum over its row of 16 lanes (quad butterflies, then the mirrored half, then
+// the mirrored row).  rows4_sum: every lane ends with the sum over the 4 lanes {l mod 16 + 16 r} (v_permlane16_swap pairs
+// odd with even rows, v_permlane32_swap the two halves: fed the same register twice they yield the two butterfly operands).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);      // row_half_mirror
+    v += dpp_mov<0x140>(v);      // row_mirror
+    return v;
+}
+__device__ __forceinline__ double rows4_sum(double v) {
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    return v;
+}
+
 __device__ __forceinline__ void glds16(const double* gsrc, double* lds_wave_base) {
     // 64 lanes x 16 B: lane l lands at lds_wave_base + 16*l bytes
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -403,10 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
                     rd += a[0] * gm[h][0] + a[1] * gm[h][1];
                 }
                 if (g.rowdot_part) {
-                    rd += __shfl_xor(rd, 1);
-                    rd += __shfl_xor(rd, 2);
-                    rd += __shfl_xor(rd, 4);
-                    rd += __shfl_xor(rd, 8);
+                    rd = row16_sum(rd);
                     if (li == 4 * mt + r) rdkeep = rd;
                 }
             }
@@ -451,12 +482,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         if (part == 0) STAMP(11);      // sums done
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            sq[nt] += __shfl_xor(sq[nt], 16);
-            sq[nt] += __shfl_xor(sq[nt], 32);
-            if (want_dot) {
-                dt[nt] += __shfl_xor(dt[nt], 16);
-                dt[nt] += __shfl_xor(dt[nt], 32);
-            }
+            sq[nt] = rows4_sum(sq[nt]);
+            if (want_dot) dt[nt] = rows4_sum(dt[nt]);
         }
         if (lk == 0) {
             const int64_t prow = ((int64_t)rb * 2 + wr) * g.Nc + col0;
