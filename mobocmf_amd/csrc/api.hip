@@ -145,8 +145,10 @@ struct ChainWs {
     int64_t slab_elems;
 };
 
-struct PanelSaved { double *K, *A, *C, *knn, *q, *r, *varraw; };
-struct PanelFwd { double *qpart, *mupart, *rpart; };
+// K_mn is dead once A = L^-1 K_mn exists (the Gram backward recomputes its exponentials from x, f, Z~): it lives in the
+// forward SCRATCH, not in the state kept for backward -- one M x N' panel less per layer (268 MB at C3, 8.6 GB at C4)
+struct PanelSaved { double *A, *C, *knn, *q, *r, *varraw; };
+struct PanelFwd { double *K, *qpart, *mupart, *rpart; };
 struct PanelBwd { double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *dapart, *hyp_part, *df_part, *dzf_part, *dx_part; int64_t slab_elems; };
 
 void carve_chain_state(Bump& b, const Dims& D, ChainWs& S) {
@@ -156,7 +158,7 @@ void carve_chain_state(Bump& b, const Dims& D, ChainWs& S) {
 }
 void carve_panel_saved(Bump& b, const Dims& D, PanelSaved& S) {
     int64_t mn = (int64_t)D.Mp * D.Np;
-    S.K = b.take(mn); S.A = b.take(mn); S.C = b.take(mn);
+    S.A = b.take(mn); S.C = b.take(mn);
     S.knn = b.take(D.Np); S.q = b.take(D.Np); S.r = b.take(D.Np); S.varraw = b.take(D.Np);
 }
 void carve_chain_fwd(Bump& b, const Dims& D, ChainWs& S) {
@@ -168,6 +170,7 @@ void carve_chain_fwd(Bump& b, const Dims& D, ChainWs& S) {
     S.klpart = b.take(D.Mp);
 }
 void carve_panel_fwd(Bump& b, const Dims& D, PanelFwd& S) {
+    S.K = b.take((int64_t)D.Mp * D.Np);
     S.qpart = b.take((int64_t)2 * D.nrb * D.Np);      // two partial rows per 128-row block (gemm_f64.hip, EPI_COLSTATS)
     S.mupart = b.take((int64_t)2 * D.nrb * D.Np);
     S.rpart = b.take((int64_t)2 * D.nrb * D.Np);
@@ -320,9 +323,9 @@ int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& 
     GramArgs g = {};
     g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
     g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase; g.jitter = desc->jitter;
-    g.K = P.K; g.ldk = Np; g.Np = Np; g.knn = P.knn; g.is_kmm = 0;
+    g.K = F.K; g.ldk = Np; g.Np = Np; g.knn = P.knn; g.is_kmm = 0;
     TRY(launch_gram_fwd(g, s));
-    GemmArgs ga = gemm_args(c.Linv, Mp, P.K, Np, P.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
+    GemmArgs ga = gemm_args(c.Linv, Mp, F.K, Np, P.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
     ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = c.a;
     ga.Kreal = D.M;      // rows >= M of K_mn (and of A, C, dA below) are zero padding
     TRY(launch_gemm(ga, false, 1, s));
