@@ -8,11 +8,14 @@ step on the MI355X path -- the flow of examples/example_acquisition_mfdgp_toy_2d
     python examples/bo_iteration_toy2d.py [--epochs 300] [--seed 0]
 """
 import argparse
+import faulthandler
 import os
 import sys
 import time
 
 import numpy as np
+
+faulthandler.enable()      # a native crash leaves the Python stack on stderr
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -11,12 +11,15 @@ matplotlib is importable.  This is configuration C1 of SURVEY 8 (the reference's
     python examples/example_acquisition_mfdgp_forrester.py --scale 0.02    # 2 % of every schedule (smoke run)
 """
 import argparse
+import faulthandler
 import os
 import sys
 import tempfile
 import time
 
 import numpy as np
+
+faulthandler.enable()      # a native crash leaves the Python stack on stderr
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
