@@ -159,6 +159,18 @@ int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* 
 int mobocmf_gram_forward(int32_t kind, int32_t d, const double* x1, const double* f1, int64_t n1, const double* x2,
                          const double* f2, int64_t n2, const double* hyp, double* K, int64_t ldk, mobocmf_stream_t stream);
 
+/* One random-Fourier-feature function sample of a layer evaluated at n points (mfdgp_hidden_layer.py:326-337, :402-444; the
+ * Pareto-grid evaluation of moop.py:232-272), without materialising the F x n feature matrix:
+ *   kind 0:  out[i] = sum_j theta[j] s0 cos(W1[j].x_i + b1[j])
+ *   kind 1:  out[i] = sum_j theta[j] s0 fprev[i] cos(W1[j].x_i + b1[j]) + theta[F+j] s1 cos(W1[j].x_i + Wf[j] fprev[i] + b1[j])
+ *                          + theta[2F+j] s2 cos(W2[j].x_i + b2[j])
+ * x [n x d], W1 / W2 [F x d], b1 / b2 / Wf [F], theta [F] or [3F]; fprev = the previous layer's sample at the same points
+ * (the layer recursion is one call per layer).  s0 = sqrt(2 alpha / F) (kind 0) resp. sqrt(2 a1 nu / F), s1 = sqrt(2 a1 af / F),
+ * s2 = sqrt(2 a2 / F). */
+int mobocmf_rff_eval(int32_t kind, int32_t d, int32_t F, int64_t n, const double* x, const double* fprev, const double* W1,
+                     const double* b1, const double* Wf, const double* W2, const double* b2, const double* theta, double s0,
+                     double s1, double s2, double* out, mobocmf_stream_t stream);
+
 /* f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n],  n < n_out  (mfdgp_hidden_layer.py:263-274). */
 int mobocmf_propagate_forward(const double* mean, const double* var, const double* eps, double* f_out, int64_t n_out,
                               int32_t div, mobocmf_stream_t stream);

@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
 objs=""
 pids=""
-for f in gemm_f64 chol gram elementwise api; do
+for f in gemm_f64 chol gram elementwise rff api; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/mobocmf_hip.h -nt $f.o ]; then
     rm -f $f.o                      # a failed compile must not leave a stale object for the link step
     $HIPCC $FLAGS -c $f.hip -o $f.o &

@@ -872,6 +872,26 @@ def gram(kind, x1, f1, x2, f2, hyp):
     return K[:n1]
 
 
+def rff_eval(kind, x, fprev, W1, b1, Wf, W2, b2, theta, s0, s1=0.0, s2=0.0):
+    """One RFF function sample of a layer at the rows of ``x`` (n, d) on the GPU (mobocmf_rff_eval); ``fprev`` (n,) = the
+    previous layer's sample at the same rows (kind 1).  No autograd."""
+    lib = _lib.require_device()
+    with torch.no_grad():
+        x, fprev, W1, b1, Wf, W2, b2, theta = (_prep(None if t is None else t.detach().reshape(t.shape))
+                                               for t in (x, fprev, W1, b1, Wf, W2, b2, theta))
+        n, d = x.shape
+        Fn = W1.shape[0]
+        if W1.shape[1] != d or b1.numel() != Fn or theta.numel() != (Fn if kind == 0 else 3 * Fn):
+            raise _lib.MobocmfError("rff_eval: shape mismatch")
+        if kind == 1 and (fprev.numel() != n or Wf.numel() != Fn or tuple(W2.shape) != (Fn, d) or b2.numel() != Fn):
+            raise _lib.MobocmfError("rff_eval: shape mismatch (layer >= 1 operands)")
+        out = _empty(n, device=x.device)
+        _lib.check(lib.mobocmf_rff_eval(kind, d, Fn, n, _ptr(x), _ptr(fprev), _ptr(W1), _ptr(b1), _ptr(Wf), _ptr(W2),
+                                        _ptr(b2), _ptr(theta), float(s0), float(s1), float(s2), _ptr(out), _stream()),
+                   "mobocmf_rff_eval")
+    return out
+
+
 def set_tuning(small_gemm_max=0, small_panel_max=0):
     """Kernel-selection thresholds of the library (size sweeps); 0 leaves a threshold unchanged."""
     _lib.check(_lib.load().mobocmf_set_tuning(int(small_gemm_max), int(small_panel_max)), "mobocmf_set_tuning")

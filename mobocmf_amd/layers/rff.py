@@ -8,9 +8,10 @@ outputscale a1*af, sharing W_x1 and b_x1 with the first block, as the reference 
 Posterior weights given q(u) = N(m, S) at the inducing inputs:  A = Phi Phi^T + s2 I,
 theta ~ N( A^-1 Phi m ,  s2 A^-1 + A^-1 Phi S Phi^T A^-1 ), drawn by Matheron's rule with M x M algebra.
 
-Host-side float64 torch: F x F factorisations on the CPU, not part of the ELBO hot path.  The returned callables take
-a numpy array (n, d) or (d,), like the reference's, and recurse through the previous layer's sample; large batches (the
-Pareto grid of MOOP, 1000 d^2 rows) are evaluated on the model's GPU with library ops, single points on the host.
+The weights are drawn on the host in float64 (M x M algebra, not part of the ELBO hot path).  The returned callables take a
+numpy array (n, d) or (d,), like the reference's, and recurse through the previous layer's sample; large batches (the
+Pareto grid of MOOP, 1000 d^2 rows) are evaluated on the model's GPU by the HIP kernel ``mobocmf_rff_eval`` (one launch per
+layer, the F x n feature matrix never materialised), single points and gradients on the host.
 """
 import math
 
@@ -65,14 +66,24 @@ class _OnDevice:
         return self._t[dev]
 
 
-def _as_callable(feature_fn, theta, prev, device=None):
+def _as_callable(feature_fn, theta, prev, device=None, kernel_args=None):
     """f(x, gradient=False): numpy in, numpy out -- (n,) values, or the (d,) gradient for a single point.
-    Single points (the SLSQP refinements) stay on the host; grids of >= GRID_ROWS_ON_DEVICE rows run on ``device``."""
+    Single points (the SLSQP refinements) stay on the host; grids of >= GRID_ROWS_ON_DEVICE rows run on ``device`` through
+    the HIP kernel (``kernel_args``: kind, the feature tensors and the three scale factors)."""
     th = _OnDevice(theta=theta)
 
     def evaluate(xt):
         f_prev = prev._torch(xt) if prev is not None else None
         return th.on(xt.device)["theta"] @ feature_fn(xt, f_prev)
+
+    def evaluate_device(xd):
+        """xd (n, d) on the GPU -> the sample's values there (layer recursion: the previous sample first)."""
+        from .. import functional as F
+        kind, P, scales = kernel_args
+        p = P.on(xd.device)
+        f_prev = prev._device(xd) if prev is not None else None
+        return F.rff_eval(kind, xd, f_prev, p["W1"], p["b1"].reshape(-1), p.get("Wf"), p.get("W2"),
+                          None if "b2" not in p else p["b2"].reshape(-1), th.on(xd.device)["theta"], *scales)
 
     def wrapper(x, gradient=False):
         xt = torch.as_tensor(np.asarray(x), dtype=torch.float64)
@@ -84,11 +95,12 @@ def _as_callable(feature_fn, theta, prev, device=None):
             (g,) = torch.autograd.grad(evaluate(xt).sum(), xt)
             return g[0].numpy()
         with torch.no_grad():
-            if device is not None and xt.shape[0] >= GRID_ROWS_ON_DEVICE:
-                return evaluate(xt.to(device)).cpu().numpy()
+            if device is not None and kernel_args is not None and xt.shape[0] >= GRID_ROWS_ON_DEVICE:
+                return evaluate_device(xt.to(device).contiguous()).cpu().numpy()
             return evaluate(xt).numpy()
 
     wrapper._torch = evaluate
+    wrapper._device = evaluate_device
     return wrapper
 
 
@@ -106,19 +118,20 @@ def _hypers(layer):
 
 
 def _draw_features(h, d, F, gen, layer0):
+    """Returns (feature function for host torch, kernel_args = (kind, tensors, (s0, s1, s2)) for mobocmf_rff_eval)."""
     rn = lambda *s: torch.randn(*s, dtype=torch.float64, generator=gen)
     ru = lambda *s: 2.0 * math.pi * torch.rand(*s, dtype=torch.float64, generator=gen)
     if layer0:
-        P = _OnDevice(W=rn(F, d) / h["ls"], b=ru(F, 1))
+        P = _OnDevice(W1=rn(F, d) / h["ls"], b1=ru(F, 1))
 
         def feats0(x, f):
             p = P.on(x.device)
-            return _phi(x, p["W"], p["b"], h["alpha"])
+            return _phi(x, p["W1"], p["b1"], h["alpha"])
 
-        return feats0
+        return feats0, (0, P, (math.sqrt(2.0 * h["alpha"] / F), 0.0, 0.0))
     W1, Wf, W2 = rn(F, d) / h["ls1"], rn(F) / h["lsf"], rn(F, d) / h["ls2"]
     b1, b2 = ru(F, 1), ru(F, 1)
-    P = _OnDevice(W1=W1, W2=W2, b1=b1, b2=b2, W1f=torch.cat([W1, Wf[:, None]], 1))
+    P = _OnDevice(W1=W1, W2=W2, b1=b1, b2=b2, Wf=Wf, W1f=torch.cat([W1, Wf[:, None]], 1))
 
     def feats(x, f):
         p = P.on(x.device)
@@ -126,7 +139,8 @@ def _draw_features(h, d, F, gen, layer0):
         return torch.cat([_phi(x, p["W1"], p["b1"], h["a1"]) * f * math.sqrt(h["nu"]),
                           _phi(xf, p["W1f"], p["b1"], h["a1"] * h["af"]), _phi(x, p["W2"], p["b2"], h["a2"])], 0)
 
-    return feats
+    scales = (math.sqrt(2.0 * h["a1"] * h["nu"] / F), math.sqrt(2.0 * h["a1"] * h["af"] / F), math.sqrt(2.0 * h["a2"] / F))
+    return feats, (1, P, scales)
 
 
 def sample_from_posterior(layer, input_dim, prev_sample=None, nFeatures=500, sigma2=1e-6, generator=None, device=None):
@@ -137,7 +151,7 @@ def sample_from_posterior(layer, input_dim, prev_sample=None, nFeatures=500, sig
     vd = vs._variational_distribution
     m = vd.variational_mean.detach().cpu().double()
     Ls = torch.tril(vd.chol_variational_covar.detach().cpu().double())
-    feats = _draw_features(h, input_dim, nFeatures, generator, layer.num_layer == 0)
+    feats, kargs = _draw_features(h, input_dim, nFeatures, generator, layer.num_layer == 0)
     if layer.num_layer == 0:
         assert prev_sample is None
         Phi = feats(Z, None)
@@ -145,7 +159,7 @@ def sample_from_posterior(layer, input_dim, prev_sample=None, nFeatures=500, sig
         assert prev_sample is not None
         Phi = feats(Z[:, :-1], Z[:, -1])          # the f column of Z~ is the previous layer's variational mean
     theta = _posterior_weights(Phi, m, Ls, sigma2, generator)
-    return _as_callable(feats, theta, prev_sample, device)
+    return _as_callable(feats, theta, prev_sample, device, kargs)
 
 
 def sample_from_prior(layer, input_dim, prev_sample=None, nFeatures=500, generator=None, device=None):
@@ -157,7 +171,7 @@ def sample_from_prior(layer, input_dim, prev_sample=None, nFeatures=500, generat
     else:
         h = {"ls1": torch.full((d,), 2.5 * d, dtype=torch.float64), "a1": 1.0, "lsf": torch.ones(1, dtype=torch.float64),
              "af": 1.0, "ls2": torch.full((d,), 0.25 * d, dtype=torch.float64), "a2": 0.01, "nu": 1.0}
-    feats = _draw_features(h, d, nFeatures, generator, layer.num_layer == 0)
+    feats, kargs = _draw_features(h, d, nFeatures, generator, layer.num_layer == 0)
     nF = nFeatures if layer.num_layer == 0 else 3 * nFeatures
     theta = torch.randn(nF, dtype=torch.float64, generator=generator)
-    return _as_callable(feats, theta, prev_sample, device)
+    return _as_callable(feats, theta, prev_sample, device, kargs)

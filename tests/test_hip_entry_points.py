@@ -101,3 +101,26 @@ def test_limits_are_reported_with_a_message():
         F.make_desc(0, 33, 8, 16)
     with pytest.raises(_lib.MobocmfError, match="samples per input row"):
         F.make_desc(1, 4, 8, 49 * 2, xdiv=49)
+
+
+@pytest.mark.parametrize("d,L", [(2, 2), (8, 2), (3, 3)])
+def test_rff_grid_evaluation_kernel_matches_host(d, L):
+    """function samples of every layer evaluated on a Pareto-sized grid by the HIP kernel (layer recursion, no
+    F x n feature matrix) vs the host evaluation of the SAME sample, and vs the numpy restatement of the reference's
+    feature maps (oracle/rff_oracle.py) for the top layer's inputs."""
+    from mobocmf_amd.layers import rff
+    from oracle import rff_oracle as R
+    prob = synthetic.make_problem(d=d, L=L, M=12, N=40, S=1, seed=d)
+    model = synthetic.model_from_problem(prob, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    fs = model.sample_function_from_each_layer(nFeatures=150, generator=g)
+    n = max(rff.GRID_ROWS_ON_DEVICE, 4200)
+    X = np.random.default_rng(0).random((n, d))
+    small = X[:7]
+    for l, f in enumerate(fs):
+        dev_vals = f(X)                                   # >= GRID_ROWS_ON_DEVICE rows: the kernel
+        host_vals = f._torch(torch.as_tensor(X)).detach().numpy()
+        assert np.abs(dev_vals - host_vals).max() < 1e-10 * max(1.0, np.abs(host_vals).max()), l
+        assert np.abs(f(small) - host_vals[:7]).max() < 1e-12 * max(1.0, np.abs(host_vals).max())      # host path
+    pr = model.sample_function_from_prior_each_layer(nFeatures=64, generator=g)
+    assert np.abs(pr[-1](X) - pr[-1]._torch(torch.as_tensor(X)).numpy()).max() < 1e-10

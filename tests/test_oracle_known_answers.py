@@ -207,3 +207,47 @@ def test_predict_for_acquisition_shapes_and_moments():
     # layer 0 has no sampling: variance = sigma^2 + tau exactly
     m0, v0 = O.predict(st, X[:, 0, :], 0, training=False)
     assert torch.allclose(mus0, m0) and torch.allclose(vs0, v0, rtol=1e-9, atol=1e-12)
+
+
+def test_rff_posterior_weight_samplers_have_the_same_moments():
+    """the product draws the posterior RFF weights by Matheron's rule in the M-dimensional function space
+    (O(F M^2)); the reference factorises F x F matrices (mfdgp_hidden_layer.py:296-307, restated in oracle/rff_oracle.py).
+    Both are samplers of ONE Gaussian: their closed-form means and covariances agree to rounding, the product's draws have
+    those moments, and so have draws of the restated reference sampler."""
+    import torch
+
+    from mobocmf_amd.layers import rff
+    from oracle import rff_oracle as R
+    rng = np.random.default_rng(3)
+    Fn, M, d, s2 = 40, 7, 2, 1e-3
+    x = rng.random((M, d))
+    W, b = rng.standard_normal((Fn, d)) / 0.4, rng.uniform(0, 2 * np.pi, (Fn, 1))
+    Phi = R.layer0_features(x, W, b, 1.3)
+    m = rng.standard_normal(M)
+    Ls = np.tril(rng.standard_normal((M, M))) * 0.3 + 0.5 * np.eye(M)
+    S = Ls @ Ls.T
+    mean_ref, cov_ref = R.posterior_moments(m, S, Phi, s2)
+    mean_mat, cov_mat = R.matheron_moments(m, S, Phi, s2)
+    assert np.abs(mean_ref - mean_mat).max() < 1e-8 * np.abs(mean_ref).max()
+    assert np.abs(cov_ref - cov_mat).max() < 1e-8 * np.abs(cov_ref).max()
+    # the product's sampler: empirical moments of 20000 draws
+    g = torch.Generator().manual_seed(0)
+    Pt, mt, Lt = torch.as_tensor(Phi), torch.as_tensor(m), torch.as_tensor(Ls)
+    draws = torch.stack([rff._posterior_weights(Pt, mt, Lt, s2, g) for _ in range(20000)]).numpy()
+    se = np.sqrt(np.diag(cov_ref) / draws.shape[0])
+    assert (np.abs(draws.mean(0) - mean_ref) < 5 * se + 1e-12).all()
+    emp = np.cov(draws.T)
+    assert np.abs(emp - cov_ref).max() < 0.06 * np.abs(cov_ref).max()
+    # the restated reference sampler, same check
+    ref = np.stack([R.posterior_weights_reference(m, S, Phi, s2, rng) for _ in range(20000)])
+    assert (np.abs(ref.mean(0) - mean_ref) < 5 * se + 1e-12).all()
+    assert np.abs(np.cov(ref.T) - cov_ref).max() < 0.06 * np.abs(cov_ref).max()
+    # layer >= 1 features: the product's feature map equals the restated one
+    f = rng.standard_normal(M)
+    W2, b2, Wf = rng.standard_normal((Fn, d)) / 0.7, rng.uniform(0, 2 * np.pi, (Fn, 1)), rng.standard_normal(Fn) / 0.9
+    want = R.layer1_features(x, f, W, Wf, W2, b, b2, 1.1, 0.8, 0.05, 0.6)
+    T = torch.as_tensor
+    got = torch.cat([rff._phi(T(x), T(W), T(b), 1.1) * T(f) * np.sqrt(0.6),
+                     rff._phi(torch.cat([T(x), T(f)[:, None]], 1), torch.cat([T(W), T(Wf)[:, None]], 1), T(b), 1.1 * 0.8),
+                     rff._phi(T(x), T(W2), T(b2), 0.05)], 0).numpy()
+    assert np.abs(got - want).max() < 1e-13

@@ -9,11 +9,11 @@ cd "$(dirname "$0")/.."
 if [ "$1" = "build" ]; then
   rev=${2:-HEAD}
   mkdir -p abtest/src
-  for f in gemm_f64 chol gram elementwise api; do git show $rev:mobocmf_amd/csrc/$f.hip > abtest/src/$f.hip; done
+  for f in gemm_f64 chol gram elementwise rff api; do git show $rev:mobocmf_amd/csrc/$f.hip > abtest/src/$f.hip; done
   git show $rev:mobocmf_amd/csrc/common.h > abtest/src/common.h
   mkdir -p abtest/include && git show $rev:include/mobocmf_hip.h > abtest/include/mobocmf_hip.h
   objs=""
-  for f in gemm_f64 chol gram elementwise api; do
+  for f in gemm_f64 chol gram elementwise rff api; do
     sed -i 's|"../../include/mobocmf_hip.h"|"../include/mobocmf_hip.h"|' abtest/src/common.h abtest/src/$f.hip
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -c abtest/src/$f.hip -o abtest/src/$f.o &
     objs="$objs abtest/src/$f.o"
