@@ -262,6 +262,14 @@ int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, 
                               const double* gmu, const double* cgv, const double* Aaux, double* rowdot_part,
                               mobocmf_stream_t stream);
 
+/* The weighted symmetric rank-k update of the layer backward, H[Mr x Mr] = A diag(w) A^T with A [Mr x Kd] (k contiguous,
+ * lda even) and w [Kd]: k-sliced over one round of resident workgroups into slabs (workspace), the slabs added and the
+ * result written as the FULL symmetric matrix.  Both M x M contractions over N' of the reference's autograd backward
+ * (A diag(gv) C^T for dU and dA K^T for dL^-1) reduce to it.  Mr, Kd multiples of 128. */
+int mobocmf_syrk_workspace_bytes(int32_t Mr, int64_t Kd, size_t* bytes);
+int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t lda, const double* w, double* H,
+                              void* workspace, int64_t workspace_bytes, mobocmf_stream_t stream);
+
 /* Kernel-selection thresholds (largest operand dimension up to which the small-operand kernels are used instead of the
  * tiled MFMA pipeline): small_gemm_max for M x M products (default 384), small_panel_max for M x N' panel products
  * (default 512).  A value <= 0 leaves that threshold unchanged.  Process-wide; meant for size sweeps, set it before

@@ -88,6 +88,43 @@ struct Dims {
     dim3 ggrid_mn, ggrid_mm;
 };
 
+GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int Mr, int64_t Nc,
+                   int64_t Kd, int tri, double alpha) {
+    GemmArgs g = {};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.Mr = Mr; g.Nc = Nc; g.Kd = Kd; g.tri = tri; g.alpha = alpha;
+    return g;
+}
+
+// k slices of the weighted syrk H = A diag(w) A^T (Mp x Mp from Mp x Np)
+int syrk_splitk(int Mp, int64_t Np) {
+    const int nrb = Mp / TILE;
+    int ntl = nrb * (nrb + 1) / 2;
+    int64_t ksteps = Np / 16;
+    int sk = 512 / ntl;   // one round of <= 512 resident workgroups (2 per CU): fewer, longer slices = fewer slabs to add
+    if (sk > ksteps / 8) sk = (int)(ksteps / 8);
+    if (sk > 128) sk = 128;
+    // multiples of 8 keep every k-slice on one XCD (gemm_f64.hip); not at the price of leaving > 1/4 of the slots empty
+    // (36 tiles at M = 1024: 14 slices fill 504 of 512 slots, 8 only 288)
+    if (sk >= 8 && 4 * (sk & ~7) >= 3 * sk) sk &= ~7;
+    if (sk < 1) sk = 1;
+    return sk;
+}
+int64_t syrk_slab_elems(int Mp, int64_t Np) {
+    const int sk = syrk_splitk(Mp, Np);
+    return (int64_t)(sk > 16 ? sk : 16) * Mp * Mp;
+}
+// H (full, symmetric) = A diag(w) A^T; skip (device word, may be NULL): *skip == 0 -> nothing is computed and H = fallback
+int weighted_syrk(const double* A, int64_t lda, const double* w, int Mp, int64_t Np, double* slabs, double* H,
+                  const int32_t* skip, const double* fallback, hipStream_t s) {
+    const int64_t mm = (int64_t)Mp * Mp;
+    GemmArgs ga = gemm_args(A, lda, A, lda, slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
+    ga.bscale = w; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm; ga.skip_if_zero = skip;
+    const int nsl = gemm_nt_slabs(ga, syrk_splitk(Mp, Np));      // 1: a small problem goes through whole, no k-slicing
+    TRY(launch_gemm(ga, true, nsl, s));
+    return launch_reduce_slabs_sym(slabs, mm, nsl, H, Mp, skip, fallback, s);
+}
+
 bool valid_desc(const mobocmf_layer_desc* d) {
     return d && (d->kind == 0 || d->kind == 1) && d->d >= 1 && d->d <= MOBOCMF_MAX_D && d->M >= 1 && d->xdiv >= 1 &&
            d->xdiv <= MOBOCMF_MAX_XDIV && d->Np >= 1 && d->Np % d->xdiv == 0 && (d->branch == 0 || d->branch == 1) && d->phase >= 0 &&
@@ -103,16 +140,7 @@ Dims dims_of(const mobocmf_layer_desc* d) {
     D.Np = round_up(d->Np, TILE);
     D.nbase = d->Np / d->xdiv;
     D.H = hyp_len(d->kind, d->d);
-    int ntl = D.nrb * (D.nrb + 1) / 2;
-    int64_t ksteps = D.Np / 16;
-    int sk = 512 / ntl;   // one round of <= 512 resident workgroups (2 per CU): fewer, longer slices = fewer slabs to add
-    if (sk > ksteps / 8) sk = (int)(ksteps / 8);
-    if (sk > 128) sk = 128;
-    // multiples of 8 keep every k-slice on one XCD (gemm_f64.hip); not at the price of leaving > 1/4 of the slots empty
-    // (36 tiles at M = 1024: 14 slices fill 504 of 512 slots, 8 only 288)
-    if (sk >= 8 && 4 * (sk & ~7) >= 3 * sk) sk &= ~7;
-    if (sk < 1) sk = 1;
-    D.splitk = sk;
+    D.splitk = syrk_splitk(D.Mp, D.Np);
     GramArgs g = {};
     g.xdiv = d->xdiv;
     g.Np = D.Np;
@@ -193,7 +221,7 @@ void carve_panel_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, PanelB
     int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
     S.gmu = b.take(D.Np); S.gv = b.take(D.Np); S.gv2 = b.take(D.Np); S.cgv = b.take(D.Np);
     S.dA = b.take(mn); S.dK = b.take(mn);
-    S.slab_elems = (int64_t)(D.splitk > 16 ? D.splitk : 16) * mm;
+    S.slab_elems = syrk_slab_elems(D.Mp, D.Np);
     S.slabs = b.take(S.slab_elems);
     S.dapart = b.take((D.Np <= 8192 ? D.Np / 16 : D.Np / 64) * (int64_t)D.Mp);   // row-dot partials of the dA epilogue (gemm_rowdot_parts)
     S.hyp_part = b.take((int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H);
@@ -246,14 +274,6 @@ bool carve_chain_block(void* block, size_t bytes, const Dims& D, ChainWs& c, siz
     c.slab_elems = c.ws_elems;
     if (used) *used = b.off;
     return b.ok;
-}
-
-GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int Mr, int64_t Nc,
-                   int64_t Kd, int tri, double alpha) {
-    GemmArgs g = {};
-    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-    g.Mr = Mr; g.Nc = Nc; g.Kd = Kd; g.tri = tri; g.alpha = alpha;
-    return g;
 }
 
 // per-layer user tensors of a chain call (tables of n entries)
@@ -365,16 +385,8 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
     // (skip_if_zero) when no column is clamped.
     if (!inputs_only) {
-        GemmArgs ga = gemm_args(P.A, Np, P.A, Np, B.slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
-        ga.bscale = B.gv; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm;
-        const int nsl = gemm_nt_slabs(ga, D.splitk);      // 1: a small problem goes through whole, no k-slicing
-        TRY(launch_gemm(ga, true, nsl, s));
-        TRY(launch_reduce_slabs_sym(B.slabs, mm, nsl, c.H, Mp, nullptr, nullptr, s));
-        if (desc->branch == 0) {
-            ga.bscale = B.cgv; ga.skip_if_zero = nclamped;
-            TRY(launch_gemm(ga, true, nsl, s));
-            TRY(launch_reduce_slabs_sym(B.slabs, mm, nsl, Hc, Mp, nclamped, c.H, s));
-        }
+        TRY(weighted_syrk(P.A, Np, B.gv, Mp, Np, B.slabs, c.H, nullptr, nullptr, s));
+        if (desc->branch == 0) TRY(weighted_syrk(P.A, Np, B.cgv, Mp, Np, B.slabs, Hc, nclamped, c.H, s));
     }
     // dK = L^-T dA
     {
@@ -787,6 +799,19 @@ int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, 
     g.colsq_part = colsq_part; g.coldot_part = coldot_part; g.avec = avec;
     g.bscale = epi == EPI_DA ? bscale : nullptr; g.gmu = gmu; g.cgv = cgv; g.Aaux = Aaux; g.rowdot_part = rowdot_part;
     return launch_gemm(g, false, 1, (hipStream_t)stream);
+}
+
+int mobocmf_syrk_workspace_bytes(int32_t Mr, int64_t Kd, size_t* bytes) {
+    if (!bytes || Mr <= 0 || Kd <= 0 || Mr % TILE || Kd % TILE) return MOBOCMF_BAD_ARG;
+    *bytes = (size_t)syrk_slab_elems(Mr, Kd) * sizeof(double);
+    return MOBOCMF_OK;
+}
+
+int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t lda, const double* w, double* H,
+                              void* workspace, int64_t workspace_bytes, mobocmf_stream_t stream) {
+    if (!A || !w || !H || !workspace || Mr <= 0 || Kd <= 0 || Mr % TILE || Kd % TILE || (lda & 1)) return MOBOCMF_BAD_ARG;
+    if (workspace_bytes < syrk_slab_elems(Mr, Kd) * (int64_t)sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    return weighted_syrk(A, lda, w, Mr, Kd, (double*)workspace, H, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream) {

@@ -892,6 +892,22 @@ def rff_eval(kind, x, fprev, W1, b1, Wf, W2, b2, theta, s0, s1=0.0, s2=0.0):
     return out
 
 
+def syrk_weighted(A, w, H=None):
+    """H = A diag(w) A^T (full symmetric, float64) on the k-sliced MFMA kernel: the weighted syrk of the layer backward
+    (mobocmf_syrk_weighted_f64).  A: [Mr, Kd] with Mr, Kd multiples of 128."""
+    lib = _lib.require_device()
+    A, w = _prep(A), _prep(w)
+    Mr, Kd = A.shape
+    nb = _lib._SZ()
+    _lib.check(lib.mobocmf_syrk_workspace_bytes(Mr, Kd, ctypes.byref(nb)), "mobocmf_syrk_workspace_bytes")
+    ws = scratch_buffer(nb.value, A.device)
+    if H is None:
+        H = _empty(Mr, Mr, device=A.device)
+    _lib.check(lib.mobocmf_syrk_weighted_f64(Mr, Kd, _ptr(A), A.stride(0), _ptr(w), _ptr(H), _ptr(ws), nb.value, _stream()),
+               "mobocmf_syrk_weighted_f64")
+    return H
+
+
 def set_tuning(small_gemm_max=0, small_panel_max=0):
     """Kernel-selection thresholds of the library (size sweeps); 0 leaves a threshold unchanged."""
     _lib.check(_lib.load().mobocmf_set_tuning(int(small_gemm_max), int(small_panel_max)), "mobocmf_set_tuning")

@@ -27,8 +27,17 @@ p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
 p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
 nwg = 4096
 stamps = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
-for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("dense store", 0, 0)):
-    fn = lambda: F.gemm_f64_epilogue(A, B, C, tri, epi, colsq_part=p1, coldot_part=p2, avec=avec)
+A2 = torch.randn(M, N, dtype=torch.float64, device=dev)
+gmu, cgv, gv = (torch.randn(N, dtype=torch.float64, device=dev) for _ in range(3))
+rdp = torch.empty(2 * (N // 128), M, dtype=torch.float64, device=dev)
+Hs = torch.empty(M, M, dtype=torch.float64, device=dev)
+for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("lower dA", 1, 2), ("weighted syrk", 0, 9), ("dense store", 0, 0)):
+    if epi == 9:
+        fn = lambda: F.syrk_weighted(A2, gv, Hs)
+    elif epi == 2:
+        fn = lambda: F.gemm_f64_epilogue(A, B, C, tri, 2, alpha=2.0, avec=avec, bscale=gv, gmu=gmu, cgv=cgv, Aaux=A2, rowdot_part=rdp)
+    else:
+        fn = lambda: F.gemm_f64_epilogue(A, B, C, tri, epi, colsq_part=p1, coldot_part=p2, avec=avec)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -89,7 +98,7 @@ for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("dense 
     print("   duration percentiles (us): p5 %.0f p25 %.0f p50 %.0f p75 %.0f p95 %.0f; XCD of block 0..7: %s" %
           (tuple(np.percentile(dur, [5, 25, 50, 75, 95])) + (xcc[:8].tolist(),)))
     lo = hw & 0xffffffff
-    cu_key = (hw >> 32) * 100000 + ((lo >> 8) & 0xf) * 64 + ((lo >> 12) & 0x1) * 16 + ((lo >> 13) & 0xf)   # xcc, cu, sh, se
+    cu_key = (hw >> 32) * 100000 + ((lo >> 8) & 0xf) * 64 + ((lo >> 12) & 0x1) * 16 + ((lo >> 13) & 0x7)   # xcc, cu, sh, se
     order = np.nonzero(used)[0]
     groups = {}
     for b, k, st in zip(order, cu_key, start):

@@ -62,6 +62,10 @@ for (t, e, s), v in res.items():
     print("%s %-8s %-3s: %s ms  -> best %.3f ms = %.1f TFLOP/s = %.3f of 78.6" %
           ("lower" if t == 1 else "upper", ("store", "colstats", "dA", "colsq")[e], "nt" if s else "", " ".join("%.3f" % x for x in v),
            best, fl / best / 1e9, fl / best / 1e9 / 78.6))
+H = torch.empty(M, M, dtype=torch.float64, device=dev)
+ts = [timeit(lambda: F.syrk_weighted(A2, gv, H)) for _ in range(3)]
+print("weighted syrk (incl. slab reduction): %s ms  -> best %.3f ms = %.1f TFLOP/s = %.3f of 78.6" %
+      (" ".join("%.3f" % x for x in ts), min(ts), fl / min(ts) / 1e9, fl / min(ts) / 1e9 / 78.6))
 D = rnd(M, M)
 for _ in range(3):
     t_d = timeit(lambda: F.gemm_f64(D, B, C))
