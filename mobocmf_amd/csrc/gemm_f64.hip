@@ -577,8 +577,11 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         grid = dim3((unsigned)((pair ? (nrb + 1) / 2 : nrb) * ncb), 1, 1);
         splitk = 1;
     }
-    // TRI instantiation: per-step skipping of structurally-zero row groups (its branches cost the dense loop ~5 %)
-    const bool tri = (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) != 0;
+    // TRI instantiation: per-step skipping of structurally-zero row groups.  A dense plain-store product takes it too
+    // (its diagonal-block loops are empty then): hipcc's register allocation of the <false, false, EPI_STORE>
+    // instantiation spills loop-invariant LDS addresses and reloads them -- a scratch round trip -- in every K step
+    // (dense 512 x 65536 x 512: 0.62 ms against 0.53 ms through this instantiation)
+    const bool tri = (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) != 0 || g.epi == EPI_STORE;
 #define LAUNCH(BT, TR, EP) hipLaunchKernelGGL((gemm_f64_kernel<BT, TR, EP>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair)
     if (B_T) {
         if (g.epi != EPI_STORE) return MOBOCMF_BAD_ARG;
