@@ -32,5 +32,11 @@ python tools/acq_bench.py 50 > $O/acq_bench.txt 2>&1
 python tools/cond_bench.py 400 > $O/cond_bench.txt 2>&1
 python tools/size_sweep.py > $O/size_sweep.txt 2>&1
 ./tools/mfma_peak > $O/mfma_peak.txt 2>&1 || true
+python examples/example_acquisition_mfdgp_forrester.py > $O/forrester_walkthrough.txt 2>&1 || true
+rocprofv3 --kernel-trace --output-format csv -d $O/c5 -- python3 bench.py --config C5 --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+python tools/step_timeline.py $(ls $O/c5/*/*kernel_trace.csv | head -1) > $O/C5_step_timeline.txt
+rm -rf $O/c5
+# in-kernel stamps of the GEMM launches (diagnostic build: bash tools/build_variant.sh stamps -DGEMM_STAMPS beforehand)
+if [ -f abtest/libstamps.so ]; then MOBOCMF_HIP_LIB=$PWD/abtest/libstamps.so python tools/gemm_stamps.py > $O/gemm_stamps.txt 2>&1 || true; fi
 rm -rf $O/prof/*/*agent_info.csv $O/prof1/*/*agent_info.csv
 du -sh $O
