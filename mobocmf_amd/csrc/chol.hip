@@ -16,12 +16,9 @@ __device__ __forceinline__ double bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// The 64x64 routines below run in ONE wavefront with the block held row-per-lane in registers.  In the factorisation
-// column j of L is published once per step in LDS (LT[j][lane], conflict-free) and read back as wave-uniform 16-byte
-// broadcasts (two k per ds_read_b128) -- half the instructions of fetching every multiplier with a pair of v_readlane;
-// only the pivot is a cross-lane register read.  The triangular solve / inverse fetch their multipliers with
-// v_readlane (the LDS-broadcast form of those two made hipcc hoist ~1000 loads and spill).  No barriers: a single
-// wavefront's LDS traffic is program-ordered.
+// The 64x64 routines below hold a block row-per-lane in registers.  Column j of L is published once per step in LDS and
+// read back as wave-uniform 16-byte broadcasts (two k per ds_read_b128) -- half the instructions of fetching every
+// multiplier with a pair of v_readlane; only the pivot is a cross-lane register read.
 typedef double v2f64c __attribute__((ext_vector_type(2)));
 
 // 1 / sqrt(a): v_rsq_f64 seed + two Newton steps (the IEEE sqrt + divide pair is ~60 dependent instructions on the pivot
@@ -35,138 +32,7 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
     return __builtin_fma(0.5 * y, e, y);
 }
 
-// a[] = row `lane` of a symmetric 64x64 block; on exit a[c] (c <= lane) = L[lane][c]; LT[j][i] = L[i][j] (0 above the
-// diagonal), rd[j] = 1 / L[j][j].  Returns the first failed pivot (1-based) or 0.
-__device__ __forceinline__ int chol64_rows(double (&a)[NB], int lane, double (*LT)[NB], double* rd, double& myrd) {
-    // The reciprocal pivot of step j+1 is started inside step j, right after column j+1 (alone) has received step j's
-    // update: its sqrt + divide (~200 cycles of dependent latency) then run under the remaining updates of step j
-    // instead of in front of step j+1 (measured: the 64 steps were ~750 cycles each, 20 us of the 45 us panel kernel).
-    int fail = 0;
-    double rinv;
-    {
-        const double a00 = bcast(a[0], 0);
-        if (!(a00 > 0.0)) fail = 1;
-        rinv = rsqrt_nr(a00);
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double lij = a[j] * rinv;          // lanes >= j: L[lane][j]  (lane j: sqrt(ajj))
-        a[j] = lij;
-        LT[j][lane] = lane >= j ? lij : 0.0;
-        if (lane == 0) rd[j] = rinv;
-        if (lane == j) myrd = rinv;            // lane k keeps 1 / L[k][k] for the solves (a multiply instead of a divide)
-        double rinv_next = 0.0;
-        if (j + 1 < NB) {
-            a[j + 1] -= lij * LT[j][j + 1];       // a[k] -= L[lane][j] * L[k][j]   (valid for lanes >= k)
-            const double an = bcast(a[j + 1], j + 1);
-            if (!(an > 0.0) && fail == 0) fail = j + 2;
-            rinv_next = rsqrt_nr(an);
-        }
-        if ((j + 2) & 1) {
-            if (j + 2 < NB) a[j + 2] -= lij * LT[j][j + 2];
-        }
-#pragma unroll
-        for (int k = (j + 3) & ~1; k < NB; k += 2) {
-            const v2f64c c = *(const v2f64c*)&LT[j][k];
-            a[k] -= lij * c[0];
-            a[k + 1] -= lij * c[1];
-        }
-        rinv = rinv_next;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return fail;
-}
-
-// x[] = row `lane` of L^-1 (lower triangular).  Multipliers come from the LDS image the factorisation left:
-// LT[k][t] = L[t][k], contiguous in t, read as wave-uniform 16-byte broadcasts (two multipliers per ds_read_b128 instead
-// of two v_readlane per multiplier); four partial sums break the dependent FMA chain; sched_barrier per step keeps the
-// loads of one step together (without it hipcc hoists ~1000 loads and spills).
-__device__ __forceinline__ void trinv64_rows(double (&x)[NB], int lane, const double (*LT)[NB], double myrd) {
-#pragma unroll
-    for (int k = NB - 1; k >= 0; --k) {
-        double s0 = (lane == k) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        if ((k + 1) & 1) {
-            if (k + 1 < NB) s0 -= x[k + 1] * LT[k][k + 1];
-        }
-#pragma unroll
-        for (int t = (k + 2) & ~1; t + 3 < NB; t += 4) {
-            const v2f64c c0 = *(const v2f64c*)&LT[k][t], c1 = *(const v2f64c*)&LT[k][t + 2];
-            s0 -= x[t] * c0[0];
-            s1 -= x[t + 1] * c0[1];
-            s2 -= x[t + 2] * c1[0];
-            s3 -= x[t + 3] * c1[1];
-        }
-        if ((NB - ((k + 2) & ~1)) & 2) {          // a last pair when the span is not a multiple of four
-            const v2f64c c = *(const v2f64c*)&LT[k][NB - 2];
-            s0 -= x[NB - 2] * c[0];
-            s1 -= x[NB - 1] * c[1];
-        }
-        x[k] = ((s0 + s1) + (s2 + s3)) * bcast(myrd, k);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// row `lane` of B <- B L^-T, right-looking: once b[t] is final it is eliminated from all later columns with the
-// multipliers L[k][t] = LT[t][k] (contiguous in k: 16-byte broadcasts, independent FMAs -- the factorisation's own loop)
-__device__ __forceinline__ void trsm64_rows(double (&b)[NB], const double (*LT)[NB], double myrd) {
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-        const double bt = b[t] * bcast(myrd, t);
-        b[t] = bt;
-        if ((t + 1) & 1) {
-            if (t + 1 < NB) b[t + 1] -= bt * LT[t][t + 1];
-        }
-#pragma unroll
-        for (int k = (t + 2) & ~1; k < NB; k += 2) {
-            const v2f64c c = *(const v2f64c*)&LT[t][k];
-            b[k] -= bt * c[0];
-            b[k + 1] -= bt * c[1];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// grid.x = number of 64-row blocks at/below the diagonal of panel jb; block = 64 threads (1 wavefront)
-// NOTE: every workgroup re-factorises the diagonal block from A, so block 0 must NOT overwrite it in place
-// (a workgroup that is scheduled late -- e.g. when other streams occupy the CUs -- would read L_jj instead of
-// A_jj).  The factor goes to the side buffer Ld; finish_l_kernel copies it into the diagonal at the end.
 struct InfoZ { int32_t* p[MAX_ZL]; };      // per-layer status words (user tensors: not strided)
-
-__global__ __launch_bounds__(64) void potrf_panel_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
-                                                         InfoZ infoz, int64_t zs) {
-    __shared__ __attribute__((aligned(16))) double LT[NB][NB];
-    __shared__ double rd[NB];
-    const int lane = threadIdx.x;
-    const int bi = blockIdx.x;
-    A += blockIdx.y * zs; Dinv += blockIdx.y * zs; Ld += blockIdx.y * zs;      // layer batching
-    int32_t* info = infoz.p[blockIdx.y];
-    const int64_t j0 = (int64_t)jb * NB;
-    double a[NB];
-    const double* drow = A + (j0 + lane) * ld + j0;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = drow[c];
-    double myrd = 0.0;
-    int fail = chol64_rows(a, lane, LT, rd, myrd);
-    if (bi == 0) {
-        double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
-        if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
-        double x[NB];
-        trinv64_rows(x, lane, LT, myrd);
-        double* irow = Dinv + (int64_t)jb * NB * NB + lane * NB;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) irow[c] = (c <= lane) ? x[c] : 0.0;
-    } else {
-        double b[NB];
-        double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) b[c] = prow[c];
-        trsm64_rows(b, LT, myrd);
-#pragma unroll
-        for (int c = 0; c < NB; ++c) prow[c] = b[c];
-    }
-}
 
 // Two wavefronts per workgroup: wavefront 0 factorises the 64 x 64 diagonal block, wavefront 1 runs the right-looking
 // triangular solve of its 64-row block TWO elimination steps behind (step t needs column t of L and 1 / L_tt only, which

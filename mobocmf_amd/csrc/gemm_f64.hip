@@ -106,13 +106,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     STAMP(0);
     STAMP_ID();
-#ifdef GEMM_STAGGER_US
-    // experiment: the second resident workgroup of every CU starts late, so that the two streams of a CU stay out of phase
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + 100ull * GEMM_STAGGER_US;
-        while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
     // ---- block id -> (tile, k-slice).  Blocks b, b+8, ... share an XCD (and its L2):
     //  * no split-K: the row blocks that re-read the same 128-column panel of B run back to back on one XCD;
     //  * split-K: all tiles of one k-slice (they share the slice's rows of A and B) run back to back on one XCD.
