@@ -31,15 +31,18 @@ __global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
     double a1, af = 0, nu = 0, a2 = 0, ilf = 0;
     if (KIND == 0) {
         a1 = hyp[0];
-        if (tid < d) il1[tid] = 1.0 / hyp[1 + tid];
+        if (tid < DB) il1[tid] = tid < d ? 1.0 / hyp[1 + tid] : 0.0;
     } else {
         a1 = hyp[0]; af = hyp[1]; nu = hyp[2]; a2 = hyp[3]; ilf = 1.0 / hyp[4];
-        if (tid < d) { il1[tid] = 1.0 / hyp[5 + tid]; il2[tid] = 1.0 / hyp[5 + d + tid]; }
+        if (tid < DB) { il1[tid] = tid < d ? 1.0 / hyp[5 + tid] : 0.0; il2[tid] = tid < d ? 1.0 / hyp[5 + d + tid] : 0.0; }
     }
-    for (int e = tid; e < gm * d; e += GT) {
-        int mm = e / d, k = e % d;
+    // columns k >= d of the DB-wide tiles are zero (inducing rows, inverse lengthscales, the thread's x row): the distance
+    // loops below run over all DB columns WITHOUT a test -- an `if (k < d)` per column made every column its own basic
+    // block with its own LDS read + s_waitcnt lgkmcnt(0): 16 serialised LDS round trips per inducing row
+    for (int e = tid; e < gm * DB; e += GT) {
+        int mm = e / DB, k = e % DB;
         int m = m0 + mm;
-        zs[mm][k] = (m < g.M) ? g.Zx[(int64_t)(m / g.zdiv) * d + k] : 0.0;
+        zs[mm][k] = (m < g.M && k < d) ? g.Zx[(int64_t)(m / g.zdiv) * d + k] : 0.0;
     }
     if (KIND == 1 && tid < gm) zfs[tid] = (m0 + tid < g.M) ? g.zf[m0 + tid] : 0.0;
     __syncthreads();
@@ -88,12 +91,10 @@ __global__ __launch_bounds__(GT) void gram_fwd_kernel(GramArgs g) {
         double d1 = 0.0, d2 = 0.0;
 #pragma unroll
         for (int k = 0; k < DB; ++k) {
-            if (k < d) {
-                double df = xr[k] - zs[mm][k];
-                double t1 = df * il1[k];
-                d1 += t1 * t1;
-                if (KIND == 1) { double t2 = df * il2[k]; d2 += t2 * t2; }
-            }
+            double df = xr[k] - zs[mm][k];
+            double t1 = df * il1[k];
+            d1 += t1 * t1;
+            if (KIND == 1) { double t2 = df * il2[k]; d2 += t2 * t2; }
         }
         const double E1 = exp(-0.5 * d1);
         if (KIND == 0) {
@@ -162,15 +163,18 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
     double a1, af = 0, nu = 0, a2 = 0, ilf = 0;
     if (KIND == 0) {
         a1 = hyp[0];
-        if (tid < d) il1[tid] = 1.0 / hyp[1 + tid];
+        if (tid < DB) il1[tid] = tid < d ? 1.0 / hyp[1 + tid] : 0.0;
     } else {
         a1 = hyp[0]; af = hyp[1]; nu = hyp[2]; a2 = hyp[3]; ilf = 1.0 / hyp[4];
-        if (tid < d) { il1[tid] = 1.0 / hyp[5 + tid]; il2[tid] = 1.0 / hyp[5 + d + tid]; }
+        if (tid < DB) { il1[tid] = tid < d ? 1.0 / hyp[5 + tid] : 0.0; il2[tid] = tid < d ? 1.0 / hyp[5 + d + tid] : 0.0; }
     }
-    for (int e = tid; e < gm * d; e += GT) {
-        int mm = e / d, k = e % d;
+    // columns k >= d of the DB-wide tiles are zero (inducing rows, inverse lengthscales, the thread's x row): the distance
+    // loops below run over all DB columns WITHOUT a test -- an `if (k < d)` per column made every column its own basic
+    // block with its own LDS read + s_waitcnt lgkmcnt(0): 16 serialised LDS round trips per inducing row
+    for (int e = tid; e < gm * DB; e += GT) {
+        int mm = e / DB, k = e % DB;
         int m = m0 + mm;
-        zs[mm][k] = (m < g.M) ? g.Zx[(int64_t)(m / g.zdiv) * d + k] : 0.0;
+        zs[mm][k] = (m < g.M && k < d) ? g.Zx[(int64_t)(m / g.zdiv) * d + k] : 0.0;
     }
     if (tid < gm) {
         dzf_s[tid] = 0.0;
@@ -230,20 +234,18 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
             double d1 = 0.0, d2 = 0.0;
 #pragma unroll
             for (int k = 0; k < DB; ++k) {
-                if (k < d) {
-                    double df = xr[k] - zs[mm][k];
-                    double t1 = df * il1[k];
-                    d1 += t1 * t1;
-                    if (KIND == 1) { double t2 = df * il2[k]; d2 += t2 * t2; }
-                }
+                double df = xr[k] - zs[mm][k];
+                double t1 = df * il1[k];
+                d1 += t1 * t1;
+                if (KIND == 1) { double t2 = df * il2[k]; d2 += t2 * t2; }
             }
             const double E1 = exp(-0.5 * d1);
             double W1 = 0.0, W2 = 0.0;
             if (KIND == 0) {
-                double Gs = 0.0;
-                for (int s = 0; s < xdiv; ++s) Gs += grow[c0 + s];
-                s_a1 += Gs * E1;
-                W1 = Gs * a1 * E1;
+                double Gsum = 0.0;
+                for (int s = 0; s < xdiv; ++s) Gsum += grow[c0 + s];
+                s_a1 += Gsum * E1;
+                W1 = Gsum * a1 * E1;
             } else {
                 const double E2 = exp(-0.5 * d2);
                 const double zfm = zfs[mm];
@@ -290,18 +292,16 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
             }
 #pragma unroll
             for (int k = 0; k < DB; ++k) {
-                if (k < d) {
-                    double df = xr[k] - zs[mm][k];
-                    double t1 = df * il1[k];
-                    aL1[k] += W1 * t1 * t1;
-                    double gx = W1 * t1 * il1[k];
-                    if (KIND == 1) {
-                        double t2 = df * il2[k];
-                        aL2[k] += W2 * t2 * t2;
-                        gx += W2 * t2 * il2[k];
-                    }
-                    if (WANT_DX) aX[k] -= gx;
+                double df = xr[k] - zs[mm][k];
+                double t1 = df * il1[k];
+                aL1[k] += W1 * t1 * t1;
+                double gx = W1 * t1 * il1[k];
+                if (KIND == 1) {
+                    double t2 = df * il2[k];
+                    aL2[k] += W2 * t2 * t2;
+                    gx += W2 * t2 * il2[k];
                 }
+                if (WANT_DX) aX[k] -= gx;
             }
         }
         if (KIND == 1) {
