@@ -2,7 +2,8 @@
 """Why the top-layer GEMM takes ~0.335 ms inside a step and ~0.307 ms launched alone in a loop: the same launch (A = L^-1 K
 with column statistics, 512 x 65536 x 512) timed (a) on ONE pair of operand / result panels, as bench.py's roofline leg and
 tools/gemm_variants.py do, (b) cycling through six pairs (3.2 GB: nothing of a panel survives in the 256 MB Infinity Cache
-until it is read again), (c) as (b) with a Gram-sized element-wise pass over another panel between the launches."""
+until it is read again), (c) as (b) with a Gram-sized element-wise pass over another panel between the launches, (d) as (a) with
+~0.4 ms of one-workgroup kernels (the M x M chain's launch pattern) in front of every timed launch."""
 import os
 import sys
 
@@ -48,9 +49,18 @@ def cyc_ew(i, s, e):
     s.record(); run(i % 6); e.record()
 
 
+tiny = torch.zeros(64, dtype=torch.float64, device=dev)
+
+
+def light(i, s, e):
+    for _ in range(80):      # ~80 x 5 us of latency-bound launches on a nearly idle chip
+        tiny.add_(1.0)
+    s.record(); run(0); e.record()
+
+
 for _ in range(400):
     run(0)
 torch.cuda.synchronize()
 for rnd_i in range(3):
-    print("same panels %.3f ms | six panel pairs in turn %.3f ms | + an element-wise pass in between %.3f ms" %
-          (timeit(one), timeit(cyc), timeit(cyc_ew)))
+    print("same panels %.3f ms | six panel pairs in turn %.3f ms | + an element-wise pass in between %.3f ms | after 80 one-workgroup launches %.3f ms" %
+          (timeit(one), timeit(cyc), timeit(cyc_ew), timeit(light)))
