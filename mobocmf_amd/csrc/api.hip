@@ -25,7 +25,7 @@ int launch_moments_finish(const double* qpart, const double* mupart, const doubl
 int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
                             const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
                             double* gv, double* gv2, double* cgv, int32_t* nclamped, hipStream_t s);
-int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, double* out, int Mp, const int32_t* flag,
+int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, int nslab_diag, double* out, int Mp, const int32_t* flag,
                             const double* fallback, hipStream_t s);
 int launch_dutot(const double* X, const double* U, const double* da, const double* a, const double* gkl, int Mp,
                  double* dU, double* da_tot, hipStream_t s);
@@ -96,22 +96,39 @@ GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb, d
     return g;
 }
 
-// k slices of the weighted syrk H = A diag(w) A^T (Mp x Mp from Mp x Np)
-int syrk_splitk(int Mp, int64_t Np) {
+// k slices of the weighted syrk H = A diag(w) A^T (Mp x Mp from Mp x Np): sF for the tiles below the diagonal, *sD for the
+// diagonal ones (0: one class).  A diagonal tile's critical wavefronts issue 10/16 of a full tile's MFMAs, so it gets
+// fewer, longer slices; together they fill one round of <= 512 resident workgroups (2 per CU).  Multiples of 8 keep every
+// k-slice on one XCD (gemm_f64.hip) and are preferred unless another pair is > 10 % shorter.
+int syrk_splitk(int Mp, int64_t Np, int* sD) {
     const int nrb = Mp / TILE;
-    int ntl = nrb * (nrb + 1) / 2;
-    int64_t ksteps = Np / 16;
-    int sk = 512 / ntl;   // one round of <= 512 resident workgroups (2 per CU): fewer, longer slices = fewer slabs to add
-    if (sk > ksteps / 8) sk = (int)(ksteps / 8);
-    if (sk > 128) sk = 128;
-    // multiples of 8 keep every k-slice on one XCD (gemm_f64.hip); not at the price of leaving > 1/4 of the slots empty
-    // (36 tiles at M = 1024: 14 slices fill 504 of 512 slots, 8 only 288)
-    if (sk >= 8 && 4 * (sk & ~7) >= 3 * sk) sk &= ~7;
-    if (sk < 1) sk = 1;
-    return sk;
+    const int64_t nF = (int64_t)nrb * (nrb - 1) / 2, nD = nrb, ksteps = Np / 16;
+    int cap = (int)(ksteps / 8);
+    if (cap > 128) cap = 128;
+    if (cap < 1) cap = 1;
+    *sD = 0;
+    if (nF == 0) {      // a single (diagonal) tile
+        int sk = 512 < cap ? 512 : cap;
+        if (sk >= 8) sk &= ~7;
+        return sk;
+    }
+    double best = 1e30;
+    int bF = 1, bD = 1;
+    for (int f = 1; f <= cap; ++f)
+        for (int d = 1; d <= f; ++d) {
+            if (nF * f + nD * d > 512) break;
+            const double cf = (double)((ksteps + f - 1) / f), cd = 0.625 * (double)((ksteps + d - 1) / d);
+            double c = cf > cd ? cf : cd;
+            if ((f & 7) || (d & 7)) c *= 1.10;
+            c += 1e-3 * (f + d);      // ties: fewer slabs to add
+            if (c < best) { best = c; bF = f; bD = d; }
+        }
+    *sD = bD;
+    return bF;
 }
 int64_t syrk_slab_elems(int Mp, int64_t Np) {
-    const int sk = syrk_splitk(Mp, Np);
+    int sD;
+    const int sk = syrk_splitk(Mp, Np, &sD);
     return (int64_t)(sk > 16 ? sk : 16) * Mp * Mp;
 }
 // H (full, symmetric) = A diag(w) A^T; skip (device word, may be NULL): *skip == 0 -> nothing is computed and H = fallback
@@ -120,9 +137,12 @@ int weighted_syrk(const double* A, int64_t lda, const double* w, int Mp, int64_t
     const int64_t mm = (int64_t)Mp * Mp;
     GemmArgs ga = gemm_args(A, lda, A, lda, slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
     ga.bscale = w; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm; ga.skip_if_zero = skip;
-    const int nsl = gemm_nt_slabs(ga, syrk_splitk(Mp, Np));      // 1: a small problem goes through whole, no k-slicing
+    int sD = 0;
+    const int sF = syrk_splitk(Mp, Np, &sD);
+    const int nsl = gemm_nt_slabs(ga, sF);      // 1: a small problem goes through whole, no k-slicing
+    if (nsl > 1) ga.splitk_diag = sD;
     TRY(launch_gemm(ga, true, nsl, s));
-    return launch_reduce_slabs_sym(slabs, mm, nsl, H, Mp, skip, fallback, s);
+    return launch_reduce_slabs_sym(slabs, mm, nsl, (nsl > 1 && sD > 0) ? sD : nsl, H, Mp, skip, fallback, s);
 }
 
 bool valid_desc(const mobocmf_layer_desc* d) {
@@ -140,7 +160,7 @@ Dims dims_of(const mobocmf_layer_desc* d) {
     D.Np = round_up(d->Np, TILE);
     D.nbase = d->Np / d->xdiv;
     D.H = hyp_len(d->kind, d->d);
-    D.splitk = syrk_splitk(D.Mp, D.Np);
+    { int sD; D.splitk = syrk_splitk(D.Mp, D.Np, &sD); }
     GramArgs g = {};
     g.xdiv = d->xdiv;
     g.Np = D.Np;

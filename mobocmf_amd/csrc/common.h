@@ -31,9 +31,12 @@ struct GemmArgs {
     int64_t Kd;        // contraction length (multiple of 16)
     int tri;           // TRI_*: restricts the k range per row block (A triangular, square A: Kd == Mr)
     int lower_out;     // 1: skip tiles strictly above the diagonal (square outputs)
-    int sym_out;       // 1 (with lower_out, A B^T with B = A: a syrk): the result is symmetric, so the 64 x 64 quadrant
-                       // strictly above the diagonal of every DIAGONAL tile is not computed either (left as zeros; the
-                       // slab reduction mirrors it from the lower quadrant)
+    int sym_out;       // 1 (with lower_out, A B^T with B = A: a syrk): the result is symmetric, so the 16 x 16 blocks
+                       // strictly above the diagonal of every DIAGONAL tile are not computed either (left as zeros; the
+                       // slab reduction mirrors them from below the diagonal)
+    int splitk_diag;   // > 0 (k-sliced sym_out launches): the diagonal tiles -- 10/16 of a full tile's MFMA work on their
+                       // critical wavefronts -- take this many k slices instead of `splitk`, so that all workgroups run
+                       // equally long; slab z of a tile is only written for z < its own slice count
     double alpha;
     int accumulate;    // 1: C += alpha*A*B  (else C = ...)
     // split-K: gridDim.z slices of the contraction, slice z writes C + z*slab_stride (reduced by reduce_slabs)

@@ -228,8 +228,8 @@ int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const dou
 
 // H (full symmetric) from the slabs of a lower_out syrk: out[i][j] = sum_z slab[z][max-tile order].  If `flag` is
 // given and *flag == 0 the slabs were never written (kernel skipped): out = fallback instead.
-__global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride, int nslab, double* out, int Mp,
-                                        const int32_t* flag, const double* fallback) {
+__global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride, int nslab, int nslab_diag, double* out,
+                                        int Mp, const int32_t* flag, const double* fallback) {
     // one thread per element of the LOWER tiles (coalesced slab reads); it also writes the mirrored element
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Mp * Mp) return;
@@ -239,18 +239,19 @@ __global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride
         return;
     }
     if (j / TILE > i / TILE) return;
-    // diagonal tiles: the quadrant strictly above the diagonal is not computed by the syrk (GemmArgs.sym_out) -- every
+    // diagonal tiles: the 16 x 16 blocks strictly above the diagonal are not computed by the syrk (GemmArgs.sym_out) -- every
     // element above the diagonal takes its mirror image, which also makes the result exactly symmetric
     const double* p = j > i ? slabs + (int64_t)j * Mp + i : slabs + (int64_t)i * Mp + j;
     double v = 0.0;
-    for (int z = 0; z < nslab; ++z) v += p[z * slab_stride];
+    const int ns = (i / TILE == j / TILE) ? nslab_diag : nslab;      // diagonal tiles may have their own slice count
+    for (int z = 0; z < ns; ++z) v += p[z * slab_stride];
     out[idx] = v;
     if (j / TILE < i / TILE) out[(int64_t)j * Mp + i] = v;     // strictly-upper tiles mirror the lower ones
 }
-int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, double* out, int Mp, const int32_t* flag,
-                            const double* fallback, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_slabs_sym_kernel, GRID1((int64_t)Mp * Mp), 0, s, slabs, slab_stride, nslab, out, Mp, flag,
-                       fallback);
+int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, int nslab_diag, double* out, int Mp,
+                            const int32_t* flag, const double* fallback, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_slabs_sym_kernel, GRID1((int64_t)Mp * Mp), 0, s, slabs, slab_stride, nslab, nslab_diag, out, Mp,
+                       flag, fallback);
     return CHECK_LAUNCH();
 }
 

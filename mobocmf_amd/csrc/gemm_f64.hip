@@ -110,12 +110,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     //  * no split-K: the row blocks that re-read the same 128-column panel of B run back to back on one XCD;
     //  * split-K: all tiles of one k-slice (they share the slice's rows of A and B) run back to back on one XCD.
     int64_t id = blockIdx.x;
-    int rb, z = 0;
+    int rb, z = 0, sk_eff = splitk;      // sk_eff: k slices of THIS tile
     int64_t cb;
     if (g.batched) {
         z = blockIdx.z;
         cb = id / nrb;
         rb = nrb - 1 - (int)(id % nrb);
+    } else if (splitk > 1 && g.lower_out && g.splitk_diag > 0) {
+        // two tile classes with their own slice counts: the nrb (nrb - 1) / 2 tiles below the diagonal first, then the nrb
+        // diagonal ones; inside a class as below (XCD-aware when the counts allow it)
+        const int64_t nF = (int64_t)nrb * (nrb - 1) / 2, nblkF = nF * splitk;
+        const bool diag = id >= nblkF;
+        const int64_t id2 = diag ? id - nblkF : id, nT = diag ? nrb : nF;
+        sk_eff = diag ? g.splitk_diag : splitk;
+        int64_t t;
+        if ((sk_eff & 7) == 0 && (nblkF & 7) == 0) {
+            const int64_t xcd = id2 & 7, seq = id2 >> 3;
+            t = seq % nT;
+            z = (int)((seq / nT) * 8 + xcd);
+        } else {
+            t = id2 % nT;
+            z = (int)(id2 / nT);
+        }
+        if (diag) {
+            rb = (int)t;
+            cb = t;
+        } else {
+            int r = 1;
+            while ((int64_t)r * (r + 1) / 2 <= t) ++r;
+            rb = r;
+            cb = t - (int64_t)r * (r - 1) / 2;
+        }
     } else if (splitk > 1) {
         const int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
         int64_t t;
@@ -212,7 +237,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // the two row-wavefronts own INTERLEAVED 16-row groups (group 2*mt + wr): inside a triangular diagonal block both
     // then skip a similar share of structurally-zero groups (critical path 20/32 of a dense block instead of 26/32)
     const int a_base = (wr * 16 + (lane & 3)) * BK;                 // + (mt*32 + 4r)*BK + colP
-    const int bt_base = (wc * 64 + li) * BK;                        // B_T: + nt*16*BK + colP
+    // A B^T: the two column-wavefronts own INTERLEAVED 16-column groups (group 2*nt + wc), like the row-wavefronts their row
+    // groups: in a diagonal tile of a symmetric product the 16 x 16 blocks strictly above the diagonal (column group > row
+    // group) then spread evenly over the four wavefronts
+    const int bt_base = (wc * 16 + li) * BK;                        // B_T: + nt*32*BK + colP
     // B: k row = 4*lk + ks; accumulator column nt of a lane = wc*64 + (nt>>1)*32 + 2*li + (nt&1)
     const int bn_base = (4 * lk) * BN + wc * 64 + 2 * li;           // + ks*BN + (nt>>1)*32
 
@@ -245,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     }
     if (!g.batched && splitk > 1) {   // slice the tile's own non-zero k range
         int64_t nkt = k1 > k0 ? (k1 - k0) / BK : 0;
-        int64_t per = (nkt + splitk - 1) / splitk;
+        int64_t per = (nkt + sk_eff - 1) / sk_eff;
         int64_t b = k0 + z * per * BK, e = b + per * BK;
         k0 = b < k1 ? b : k1;
         k1 = e < k1 ? e : k1;
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #define LOAD_B(dst, P)                                                                                      \
     if (B_T) {                                                                                              \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
-            v2f64 v = *(const v2f64*)(Bs + bt_base + t * 16 * BK + ((P) ? colP1 : colP0));                  \
+            v2f64 v = *(const v2f64*)(Bs + bt_base + t * 32 * BK + ((P) ? colP1 : colP0));                  \
             dst[0][t] = v[0];                                                                               \
             dst[1][t] = v[1];                                                                               \
         }                                                                                                   \
@@ -308,9 +336,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #define MMA_IF(asrc, bsrc, MT)                                                                              \
     if (act & (1 << (MT))) { MMA_DO(asrc, bsrc, MT) }                                                       \
     __builtin_amdgcn_sched_barrier(0);
-// K steps [KT0, KT1) of the pipeline.  COND = 1: inside a triangular diagonal block, 16-row groups that are structurally
-// zero for the step are skipped (bit mt of `act`); COND = 2: a fixed set of row groups; COND = 0: branch-free body.
-#define STAGE_LOOP(KT0, KT1, COND, MMA)                                                                     \
+// The standard K step: all four row groups, MMA = MMA_ALL or the skipping MMA_IF.
+#define KSTEP_STD(MMA)                                                                                      \
+        LOAD_B(b0, 0)                                                                                       \
+        LOAD_A(a0, 0, 0)                                                                                    \
+        LOAD_A(a1, 0, 1) MMA(a0, b0, 0)                                                                     \
+        LOAD_A(a0, 0, 2) MMA(a1, b0, 1)                                                                     \
+        LOAD_A(a1, 0, 3) MMA(a0, b0, 2)                                                                     \
+        LOAD_A(a0, 1, 0) LOAD_B(b1, 1) MMA(a1, b0, 3)                                                       \
+        LOAD_A(a1, 1, 1) MMA(a0, b1, 0)                                                                     \
+        LOAD_A(a0, 1, 2) MMA(a1, b1, 1)                                                                     \
+        LOAD_A(a1, 1, 3) MMA(a0, b1, 2)                                                                     \
+        MMA(a1, b1, 3)
+// Diagonal tile of a symmetric A B^T product (sym_out): with row group 2*mt + wr and column group 2*nt + wc a 16 x 16
+// block lies on or below the diagonal iff 2*nt + wc <= 2*mt + wr, i.e. nt <= mt for three of the wavefronts (KSTEP_LE:
+// 10 of 16 blocks) and nt < mt for (wr, wc) = (0, 1) (KSTEP_LT: 6 of 16); the slab reduction mirrors the rest.
+// GRPJ = the first JN column groups of row group MT, compile-time counts, no branch inside the K step.
+#define GRPJ(asrc, bsrc, MT, JN)                                                                            \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                      \
+            _Pragma("unroll") for (int j = 0; j < (JN); ++j)                                               \
+                acc[MT][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(asrc[r][e], bsrc[e][j], acc[MT][j][r], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+#define KSTEP_LE                                                                                            \
+        LOAD_B(b0, 0)                                                                                       \
+        LOAD_A(a0, 0, 0)                                                                                    \
+        LOAD_A(a1, 0, 1) GRPJ(a0, b0, 0, 1)                                                                 \
+        LOAD_A(a0, 0, 2) GRPJ(a1, b0, 1, 2)                                                                 \
+        LOAD_A(a1, 0, 3) GRPJ(a0, b0, 2, 3)                                                                 \
+        LOAD_A(a0, 1, 0) LOAD_B(b1, 1) GRPJ(a1, b0, 3, 4)                                                   \
+        LOAD_A(a1, 1, 1) GRPJ(a0, b1, 0, 1)                                                                 \
+        LOAD_A(a0, 1, 2) GRPJ(a1, b1, 1, 2)                                                                 \
+        LOAD_A(a1, 1, 3) GRPJ(a0, b1, 2, 3)                                                                 \
+        GRPJ(a1, b1, 3, 4)
+#define KSTEP_LT                                                                                            \
+        LOAD_B(b0, 0)                                                                                       \
+        LOAD_A(a0, 0, 1)                                                                                    \
+        LOAD_A(a1, 0, 2) GRPJ(a0, b0, 1, 1)                                                                 \
+        LOAD_A(a0, 0, 3) GRPJ(a1, b0, 2, 2)                                                                 \
+        LOAD_A(a1, 1, 1) LOAD_B(b1, 1) GRPJ(a0, b0, 3, 3)                                                   \
+        LOAD_A(a0, 1, 2) GRPJ(a1, b1, 1, 1)                                                                 \
+        LOAD_A(a1, 1, 3) GRPJ(a0, b1, 2, 2)                                                                 \
+        GRPJ(a1, b1, 3, 3)
+// K steps [KT0, KT1) of the pipeline with the K-step body BODY.  COND = 1: inside a triangular diagonal block, 16-row
+// groups that are structurally zero for the step are skipped (bit mt of `act`, used by MMA_IF).
+#define STAGE_LOOP(KT0, KT1, COND, BODY)                                                                    \
     for (int64_t kt = (KT0); kt < (KT1); ++kt) {                                                            \
         const int buf = (int)(kt & 1);                                                                      \
         const v4f64 w4 = w_nxt;    /* contraction weights of k = 4*lk + ks of this step (B_T) */            \
@@ -321,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }                                                                                                   \
         const double* As = lds + buf * 2 * TILE_ELEMS;                                                      \
         const double* Bs = As + TILE_ELEMS;                                                                 \
-        int act = (COND) == 2 ? 12 : 15;                                                                    \
+        int act = 15;                                                                                       \
         if ((COND) == 1) {                                                                                  \
             const int64_t kk = k0 + KSTEP(kt) * BK;                                                         \
             const int64_t r0 = (int64_t)rb * BM + wr * 16;                                                  \
@@ -333,16 +403,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
             act = __builtin_amdgcn_readfirstlane(act);                                                      \
         }                                                                                                   \
         (void)act;                                                                                          \
-        LOAD_B(b0, 0)                                                                                       \
-        LOAD_A(a0, 0, 0)                                                                                    \
-        LOAD_A(a1, 0, 1) MMA(a0, b0, 0)                                                                     \
-        LOAD_A(a0, 0, 2) MMA(a1, b0, 1)                                                                     \
-        LOAD_A(a1, 0, 3) MMA(a0, b0, 2)                                                                     \
-        LOAD_A(a0, 1, 0) LOAD_B(b1, 1) MMA(a1, b0, 3)                                                       \
-        LOAD_A(a1, 1, 1) MMA(a0, b1, 0)                                                                     \
-        LOAD_A(a0, 1, 2) MMA(a1, b1, 1)                                                                     \
-        LOAD_A(a1, 1, 3) MMA(a0, b1, 2)                                                                     \
-        MMA(a1, b1, 3)                                                                                      \
+        BODY                                                                                                \
         /* all LDS reads of buf returned (lgkmcnt) and this wavefront's DMA into buf^1 landed (vmcnt) */    \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
         __syncthreads();                                                                                    \
@@ -354,21 +415,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         const bool diag_first = upper != rev;     // the diagonal block is the lowest k of an upper-, the highest of a lower-
         const int64_t d0 = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && diag_first) ? nd : 0;
         const int64_t d1 = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !diag_first) ? nk - nd : nk;
-        STAGE_LOOP(0, d0, 1, MMA_IF)
+        STAGE_LOOP(0, d0, 1, KSTEP_STD(MMA_IF))
         STAMP(2 + 4 * part);
-        STAGE_LOOP(d0, d1, 0, MMA_ALL)
+        STAGE_LOOP(d0, d1, 0, KSTEP_STD(MMA_ALL))
         STAMP(3 + 4 * part);
-        STAGE_LOOP(d1, nk, 1, MMA_IF)
-    } else if (B_T && g.sym_out && g.lower_out && rb == cb && wc == 1) {
-        // symmetric output, diagonal tile: rows 0..63 x columns 64..127 lie strictly above the diagonal.  The two
-        // row-wavefronts own interleaved 16-row groups, so both column-1 wavefronts skip their row groups mt = 0, 1
-        // (10 % of a syrk's MFMA work at four row blocks); the slab reduction mirrors those elements
-        STAGE_LOOP(0, nk, 2, MMA_IF)
+        STAGE_LOOP(d1, nk, 1, KSTEP_STD(MMA_IF))
+    } else if (B_T && g.sym_out && g.lower_out && rb == cb) {
+        // symmetric output, diagonal tile: the 16 x 16 blocks strictly above the diagonal are not computed
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // scalar branch: whole loops per wavefront role
+        if (wave_u == 1) {      // (wr, wc) = (0, 1)
+            STAGE_LOOP(0, nk, 0, KSTEP_LT)
+        } else {
+            STAGE_LOOP(0, nk, 0, KSTEP_LE)
+        }
     } else {
-        STAGE_LOOP(0, nk, 0, MMA_ALL)
+        STAGE_LOOP(0, nk, 0, KSTEP_STD(MMA_ALL))
     }
 #undef STAGE_LOOP
 #undef KSTEP
+#undef KSTEP_STD
+#undef KSTEP_LE
+#undef KSTEP_LT
+#undef GRPJ
 #undef MMA_IF
 #undef MMA_ALL
 #undef MMA_DO
@@ -383,11 +451,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     STAMP(4 + 4 * part);      // main loop done
 
     // accumulator acc[mt][nt][r] of a lane: row = row0 + mt*32 + 4*r; column = col0 + COLOFF(nt).  NN: the lane's columns
-    // come in adjacent pairs (nt = 2h, 2h+1 -> col0 + 32h, +1): 16-byte accesses; A B^T keeps one column per 16-lane group.
+    // come in adjacent pairs (nt = 2h, 2h+1 -> col0 + 32h, +1): 16-byte accesses; A B^T keeps one column per 16-lane group
+    // (column group 2*nt + wc).
     const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;
-    const int64_t col0 = cb * BN + wc * 64 + (B_T ? li : 2 * li);
-    const int ccol = wc * 64 + (B_T ? li : 2 * li);            // the same inside the tile
-#define COLOFF(nt) (B_T ? (nt) * 16 : ((nt) >> 1) * 32 + ((nt) & 1))
+    const int64_t col0 = cb * BN + (B_T ? wc * 16 + li : wc * 64 + 2 * li);
+    const int ccol = B_T ? wc * 16 + li : wc * 64 + 2 * li;    // the same inside the tile
+#define COLOFF(nt) (B_T ? (nt) * 32 : ((nt) >> 1) * 32 + ((nt) & 1))
     if (EPI == EPI_DA && !B_T) {
         // dA = alpha*acc + avec[i]*gmu[n] - 2*Aaux[i][n]*cgv[n];   optionally rd[row] = sum_n Aaux[row][n] * gmu[n].
         // No LDS, no workgroup barrier (see the column-statistics epilogue): avec comes by broadcast loads.  The Aaux tile
@@ -562,7 +631,9 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         splitk = 1;
     } else if (splitk > 1) {
         int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
-        grid = dim3((unsigned)(ntile * splitk), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
+        if (g.lower_out && g.splitk_diag > 0) ntile = 0;      // two classes: counted below
+        const int64_t nblk = ntile ? ntile * splitk : (int64_t)nrb * (nrb - 1) / 2 * splitk + (int64_t)nrb * g.splitk_diag;
+        grid = dim3((unsigned)nblk, 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
     } else {
         // pairing balances the work per workgroup; it only pays when there are more tiles than resident workgroup
         // slots (2 per CU), otherwise the longest single tile is the critical path and pairing lengthens it
