@@ -336,10 +336,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #define MMA_IF(asrc, bsrc, MT)                                                                              \
     if (act & (1 << (MT))) { MMA_DO(asrc, bsrc, MT) }                                                       \
     __builtin_amdgcn_sched_barrier(0);
+// The LDS-DMA of the NEXT stage is issued behind the step's first fragment reads (it writes the other buffer): in front
+// of them its address arithmetic and eight issues sat on the critical path between the barrier and the first MFMA.
+#define STAGE_NEXT                                                                                          \
+        if (kt + 1 < nk) {                                                                                  \
+            /* the weight load is issued BEFORE the DMA: waiting for it never drains the DMA (vmcnt is in order) */ \
+            if (B_T && g.bscale) w_nxt = *(const v4f64*)(g.bscale + k0 + (kt + 1) * BK + 4 * lk);           \
+            stage(Ag, k0 + KSTEP(kt + 1) * BK, buf ^ 1);                                                    \
+        }
 // The standard K step: all four row groups, MMA = MMA_ALL or the skipping MMA_IF.
 #define KSTEP_STD(MMA)                                                                                      \
         LOAD_B(b0, 0)                                                                                       \
         LOAD_A(a0, 0, 0)                                                                                    \
+        STAGE_NEXT                                                                                          \
         LOAD_A(a1, 0, 1) MMA(a0, b0, 0)                                                                     \
         LOAD_A(a0, 0, 2) MMA(a1, b0, 1)                                                                     \
         LOAD_A(a1, 0, 3) MMA(a0, b0, 2)                                                                     \
@@ -361,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #define KSTEP_LE                                                                                            \
         LOAD_B(b0, 0)                                                                                       \
         LOAD_A(a0, 0, 0)                                                                                    \
+        STAGE_NEXT                                                                                          \
         LOAD_A(a1, 0, 1) GRPJ(a0, b0, 0, 1)                                                                 \
         LOAD_A(a0, 0, 2) GRPJ(a1, b0, 1, 2)                                                                 \
         LOAD_A(a1, 0, 3) GRPJ(a0, b0, 2, 3)                                                                 \
@@ -372,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #define KSTEP_LT                                                                                            \
         LOAD_B(b0, 0)                                                                                       \
         LOAD_A(a0, 0, 1)                                                                                    \
+        STAGE_NEXT                                                                                          \
         LOAD_A(a1, 0, 2) GRPJ(a0, b0, 1, 1)                                                                 \
         LOAD_A(a0, 0, 3) GRPJ(a1, b0, 2, 2)                                                                 \
         LOAD_A(a1, 1, 1) LOAD_B(b1, 1) GRPJ(a0, b0, 3, 3)                                                   \
@@ -384,11 +395,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     for (int64_t kt = (KT0); kt < (KT1); ++kt) {                                                            \
         const int buf = (int)(kt & 1);                                                                      \
         const v4f64 w4 = w_nxt;    /* contraction weights of k = 4*lk + ks of this step (B_T) */            \
-        if (kt + 1 < nk) {                                                                                  \
-            /* the weight load is issued BEFORE the DMA: waiting for it never drains the DMA (vmcnt is in order) */ \
-            if (B_T && g.bscale) w_nxt = *(const v4f64*)(g.bscale + k0 + (kt + 1) * BK + 4 * lk);           \
-            stage(Ag, k0 + KSTEP(kt + 1) * BK, buf ^ 1);                                                    \
-        }                                                                                                   \
         const double* As = lds + buf * 2 * TILE_ELEMS;                                                      \
         const double* Bs = As + TILE_ELEMS;                                                                 \
         int act = 15;                                                                                       \
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #undef STAGE_LOOP
 #undef KSTEP
 #undef KSTEP_STD
+#undef STAGE_NEXT
 #undef KSTEP_LE
 #undef KSTEP_LT
 #undef GRPJ
