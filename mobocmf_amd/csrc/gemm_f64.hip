@@ -84,7 +84,7 @@ extern "C" int mobocmf_debug_set_stamps(unsigned long long* p) {
 }
 #define STAMP(i)                                                                                            \
     do {                                                                                                    \
-        if (g_stamp_buf && threadIdx.x == 0) g_stamp_buf[(int64_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if (g_stamp_buf && threadIdx.x == 0) g_stamp_buf[(int64_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #define STAMP_ID()                                                                                          \
     do {                                                                                                    \
@@ -92,12 +92,24 @@ extern "C" int mobocmf_debug_set_stamps(unsigned long long* p) {
             unsigned hw, xcc;                                                                               \
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                             \
-            g_stamp_buf[(int64_t)blockIdx.x * 16 + 15] = ((unsigned long long)xcc << 32) | hw;              \
+            g_stamp_buf[(int64_t)blockIdx.x * 32 + 15] = ((unsigned long long)xcc << 32) | hw;              \
         }                                                                                                   \
+    } while (0)
+// stamps INSIDE one light and one dense K step of part 0, kept in scalar registers until the kernel's end (a store per
+// stamp would sit in the vector-memory queue the step's own s_waitcnt vmcnt(0) drains)
+#define STEP_STAMPS_DECL unsigned long long sst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STEP_STAMP(i) do { if (sbase >= 0) sst[sbase + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STEP_STAMPS_FLUSH                                                                                   \
+    do {                                                                                                    \
+        if (g_stamp_buf && threadIdx.x == 0)                                                                \
+            for (int q = 0; q < 10; ++q) g_stamp_buf[(int64_t)blockIdx.x * 32 + 16 + q] = sst[q];           \
     } while (0)
 #else
 #define STAMP(i)
 #define STAMP_ID()
+#define STEP_STAMPS_DECL
+#define STEP_STAMP(i)
+#define STEP_STAMPS_FLUSH
 #endif
 
 template <bool B_T, bool TRI, int EPI>
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // B: k row = 4*lk + ks; accumulator column nt of a lane = wc*64 + (nt>>1)*32 + 2*li + (nt&1)
     const int bn_base = (4 * lk) * BN + wc * 64 + 2 * li;           // + ks*BN + (nt>>1)*32
 
+  STEP_STAMPS_DECL
   for (int part = 0; part < nparts; ++part) {
     // Paired row blocks: the LONG one first, and the two workgroups that share a column block of B -- pairs (0, nrb-1)
     // and (1, nrb-2), dispatched back to back on one XCD -- walk k in the SAME direction at the same time: the first
@@ -343,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
             /* the weight load is issued BEFORE the DMA: waiting for it never drains the DMA (vmcnt is in order) */ \
             if (B_T && g.bscale) w_nxt = *(const v4f64*)(g.bscale + k0 + (kt + 1) * BK + 4 * lk);           \
             stage(Ag, k0 + KSTEP(kt + 1) * BK, buf ^ 1);                                                    \
-        }
+        }                                                                                                   \
+        STEP_STAMP(1);
 // The standard K step: all four row groups, MMA = MMA_ALL or the skipping MMA_IF.
 #define KSTEP_STD(MMA)                                                                                      \
         LOAD_B(b0, 0)                                                                                       \
@@ -395,6 +409,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     for (int64_t kt = (KT0); kt < (KT1); ++kt) {                                                            \
         const int buf = (int)(kt & 1);                                                                      \
         const v4f64 w4 = w_nxt;    /* contraction weights of k = 4*lk + ks of this step (B_T) */            \
+        const int sbase = (part == 0 && kt == nk - 2) ? 0 : (part == 0 && kt == 4) ? 5 : -1;                \
+        (void)sbase;                                                                                        \
+        STEP_STAMP(0);                                                                                      \
         const double* As = lds + buf * 2 * TILE_ELEMS;                                                      \
         const double* Bs = As + TILE_ELEMS;                                                                 \
         int act = 15;                                                                                       \
@@ -410,9 +427,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         }                                                                                                   \
         (void)act;                                                                                          \
         BODY                                                                                                \
+        STEP_STAMP(2);                                                                                      \
         /* all LDS reads of buf returned (lgkmcnt) and this wavefront's DMA into buf^1 landed (vmcnt) */    \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+        STEP_STAMP(3);                                                                                      \
         __syncthreads();                                                                                    \
+        STEP_STAMP(4);                                                                                      \
     }
     if (TRI) {
         // the 8 K steps of the diagonal block (last for a lower-, first for an upper-triangular A) take the skipping
@@ -613,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
 #undef COLOFF
     STAMP(9 + part);          // epilogue issued
   }   // parts
+  STEP_STAMPS_FLUSH;
 }
 
 static bool small_panel_ok(const GemmArgs& g, bool B_T, int splitk);

@@ -26,7 +26,7 @@ avec = torch.randn(M, dtype=torch.float64, device=dev)
 p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
 p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
 nwg = 4096
-stamps = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
 A2 = torch.randn(M, N, dtype=torch.float64, device=dev)
 gmu, cgv, gv = (torch.randn(N, dtype=torch.float64, device=dev) for _ in range(3))
 rdp = torch.empty(2 * (N // 128), M, dtype=torch.float64, device=dev)
@@ -46,7 +46,7 @@ for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("lower 
     fn()
     torch.cuda.synchronize()
     raw.mobocmf_debug_set_stamps(ctypes.c_void_p(0))
-    s = stamps.cpu().numpy().reshape(nwg, 16)
+    s = stamps.cpu().numpy().reshape(nwg, 32)
     used = s[:, 0] > 0
     s = s[used]
     t0 = s[:, 0].min()
@@ -75,6 +75,12 @@ for name, tri, epi in (("lower colstats", 1, 1), ("lower store", 1, 0), ("lower 
             d1 = (s[sel, 3 + 4 * part] - s[sel, 2 + 4 * part]) / 100.0
             d2 = (s[sel, 4 + 4 * part] - s[sel, 3 + 4 * part]) / 100.0
             print("           diag-first %.2f | dense %.2f | diag-last %.2f" % (np.median(d0), np.median(d1), np.median(d2)))
+    for lbl, b in (("K step nk-2 of part 0 (a light diagonal-block step for a triangular A)", 16), ("K step 4 of part 0 (dense)", 21)):
+        sel = s[:, b] > 0
+        if sel.any():
+            dd = lambda i, j: np.median((s[sel, j] - s[sel, i]) / 100.0)
+            print("   %s: fragment reads + DMA issue %.2f | MFMA phase %.2f | wait for DMA / LDS %.2f | barrier %.2f  = %.2f us [median, wavefront 0]" %
+                  (lbl, dd(b, b + 1), dd(b + 1, b + 2), dd(b + 2, b + 3), dd(b + 3, b + 4), dd(b, b + 4)))
     end = us(np.maximum(s[:, 9], s[:, 10]))
     print("   end: first %.1f, median %.1f, last %.1f us" % (end.min(), np.median(end), end.max()))
     span = end.max()
