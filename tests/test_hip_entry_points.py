@@ -126,10 +126,11 @@ def test_rff_grid_evaluation_kernel_matches_host(d, L):
     assert np.abs(pr[-1](X) - pr[-1]._torch(torch.as_tensor(X)).numpy()).max() < 1e-10
 
 
-@pytest.mark.parametrize("Mp,Np", [(128, 2048), (384, 4096), (512, 8192), (1024, 4096)])
+@pytest.mark.parametrize("Mp,Np", [(128, 2048), (256, 16384), (384, 4096), (512, 8192), (640, 8192), (1024, 4096), (512, 65536)])
 def test_weighted_syrk_matches_torch(Mp, Np):
-    """H = A diag(w) A^T through mobocmf_syrk_weighted_f64 (small-operand kernel, k-sliced tiled kernel with the skipped
-    upper quadrants of diagonal tiles mirrored by the slab reduction) vs float64 torch; the result is exactly symmetric."""
+    """H = A diag(w) A^T through mobocmf_syrk_weighted_f64 (small-operand kernel; k-sliced tiled kernel with per-class slice
+    counts -- one, two, ... five row blocks -- and the skipped 16 x 16 blocks above the diagonal of diagonal tiles mirrored
+    by the slab reduction) vs float64 torch; the result is exactly symmetric."""
     from mobocmf_amd import functional as F
     g = torch.Generator(device=DEV)
     g.manual_seed(Mp * 7 + Np)
