@@ -240,6 +240,16 @@ int mobocmf_adam_multi(int32_t n_tensors, double* const* params, const double* c
                        double* const* exp_avg_sq, const int64_t* sizes, double lr, double beta1, double beta2, double eps,
                        int64_t* step_state, mobocmf_stream_t stream);
 
+/* Constrained hyper-parameters of a layer in one launch: out = softplus of n_tensors raw parameter tensors (HOST arrays of
+ * device pointers / sizes, copied into the kernel arguments: capturable), concatenated in the given order -- the `hyp`
+ * vector of mobocmf_layer_forward built from GPyTorch's raw_outputscale / raw_lengthscale / raw_variance parameters with
+ * their Positive() constraints (gpytorch.constraints.Positive = softplus; mfdgp_hidden_layer.py:43-47,68-88).  The
+ * backward writes one gradient tensor per raw tensor.  n_tensors <= 16. */
+int mobocmf_softplus_pack(int32_t n_tensors, const double* const* raw, const int32_t* sizes, double* out,
+                          mobocmf_stream_t stream);
+int mobocmf_softplus_pack_backward(int32_t n_tensors, const double* const* raw, const int32_t* sizes, const double* g_out,
+                                   double* const* g_raw, mobocmf_stream_t stream);
+
 /* The f64 MFMA GEMM used by the layer (exposed for tests and for the roofline measurement of bench.py):
  * C[Mr x Nc] (+)= alpha * A[Mr x Kd] * B, B is [Kd x Nc] (trans_b = 0) or [Nc x Kd] (trans_b = 1).
  * Mr, Nc multiples of 128, Kd multiple of 16, leading dimensions even, pointers 16-byte aligned.

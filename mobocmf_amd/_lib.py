@@ -65,6 +65,8 @@ SYMBOLS = {
     "mobocmf_gemm_f64_epilogue": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32] + [_P] * 8 + [_P],
     "mobocmf_syrk_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ)],
     "mobocmf_syrk_weighted_f64": [_I32, _I64, _P, _I64, _P, _P, _P, _I64, _P],
+    "mobocmf_softplus_pack": [_I32, _P, _P, _P, _P],
+    "mobocmf_softplus_pack_backward": [_I32, _P, _P, _P, _P, _P],
     "mobocmf_set_tuning": [_I32, _I32],
     "mobocmf_rff_eval": [_I32, _I32, _I32, _I64] + [_P] * 8 + [_D, _D, _D, _P, _P],
     "mobocmf_gram_forward": [_I32, _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P],

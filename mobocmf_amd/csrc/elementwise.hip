@@ -673,6 +673,60 @@ int mobocmf_adam_multi(int32_t n_tensors, double* const* params, const double* c
     return CHECK_LAUNCH();
 }
 
+// Constrained hyper-parameters of a layer: softplus of every raw parameter tensor, packed into one vector in the C-ABI
+// order (and the backward of that), one launch each.  The tensors are tiny (<= 5 + 2 d entries in total): one workgroup.
+#define PACK_MAX_TENSORS 16
+struct PackTable {
+    const double* raw[PACK_MAX_TENSORS];
+    double* g_raw[PACK_MAX_TENSORS];
+    int32_t off[PACK_MAX_TENSORS + 1];
+};
+__global__ void softplus_pack_kernel(PackTable t, int nt, double* out) {
+    for (int e = threadIdx.x; e < t.off[nt]; e += blockDim.x) {
+        int ti = 0;
+        while (e >= t.off[ti + 1]) ++ti;
+        const double x = t.raw[ti][e - t.off[ti]];
+        out[e] = x > 20.0 ? x : log1p(exp(x));      // torch.nn.functional.softplus (beta 1, threshold 20)
+    }
+}
+__global__ void softplus_pack_bwd_kernel(PackTable t, int nt, const double* g_out) {
+    for (int e = threadIdx.x; e < t.off[nt]; e += blockDim.x) {
+        int ti = 0;
+        while (e >= t.off[ti + 1]) ++ti;
+        const double x = t.raw[ti][e - t.off[ti]];
+        t.g_raw[ti][e - t.off[ti]] = x > 20.0 ? g_out[e] : g_out[e] / (1.0 + exp(-x));
+    }
+}
+static int fill_pack_table(PackTable& t, int32_t n, const double* const* raw, double* const* g_raw, const int32_t* sizes) {
+    if (n < 1 || n > PACK_MAX_TENSORS || !raw || !sizes) return MOBOCMF_BAD_ARG;
+    t.off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!raw[i] || sizes[i] < 1 || (g_raw && !g_raw[i])) return MOBOCMF_BAD_ARG;
+        t.raw[i] = raw[i];
+        t.g_raw[i] = g_raw ? g_raw[i] : nullptr;
+        t.off[i + 1] = t.off[i] + sizes[i];
+    }
+    return MOBOCMF_OK;
+}
+int mobocmf_softplus_pack(int32_t n_tensors, const double* const* raw, const int32_t* sizes, double* out,
+                          mobocmf_stream_t stream) {
+    PackTable t;
+    if (!out) return MOBOCMF_BAD_ARG;
+    const int rc = fill_pack_table(t, n_tensors, raw, nullptr, sizes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(softplus_pack_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, t, n_tensors, out);
+    return CHECK_LAUNCH();
+}
+int mobocmf_softplus_pack_backward(int32_t n_tensors, const double* const* raw, const int32_t* sizes, const double* g_out,
+                                   double* const* g_raw, mobocmf_stream_t stream) {
+    PackTable t;
+    if (!g_out || !g_raw) return MOBOCMF_BAD_ARG;
+    const int rc = fill_pack_table(t, n_tensors, raw, g_raw, sizes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(softplus_pack_bwd_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, t, n_tensors, g_out);
+    return CHECK_LAUNCH();
+}
+
 int mobocmf_propagate_forward(const double* mean, const double* var, const double* eps, double* f_out, int64_t n_out,
                               int32_t div, mobocmf_stream_t stream) {
     if (n_out < 0 || div < 1) return MOBOCMF_BAD_ARG;

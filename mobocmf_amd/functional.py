@@ -892,6 +892,41 @@ def rff_eval(kind, x, fprev, W1, b1, Wf, W2, b2, theta, s0, s1=0.0, s2=0.0):
     return out
 
 
+class _SoftplusPackFn(torch.autograd.Function):
+    """softplus of several raw parameter tensors, concatenated: one launch forward, one backward (mobocmf_softplus_pack)."""
+
+    @staticmethod
+    def forward(ctx, *raws):
+        lib = _lib.require_device()
+        flat = [_prep(r.detach().reshape(-1)) for r in raws]
+        n = len(flat)
+        sizes = (ctypes.c_int32 * n)(*[f.numel() for f in flat])
+        ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in flat])
+        out = _empty(sum(f.numel() for f in flat), device=flat[0].device)
+        _lib.check(lib.mobocmf_softplus_pack(n, ptrs, sizes, _ptr(out), _stream()), "mobocmf_softplus_pack")
+        ctx.save_for_backward(*raws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.require_device()
+        raws = ctx.saved_tensors
+        flat = [_prep(r.detach().reshape(-1)) for r in raws]
+        n = len(flat)
+        grads = [_empty_like(r) for r in raws]
+        sizes = (ctypes.c_int32 * n)(*[f.numel() for f in flat])
+        ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in flat])
+        gptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
+        _lib.check(lib.mobocmf_softplus_pack_backward(n, ptrs, sizes, _ptr(_prep(g)), gptrs, _stream()),
+                   "mobocmf_softplus_pack_backward")
+        return tuple(grads)
+
+
+def softplus_pack(raws):
+    """``softplus(cat(raws))`` for float64 device tensors (<= 16 of them) in one launch, differentiable."""
+    return _SoftplusPackFn.apply(*raws)
+
+
 def syrk_weighted(A, w, H=None):
     """H = A diag(w) A^T (full symmetric, float64) on the k-sliced MFMA kernel: the weighted syrk of the layer backward
     (mobocmf_syrk_weighted_f64).  A: [Mr, Kd] with Mr, Kd multiples of 128."""

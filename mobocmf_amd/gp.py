@@ -157,12 +157,18 @@ def _hyper_sources(covar_module, kind):
 
 def pack_hypers(covar_module, kind):
     """Constrained hyper-parameters in the C-ABI order (include/mobocmf_hip.h).  Differentiable.
-    All of them carry the softplus constraint, so the transform is applied ONCE to the concatenated raw values (two
-    launches instead of one softplus per parameter plus the concatenation -- the per-step glue that dominated the
-    small configurations); any other constraint falls back to transforming parameter by parameter."""
+    All of them carry the softplus constraint: on the device one launch transforms and packs every raw tensor
+    (mobocmf_softplus_pack; its backward writes every raw gradient in one launch too -- instead of a concatenation, a
+    softplus, its backward and one gradient copy per parameter: the per-step glue that dominated the small
+    configurations); on the CPU the transform is applied once to the concatenated raw values; any other constraint falls
+    back to transforming parameter by parameter."""
     src = _hyper_sources(covar_module, kind)
-    raws = [getattr(m, n).reshape(-1) for m, n in src]
+    params = [getattr(m, n) for m, n in src]
+    raws = [p.reshape(-1) for p in params]
     if all(type(getattr(m, n + "_constraint")) is Positive for m, n in src):
+        if all(p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() for p in params):
+            from . import functional as F      # one launch forward, one backward (instead of cat + softplus and a
+            return F.softplus_pack(params)     # softplus backward + one gradient copy per parameter)
         return torch.nn.functional.softplus(torch.cat(raws))
     return torch.cat([getattr(m, n + "_constraint").transform(r) for (m, n), r in zip(src, raws)])
 

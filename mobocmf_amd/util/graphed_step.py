@@ -32,6 +32,7 @@ class GraphedELBOStep:
         else:
             self.optimizer = FusedAdam(params, lr=lr, betas=betas, eps=eps)     # one launch; step count on the device
         self.loss = torch.zeros((), dtype=torch.float64, device=x.device)
+        self._minus_one = torch.full((), -1.0, dtype=torch.float64, device=x.device)
         self.kl = torch.zeros((), dtype=torch.float64, device=x.device)
         self.graph = None
         self.graph_update = None
@@ -49,9 +50,9 @@ class GraphedELBOStep:
             [None] + [torch.randn(n, dtype=torch.float64, device=self.x.device) for _ in range(1, self.L)]
         out = self.model(self.x, eps=eps)
         res = self.elbo(out, self.y.T, self.fid)
-        neg = -res[0]
-        neg.backward()
-        self.loss.copy_(neg.detach())
+        # d(-ELBO): the sign goes in as the upstream gradient (no negation node, no ones fill, no negation backward)
+        res[0].backward(gradient=self._minus_one)
+        torch.neg(res[0].detach(), out=self.loss)
         self.kl.copy_(res[1].detach())
         self.model.clear_kl_cache()
 

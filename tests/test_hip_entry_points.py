@@ -142,3 +142,24 @@ def test_weighted_syrk_matches_torch(Mp, Np):
     assert rel(H, ref) < 1e-12
     assert torch.equal(H, H.T)
 
+
+def test_softplus_pack_matches_torch():
+    """mobocmf_softplus_pack / _backward (the constrained hyper-parameter vector of a layer in one launch) vs
+    softplus(cat(raws)) and its autograd gradient, including 0-d tensors and values beyond softplus' threshold."""
+    from mobocmf_amd import functional as F
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    shapes = [(), (), (1, 1), (), (1, 1), (1, 8), (1, 8)]
+    raws = [(5.0 * torch.randn(s, dtype=torch.float64, device=DEV, generator=g)).requires_grad_(True) for s in shapes]
+    with torch.no_grad():
+        raws[1].fill_(25.0)      # beyond the threshold: identity branch
+    ref_in = [r.detach().clone().requires_grad_(True) for r in raws]
+    w = torch.randn(sum(r.numel() for r in raws), dtype=torch.float64, device=DEV, generator=g)
+    out = F.softplus_pack(raws)
+    (out * w).sum().backward()
+    ref = torch.nn.functional.softplus(torch.cat([r.reshape(-1) for r in ref_in]))
+    (ref * w).sum().backward()
+    assert rel(out, ref) < 1e-15
+    for a, b in zip(raws, ref_in):
+        assert a.grad.shape == b.grad.shape and rel(a.grad.reshape(-1), b.grad.reshape(-1)) < 1e-14
+
