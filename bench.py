@@ -12,9 +12,11 @@ the timed region and is reported as `exchange_ms`.
     python bench.py --gpus N ...            (starts the N ranks itself, one fresh process per GPU, RCCL)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-The line's `value` is the median of --repeats (default 3) timed regions of exactly K steps each (all listed in
+The line's `value` is the median of --repeats (default 5) timed regions of exactly K steps each (all listed in
 `repeat_values`); `roofline` times the GEMM instantiations the layer really launches (column-statistics and dA
-epilogues included), each on its own; `cpu_baseline` is 3 warm-up + 10 timed oracle steps on the box's host cores.
+epilogues included), each on its own, and `per_kernel_instep_ms` the same launches INSIDE a training step (HIP events
+recorded by the library around them, mobocmf_set_probe_events); `cpu_baseline` is 3 warm-up + 10 timed oracle steps on
+the box's host cores.
 """
 import argparse
 import json
@@ -200,6 +202,42 @@ def measure_dominant_kernel(cfg, device, iters=20):
                       "clock), each variant alone on the chip" % iters}
 
 
+PROBE_SPANS = (("Gram forward K_mn", 9, 0), ("A = L^-1 K (lower, colstats q+mean)", 0, 1),
+               ("C = U^T A (upper, colstats r, stream-out)", 1, 2), ("dA (lower, dA epilogue + row dots)", 3, 4),
+               ("H = A diag(gv) A^T (weighted syrk + slab reduction)", 5, 6), ("dK = L^-T dA (upper, plain store)", 7, 8),
+               ("Gram backward of K_mn", 8, 10))
+
+
+def measure_instep_kernels(gstep, cfg, steps=6, skip=2):
+    """Durations of the top layer's grid-filling launches INSIDE a training step of one surrogate (the other surrogates
+    idle): the library records caller-created HIP events around them (mobocmf_set_probe_events) while the step is issued
+    eagerly on the surrogate's own stream -- the same launch sequence the captured graph replays.  Mean over the last
+    steps - skip steps."""
+    import ctypes
+
+    from mobocmf_amd import _lib
+    lib = _lib.load()
+    n_ev = 11
+    Np_top = cfg["N"] * cfg["S"]
+    acc = {name: [] for name, _, _ in PROBE_SPANS}
+    try:
+        for k in range(steps):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+            with torch.cuda.stream(gstep.stream):
+                for e in evs:
+                    e.record(gstep.stream)      # creates the underlying hipEvent_t (lazy in torch) before it is handed over
+                table = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in evs])
+                _lib.check(lib.mobocmf_set_probe_events(table, n_ev, Np_top), "mobocmf_set_probe_events")
+                gstep._eager()
+            gstep.stream.synchronize()
+            if k >= skip:
+                for name, a, b in PROBE_SPANS:
+                    acc[name].append(evs[a].elapsed_time(evs[b]))
+    finally:
+        lib.mobocmf_set_probe_events(None, 0, 0)
+    return {name: sum(v) / len(v) for name, v in acc.items() if v}
+
+
 def usable_cores():
     """Host cores this process may actually use: min(os.cpu_count(), affinity mask, cgroup CPU quota)."""
     n = os.cpu_count() or 1
@@ -327,7 +365,7 @@ def main():
                          "the same surrogates on 1/W of the batch rows + one gradient all-reduce per step (strong scaling)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="serialise each surrogate's layers on one stream (no chain/panel split across streams)")
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; value = median")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = median")
     ap.add_argument("--launch", action="store_true", help="go through the rank launcher even for --gpus 1")
     args = ap.parse_args()
     if args.no_overlap:
@@ -335,12 +373,10 @@ def main():
         MFDGP.overlap_chains = False
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.launch):
-        # plain `python bench.py --gpus N`: start the N ranks here -- one fresh process per GPU, RCCL -- before anything
-        # in this process touches the GPU (device_count() does not initialise it); rank 0 prints the single JSON line
-        have = torch.cuda.device_count()
-        if args.force_device < 0 and have < args.gpus:
-            sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (args.gpus, have))
-            raise SystemExit(3)
+        # plain `python bench.py --gpus N`: start the N ranks here -- one fresh process per GPU, RCCL.  This launcher
+        # process never touches the GPU (not even torch.cuda.device_count(): without amdsmi it falls back to
+        # hipGetDeviceCount, which initialises the HIP runtime): every rank checks its own LOCAL_RANK against the visible
+        # devices and exits 3, which takes its siblings down (parallel.launch_ranks) -- never a silent 1-GPU line
         from mobocmf_amd import parallel
         os.dup2(json_fd, 1)
         codes = parallel.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
@@ -354,6 +390,10 @@ def main():
         raise SystemExit(2)
     if args.force_device >= 0:
         local_rank = args.force_device
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d needs device %d but only %d device(s) are visible\n" %
+                         (rank, local_rank, torch.cuda.device_count()))
+        raise SystemExit(3)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -465,6 +505,14 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = measure_dominant_kernel(cfg, device)
+            if not args.eager and not rows:
+                ins = measure_instep_kernels(gsteps[0], cfg)
+                iso = {v["kernel"]: v["kernel_ms"] for v in line["roofline"]["variants"]}
+                line["per_kernel_instep_ms"] = {
+                    "kernels": ins, "instep_over_isolated": {k: ins[k] / iso[k] for k in ins if k in iso},
+                    "how": "top layer of ONE surrogate, step issued eagerly on its own stream (the launch sequence the graph "
+                           "replays), HIP events recorded by the library around each launch (mobocmf_set_probe_events), mean "
+                           "of 4 steps; `instep_over_isolated` divides by the same launch timed alone (roofline.variants)"}
         if world == 1 and not args.no_cpu_baseline:
             cb, parity = cpu_baseline(cfg, device=device)
             line["cpu_baseline"] = cb

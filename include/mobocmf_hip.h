@@ -120,7 +120,8 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
  * parameters only), so batching them divides the length of that string by the number of layers.
  * Memory: one CHAIN BLOCK per layer (mobocmf_chain_block_bytes; all M x M-sized: the chain state L, L^-1, U, ... that the
  * PANEL halves read, H / Hc / da that the PANEL backward leaves for the chain backward, and the chain's scratch), the n
- * blocks `block_stride` bytes apart (a multiple of 256, >= the block size) starting at `blocks`; per layer a PANEL `saved`
+ * blocks `block_stride` bytes apart (a multiple of 256, >= the block size) starting at `blocks`, which holds `blocks_bytes`
+ * >= n * block_stride bytes (checked: MOBOCMF_WORKSPACE_TOO_SMALL); per layer a PANEL `saved`
  * and `scratch` (mobocmf_panel_workspace_bytes).  Call order of a step: layers_chain_forward; layer_panel_forward per layer
  * (bottom up); layer_panel_backward per layer (top down); layers_chain_backward.  Arrays of pointers are HOST arrays of n
  * entries (device pointers inside).  The PANEL backward OVERWRITES g_hyp / g_zf with the K_mn share, the chain backward
@@ -131,11 +132,12 @@ int mobocmf_panel_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_
 int mobocmf_layers_chain_forward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
                                  const double* const* zf, const double* const* hyp, const double* const* m,
                                  const double* const* L_S, double* const* kl, int32_t* const* info, void* blocks,
-                                 size_t block_stride, mobocmf_stream_t stream);
+                                 size_t block_stride, size_t blocks_bytes, mobocmf_stream_t stream);
 int mobocmf_layers_chain_backward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
                                   const double* const* zf, const double* const* hyp, const double* const* g_kl,
                                   const int32_t* had_panel, double* const* g_zf, double* const* g_hyp, double* const* g_m,
-                                  double* const* g_LS, void* blocks, size_t block_stride, mobocmf_stream_t stream);
+                                  double* const* g_LS, void* blocks, size_t block_stride, size_t blocks_bytes,
+                                  mobocmf_stream_t stream);
 int mobocmf_layer_panel_forward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
                                 const double* zf, const double* hyp, double* mean, double* var, void* chain_block,
                                 size_t block_bytes, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
@@ -147,11 +149,17 @@ int mobocmf_layer_panel_backward(const mobocmf_layer_desc* desc, const double* x
                                  size_t block_bytes, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                                  mobocmf_stream_t stream);
 
-/* cov[Np x Np] = K_nn - A^T A + C^T C from the state a forward call left in `saved` (eval branch, full
- * predictive covariance; MFMA contraction).  Np must be <= 16384. */
-int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f,
-                                  const double* hyp, double* cov, int64_t ldcov, void* saved, size_t saved_bytes,
-                                  void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+/* cov[Np x Np] = K_nn - A^T A + C^T C (A = L^-1 K_mn, C = U^T A): the full predictive covariance of the eval branch of the
+ * variational strategy (the dense matrix GPyTorch materialises in .eval(), JESMOC_MFDGP.py:42 -> mfdgp.py:248), written as
+ * the full symmetric matrix with leading dimension ldcov >= Np.  Only the layer's CHAIN state is read (`chain_state` = the
+ * first mobocmf_layer_chain_state_bytes of the `saved` buffer a forward / CHAIN-half call filled: L^-1 and U), so a frozen
+ * chain serves any number of input batches.  The contractions over the M inducing points are symmetric rank-M updates on
+ * the MFMA (lower 128-tiles only), one column panel at a time: the scratch (mobocmf_predictive_covariance_workspace_bytes)
+ * grows with Np x panel width, not Np^2, and Np is not capped.  Ordinary layer scratch sizes do not include it. */
+int mobocmf_predictive_covariance_workspace_bytes(const mobocmf_layer_desc* desc, size_t* scratch_bytes);
+int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                                  const double* zf, const double* hyp, double* cov, int64_t ldcov, const void* chain_state,
+                                  size_t chain_state_bytes, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
 
 /* Dense prior covariance K[i][j] = k([x1[i], f1[i]], [x2[j], f2[j]]) of one layer's kernel (the lazy prior of
  * MFDGPHiddenLayer.forward, mfdgp_hidden_layer.py:232-243, evaluated): x1 [n1 x d], x2 [n2 x d], f1 [n1] / f2 [n2] (kind 1,
@@ -285,6 +293,15 @@ int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t l
  * (default 512).  A value <= 0 leaves that threshold unchanged.  Process-wide; meant for size sweeps, set it before
  * the work it should affect is enqueued. */
 int mobocmf_set_tuning(int32_t small_gemm_max, int32_t small_panel_max);
+
+/* Diagnostic, process-wide, off by default: HIP events (hipEvent_t, created by the caller with timing enabled) recorded on the
+ * call's stream around the grid-filling launches of the PANEL halves of every layer call whose desc->Np equals `Np`:
+ *   [9] Gram forward [0] A = L^-1 K [1] C = U^T A [2]   ...   [3] dA [4] ... [5] weighted syrk + slab reduction [6] ...
+ *   [7] dK = L^-T dA [8] Gram backward [10]
+ * -- per-kernel durations INSIDE a training step without a profiler (bench.py: per_kernel_instep_ms).  n = 0 disarms.  Not
+ * for use under stream capture or from several threads at once. */
+#define MOBOCMF_PROBE_EVENTS 11
+int mobocmf_set_probe_events(void* const* events, int32_t n, int64_t Np);
 
 /* Host-side, synchronising: copies the device word and returns MOBOCMF_OK or MOBOCMF_NOT_PD (pivot in *pivot). */
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream);

@@ -41,11 +41,12 @@ SYMBOLS = {
     "mobocmf_layer_backward": [ctypes.POINTER(LayerDesc)] + [_P] * 16 + [_P, _SZ, _P, _SZ, _P],
     "mobocmf_chain_block_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
     "mobocmf_panel_workspace_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
-    "mobocmf_layers_chain_forward": [_I32] + [_P] * 8 + [_P, _SZ, _P],
-    "mobocmf_layers_chain_backward": [_I32] + [_P] * 10 + [_P, _SZ, _P],
+    "mobocmf_layers_chain_forward": [_I32] + [_P] * 8 + [_P, _SZ, _SZ, _P],
+    "mobocmf_layers_chain_backward": [_I32] + [_P] * 10 + [_P, _SZ, _SZ, _P],
     "mobocmf_layer_panel_forward": [ctypes.POINTER(LayerDesc)] + [_P] * 7 + [_P, _SZ, _P, _SZ, _P, _SZ, _P],
     "mobocmf_layer_panel_backward": [ctypes.POINTER(LayerDesc)] + [_P] * 11 + [_P, _SZ, _P, _SZ, _P, _SZ, _P],
-    "mobocmf_predictive_covariance": [ctypes.POINTER(LayerDesc), _P, _P, _P, _P, _I64, _P, _SZ, _P, _SZ, _P],
+    "mobocmf_predictive_covariance_workspace_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ)],
+    "mobocmf_predictive_covariance": [ctypes.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _I64, _P, _SZ, _P, _SZ, _P],
     "mobocmf_propagate_forward": [_P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_propagate_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_elbo_data_forward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _SZ, _P],
@@ -70,6 +71,7 @@ SYMBOLS = {
     "mobocmf_set_tuning": [_I32, _I32],
     "mobocmf_rff_eval": [_I32, _I32, _I32, _I64] + [_P] * 8 + [_D, _D, _D, _P, _P],
     "mobocmf_gram_forward": [_I32, _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P],
+    "mobocmf_set_probe_events": [_P, _I32, _I64],
     "mobocmf_check_info": [_P, ctypes.POINTER(_I32), _P],
 }
 MAX_D, MAX_XDIV = 32, 48        # MOBOCMF_MAX_D / MOBOCMF_MAX_XDIV of include/mobocmf_hip.h

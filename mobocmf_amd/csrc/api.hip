@@ -39,6 +39,8 @@ int launch_symmetrize(const double* S, int Mp, double* G, hipStream_t s);
 int launch_gls_out(const double* X, const double* LSp, const double* gkl, int M, int Mp, double* gLS, hipStream_t s);
 int launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
 int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s);
+int launch_mirror_lower(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t row0, int64_t rows, int64_t cols,
+                        int64_t n_real, hipStream_t s);
 // layer-batched forms (blockIdx.z = layer, workspace pointers + z*zs doubles, user tensors as tables)
 int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
                    hipStream_t s);
@@ -59,6 +61,18 @@ int launch_dl_from_t2_z(const double* T2, const double* L, const double* const* 
 int launch_phi_z(const double* T3, int Mp, double* P, int nz, int64_t zs, hipStream_t s);
 int launch_symmetrize_z(const double* S, int Mp, double* G, int nz, int64_t zs, hipStream_t s);
 
+// Diagnostic probe (bench.py's per_kernel_instep_ms; include/mobocmf_hip.h, mobocmf_set_probe_events): caller-created HIP
+// events recorded around the grid-filling launches of the PANEL halves of the layer whose N' matches -- per-kernel
+// durations INSIDE a step, in the driver's own run, without a profiler.  Off (n = 0) unless armed.
+#include <atomic>
+static hipEvent_t g_probe_ev[MOBOCMF_PROBE_EVENTS];
+static std::atomic<int> g_probe_n{0};
+static std::atomic<int64_t> g_probe_Np{0};
+static inline void probe_at(int i, int64_t N, hipStream_t s) {
+    if (i < g_probe_n.load(std::memory_order_acquire) && N == g_probe_Np.load(std::memory_order_relaxed))
+        (void)hipEventRecord(g_probe_ev[i], s);
+}
+
 #define TRY(x)              \
     do {                    \
         int _rc = (x);      \
@@ -68,14 +82,14 @@ int launch_symmetrize_z(const double* S, int Mp, double* G, int nz, int64_t zs, 
 namespace {
 
 struct Bump {
-    char* base;
+    uintptr_t base;      // 0: size query (nothing is dereferenced, take() returns nullptr)
     size_t off, cap;
     bool ok;
-    Bump(void* p, size_t c) : base((char*)p), off(0), cap(c), ok(true) {}
+    Bump(void* p, size_t c) : base((uintptr_t)p), off(0), cap(c), ok(true) {}
     double* take(int64_t n) {
         size_t bytes = ((size_t)n * sizeof(double) + 255) & ~(size_t)255;
-        if (off + bytes > cap) { ok = false; off += bytes; return nullptr; }
-        double* r = (double*)(base + off);
+        if (bytes > cap || off > cap - bytes) { ok = false; off += bytes; return nullptr; }
+        double* r = base ? (double*)(base + off) : nullptr;
         off += bytes;
         return r;
     }
@@ -364,16 +378,20 @@ int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& 
     g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
     g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase; g.jitter = desc->jitter;
     g.K = F.K; g.ldk = Np; g.Np = Np; g.knn = P.knn; g.is_kmm = 0;
+    probe_at(9, D.N, s);
     TRY(launch_gram_fwd(g, s));
+    probe_at(0, D.N, s);
     GemmArgs ga = gemm_args(c.Linv, Mp, F.K, Np, P.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
     ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = c.a;
     ga.Kreal = D.M;      // rows >= M of K_mn (and of A, C, dA below) are zero padding
     TRY(launch_gemm(ga, false, 1, s));
+    probe_at(1, D.N, s);
     GemmArgs gc = gemm_args(c.UT, Mp, P.A, Np, P.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
     gc.epi = EPI_COLSTATS; gc.colsq_part = F.rpart; gc.coldot_part = nullptr; gc.avec = c.a;
     gc.Kreal = D.M;
     gc.stream_out = (desc->branch == 0 && Np * Mp * 8 >= ((int64_t)64 << 20)) ? 1 : 0;   // C is next read in backward
     TRY(launch_gemm(gc, false, 1, s));
+    probe_at(2, D.N, s);
     TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, 2 * D.nrb, Np, D.N, P.knn, desc->branch, desc->min_var, P.q, P.r,
                               P.varraw, mean, var, s));
     return MOBOCMF_OK;
@@ -397,7 +415,9 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
         ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = c.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = P.A;
         ga.Kreal = D.M;
         ga.rowdot_part = inputs_only ? nullptr : B.dapart;      // da = A gmu rides in the epilogue (it reads A anyway)
+        probe_at(3, D.N, s);
         TRY(launch_gemm(ga, false, 1, s));
+        probe_at(4, D.N, s);
         if (!inputs_only) TRY(launch_sum_partials(B.dapart, gemm_rowdot_parts(ga), Mp, c.da, Mp, 1.0, 0, s));
     }
     // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
@@ -405,14 +425,18 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
     // (skip_if_zero) when no column is clamped.
     if (!inputs_only) {
+        probe_at(5, D.N, s);
         TRY(weighted_syrk(P.A, Np, B.gv, Mp, Np, B.slabs, c.H, nullptr, nullptr, s));
+        probe_at(6, D.N, s);
         if (desc->branch == 0) TRY(weighted_syrk(P.A, Np, B.cgv, Mp, Np, B.slabs, Hc, nclamped, c.H, s));
     }
     // dK = L^-T dA
     {
         GemmArgs ga = gemm_args(c.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
         ga.Kreal = D.M;
+        probe_at(7, D.N, s);
         TRY(launch_gemm(ga, false, 1, s));
+        probe_at(8, D.N, s);
     }
     // Gram backward of K_mn and k_nn
     GramArgs g = {};
@@ -421,6 +445,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
     g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
     TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
+    probe_at(10, D.N, s);
     SumTask tk[4];
     int nt = 0;
     tk[nt++] = {B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, nullptr, 0, 0, g_hyp, D.H, 0};
@@ -536,6 +561,32 @@ bool same_chain_shape(int n, const mobocmf_layer_desc* const* d) {
 
 }  // namespace
 
+// ---- K10: the full eval-branch predictive covariance  cov = K_nn - A^T A + C^T C  (A = L^-1 K_mn, C = U^T A).
+// Everything is formed TRANSPOSED, rows = data points, so that both contractions over the M inducing points are A B^T
+// products with the contraction index contiguous (no transposes of M x N' panels):
+//   K_nm (Gram with the data rows on the row side);  A^T = K_nm L^-T  (A B^T with B = L^-1, logical B upper-triangular);
+//   C^T = A^T U  (A B with B = U lower-triangular);  cov = K_nn - A^T (A^T)^T + C^T (C^T)^T  on the LOWER 128-tiles only
+// (symmetric: half the flops of the two dense products), one column panel of width covpanel_cols at a time -- the
+// scratch is O(N' x panel), not O(N'^2), so N' is not capped -- and mirrored into the caller's matrix.
+namespace {
+int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; }
+// panel width: a multiple of 128 (tiles) and of xdiv (a panel starts at a base row of the replicated inputs), ~2048 columns
+int64_t covpanel_cols(const mobocmf_layer_desc* d, int64_t Np) {
+    const int64_t l = (int64_t)TILE / gcd64(TILE, d->xdiv) * d->xdiv;
+    int64_t w = l * (2048 / l > 1 ? 2048 / l : 1);
+    return w < Np ? w : Np;
+}
+struct CovWs { double *Knm, *AT, *CT, *Cv; };
+bool carve_cov(void* scratch, size_t bytes, const mobocmf_layer_desc* d, const Dims& D, CovWs& w, size_t* used = nullptr) {
+    Bump b(scratch, bytes);
+    const int64_t nm = D.Np * D.Mp;
+    w.Knm = b.take(nm); w.AT = b.take(nm); w.CT = b.take(nm);
+    w.Cv = b.take(D.Np * covpanel_cols(d, D.Np));
+    if (used) *used = b.off;
+    return b.ok;
+}
+}  // namespace
+
 extern "C" {
 
 int mobocmf_version(void) { return 200; }
@@ -562,11 +613,7 @@ int mobocmf_layer_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_
     carve_single_fwd(nullptr, big, D, c, F, &sf);
     carve_single_bwd(nullptr, big, D, desc, c, B, &sb);
     *saved_bytes = sv;
-    // predictive covariance scratch: A^T, C^T (Np x Mp) + padded cov (Np x Np), only sized for Np <= 16384
-    size_t cov = 0;
-    if (D.Np <= 16384) cov = (size_t)(2 * D.Np * D.Mp + D.Np * D.Np) * sizeof(double) + 1024;
-    size_t m = sf > sb ? sf : sb;
-    *scratch_bytes = m > cov ? m : cov;
+    *scratch_bytes = sf > sb ? sf : sb;
     return MOBOCMF_OK;
 }
 
@@ -669,10 +716,11 @@ int mobocmf_panel_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_
 int mobocmf_layers_chain_forward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
                                  const double* const* zf, const double* const* hyp, const double* const* m,
                                  const double* const* L_S, double* const* kl, int32_t* const* info, void* blocks,
-                                 size_t block_stride, mobocmf_stream_t stream) {
+                                 size_t block_stride, size_t blocks_bytes, mobocmf_stream_t stream) {
     if (n < 1 || n > MAX_ZL || !desc || !Zx || !zf || !hyp || !m || !L_S || !kl || !info || !blocks || (block_stride & 255))
         return MOBOCMF_BAD_ARG;
     if (!same_chain_shape(n, desc)) return MOBOCMF_BAD_ARG;
+    if (blocks_bytes / (size_t)n < block_stride) return MOBOCMF_WORKSPACE_TOO_SMALL;      // layer z works at blocks + z * stride
     for (int z = 0; z < n; ++z)
         if (!Zx[z] || !hyp[z] || !m[z] || !L_S[z] || !kl[z] || !info[z] || (desc[z]->kind == 1 && !zf[z])) return MOBOCMF_BAD_ARG;
     Dims D = dims_of(desc[0]);
@@ -686,11 +734,13 @@ int mobocmf_layers_chain_forward(int32_t n, const mobocmf_layer_desc* const* des
 int mobocmf_layers_chain_backward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
                                   const double* const* zf, const double* const* hyp, const double* const* g_kl,
                                   const int32_t* had_panel, double* const* g_zf, double* const* g_hyp, double* const* g_m,
-                                  double* const* g_LS, void* blocks, size_t block_stride, mobocmf_stream_t stream) {
+                                  double* const* g_LS, void* blocks, size_t block_stride, size_t blocks_bytes,
+                                  mobocmf_stream_t stream) {
     if (n < 1 || n > MAX_ZL || !desc || !Zx || !zf || !hyp || !g_kl || !had_panel || !g_zf || !g_hyp || !g_m || !g_LS ||
         !blocks || (block_stride & 255))
         return MOBOCMF_BAD_ARG;
     if (!same_chain_shape(n, desc)) return MOBOCMF_BAD_ARG;
+    if (blocks_bytes / (size_t)n < block_stride) return MOBOCMF_WORKSPACE_TOO_SMALL;
     bool zero[MAX_ZL];
     int acc[MAX_ZL];
     for (int z = 0; z < n; ++z) {
@@ -748,39 +798,63 @@ int mobocmf_layer_panel_backward(const mobocmf_layer_desc* desc, const double* x
                           g_zf, g_hyp, g_x, (hipStream_t)stream);
 }
 
-int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* hyp,
-                                  double* cov, int64_t ldcov, void* saved, size_t saved_bytes, void* scratch,
-                                  size_t scratch_bytes, mobocmf_stream_t stream) {
-    if (!valid_desc(desc) || !x || !hyp || !cov || !saved || !scratch || ldcov < desc->Np) return MOBOCMF_BAD_ARG;
-    if (desc->kind == 1 && !f) return MOBOCMF_BAD_ARG;
+int mobocmf_predictive_covariance_workspace_bytes(const mobocmf_layer_desc* desc, size_t* scratch_bytes) {
+    if (!valid_desc(desc) || !scratch_bytes) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc);
+    CovWs w;
+    carve_cov(nullptr, ~(size_t)0 >> 1, desc, D, w, scratch_bytes);
+    return MOBOCMF_OK;
+}
+
+int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
+                                  const double* zf, const double* hyp, double* cov, int64_t ldcov, const void* chain_state,
+                                  size_t chain_state_bytes, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
+    if (!valid_desc(desc) || !x || !Zx || !hyp || !cov || !chain_state || !scratch || ldcov < desc->Np) return MOBOCMF_BAD_ARG;
+    if (desc->kind == 1 && (!f || !zf)) return MOBOCMF_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     Dims D = dims_of(desc);
-    if (D.Np > 16384) return MOBOCMF_BAD_ARG;
-    Bump bc(scratch, scratch_bytes);
     ChainWs cw = {};
-    PanelSaved S;
-    if (!carve_single_saved(saved, saved_bytes, D, cw, S)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    {
+        Bump b((void*)chain_state, chain_state_bytes);
+        carve_chain_state(b, D, cw);
+        if (!b.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    }
+    CovWs w;
+    if (!carve_cov(scratch, scratch_bytes, desc, D, w)) return MOBOCMF_WORKSPACE_TOO_SMALL;
     const int Mp = D.Mp;
     const int64_t Np = D.Np;
-    double* AT = bc.take(Np * Mp);
-    double* CT = bc.take(Np * Mp);
-    double* Cv = bc.take(Np * Np);
-    if (!bc.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
-    // K_nn: Gram with the data rows on both sides
+    if (Np > 0x7fffff80) return MOBOCMF_BAD_ARG;
+    // K_nm: data rows on the row side (replicated zdiv-fold like the layer's columns), Z~ on the column side
     GramArgs g = {};
-    g.kind = desc->kind; g.d = desc->d; g.xdiv = desc->xdiv; g.zdiv = desc->xdiv;
-    g.x = x; g.f = f; g.nbase = D.nbase; g.Zx = x; g.zf = f; g.M = (int)D.N; g.hyp = hyp;
-    g.K = Cv; g.ldk = Np; g.Mp = (int)Np; g.Np = Np; g.knn = nullptr; g.jitter = 0.0; g.is_kmm = 0;
+    g.kind = desc->kind; g.d = desc->d; g.xdiv = 1; g.zdiv = desc->xdiv;
+    g.x = Zx; g.f = zf; g.nbase = D.M; g.Zx = x; g.zf = f; g.M = (int)D.N; g.hyp = hyp;
+    g.K = w.Knm; g.ldk = Mp; g.Mp = (int)Np; g.Np = Mp; g.knn = nullptr; g.jitter = 0.0; g.is_kmm = 0;
     TRY(launch_gram_fwd(g, s));
-    TRY(launch_transpose(S.A, Np, AT, Mp, Mp, Np, s));
-    TRY(launch_transpose(S.C, Np, CT, Mp, Mp, Np, s));
-    GemmArgs ga = gemm_args(AT, Mp, S.A, Np, Cv, Np, (int)Np, Np, Mp, TRI_NONE, -1.0);
-    ga.accumulate = 1;
-    TRY(launch_gemm(ga, false, 1, s));
-    GemmArgs gc = gemm_args(CT, Mp, S.C, Np, Cv, Np, (int)Np, Np, Mp, TRI_NONE, 1.0);
-    gc.accumulate = 1;
-    TRY(launch_gemm(gc, false, 1, s));
-    TRY(launch_copy_block(Cv, Np, cov, ldcov, D.N, D.N, s));
+    {   // A^T[n][j] = sum_k K_nm[n][k] L^-1[j][k]
+        GemmArgs ga = gemm_args(w.Knm, Mp, cw.Linv, Mp, w.AT, Mp, (int)Np, Mp, Mp, TRI_UPPER_B, 1.0);
+        TRY(launch_gemm(ga, true, 1, s));
+        // C^T[n][j] = sum_k A^T[n][k] U[k][j]
+        GemmArgs gc = gemm_args(w.AT, Mp, cw.U, Mp, w.CT, Mp, (int)Np, Mp, Mp, TRI_LOWER_B, 1.0);
+        TRY(launch_gemm(gc, false, 1, s));
+    }
+    const int64_t W = covpanel_cols(desc, Np);
+    for (int64_t J0 = 0; J0 < Np && J0 < D.N; J0 += W) {
+        const int64_t Wp = Np - J0 < W ? Np - J0 : W, R = Np - J0, b0 = J0 / desc->xdiv;
+        // K_nn block: rows J0.. (row side), columns J0..J0+Wp (column side); J0 is a multiple of xdiv
+        GramArgs k = {};
+        k.kind = desc->kind; k.d = desc->d; k.xdiv = desc->xdiv; k.zdiv = desc->xdiv;
+        k.x = x + b0 * desc->d; k.f = f ? f + J0 : nullptr; k.nbase = D.nbase - b0;
+        k.Zx = x + b0 * desc->d; k.zf = f ? f + J0 : nullptr; k.M = (int)(D.N - J0); k.hyp = hyp;
+        k.K = w.Cv; k.ldk = Wp; k.Mp = (int)R; k.Np = Wp; k.knn = nullptr; k.jitter = 0.0; k.is_kmm = 0;
+        TRY(launch_gram_fwd(k, s));
+        GemmArgs ga = gemm_args(w.AT + J0 * Mp, Mp, w.AT + J0 * Mp, Mp, w.Cv, Wp, (int)R, Wp, Mp, TRI_NONE, -1.0);
+        ga.accumulate = 1; ga.lower_out = 1;
+        TRY(launch_gemm(ga, true, 1, s));
+        GemmArgs gc = gemm_args(w.CT + J0 * Mp, Mp, w.CT + J0 * Mp, Mp, w.Cv, Wp, (int)R, Wp, Mp, TRI_NONE, 1.0);
+        gc.accumulate = 1; gc.lower_out = 1;
+        TRY(launch_gemm(gc, true, 1, s));
+        TRY(launch_mirror_lower(w.Cv, Wp, cov, ldcov, J0, R, Wp, D.N, s));
+    }
     return MOBOCMF_OK;
 }
 
@@ -833,6 +907,96 @@ int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t l
     if (workspace_bytes < syrk_slab_elems(Mr, Kd) * (int64_t)sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
     return weighted_syrk(A, lda, w, Mr, Kd, (double*)workspace, H, nullptr, nullptr, (hipStream_t)stream);
 }
+
+int mobocmf_set_probe_events(void* const* events, int32_t n, int64_t Np) {
+    if (n < 0 || n > MOBOCMF_PROBE_EVENTS || (n > 0 && !events)) return MOBOCMF_BAD_ARG;
+    g_probe_n.store(0, std::memory_order_release);
+    for (int i = 0; i < n; ++i) g_probe_ev[i] = (hipEvent_t)events[i];
+    g_probe_Np.store(Np, std::memory_order_relaxed);
+    g_probe_n.store(n, std::memory_order_release);
+    return MOBOCMF_OK;
+}
+
+#ifdef MOBOCMF_HOST_FUZZ
+// Host-sanitizer build only (tools/asan_host.sh; never in the product library): carves every workspace layout out of HOST
+// buffers of the given sizes and writes the first and the last double of every region, so that AddressSanitizer sees any
+// region that reaches past the size the *_bytes functions reported.  No kernel is launched, no GPU is needed.
+static void touch(double* p, int64_t n, int* cnt) {
+    if (!p || n <= 0) return;
+    p[0] = 1.0;
+    p[n - 1] = 2.0;
+    ++*cnt;
+}
+int mobocmf_debug_touch_workspaces(const mobocmf_layer_desc* desc, void* saved, size_t saved_bytes, void* scratch,
+                                   size_t scratch_bytes, void* block, size_t block_bytes, void* psaved, size_t psaved_bytes,
+                                   void* pscratch, size_t pscratch_bytes, void* cov, size_t cov_bytes, int32_t* regions) {
+    if (!valid_desc(desc) || !regions) return MOBOCMF_BAD_ARG;
+    Dims D = dims_of(desc);
+    const int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
+    int n = 0;
+    auto chain_state = [&](ChainWs& c) {
+        touch(c.L, mm, &n); touch(c.Linv, mm, &n); touch(c.LinvT, mm, &n); touch(c.U, mm, &n); touch(c.UT, mm, &n);
+        touch(c.LSp, mm, &n); touch(c.a, D.Mp, &n); touch(c.mp, D.Mp, &n);
+    };
+    auto chain_fwd = [&](ChainWs& c) {
+        touch(c.Dinv, (int64_t)(D.Mp / NB) * NB * NB, &n); touch(c.Ld, (int64_t)(D.Mp / NB) * NB * NB, &n);
+        touch(c.T, mm, &n); touch(c.ws, c.ws_elems, &n); touch(c.klpart, D.Mp, &n);
+    };
+    auto chain_bwd = [&](ChainWs& c) {
+        touch(c.H, mm, &n); touch(c.Hc, mm, &n); touch(c.da, D.Mp, &n); touch(c.flag, 4, &n);
+        for (int i = 0; i < 8; ++i) touch(c.W[i], mm, &n);
+        touch(c.da_tot, D.Mp, &n);
+        touch(c.hyp_part2, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y * hyp_len(1, MOBOCMF_MAX_D), &n);
+        touch(c.df_part2, (int64_t)D.ggrid_mm.y * D.Mp, &n); touch(c.dzf_part2, (int64_t)D.ggrid_mm.x * D.Mp, &n);
+        touch(c.slabs, c.slab_elems, &n);
+    };
+    auto panel_saved = [&](PanelSaved& P) {
+        touch(P.A, mn, &n); touch(P.C, mn, &n); touch(P.knn, D.Np, &n); touch(P.q, D.Np, &n); touch(P.r, D.Np, &n);
+        touch(P.varraw, D.Np, &n);
+    };
+    auto panel_fwd = [&](PanelFwd& F) {
+        touch(F.K, mn, &n); touch(F.qpart, (int64_t)2 * D.nrb * D.Np, &n); touch(F.mupart, (int64_t)2 * D.nrb * D.Np, &n);
+        touch(F.rpart, (int64_t)2 * D.nrb * D.Np, &n);
+    };
+    auto panel_bwd = [&](PanelBwd& B) {
+        touch(B.gmu, D.Np, &n); touch(B.gv, D.Np, &n); touch(B.gv2, D.Np, &n); touch(B.cgv, D.Np, &n);
+        touch(B.dA, mn, &n); touch(B.dK, mn, &n); touch(B.slabs, B.slab_elems, &n);
+        touch(B.dapart, (D.Np <= 8192 ? D.Np / 16 : D.Np / 64) * (int64_t)D.Mp, &n);
+        touch(B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H, &n);
+        if (desc->kind == 1) { touch(B.df_part, (int64_t)D.ggrid_mn.y * D.Np, &n); touch(B.dzf_part, (int64_t)D.ggrid_mn.x * D.Mp, &n); }
+        if (desc->want_dx) touch(B.dx_part, (int64_t)D.ggrid_mn.y * D.nbase * desc->d, &n);
+    };
+    if (saved && scratch) {       // single-layer layout (mobocmf_layer_workspace_bytes)
+        ChainWs c = {}; PanelSaved P; PanelFwd F; PanelBwd B;
+        if (!carve_single_saved(saved, saved_bytes, D, c, P) || !carve_single_fwd(scratch, scratch_bytes, D, c, F))
+            return MOBOCMF_WORKSPACE_TOO_SMALL;
+        chain_state(c); panel_saved(P); chain_fwd(c); panel_fwd(F);
+        ChainWs c2 = {};
+        if (!carve_single_saved(saved, saved_bytes, D, c2, P) || !carve_single_bwd(scratch, scratch_bytes, D, desc, c2, B))
+            return MOBOCMF_WORKSPACE_TOO_SMALL;
+        panel_bwd(B); chain_bwd(c2);
+    }
+    if (block) {                  // multi-layer layout (mobocmf_chain_block_bytes / mobocmf_panel_workspace_bytes)
+        ChainWs c = {};
+        if (!carve_chain_block(block, block_bytes, D, c)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+        chain_state(c); chain_fwd(c); chain_bwd(c);
+    }
+    if (psaved && pscratch) {
+        Bump bs(psaved, psaved_bytes), bf(pscratch, pscratch_bytes), bb(pscratch, pscratch_bytes);
+        PanelSaved P; PanelFwd F; PanelBwd B;
+        carve_panel_saved(bs, D, P); carve_panel_fwd(bf, D, F); carve_panel_bwd(bb, D, desc, B);
+        if (!bs.ok || !bf.ok || !bb.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
+        panel_saved(P); panel_fwd(F); panel_bwd(B);
+    }
+    if (cov) {                    // predictive covariance (mobocmf_predictive_covariance_workspace_bytes)
+        CovWs w;
+        if (!carve_cov(cov, cov_bytes, desc, D, w)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+        touch(w.Knm, mn, &n); touch(w.AT, mn, &n); touch(w.CT, mn, &n); touch(w.Cv, D.Np * covpanel_cols(desc, D.Np), &n);
+    }
+    *regions = n;
+    return MOBOCMF_OK;
+}
+#endif
 
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream) {
     int32_t h = 0;

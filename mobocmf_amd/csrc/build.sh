@@ -1,15 +1,23 @@
 #!/bin/bash
 # Builds libmobocmf_hip.so for gfx950 (cross-compiles without a GPU).
+# An object is reused only when the hash of everything that went into it -- compiler version, flags, its source, common.h
+# and the public header -- equals the stamp written next to it (file times say nothing after a checkout or a flag
+# change).  `build.sh -B` rebuilds everything.
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $EXTRA_HIPCC_FLAGS"
+force=0
+[ "$1" = "-B" ] && force=1
+ccver=$($HIPCC --version 2>/dev/null | sha256sum | cut -c1-16)
 objs=""
 pids=""
 for f in gemm_f64 chol gram elementwise rff api; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/mobocmf_hip.h -nt $f.o ]; then
-    rm -f $f.o                      # a failed compile must not leave a stale object for the link step
-    $HIPCC $FLAGS -c $f.hip -o $f.o &
+  want=$( (echo "$ccver $FLAGS"; cat $f.hip common.h ../../include/mobocmf_hip.h) | sha256sum | cut -c1-32)
+  have=$(cat $f.o.stamp 2>/dev/null || true)
+  if [ $force = 1 ] || [ ! -f $f.o ] || [ "$want" != "$have" ]; then
+    rm -f $f.o $f.o.stamp           # a failed compile must not leave a stale object for the link step
+    ( $HIPCC $FLAGS -c $f.hip -o $f.o && echo "$want" > $f.o.stamp ) &
     pids="$pids $!"
   fi
   objs="$objs $f.o"

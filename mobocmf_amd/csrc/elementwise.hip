@@ -409,6 +409,35 @@ int launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, 
     return CHECK_LAUNCH();
 }
 
+// dst (symmetric, n_real x n_real, ldd) <- the lower triangle of a column panel: src [rows x cols] holds the block of rows
+// row0.. and columns row0..row0+cols of a symmetric matrix, valid on and below the panel's own diagonal.  Every 32 x 32
+// tile on or below that diagonal is written once as it is and once transposed (through LDS: both writes coalesced).
+__global__ __launch_bounds__(256) void mirror_lower_kernel(const double* src, int64_t lds_, double* dst, int64_t ldd,
+                                                           int64_t row0, int64_t rows, int64_t cols, int64_t n_real) {
+    __shared__ double t[32][33];
+    const int64_t ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t i = ti * 32 + r, j = tj * 32 + tx;
+        double v = 0.0;
+        if (i < rows && j < cols) v = src[i * lds_ + j];
+        t[r][tx] = v;
+        if (i >= j && row0 + i < n_real && row0 + j < n_real && j < cols) dst[(row0 + i) * ldd + row0 + j] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {      // transposed: element (i, j) of the tile goes to dst[j][i]
+        const int64_t j = tj * 32 + r, i = ti * 32 + tx;
+        if (i > j && row0 + i < n_real && row0 + j < n_real && j < cols && i < rows) dst[(row0 + j) * ldd + row0 + i] = t[tx][r];
+    }
+}
+int launch_mirror_lower(const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t row0, int64_t rows, int64_t cols,
+                        int64_t n_real, hipStream_t s) {
+    const dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(mirror_lower_kernel, grid, dim3(256), 0, s, src, lds_, dst, ldd, row0, rows, cols, n_real);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ public elementwise entry points
 __global__ void propagate_fwd_kernel(const double* mean, const double* var, const double* eps, double* f, int64_t n,
                                      int div) {

@@ -403,7 +403,7 @@ class _ChainsFn(torch.autograd.Function):
         rc = lib.mobocmf_layers_chain_forward(n, _desc_table(descs), P(0), P(1), P(2), P(3), P(4),
                                               _table([k.data_ptr() for k in CB.kls]),
                                               _table([t.data_ptr() for t in CB.infos]), _ptr(CB.blocks), CB.stride,
-                                              _stream())
+                                              CB.blocks.numel(), _stream())
         _lib.check(rc, "mobocmf_layers_chain_forward")
         ctx.CB = CB
         ctx.descs = descs
@@ -428,7 +428,8 @@ class _ChainsFn(torch.autograd.Function):
         T = lambda ts: _table([0 if t is None else t.data_ptr() for t in ts])
         rc = lib.mobocmf_layers_chain_backward(n, _desc_table(ctx.descs), T([p[0] for p in per]), T([p[1] for p in per]),
                                                T([p[2] for p in per]), T(gk), (ctypes.c_int32 * n)(*CB.had_panel),
-                                               T(g_zf), T(g_hyp), T(g_m), T(g_LS), _ptr(CB.blocks), CB.stride, _stream())
+                                               T(g_zf), T(g_hyp), T(g_m), T(g_LS), _ptr(CB.blocks), CB.stride,
+                                               CB.blocks.numel(), _stream())
         _lib.check(rc, "mobocmf_layers_chain_backward")
         out = [None]
         for z in range(n):
@@ -562,30 +563,28 @@ def layer_forward(x, f, Zx, zf, hyp, m, L_S, kind, xdiv=1, branch=0, jitter=JITT
     return _LayerFn.apply(x, f, Zx, zf, hyp, m, L_S, kind, xdiv, branch, jitter, min_var, want_dx, info_out)
 
 
-def predictive_covariance(x, f, Zx, zf, hyp, m, L_S, kind, xdiv=1, jitter=JITTER):
-    """Full eval-branch predictive covariance (N' x N') -- K10, MFMA contraction.  No autograd."""
+def predictive_covariance(x, f, Zx, zf, hyp, m, L_S, kind, xdiv=1, jitter=JITTER, chain=None):
+    """Full eval-branch predictive covariance (N' x N') -- K10: symmetric rank-M updates on the MFMA, lower tiles only,
+    any N'.  Returns (mean, cov).  ``chain``: a FrozenChain of the same layer (then m, L_S are not needed and the M x M
+    chain is not recomputed).  No autograd."""
     lib = _lib.require_device()
     with torch.no_grad():
         x, f, Zx, zf, hyp, m, L_S = (_prep(t) for t in (x, f, Zx, zf, hyp, m, L_S))
         d, M = Zx.shape[1], Zx.shape[0]
         Np = x.shape[0] * xdiv
-        desc = make_desc(kind, d, M, Np, xdiv, 1, False, jitter, MIN_VARIANCE)
-        sb, cb = workspace_bytes(desc)
         dev = x.device
-        saved = _poison(torch.empty(sb, dtype=torch.uint8, device=dev))
-        scratch = scratch_buffer(cb, dev)
-        mean = _empty(Np, device=dev)
-        var = _empty(Np, device=dev)
-        kl = _empty((), device=dev)
-        info = torch.zeros((), dtype=torch.int32, device=dev)
-        _lib.check(lib.mobocmf_layer_forward(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp),
-                                             _ptr(m), _ptr(L_S), _ptr(mean), _ptr(var), _ptr(kl), _ptr(info),
-                                             _ptr(saved), sb, _ptr(scratch), scratch.numel(), _stream()),
-                   "mobocmf_layer_forward")
+        if chain is None:
+            chain = freeze_chain(Zx, zf, hyp, m, L_S, kind, branch=1, jitter=jitter)
+        desc = make_desc(kind, d, M, Np, xdiv, 1, False, jitter, MIN_VARIANCE)
+        mean, _ = layer_panel_frozen(chain, x, f, xdiv=xdiv)
+        cb = ctypes.c_size_t()
+        _lib.check(lib.mobocmf_predictive_covariance_workspace_bytes(ctypes.byref(desc), ctypes.byref(cb)),
+                   "mobocmf_predictive_covariance_workspace_bytes")
+        scratch = scratch_buffer(cb.value, dev)
         cov = _empty(Np, Np, device=dev)
-        _lib.check(lib.mobocmf_predictive_covariance(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(hyp), _ptr(cov), Np,
-                                                     _ptr(saved), sb, _ptr(scratch), scratch.numel(), _stream()),
-                   "mobocmf_predictive_covariance")
+        _lib.check(lib.mobocmf_predictive_covariance(ctypes.byref(desc), _ptr(x), _ptr(f), _ptr(Zx), _ptr(zf), _ptr(hyp),
+                                                     _ptr(cov), Np, _ptr(chain.state), chain.state.numel(), _ptr(scratch),
+                                                     scratch.numel(), _stream()), "mobocmf_predictive_covariance")
     return mean, cov
 
 

@@ -15,50 +15,131 @@ def world():
     return 0, 1
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
 def launch_ranks(argv, n, port=None, extra_env=None, timeout=None):
     """One fresh process per rank (= per GPU) of ``argv`` (e.g. [sys.executable, "bench.py", ...]), with the
     torch.distributed.run environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT).  The caller
     must not have touched the GPU (children are started with fork+exec).  Rank 0 inherits stdout, the other ranks'
     stdout goes to stderr, so a program whose rank 0 prints one record still prints exactly one.  Returns the list of
-    exit codes; if a rank fails, the others are terminated (a rank blocked in a collective would wait for ever)."""
+    exit codes.
+
+    No rank outlives this call: every rank runs in its own session (= process group); if a rank fails, the timeout
+    expires, the parent receives SIGTERM / SIGINT / SIGHUP, or anything raises inside the poll loop, every live rank's
+    GROUP gets SIGTERM, then SIGKILL after a grace period (a rank blocked in an RCCL collective would otherwise hold its
+    GPU for ever), and all children are reaped.  A signal is re-raised as KeyboardInterrupt / SystemExit(128 + signo)
+    after the clean-up.  ``port=None`` picks a free port; since another process may grab it before rank 0 binds it, a
+    launch whose ranks all die within the first seconds with rank 0 reporting the address in use is retried once on a
+    fresh port."""
     import os
-    import socket
+    import signal
     import subprocess
     import sys
+    import threading
     import time
-    if port is None:
-        sk = socket.socket()
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-        sk.close()
+
+    def start(port_):
+        procs_ = []
+        try:
+            for r in range(n):
+                env = dict(os.environ)
+                env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                            "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port_), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                env.update(extra_env or {})
+                procs_.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else sys.stderr,
+                                               start_new_session=True))
+        except BaseException:
+            stop(procs_)
+            raise
+        return procs_
+
+    def stop(procs_, grace=20.0):
+        """SIGTERM every live rank's process group, SIGKILL what is left after ``grace`` seconds, reap everything."""
+        live = [pr for pr in procs_ if pr.poll() is None]
+        for pr in live:
+            try:
+                os.killpg(pr.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t_end = time.time() + grace
+        for pr in live:
+            try:
+                pr.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                pr.wait()
+        for pr in procs_:
+            if pr.poll() is None:
+                pr.wait()
+
+    class _Signalled(BaseException):
+        pass
+
+    got = []
+
+    def on_signal(signo, _frame):
+        got.append(signo)
+        raise _Signalled()
+
+    handlers = {}
+    if threading.current_thread() is threading.main_thread():      # signal handlers can only be set there
+        for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            handlers[sg] = signal.signal(sg, on_signal)
+    attempts = 2 if port is None else 1
     procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-        env.update(extra_env or {})
-        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else sys.stderr))
-    t0 = time.time()
-    codes = [None] * n
-    while any(c is None for c in codes):
-        for r, pr in enumerate(procs):
-            if codes[r] is None:
-                codes[r] = pr.poll()
-        failed = any(c not in (None, 0) for c in codes)
-        if failed or (timeout is not None and time.time() - t0 > timeout):
-            for r, pr in enumerate(procs):
-                if codes[r] is None:
-                    pr.terminate()
-            for r, pr in enumerate(procs):
-                if codes[r] is None:
-                    try:
-                        codes[r] = pr.wait(timeout=20)
-                    except subprocess.TimeoutExpired:
-                        pr.kill()
-                        codes[r] = pr.wait()
-            break
-        time.sleep(0.05)
-    return codes
+    try:
+        for attempt in range(attempts):
+            use_port = _free_port() if port is None else port
+            procs = start(use_port)
+            t0 = time.time()
+            codes = [None] * n
+            while any(c is None for c in codes):
+                for r, pr in enumerate(procs):
+                    if codes[r] is None:
+                        codes[r] = pr.poll()
+                failed = any(c not in (None, 0) for c in codes)
+                if failed or (timeout is not None and time.time() - t0 > timeout):
+                    stop(procs)
+                    codes = [pr.returncode for pr in procs]
+                    break
+                time.sleep(0.05)
+            # the port-probe race: rank 0 could not bind (torch reports EADDRINUSE and exits within seconds)
+            lost_race = (attempt + 1 < attempts and n > 1 and codes[0] not in (0, None) and time.time() - t0 < 15.0
+                         and not _port_is_free(use_port))
+            if not lost_race:
+                return codes
+        return codes
+    except _Signalled:
+        stop(procs)
+        if got and got[0] == signal.SIGINT:
+            raise KeyboardInterrupt()
+        raise SystemExit(128 + (got[0] if got else signal.SIGTERM))
+    finally:
+        stop(procs, grace=5.0)          # no-op when everything has been reaped already
+        for sg, h in handlers.items():
+            signal.signal(sg, h)
+
+
+def _port_is_free(port):
+    import socket
+    sk = socket.socket()
+    try:
+        sk.bind(("127.0.0.1", port))
+        return True
+    except OSError:
+        return False
+    finally:
+        sk.close()
 
 
 def shard_blackboxes(names, rank=None, world_size=None):

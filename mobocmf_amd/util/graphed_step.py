@@ -69,8 +69,19 @@ class GraphedELBOStep:
         self._update()
 
     def _capture(self, warmup):
+        from .. import functional as F
         cur = torch.cuda.current_stream(self.x.device)
         self.stream.wait_stream(cur)
+        F.take_capture_pins()          # pins left behind by a capture that aborted elsewhere are not this graph's
+        try:
+            self._capture_on_stream(warmup)
+        finally:
+            # the graph replays on these buffers: they live as long as it does (also taken when the capture raised, so that
+            # a failed capture cannot leak its pins into the next step's list)
+            self._pinned_scratch = F.take_capture_pins()
+        cur.wait_stream(self.stream)
+
+    def _capture_on_stream(self, warmup):
         with torch.cuda.stream(self.stream):
             # the side-stream warm-up also sizes the per-stream scratch arena and the optimizer state
             snapshot = [p.detach().clone() for p in self.model.parameters()]
@@ -89,9 +100,6 @@ class GraphedELBOStep:
                 with torch.cuda.graph(self.graph_update, stream=self.stream, capture_error_mode="thread_local"):
                     self._update()
                 self._reset_after_warmup(snapshot)     # the capture pass above ran the exchange + nothing else for real
-        from .. import functional as F
-        self._pinned_scratch = F.take_capture_pins()      # the graph replays on these buffers: they live as long as it does
-        cur.wait_stream(self.stream)
 
     def _reset_after_warmup(self, snapshot):
         with torch.no_grad():           # warm-up steps must not count as training

@@ -87,7 +87,8 @@ def forrester_problem(output=0):
     return x, y, fid
 
 
-def model_from_problem(prob, num_samples_for_training=None, num_samples_for_acquisition=None, device="cuda"):
+def model_from_problem(prob, num_samples_for_training=None, num_samples_for_acquisition=None, device="cuda",
+                       **model_kwargs):
     """``mobocmf_amd.models.MFDGP`` carrying exactly the parameters of a problem dict (section 8(d): parameters are
     explicit inputs so that parity / throughput runs do not depend on the init heuristics)."""
     import torch
@@ -100,7 +101,7 @@ def model_from_problem(prob, num_samples_for_training=None, num_samples_for_acqu
     model = MFDGP(t(prob["x"]), t(prob["y"])[:, None], t(prob["fid"])[:, None], num_fidelities=prob["L"],
                   type_lengthscale=TL.ONES, inducing_points=t(prob["Zx"]),
                   num_samples_for_acquisition=num_samples_for_acquisition or S,
-                  num_samples_for_training=num_samples_for_training or S)
+                  num_samples_for_training=num_samples_for_training or S, **model_kwargs)
     model.double()
     with torch.no_grad():
         for l, lay in enumerate(prob["layers"]):

@@ -103,13 +103,46 @@ def test_limits_are_reported_with_a_message():
         F.make_desc(1, 4, 8, 49 * 2, xdiv=49)
 
 
-@pytest.mark.parametrize("d,L", [(2, 2), (8, 2), (3, 3)])
-def test_rff_grid_evaluation_kernel_matches_host(d, L):
-    """function samples of every layer evaluated on a Pareto-sized grid by the HIP kernel (layer recursion, no
-    F x n feature matrix) vs the host evaluation of the SAME sample, and vs the numpy restatement of the reference's
-    feature maps (oracle/rff_oracle.py) for the top layer's inputs."""
-    from mobocmf_amd.layers import rff
+@pytest.mark.parametrize("d,L,nF", [(2, 2, 150), (8, 2, 500), (3, 3, 64), (32, 2, 97)])
+def test_rff_grid_evaluation_kernel_matches_oracle(d, L, nF):
+    """mobocmf_rff_eval (one function sample of every layer on a Pareto-sized grid, layer recursion, no
+    F x n feature matrix) against the numpy restatement of the reference's feature maps, oracle/rff_oracle.py
+    ``layer0_features`` / ``layer1_features`` (mfdgp_hidden_layer.py:288-292, :319-321, :384-399) times theta, with explicit
+    W, b, theta and hyper-parameters: nothing of mobocmf_amd.layers.rff takes part."""
+    from mobocmf_amd import functional as F
     from oracle import rff_oracle as R
+    rng = np.random.default_rng(100 * d + L)
+    n = 4200 + 37                                       # >= the 1000 d^2 + N rows of moop.py:232 at d = 2; ragged last block
+    X = rng.random((n, d))
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV)
+    f_ref, f_dev = None, None
+    for l in range(L):
+        if l == 0:
+            alpha, ls = 1.3, 0.3 + rng.random(d)
+            W, b, theta = rng.standard_normal((nF, d)) / ls, 2 * np.pi * rng.random((nF, 1)), rng.standard_normal(nF)
+            ref = theta @ R.layer0_features(X, W, b, alpha)
+            out = F.rff_eval(0, dev(X), None, dev(W), dev(b[:, 0]), None, None, None, dev(theta), np.sqrt(2.0 * alpha / nF))
+        else:
+            a1, af, a2, nu = 0.8 + rng.random(), 0.5 + rng.random(), 0.01 + 0.1 * rng.random(), 0.4 + rng.random()
+            ls1, lsf, ls2 = 2.0 + rng.random(d), 0.7 + rng.random(), 0.3 + rng.random(d)
+            W1, Wf, W2 = rng.standard_normal((nF, d)) / ls1, rng.standard_normal(nF) / lsf, rng.standard_normal((nF, d)) / ls2
+            b1, b2 = 2 * np.pi * rng.random((nF, 1)), 2 * np.pi * rng.random((nF, 1))
+            theta = rng.standard_normal(3 * nF)
+            ref = theta @ R.layer1_features(X, f_ref, W1, Wf, W2, b1, b2, a1, af, a2, nu)
+            out = F.rff_eval(1, dev(X), f_dev, dev(W1), dev(b1[:, 0]), dev(Wf), dev(W2), dev(b2[:, 0]), dev(theta),
+                             np.sqrt(2.0 * a1 * nu / nF), np.sqrt(2.0 * a1 * af / nF), np.sqrt(2.0 * a2 / nF))
+        got = out.cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), (l, np.abs(got - ref).max())
+        f_ref, f_dev = ref, dev(ref)                    # the next layer of both sides sees the ORACLE's sample
+
+
+@pytest.mark.parametrize("d,L", [(2, 2), (8, 2), (3, 3)])
+def test_rff_sample_callables_use_the_kernel_for_grids(d, L):
+    """Host plumbing of the samplers only (the kernel itself is checked against the oracle above): the callables of
+    ``sample_function_from_each_layer`` send batches of >= GRID_ROWS_ON_DEVICE rows through mobocmf_rff_eval and smaller
+    ones through the host evaluation of the SAME sample, and both agree."""
+    from mobocmf_amd.layers import rff
     prob = synthetic.make_problem(d=d, L=L, M=12, N=40, S=1, seed=d)
     model = synthetic.model_from_problem(prob, device=DEV)
     g = torch.Generator().manual_seed(5)

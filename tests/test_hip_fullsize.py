@@ -28,12 +28,19 @@ def _to_dev(raw):
     return out
 
 
-@pytest.mark.parametrize("name", ["C3", "C5"])
-def test_full_size_elbo_and_gradients(name):
-    """ELBO, per-layer moments and every raw-parameter gradient at the headline sizes (tolerance: north-star 1e-4;
-    observed ~1e-9 for values, ~1e-6 for gradients)."""
+# SURVEY 8(d) parity clause: seeds 0-2 for C1-C3 (C1's three outputs and seeds are the golden cases of test_hip_model.py);
+# output 2 is the constraint surrogate of the headline config
+FULL_CASES = [("C2", s, 0) for s in range(3)] + [("C3", s, o) for s in range(3) for o in (0, 2)] + [("C5", 0, 0)]
+
+
+@pytest.mark.parametrize("name,seed,output", FULL_CASES, ids=["%s_seed%d_out%d" % c for c in FULL_CASES])
+def test_full_size_elbo_and_gradients(name, seed, output):
+    """ELBO, per-layer moments and every raw-parameter gradient at the configured sizes, seeds 0-2, objective and
+    constraint outputs (tolerance: north-star 1e-4; observed ~1e-9 for values, ~1e-6 for gradients at C3).  C2: 128
+    inducing points in 2-D, cond(K_mm + 1e-6 I) ~ 1e9 -- either implementation carries ~cond * eps, the gates there are
+    the north star's 1e-4 (1e-5 for the ELBO)."""
     cfg = {k: v for k, v in synthetic.CONFIGS[name].items() if k != "outputs"}
-    prob = synthetic.make_problem(**cfg, seed=0)
+    prob = synthetic.make_problem(**cfg, output=output, seed=seed)
     S, L = cfg["S"], cfg["L"]
     model = build_model(prob, S_train=S)
     raw = _to_dev(_raw_from_model(model, L))
@@ -47,15 +54,19 @@ def test_full_size_elbo_and_gradients(name):
         outs_o = O.model_forward(st, x, eps=eps, S=S, ref_equiv=True)
     (e, skl), out = hip_elbo(model, prob, S)
     (-e).backward()
-    assert rel(e, e_o) < 1e-7 and rel(skl, skl_o) < 1e-7
+    ill = name == "C2"
+    assert rel(e, e_o) < (1e-5 if ill else 1e-7) and rel(skl, skl_o) < (1e-5 if ill else 1e-7)
     for l in range(L):
-        assert rel(out[l].mean.reshape(-1), outs_o[l][0]) < 1e-6
-        assert rel(out[l].variance.reshape(-1), outs_o[l][1]) < 1e-5
+        assert rel(out[l].mean.reshape(-1), outs_o[l][0]) < (1e-4 if ill else 1e-6)
+        assert rel(out[l].variance.reshape(-1), outs_o[l][1]) < (1e-4 if ill else 1e-5)
     for l in range(L):
         for key, tt in raw["layers"][l].items():
             p = _model_param_for(model, l, key)
             gref = tt.grad if key != "L_S" else torch.tril(tt.grad)
             assert rel(p.grad.reshape(gref.shape), gref) < 1e-4, (l, key, rel(p.grad.reshape(gref.shape), gref))
+        assert rel(getattr(model, f"hidden_layer_likelihood_{l}").raw_noise.grad.reshape(()), raw["raw_noise"][l].grad) < 1e-4
+    del out, model, st, raw
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("batched", [False, True], ids=["layer_by_layer", "batched_chains"])

@@ -172,16 +172,32 @@ def test_not_pd_is_reported():
     assert F.check_info(info2) == 0
 
 
-def test_predictive_covariance_matches_oracle():
+@pytest.mark.parametrize("kind,d,M,nbase,xdiv", [(1, 3, 40, 50, 3), (0, 2, 8, 12, 1), (1, 5, 130, 30, 25), (1, 8, 512, 200, 25),
+                                               (0, 8, 512, 5000, 1), (1, 2, 130, 700, 7)],
+                         ids=["small", "tiny_kind0", "S25_ragged", "reference_5000x5000", "kind0_5000", "three_panels"])
+def test_predictive_covariance_matches_oracle(kind, d, M, nbase, xdiv):
+    """K10 (north star: "MFMA for the K_nm K_mm^-1 K_mn predictive-covariance contraction"): the full eval-branch covariance
+    K_nn - A^T A + C^T C vs the oracle's ``full_cov`` -- at the reference's own shape too: (T S)^2 = 5000^2 with its default
+    S = 25 (mfdgp.py:22-25, :248) at M = 512, d = 8 (oracle evaluated on the GPU through rocBLAS / rocSOLVER there), through
+    the column-panel loop (700 x 7 rows = three panels) and with rows / columns that are no multiple of the tile."""
     from mobocmf_amd import functional as F
-    kind, d, M, nbase, xdiv = 1, 3, 40, 50, 3
-    x, f, Zx, zf, hyp, m, L_S = _mk(kind, d, M, nbase, xdiv, seed=11)
-    xr = x.repeat_interleave(xdiv, 0)
-    Xt = torch.cat([xr, f[:, None]], 1)
-    Zt = torch.cat([Zx, zf[:, None]], 1)
-    mean_o, var_o, ex = O.layer_moments(hyp, Xt, Zt, m, L_S, training=False, full_cov=True, shortcut=False)
+    x, f, Zx, zf, hyp, m, L_S = _mk(kind, d, M, nbase, xdiv, seed=11 + M)
     dev = torch.device("cuda")
-    mean, cov = F.predictive_covariance(x.to(dev), f.to(dev), Zx.to(dev), zf.to(dev), _pack(kind, hyp).to(dev),
-                                        m.to(dev), L_S.to(dev), kind, xdiv=xdiv)
+    odev = dev if nbase * xdiv > 1000 else torch.device("cpu")      # big cases: the torch oracle on rocBLAS
+    mv = lambda t: None if t is None else t.to(odev)
+    xo, fo, Zxo, zfo, mo, LSo = (mv(t) for t in (x, f, Zx, zf, m, L_S))
+    hypo = {k: v.to(odev) for k, v in hyp.items()}
+    xr = xo.repeat_interleave(xdiv, 0)
+    Xt = xr if kind == 0 else torch.cat([xr, fo[:, None]], 1)
+    Zt = Zxo if kind == 0 else torch.cat([Zxo, zfo[:, None]], 1)
+    mean_o, var_o, ex = O.layer_moments(hypo, Xt, Zt, mo, LSo, training=False, full_cov=True, shortcut=False)
+    g = lambda t: None if t is None else t.to(dev)
+    mean, cov = F.predictive_covariance(g(x), g(f), g(Zx), g(zf), _pack(kind, hyp).to(dev), g(m), g(L_S), kind, xdiv=xdiv)
+    assert cov.shape == (nbase * xdiv, nbase * xdiv)
     _close(mean, mean_o, 1e-9, "mean")
     _close(cov, ex["cov"], 1e-8, "cov")
+    assert torch.equal(cov, cov.T)                                   # mirrored, not recomputed
+    # the frozen-chain form (acquisition optimisation against a fixed model) gives the same matrix
+    fc = F.freeze_chain(g(Zx), g(zf), _pack(kind, hyp).to(dev), g(m), g(L_S), kind, branch=1)
+    _, cov2 = F.predictive_covariance(g(x), g(f), g(Zx), g(zf), _pack(kind, hyp).to(dev), None, None, kind, xdiv=xdiv, chain=fc)
+    assert torch.equal(cov, cov2)

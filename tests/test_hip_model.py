@@ -366,6 +366,48 @@ def test_only_highest_fidelity_ablation_trains_on_gpu():
     assert bool(torch.isfinite(mu).all()) and bool((v > 0).all())
 
 
+@pytest.mark.parametrize("cfg", [dict(d=2, L=2, M=8, N=12, S=1, seed=0), dict(d=4, L=2, M=40, N=150, S=1, seed=3),
+                                 dict(d=3, L=3, M=10, N=16, S=2, seed=7)], ids=["small2d", "S1_M40", "3layer"])
+def test_only_highest_fidelity_ablation_matches_oracle(cfg):
+    """The only-hf ablation on the HIP path vs the oracle (mfdgp.py:189-190 zeroes the previous layer's output,
+    mfdgp_hidden_layer_only_hf.py:85-89 initialises a_x1 = a_f = nu = 0, a_x2 = 1 and :191-199 freezes the x1 / f / linear
+    hyper-parameters): ELBO, scaled KL, per-layer moments and the gradient of every parameter the ablation leaves
+    trainable; the frozen ones get no gradient."""
+    prob = synthetic.make_problem(**cfg)
+    S, L = cfg["S"], cfg["L"]
+    for lay in prob["layers"][1:]:
+        lay["hyp"].update(a1=np.array(0.0), af=np.array(0.0), nu=np.array(0.0), a2=np.array(1.0))
+    model = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV, use_only_highest_fidelity=True)
+    assert model.use_only_highest_fidelity
+    raw = _raw_from_model(model, L)
+    x, y, fid = to_t(prob["x"]), to_t(prob["y"]), to_t(prob["fid"])
+    eps = [None] + [to_t(e) for e in prob["eps"][1:]]
+    st = O.state_from_raw(raw)
+    e_o, skl_o = O.elbo(st, x, y, fid, eps=eps, S=S, only_hf=True)
+    (-e_o).backward()
+    with torch.no_grad():
+        outs_o = O.model_forward(st, x, eps=eps, S=S, only_hf=True)
+        outs_full = O.model_forward(st, x, eps=eps, S=S, only_hf=False)
+    (e, skl), out = hip_elbo(model, prob, S)
+    (-e).backward()
+    assert rel(e, e_o) < 1e-8 and rel(skl, skl_o) < 1e-8
+    for l in range(L):
+        assert rel(out[l].mean.reshape(-1), outs_o[l][0]) < 1e-7
+        assert rel(out[l].variance.reshape(-1), outs_o[l][1]) < 1e-6
+        # D6: with a_x1 = 0 the layer ignores its f column altogether -- sampling f~ or zeroing it gives the same moments
+        assert rel(outs_full[l][0], outs_o[l][0]) < 1e-12
+    frozen = {"raw_ls1", "raw_a1", "raw_lsf", "raw_af", "raw_nu"}
+    for l in range(L):
+        for key, t in raw["layers"][l].items():
+            p = _model_param_for(model, l, key)
+            if l > 0 and key in frozen:
+                assert not p.requires_grad and p.grad is None, (l, key)
+                continue
+            gref = t.grad if key != "L_S" else torch.tril(t.grad)
+            assert rel(p.grad.reshape(gref.shape), gref) < 1e-6, (l, key)
+        assert rel(getattr(model, f"hidden_layer_likelihood_{l}").raw_noise.grad.reshape(()), raw["raw_noise"][l].grad) < 1e-6
+
+
 def test_warm_start_from_previously_trained_model_on_gpu():
     """``previously_trained_model`` (mfdgp.py:22-25; the reference's BO loop can pass last iteration's surrogate): kernel
     hyper-parameters and the fixed acquisition samples carry over from a model that lives on the GPU; the new model has

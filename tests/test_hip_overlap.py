@@ -204,3 +204,38 @@ def test_batched_chains_kl_only_and_truncated_forward():
     for n in grads[0]:
         err = float((grads[0][n] - grads[1][n]).abs().max() / grads[0][n].abs().max().clamp_min(1e-300))
         assert err < 1e-7, (n, err)
+
+
+def test_chain_entry_points_refuse_a_short_block_buffer():
+    """mobocmf_layers_chain_forward / _backward with n = 3 layers and a buffer of two blocks must return
+    MOBOCMF_WORKSPACE_TOO_SMALL before anything is enqueued (layer 2 would write past the allocation)."""
+    import ctypes
+
+    from mobocmf_amd import _lib
+    from mobocmf_amd import functional as F
+    lib = _lib.require_device()
+    dev = torch.device("cuda")
+    M, d, n = 24, 3, 3
+    descs = [F.make_desc(0 if z == 0 else 1, d, M, 1, 1, 0, False, F.JITTER, F.MIN_VARIANCE, F.PHASE_CHAIN) for z in range(n)]
+    bb, st = ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.check(lib.mobocmf_chain_block_bytes(ctypes.byref(descs[0]), ctypes.byref(bb), ctypes.byref(st)), "chain_block_bytes")
+    stride = (bb.value + 255) // 256 * 256
+    blocks = torch.zeros(2 * stride, dtype=torch.uint8, device=dev)            # one block short
+    t = lambda *s: torch.rand(*s, dtype=torch.float64, device=dev)
+    Zx, zf, m, LS = t(M, d), t(M), t(M), torch.tril(t(M, M)) + torch.eye(M, dtype=torch.float64, device=dev)
+    hyps = [torch.ones(F.hyp_len(descs[z].kind, d), dtype=torch.float64, device=dev) for z in range(n)]
+    kls = [torch.zeros((), dtype=torch.float64, device=dev) for _ in range(n)]
+    infos = [torch.zeros((), dtype=torch.int32, device=dev) for _ in range(n)]
+    T = lambda ts: F._table([x.data_ptr() for x in ts])
+    rc = lib.mobocmf_layers_chain_forward(n, F._desc_table(descs), T([Zx] * n), T([zf] * n), T(hyps), T([m] * n), T([LS] * n),
+                                          T(kls), T(infos), F._ptr(blocks), stride, blocks.numel(), F._stream())
+    assert rc == _lib.WORKSPACE_TOO_SMALL
+    g = [t(M) for _ in range(n)]
+    gh = [torch.zeros_like(h) for h in hyps]
+    gL = [t(M, M) for _ in range(n)]
+    rc = lib.mobocmf_layers_chain_backward(n, F._desc_table(descs), T([Zx] * n), T([zf] * n), T(hyps), T(kls),
+                                           (ctypes.c_int32 * n)(0, 0, 0), T(g), T(gh), T(g), T(gL), F._ptr(blocks), stride,
+                                           blocks.numel(), F._stream())
+    assert rc == _lib.WORKSPACE_TOO_SMALL
+    torch.cuda.synchronize()
+    assert float(blocks.sum()) == 0.0                                          # nothing was written
