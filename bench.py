@@ -135,8 +135,8 @@ def measure_gemm_variants(cfg, device, iters=20):
     A2 = rnd(Mp, Np)
     C = torch.empty(Mp, Np, dtype=torch.float64, device=device)
     avec, gmu, cgv, gv = rnd(Mp), rnd(Np), rnd(Np), rnd(Np)
-    p1 = torch.empty(2 * nrb, Np, dtype=torch.float64, device=device)
-    p2 = torch.empty(2 * nrb, Np, dtype=torch.float64, device=device)
+    p1 = torch.empty(4 * nrb, Np, dtype=torch.float64, device=device)
+    p2 = torch.empty(4 * nrb, Np, dtype=torch.float64, device=device)
     rdp = torch.empty(2 * (Np // 128), Mp, dtype=torch.float64, device=device)
     stream_out = Np * Mp * 8 >= (64 << 20)
     variants = [
@@ -366,6 +366,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="serialise each surrogate's layers on one stream (no chain/panel split across streams)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = median")
+    ap.add_argument("--tile-rows", type=int, default=0, help="A/B knob: tile height of the panel products (0 automatic, 64, 128)")
     ap.add_argument("--launch", action="store_true", help="go through the rank launcher even for --gpus 1")
     args = ap.parse_args()
     if args.no_overlap:
@@ -396,6 +397,9 @@ def main():
         raise SystemExit(3)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.tile_rows:
+        from mobocmf_amd import functional as F_
+        F_.set_tile_rows(args.tile_rows)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -268,7 +268,8 @@ int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64
 
 /* The same kernel with the epilogues the layer launches it with (tests, and bench.py's per-variant roofline):
  *   epi 0  plain store (dK = L^-T dA);
- *   epi 1  store + partial column statistics, 2 * Mr / 128 partial rows of Nc entries each: sum_p colsq_part[p][n] =
+ *   epi 1  store + partial column statistics, mobocmf_gemm_colstat_rows() partial rows of Nc entries each (two per row
+ *          block of the tile height the launch uses): sum_p colsq_part[p][n] =
  *          sum_i C[i][n]^2 and (coldot_part non-NULL) sum_p coldot_part[p][n] = sum_i avec[i] C[i][n]   (A = L^-1 K -> q,
  *          mean; C = U^T A -> r);
  *   epi 2  C[i][n] = alpha bscale[n] (A B)[i][n] + avec[i] gmu[n] - 2 Aaux[i][n] cgv[n]   (dA), and (rowdot_part
@@ -279,6 +280,15 @@ int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, 
                               double* colsq_part, double* coldot_part, const double* avec, const double* bscale,
                               const double* gmu, const double* cgv, const double* Aaux, double* rowdot_part,
                               mobocmf_stream_t stream);
+
+/* Partial rows an epi-1 launch of that shape writes to colsq_part / coldot_part (depends on the tile height in force). */
+int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, int32_t* rows);
+
+/* Tile height of the M x N' panel products: 0 = automatic (default), 64 = 64 x 128 tiles (three workgroups per CU, a
+ * triangular operand resolved in 64-row blocks), 128 = 128 x 128 tiles.  pair_mode: 0 = automatic, 1 = never, 2 = always
+ * let one workgroup do the two row blocks (p, n-1-p) of a triangular product (equal work per workgroup).  Process-wide,
+ * like mobocmf_set_tuning: size sweeps, tests, A/B timing. */
+int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode);
 
 /* The weighted symmetric rank-k update of the layer backward, H[Mr x Mr] = A diag(w) A^T with A [Mr x Kd] (k contiguous,
  * lda even) and w [Kd]: k-sliced over one round of resident workgroups into slabs (workspace), the slabs added and the

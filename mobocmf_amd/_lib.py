@@ -64,6 +64,8 @@ SYMBOLS = {
     "mobocmf_adam_step": [_P, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P],
     "mobocmf_gemm_f64": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32, _P],
     "mobocmf_gemm_f64_epilogue": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32] + [_P] * 8 + [_P],
+    "mobocmf_gemm_colstat_rows": [_I32, _I32, _I64, _I64, ctypes.POINTER(_I32)],
+    "mobocmf_set_tile_rows": [_I32, _I32],
     "mobocmf_syrk_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ)],
     "mobocmf_syrk_weighted_f64": [_I32, _I64, _P, _I64, _P, _P, _P, _I64, _P],
     "mobocmf_softplus_pack": [_I32, _P, _P, _P, _P],

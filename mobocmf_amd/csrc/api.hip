@@ -73,6 +73,12 @@ static inline void probe_at(int i, int64_t N, hipStream_t s) {
         (void)hipEventRecord(g_probe_ev[i], s);
 }
 
+// Tile height of the M x N' panel products (gemm_f64.hip: 128 x 128 tiles, or 64 x 128 tiles with three workgroups per
+// CU and the triangular operand resolved in 64-row blocks).  0 = automatic: launch_gemm picks it from the shape
+// (gemm_f64.hip tile_rows); 64 / 128 force it for every panel product (mobocmf_set_tile_rows: sweeps, tests, A/B timing).
+static std::atomic<int> g_tile_rows{0}, g_pair_mode{0};
+static int panel_tile_rows(int, int64_t) { return g_tile_rows.load(std::memory_order_relaxed); }
+
 #define TRY(x)              \
     do {                    \
         int _rc = (x);      \
@@ -233,9 +239,9 @@ void carve_chain_fwd(Bump& b, const Dims& D, ChainWs& S) {
 }
 void carve_panel_fwd(Bump& b, const Dims& D, PanelFwd& S) {
     S.K = b.take((int64_t)D.Mp * D.Np);
-    S.qpart = b.take((int64_t)2 * D.nrb * D.Np);      // two partial rows per 128-row block (gemm_f64.hip, EPI_COLSTATS)
-    S.mupart = b.take((int64_t)2 * D.nrb * D.Np);
-    S.rpart = b.take((int64_t)2 * D.nrb * D.Np);
+    S.qpart = b.take((int64_t)4 * D.nrb * D.Np);      // two partial rows per row block of the tile height (64-row tiles:
+    S.mupart = b.take((int64_t)4 * D.nrb * D.Np);     // 4 per 128 rows; gemm_f64.hip, EPI_COLSTATS / gemm_colstat_rows)
+    S.rpart = b.take((int64_t)4 * D.nrb * D.Np);
 }
 void carve_chain_bwd_in(Bump& b, const Dims& D, ChainWs& S) {
     int64_t mm = (int64_t)D.Mp * D.Mp;
@@ -384,15 +390,18 @@ int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& 
     GemmArgs ga = gemm_args(c.Linv, Mp, F.K, Np, P.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
     ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = c.a;
     ga.Kreal = D.M;      // rows >= M of K_mn (and of A, C, dA below) are zero padding
+    ga.rm = panel_tile_rows(Mp, Np);
+    ga.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
     TRY(launch_gemm(ga, false, 1, s));
     probe_at(1, D.N, s);
     GemmArgs gc = gemm_args(c.UT, Mp, P.A, Np, P.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
     gc.epi = EPI_COLSTATS; gc.colsq_part = F.rpart; gc.coldot_part = nullptr; gc.avec = c.a;
     gc.Kreal = D.M;
     gc.stream_out = (desc->branch == 0 && Np * Mp * 8 >= ((int64_t)64 << 20)) ? 1 : 0;   // C is next read in backward
+    gc.rm = ga.rm; gc.pair_mode = ga.pair_mode;
     TRY(launch_gemm(gc, false, 1, s));
     probe_at(2, D.N, s);
-    TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, 2 * D.nrb, Np, D.N, P.knn, desc->branch, desc->min_var, P.q, P.r,
+    TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, gemm_colstat_rows(ga), Np, D.N, P.knn, desc->branch, desc->min_var, P.q, P.r,
                               P.varraw, mean, var, s));
     return MOBOCMF_OK;
 }
@@ -415,6 +424,8 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
         ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = c.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = P.A;
         ga.Kreal = D.M;
         ga.rowdot_part = inputs_only ? nullptr : B.dapart;      // da = A gmu rides in the epilogue (it reads A anyway)
+        ga.rm = panel_tile_rows(Mp, Np);
+        ga.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
         probe_at(3, D.N, s);
         TRY(launch_gemm(ga, false, 1, s));
         probe_at(4, D.N, s);
@@ -434,6 +445,8 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     {
         GemmArgs ga = gemm_args(c.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
         ga.Kreal = D.M;
+        ga.rm = panel_tile_rows(Mp, Np);
+        ga.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
         probe_at(7, D.N, s);
         TRY(launch_gemm(ga, false, 1, s));
         probe_at(8, D.N, s);
@@ -892,7 +905,25 @@ int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, 
     g.epi = epi; g.stream_out = stream_out;
     g.colsq_part = colsq_part; g.coldot_part = coldot_part; g.avec = avec;
     g.bscale = epi == EPI_DA ? bscale : nullptr; g.gmu = gmu; g.cgv = cgv; g.Aaux = Aaux; g.rowdot_part = rowdot_part;
+    g.rm = panel_tile_rows(Mr, Nc);
+    g.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
     return launch_gemm(g, false, 1, (hipStream_t)stream);
+}
+
+int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, int32_t* rows) {
+    if (!rows || Mr <= 0 || Nc <= 0 || Kd <= 0) return MOBOCMF_BAD_ARG;
+    GemmArgs g = gemm_args(nullptr, Kd, nullptr, Nc, nullptr, Nc, Mr, Nc, Kd, tri, 1.0);
+    g.epi = EPI_COLSTATS;
+    g.rm = panel_tile_rows(Mr, Nc);
+    *rows = gemm_colstat_rows(g);
+    return MOBOCMF_OK;
+}
+
+int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode) {
+    if ((rows != 0 && rows != 64 && rows != 128) || pair_mode < 0 || pair_mode > 2) return MOBOCMF_BAD_ARG;
+    g_tile_rows.store(rows, std::memory_order_relaxed);
+    g_pair_mode.store(pair_mode, std::memory_order_relaxed);
+    return MOBOCMF_OK;
 }
 
 int mobocmf_syrk_workspace_bytes(int32_t Mr, int64_t Kd, size_t* bytes) {

@@ -39,6 +39,9 @@ struct GemmArgs {
                        // equally long; slab z of a tile is only written for z < its own slice count
     double alpha;
     int accumulate;    // 1: C += alpha*A*B  (else C = ...)
+    int rm;            // tile height: 0 / 128 = 128 x 128 tiles; 64 = 64 x 128 tiles, three workgroups per CU (plain A B panel
+                       // products only: gemm_f64.hip tile_rows(); anything else silently runs on 128-row tiles)
+    int pair_mode;     // row-block pairing of triangular launches: 0 = automatic, 1 = never, 2 = always (tuning / tests)
     // split-K: gridDim.z slices of the contraction, slice z writes C + z*slab_stride (reduced by reduce_slabs)
     int64_t slab_stride;
     // batching (only without split-K): blockIdx.z selects the batch
@@ -80,6 +83,7 @@ struct SumTask {
 int launch_sum_partials_multi(const SumTask* tasks, int n, hipStream_t s);
 int gemm_nt_slabs(const GemmArgs& g, int splitk);   // k-slices (slabs) an A B^T launch will really write
 int gemm_rowdot_parts(const GemmArgs& g);   // number of column slices EPI_DA writes to rowdot_part
+int gemm_colstat_rows(const GemmArgs& g);   // number of partial rows EPI_COLSTATS writes to colsq_part / coldot_part
 int launch_gemm_auto(const GemmArgs& g, bool B_T, double* ws, int64_t ws_elems, hipStream_t s);
 // out[i][j] = scale * sum_z slabs[z][i][j]  (lower_only: zero above the diagonal), Mr x Mr
 int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, double* out, int64_t ld, int Mr,

@@ -112,9 +112,18 @@ extern "C" int mobocmf_debug_set_stamps(unsigned long long* p) {
 #define STEP_STAMPS_FLUSH
 #endif
 
-template <bool B_T, bool TRI, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
-    __shared__ __attribute__((aligned(16))) double lds[4 * TILE_ELEMS];   // [buf][A | B]
+// RM = rows of a tile (128 or 64; columns always 128).  RM = 64 (NN form only): 64 x 128 tiles, each wavefront 32 x 64, half
+// the MFMAs per K step, 48 KB of LDS and <= 168 VGPRs per workgroup -> THREE workgroups per CU.  A triangular A operand is
+// resolved in 64-row blocks then: the k range of a row block ends (lower) / starts (upper) at a 64 boundary, so the product
+// walks n(n+1)/2 = 36 half-height block steps for M = 512 where 128-row tiles walk 10 full-height ones (= 40), of an ideal 32;
+// and N' = 8192 makes 512 tiles instead of 256 -- every CU busy after pairing.
+template <bool B_T, bool TRI, int EPI, int RM>
+__global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArgs g, int nrb, int64_t ncb, int splitk, int pair) {
+    static_assert(RM == 128 || (RM == 64 && !B_T), "tile heights: 128, or 64 for the A B form");
+    constexpr int MT = RM / 32;               // 16-row groups per wavefront (interleaved between the two row-wavefronts)
+    constexpr int A_ELEMS = RM * BK;          // A image [RM rows][16 k]
+    constexpr int STAGE_ELEMS = A_ELEMS + TILE_ELEMS;
+    __shared__ __attribute__((aligned(16))) double lds[2 * STAGE_ELEMS];   // [buf][A | B]
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     STAMP(0);
     STAMP_ID();
@@ -228,10 +237,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     const double* Bg = B_T ? B + (cb * BN + a_row) * g.ldb + a_lchk * 2
                            : B + (int64_t)wave * g.ldb + cb * BN;
     auto stage = [&](const double* Ag, int64_t k, int buf) {
-        double* As = lds + buf * 2 * TILE_ELEMS;
-        double* Bs = As + TILE_ELEMS;
+        double* As = lds + buf * STAGE_ELEMS;
+        double* Bs = As + A_ELEMS;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) glds16(Ag + (int64_t)(32 * r) * g.lda + k, As + (r * 4 + wave) * 128);
+        for (int r = 0; r < RM / 32; ++r) glds16(Ag + (int64_t)(32 * r) * g.lda + k, As + (r * 4 + wave) * 128);
         if (B_T) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) glds16(Bg + (int64_t)(32 * r) * g.ldb + k, Bs + (r * 4 + wave) * 128);
@@ -269,11 +278,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     const bool rev = TRI && nparts == 2 && (upper ? part == 0 : part == 1);   // walk k downwards
     int64_t k0 = 0, k1 = g.Kd;
     if (g.tri & TRI_LOWER_A) {
-        int64_t e = (int64_t)(rb + 1) * BM;
+        int64_t e = (int64_t)(rb + 1) * RM;
         if (k1 > e) k1 = e;
     }
     if (g.tri & TRI_UPPER_A) {
-        int64_t b = (int64_t)rb * BM;
+        int64_t b = (int64_t)rb * RM;
         if (k0 < b) k0 = b;
     }
     if (g.tri & TRI_LOWER_B) {
@@ -291,11 +300,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         k0 = b < k1 ? b : k1;
         k1 = e < k1 ? e : k1;
     }
-    const double* Ag = Ag0 + (int64_t)rb * BM * g.lda;
+    const double* Ag = Ag0 + (int64_t)rb * RM * g.lda;
 
-    v4f64 acc[4][4];
+    v4f64 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
@@ -363,14 +372,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         LOAD_B(b0, 0)                                                                                       \
         LOAD_A(a0, 0, 0)                                                                                    \
         STAGE_NEXT                                                                                          \
-        LOAD_A(a1, 0, 1) MMA(a0, b0, 0)                                                                     \
-        LOAD_A(a0, 0, 2) MMA(a1, b0, 1)                                                                     \
-        LOAD_A(a1, 0, 3) MMA(a0, b0, 2)                                                                     \
-        LOAD_A(a0, 1, 0) LOAD_B(b1, 1) MMA(a1, b0, 3)                                                       \
-        LOAD_A(a1, 1, 1) MMA(a0, b1, 0)                                                                     \
-        LOAD_A(a0, 1, 2) MMA(a1, b1, 1)                                                                     \
-        LOAD_A(a1, 1, 3) MMA(a0, b1, 2)                                                                     \
-        MMA(a1, b1, 3)
+        if constexpr (MT == 4) {                                                                            \
+            LOAD_A(a1, 0, 1) MMA(a0, b0, 0)                                                                 \
+            LOAD_A(a0, 0, 2) MMA(a1, b0, 1)                                                                 \
+            LOAD_A(a1, 0, 3) MMA(a0, b0, 2)                                                                 \
+            LOAD_A(a0, 1, 0) LOAD_B(b1, 1) MMA(a1, b0, 3)                                                   \
+            LOAD_A(a1, 1, 1) MMA(a0, b1, 0)                                                                 \
+            LOAD_A(a0, 1, 2) MMA(a1, b1, 1)                                                                 \
+            LOAD_A(a1, 1, 3) MMA(a0, b1, 2)                                                                 \
+            MMA(a1, b1, 3)                                                                                  \
+        } else {      /* 64-row tiles: four groups of 32 MFMAs */                                           \
+            LOAD_A(a1, 0, MT - 1) MMA(a0, b0, 0)                                                            \
+            LOAD_A(a0, 1, 0) LOAD_B(b1, 1) MMA(a1, b0, MT - 1)                                              \
+            LOAD_A(a1, 1, MT - 1) MMA(a0, b1, 0)                                                            \
+            MMA(a1, b1, MT - 1)                                                                             \
+        }
 // Diagonal tile of a symmetric A B^T product (sym_out): with row group 2*mt + wr and column group 2*nt + wc a 16 x 16
 // block lies on or below the diagonal iff 2*nt + wc <= 2*mt + wr, i.e. nt <= mt for three of the wavefronts (KSTEP_LE:
 // 10 of 16 blocks) and nt < mt for (wr, wc) = (0, 1) (KSTEP_LT: 6 of 16); the slab reduction mirrors the rest.
@@ -412,14 +428,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         const int sbase = (part == 0 && kt == nk - 2) ? 0 : (part == 0 && kt == 4) ? 5 : -1;                \
         (void)sbase;                                                                                        \
         STEP_STAMP(0);                                                                                      \
-        const double* As = lds + buf * 2 * TILE_ELEMS;                                                      \
-        const double* Bs = As + TILE_ELEMS;                                                                 \
+        const double* As = lds + buf * STAGE_ELEMS;                                                         \
+        const double* Bs = As + A_ELEMS;                                                                    \
         int act = 15;                                                                                       \
         if ((COND) == 1) {                                                                                  \
             const int64_t kk = k0 + KSTEP(kt) * BK;                                                         \
-            const int64_t r0 = (int64_t)rb * BM + wr * 16;                                                  \
+            const int64_t r0 = (int64_t)rb * RM + wr * 16;                                                  \
             act = 0;                                                                                        \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                             \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                            \
                 const bool nz = (g.tri & TRI_LOWER_A) ? (kk <= r0 + mt * 32 + 15) : (kk + 15 >= r0 + mt * 32); \
                 act |= nz ? (1 << mt) : 0;                                                                  \
             }                                                                                               \
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     if (TRI) {
         // the 8 K steps of the diagonal block (last for a lower-, first for an upper-triangular A) take the skipping
         // body, every other step the branch-free one
-        const int64_t nd = nk < 8 ? nk : 8;
+        const int64_t nd = nk < RM / BK ? nk : RM / BK;
         const bool diag_first = upper != rev;     // the diagonal block is the lowest k of an upper-, the highest of a lower-
         const int64_t d0 = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && diag_first) ? nd : 0;
         const int64_t d1 = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !diag_first) ? nk - nd : nk;
@@ -446,16 +462,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         STAGE_LOOP(d0, d1, 0, KSTEP_STD(MMA_ALL))
         STAMP(3 + 4 * part);
         STAGE_LOOP(d1, nk, 1, KSTEP_STD(MMA_IF))
-    } else if (B_T && g.sym_out && g.lower_out && rb == cb) {
-        // symmetric output, diagonal tile: the 16 x 16 blocks strictly above the diagonal are not computed
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // scalar branch: whole loops per wavefront role
-        if (wave_u == 1) {      // (wr, wc) = (0, 1)
-            STAGE_LOOP(0, nk, 0, KSTEP_LT)
-        } else {
-            STAGE_LOOP(0, nk, 0, KSTEP_LE)
-        }
     } else {
-        STAGE_LOOP(0, nk, 0, KSTEP_STD(MMA_ALL))
+        bool done = false;
+        if constexpr (B_T) {
+            if (g.sym_out && g.lower_out && rb == cb) {
+                // symmetric output, diagonal tile: the 16 x 16 blocks strictly above the diagonal are not computed
+                const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // scalar branch: whole loops per wavefront role
+                if (wave_u == 1) {      // (wr, wc) = (0, 1)
+                    STAGE_LOOP(0, nk, 0, KSTEP_LT)
+                } else {
+                    STAGE_LOOP(0, nk, 0, KSTEP_LE)
+                }
+                done = true;
+            }
+        }
+        if (!done) { STAGE_LOOP(0, nk, 0, KSTEP_STD(MMA_ALL)) }
     }
 #undef STAGE_LOOP
 #undef KSTEP
@@ -480,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     // accumulator acc[mt][nt][r] of a lane: row = row0 + mt*32 + 4*r; column = col0 + COLOFF(nt).  NN: the lane's columns
     // come in adjacent pairs (nt = 2h, 2h+1 -> col0 + 32h, +1): 16-byte accesses; A B^T keeps one column per 16-lane group
     // (column group 2*nt + wc).
-    const int64_t row0 = (int64_t)rb * BM + wr * 16 + lk;
+    const int64_t row0 = (int64_t)rb * RM + wr * 16 + lk;
     const int64_t col0 = cb * BN + (B_T ? wc * 16 + li : wc * 64 + 2 * li);
     const int ccol = B_T ? wc * 16 + li : wc * 64 + 2 * li;    // the same inside the tile
 #define COLOFF(nt) (B_T ? (nt) * 32 : ((nt) >> 1) * 32 + ((nt) & 1))
@@ -503,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         // one with 4*mt + r == li -- one register for the wavefront's 16 x 4 row sums
         double rdkeep = 0.0;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             v2f64 av[2][4];
             double ar[4];
 #pragma unroll
@@ -532,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
             }
             __builtin_amdgcn_sched_barrier(0);      // one 16-row group at a time: bounded live ranges, no spills
         }
-        if (g.rowdot_part)      // lane li: row (mt, r) = (li >> 2, li & 3) of this wavefront's 64-column slice
+        if (g.rowdot_part && li < 4 * MT)      // lane li: row (mt, r) = (li >> 2, li & 3) of this wavefront's 64-column slice
             g.rowdot_part[((int64_t)cb * 2 + wc) * g.Mr + row0 + (li >> 2) * 32 + 4 * (li & 3)] = rdkeep;
         STAMP(9 + part);
         continue;
@@ -547,19 +568,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
         // the unluckiest one (3.6 us of a 7 us epilogue, in-kernel stamps).
         double sq[4] = {0.0, 0.0, 0.0, 0.0}, dt[4] = {0.0, 0.0, 0.0, 0.0};
         const bool want_dot = g.coldot_part != nullptr;
-        double ar[4][4];
+        double ar[MT][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ar[mt][r] = 0.0;
         if (want_dot) {      // 16 broadcast loads (L2 hits), all in flight together; no store is outstanding here
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ar[mt][r] = g.avec[row0 + mt * 32 + 4 * r];
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -600,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g, int nrb, i
     {                                                                                                       \
         double* cp = C + row0 * g.ldc + col0;                                                               \
         const int64_t step4 = 4 * g.ldc, step_mt = 32 * g.ldc - 16 * g.ldc;                                 \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
                 if (B_T) {                                                                                  \
                     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                     \
@@ -641,6 +662,28 @@ template <int EPI> static int launch_small_panel(const GemmArgs& g, hipStream_t 
 static bool small_gemm_ok(const GemmArgs& g, bool B_T);
 static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s);
 
+// 64-row tiles serve the plain M x N' panel products only: A B form, no k-slicing, no batching, no lower-triangular output;
+// anything else runs on 128-row tiles.  GemmArgs::rm = 0 picks the height from the shape (tools/tile_sweep.py, MI355X,
+// triangular A, colstats / dA epilogues, ms):
+//     M x N'        128 unpaired  128 paired  64 unpaired  64 paired
+//     512 x 8192       0.070        0.086       0.074       0.052      <- 256 tiles of 128 rows: one per CU, the longest one
+//     512 x 16384      0.124        0.090       0.119       0.084         walks 32 dependent K steps; paired they fill half
+//     512 x 32768      0.243        0.158       0.230       0.165         the chip.  64-row tiles: twice the tiles, pairs of
+//     512 x 65536      0.480        0.328       0.421       0.326         equal work on every CU
+//     1024 x 8192      0.247        0.158       0.209       0.154
+//     1024 x 65536     1.547        1.106       1.346       1.126
+//     256 x 8192       0.036        0.052       0.025       0.030
+//     768 x 16384      0.272        0.213       0.244       0.168
+// Rule: 128-row tiles (paired) once their pairs fill two workgroups per CU (>= 512); below that 64-row tiles, paired when the
+// pairs still give every CU one workgroup (>= 256), else unpaired.
+static int tile_rows(const GemmArgs& g, bool B_T, int splitk) {
+    if (B_T || splitk > 1 || g.batched || g.lower_out || g.zlayers > 1) return BM;
+    if (g.rm == 64 || g.rm == BM) return g.rm;
+    if (!(g.tri & (TRI_LOWER_A | TRI_UPPER_A))) return BM;
+    const int64_t pairs128 = (int64_t)((g.Mr / BM + 1) / 2) * (g.Nc / BN);
+    return pairs128 >= 512 ? BM : 64;
+}
+
 int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
     if (g.Mr % BM || g.Nc % BN || g.Kd % BK) return MOBOCMF_BAD_ARG;
     if (!B_T && ((g.ldc & 1) || ((uintptr_t)g.C & 15))) return MOBOCMF_BAD_ARG;   // 16-byte epilogue accesses (A B form)
@@ -650,7 +693,8 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         return launch_small_panel<EPI_STORE>(g, s);
     }
     if (B_T && splitk <= 1 && small_gemm_ok(g, true)) return launch_small_gemm(g, true, s);   // small weighted syrk
-    int nrb = g.Mr / BM;
+    const int rm = tile_rows(g, B_T, splitk);
+    int nrb = g.Mr / rm;
     int64_t ncb = g.Nc / BN;
     dim3 grid;
     int pair = 0;
@@ -663,9 +707,13 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         const int64_t nblk = ntile ? ntile * splitk : (int64_t)nrb * (nrb - 1) / 2 * splitk + (int64_t)nrb * g.splitk_diag;
         grid = dim3((unsigned)nblk, 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
     } else {
-        // pairing balances the work per workgroup; it only pays when there are more tiles than resident workgroup
-        // slots (2 per CU), otherwise the longest single tile is the critical path and pairing lengthens it
-        pair = ((g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !g.lower_out && nrb > 1 && (int64_t)nrb * ncb > 512) ? 1 : 0;
+        // pairing balances the work per workgroup; it only pays when the pairs still fill the chip (table above), otherwise
+        // the longest single tile is the critical path and pairing lengthens it
+        const bool can_pair = (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !g.lower_out && nrb > 1;
+        if (rm == 64) pair = (can_pair && (int64_t)(nrb / 2) * ncb >= 256) ? 1 : 0;      // pairs still cover every CU
+        else pair = (can_pair && (int64_t)nrb * ncb > 512) ? 1 : 0;
+        if (g.pair_mode == 1) pair = 0;
+        if (g.pair_mode == 2 && (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) && !g.lower_out && nrb > 1) pair = 1;
         grid = dim3((unsigned)((pair ? (nrb + 1) / 2 : nrb) * ncb), 1, 1);
         splitk = 1;
     }
@@ -674,21 +722,32 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
     // instantiation spills loop-invariant LDS addresses and reloads them -- a scratch round trip -- in every K step
     // (dense 512 x 65536 x 512: 0.62 ms against 0.53 ms through this instantiation)
     const bool tri = (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) != 0 || g.epi == EPI_STORE;
-#define LAUNCH(BT, TR, EP) hipLaunchKernelGGL((gemm_f64_kernel<BT, TR, EP>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair)
+#define LAUNCH(BT, TR, EP, RM_) hipLaunchKernelGGL((gemm_f64_kernel<BT, TR, EP, RM_>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair)
     if (B_T) {
         if (g.epi != EPI_STORE) return MOBOCMF_BAD_ARG;
-        LAUNCH(true, false, EPI_STORE);
+        LAUNCH(true, false, EPI_STORE, 128);
+    } else if (rm == 64) {      // 64-row tiles: always the TRI instantiation (a dense operand has empty diagonal-block loops)
+        if (g.epi == EPI_COLSTATS) LAUNCH(false, true, EPI_COLSTATS, 64);
+        else if (g.epi == EPI_DA) LAUNCH(false, true, EPI_DA, 64);
+        else LAUNCH(false, true, EPI_STORE, 64);
     } else if (tri) {
-        if (g.epi == EPI_COLSTATS) LAUNCH(false, true, EPI_COLSTATS);
-        else if (g.epi == EPI_DA) LAUNCH(false, true, EPI_DA);
-        else LAUNCH(false, true, EPI_STORE);
+        if (g.epi == EPI_COLSTATS) LAUNCH(false, true, EPI_COLSTATS, 128);
+        else if (g.epi == EPI_DA) LAUNCH(false, true, EPI_DA, 128);
+        else LAUNCH(false, true, EPI_STORE, 128);
     } else {
-        if (g.epi == EPI_COLSTATS) LAUNCH(false, false, EPI_COLSTATS);
-        else if (g.epi == EPI_DA) LAUNCH(false, false, EPI_DA);
-        else LAUNCH(false, false, EPI_STORE);
+        if (g.epi == EPI_COLSTATS) LAUNCH(false, false, EPI_COLSTATS, 128);
+        else if (g.epi == EPI_DA) LAUNCH(false, false, EPI_DA, 128);
+        else LAUNCH(false, false, EPI_STORE, 128);
     }
 #undef LAUNCH
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+// partial rows (of Nc entries each) an EPI_COLSTATS launch writes to colsq_part / coldot_part: two per row block of the tile
+// height the launch will use (the small-panel kernel: two per 128 rows, the second one zero)
+int gemm_colstat_rows(const GemmArgs& g) {
+    if (small_panel_ok(g, false, 1)) return 2 * (g.Mr / BM);
+    return 2 * (g.Mr / tile_rows(g, false, 1));
 }
 
 // out[i][j] (+)= sum_z slabs[z][i][j]   (rows x cols, slabs dense with ld = cols); lower_only: tiles above the

@@ -842,6 +842,20 @@ def check_info(info):
     return 0
 
 
+def gemm_colstat_rows(Mr, Nc, Kd, tri=0):
+    """Partial rows the column-statistics epilogue writes for a product of that shape (two per row block of the tile
+    height in force: mobocmf_gemm_colstat_rows)."""
+    rows = ctypes.c_int32()
+    _lib.check(_lib.load().mobocmf_gemm_colstat_rows(tri, Mr, Nc, Kd, ctypes.byref(rows)), "mobocmf_gemm_colstat_rows")
+    return rows.value
+
+
+def set_tile_rows(rows=0, pair_mode=0):
+    """Tile height of the M x N' panel products: 0 automatic, 64 or 128; row-block pairing 0 automatic, 1 never, 2 always
+    (mobocmf_set_tile_rows)."""
+    _lib.check(_lib.load().mobocmf_set_tile_rows(int(rows), int(pair_mode)), "mobocmf_set_tile_rows")
+
+
 def gemm_f64_epilogue(A, B, C, tri, epi, alpha=1.0, stream_out=False, colsq_part=None, coldot_part=None, avec=None,
                       bscale=None, gmu=None, cgv=None, Aaux=None, rowdot_part=None):
     """The GEMM with the epilogue the layer launches it with (mobocmf_gemm_f64_epilogue): tests and per-variant timing."""
@@ -849,6 +863,12 @@ def gemm_f64_epilogue(A, B, C, tri, epi, alpha=1.0, stream_out=False, colsq_part
     A, B = _prep(A), _prep(B)
     Mr, Kd = A.shape
     Nc = B.shape[1]
+    if epi == 1:
+        need = gemm_colstat_rows(Mr, Nc, Kd, tri) * Nc
+        for part in (colsq_part, coldot_part):
+            if part is not None and part.numel() < need:
+                raise _lib.MobocmfError("gemm_f64_epilogue: the partial-statistics buffers need gemm_colstat_rows() = %d rows"
+                                        % (need // Nc))
     _lib.check(lib.mobocmf_gemm_f64_epilogue(tri, epi, Mr, Nc, Kd, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C),
                                              C.stride(0), alpha, int(stream_out), _ptr(colsq_part), _ptr(coldot_part),
                                              _ptr(avec), _ptr(bscale), _ptr(gmu), _ptr(cgv), _ptr(Aaux), _ptr(rowdot_part),

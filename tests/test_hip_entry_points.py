@@ -17,11 +17,21 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
 
 
-@pytest.mark.parametrize("Mp,Np", [(128, 256), (256, 2048), (512, 8192), (640, 1024), (512, 32768), (384, 65536)])
-def test_gemm_epilogue_variants_match_torch(Mp, Np):
+@pytest.mark.parametrize("rows", [64, 128], ids=["tiles64x128", "tiles128x128"])
+@pytest.mark.parametrize("Mp,Np", [(128, 256), (256, 2048), (512, 8192), (640, 1024), (512, 32768), (384, 65536), (1024, 16384)])
+def test_gemm_epilogue_variants_match_torch(Mp, Np, rows):
     """The four launches of a layer's panel work through mobocmf_gemm_f64_epilogue vs float64 torch ops: small-panel
-    kernel (Mp <= 512, few workgroups), tiled kernel without and with row-block pairing."""
+    kernel (Mp <= 512, few workgroups), tiled kernel without and with row-block pairing, on 128 x 128 tiles and on 64 x 128
+    tiles (three workgroups per CU, triangular operand resolved in 64-row blocks; mobocmf_set_tile_rows)."""
     from mobocmf_amd import functional as F
+    F.set_tile_rows(rows)
+    try:
+        _gemm_epilogue_variants(F, Mp, Np)
+    finally:
+        F.set_tile_rows(0)
+
+
+def _gemm_epilogue_variants(F, Mp, Np):
     g = torch.Generator(device=DEV)
     g.manual_seed(Mp + Np)
     rnd = lambda *s: torch.randn(*s, dtype=torch.float64, device=DEV, generator=g)
@@ -38,8 +48,10 @@ def test_gemm_epilogue_variants_match_torch(Mp, Np):
         # column statistics (+ non-temporal stores)
         for so in (False, True):
             C.fill_(float("nan"))
-            p1 = torch.full((2 * nrb, Np), float("nan"), dtype=torch.float64, device=DEV)      # two partial rows per block
-            p2 = torch.full((2 * nrb, Np), float("nan"), dtype=torch.float64, device=DEV)
+            npart = F.gemm_colstat_rows(Mp, Np, Mp, tri)                      # two partial rows per row block of the tile height
+            assert npart in (2 * nrb, 4 * nrb)
+            p1 = torch.full((npart, Np), float("nan"), dtype=torch.float64, device=DEV)
+            p2 = torch.full((npart, Np), float("nan"), dtype=torch.float64, device=DEV)
             F.gemm_f64_epilogue(T, B, C, tri, 1, stream_out=so, colsq_part=p1, coldot_part=p2, avec=avec)
             assert rel(C, ref) < 1e-12
             assert rel(p1.sum(0), (ref * ref).sum(0)) < 1e-12

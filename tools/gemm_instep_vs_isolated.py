@@ -21,8 +21,8 @@ Lw = torch.tril(rnd(M, M))
 Bs = [rnd(M, N) for _ in range(6)]
 Cs = [torch.empty(M, N, dtype=torch.float64, device=dev) for _ in range(6)]
 avec = rnd(M)
-p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
-p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
+p1 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
+p2 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
 run = lambda i: F.gemm_f64_epilogue(Lw, Bs[i], Cs[i], 1, 1, colsq_part=p1, coldot_part=p2, avec=avec)
 
 

@@ -23,8 +23,8 @@ A = torch.tril(torch.randn(M, M, dtype=torch.float64, device=dev))
 B = torch.randn(M, N, dtype=torch.float64, device=dev)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)
 avec = torch.randn(M, dtype=torch.float64, device=dev)
-p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
-p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
+p1 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
+p2 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
 nwg = 4096
 stamps = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
 A2 = torch.randn(M, N, dtype=torch.float64, device=dev)

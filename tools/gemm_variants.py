@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mobocmf_amd import functional as F  # noqa: E402
 
 dev = torch.device("cuda")
+F.set_tile_rows(int(os.environ.get("TILE_ROWS", "0")), int(os.environ.get("PAIR_MODE", "0")))      # rows: 0 automatic | 64 | 128; pairing: 0 auto | 1 never | 2 always
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 g = torch.Generator(device=dev)
@@ -20,8 +21,8 @@ Lw, Up = torch.tril(rnd(M, M)), torch.triu(rnd(M, M))
 B, A2 = rnd(M, N), rnd(M, N)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)
 avec, gmu, cgv, gv = rnd(M), rnd(N), rnd(N), rnd(N)
-p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
-p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
+p1 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
+p2 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
 rdp = torch.empty(2 * (N // 128), M, dtype=torch.float64, device=dev)
 
 

@@ -30,8 +30,8 @@ Lw, Up = torch.tril(rnd(M, M)), torch.triu(rnd(M, M))
 B, A2 = rnd(M, N), rnd(M, N)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)
 avec, gmu, cgv, gv = rnd(M), rnd(N), rnd(N), rnd(N)
-p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
-p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
+p1 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
+p2 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
 rdp = torch.empty(2 * (N // 128), M, dtype=torch.float64, device=dev)
 H = torch.empty(M, M, dtype=torch.float64, device=dev)
 variants = [

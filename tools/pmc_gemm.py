@@ -15,8 +15,8 @@ A = torch.tril(torch.randn(M, M, dtype=torch.float64, device=dev))
 B = torch.randn(M, N, dtype=torch.float64, device=dev)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)
 avec = torch.randn(M, dtype=torch.float64, device=dev)
-p1 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
-p2 = torch.empty(2 * (M // 128), N, dtype=torch.float64, device=dev)
+p1 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
+p2 = torch.empty(4 * (M // 128), N, dtype=torch.float64, device=dev)
 for _ in range(5):
     F.gemm_f64_epilogue(A, B, C, 1, 1, colsq_part=p1, coldot_part=p2, avec=avec)
 torch.cuda.synchronize()
