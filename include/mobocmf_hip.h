@@ -126,7 +126,8 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
  * (bottom up); layer_panel_backward per layer (top down); layers_chain_backward.  Arrays of pointers are HOST arrays of n
  * entries (device pointers inside).  The PANEL backward OVERWRITES g_hyp / g_zf with the K_mn share, the chain backward
  * OVERWRITES its own g_hyp / g_zf arguments with the K_mm share (the caller adds the two).  had_panel[l] = 0: layer l got no
- * upstream mean / var gradient (only its KL was differentiated). */
+ * upstream mean / var gradient (only its KL was differentiated); 1: its PANEL backward ran; 2: it ran AND the g_hyp[l] / g_zf[l]
+ * passed to the chain backward already hold its share -- the chain backward adds to them instead of overwriting. */
 int mobocmf_chain_block_bytes(const mobocmf_layer_desc* desc, size_t* block_bytes, size_t* state_bytes);
 int mobocmf_panel_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes);
 int mobocmf_layers_chain_forward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,
@@ -212,6 +213,24 @@ int mobocmf_elbo_combine_forward(int32_t n_data, const double* const* data_terms
                                  double scale, double* out2, mobocmf_stream_t stream);
 int mobocmf_elbo_combine_backward(const double* g_elbo, const double* g_skl, double scale, double* g2,
                                   mobocmf_stream_t stream);
+
+/* The whole ELBO of variational_elbo_mf.py:24-51 in one call (a reduction launch + a one-block tail; the same in backward;
+ * the per-fidelity functions above take two launches per fidelity + mobocmf_elbo_combine): for every layer l < L with mean[l]
+ * non-NULL the masked expected log-likelihood of the rows with fid == l (mean[l] / var[l] hold B * div[l] rows, row i belongs
+ * to y[i / div[l]]; averaged over the div[l] samples of a row), noise tau_l = lo[l] + (hi[l] - lo[l]) sigmoid(raw_noise[l][0])
+ * (hi[l] <= lo[l]: raw_noise[l][0] is tau itself); n_kl KL scalars; scale = batch / num_data:
+ *   out3[0] = sum data terms - scale * sum kls,  out3[1] = scale * sum kls,  out3[2] = -out3[0]  (the loss).
+ * Arrays of pointers / per-layer values are HOST arrays of L (n_kl) entries, L, n_kl <= 8.  scratch >= 8 * 512 * 8 bytes.  Backward: g_mean[l] / g_var[l] (B * div[l]), g_raw_noise[l] (w.r.t. the RAW parameter; may be
+ * NULL per layer), g_kl[0] = the gradient w.r.t. every KL = scale * (g_skl - g_elbo); g_elbo / g_skl device scalars or NULL. */
+int mobocmf_elbo_forward(int32_t L, const double* const* mean, const double* const* var, const int32_t* div,
+                         const double* const* raw_noise, const double* lo, const double* hi, const double* y,
+                         const double* fid, int64_t B, int32_t n_kl, const double* const* kls, double scale, double* out3,
+                         void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+int mobocmf_elbo_backward(int32_t L, const double* const* mean, const double* const* var, const int32_t* div,
+                          const double* const* raw_noise, const double* lo, const double* hi, const double* y,
+                          const double* fid, int64_t B, double scale, const double* g_elbo, const double* g_skl,
+                          double* const* g_mean, double* const* g_var, double* const* g_raw_noise, double* g_kl,
+                          void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
 
 /* The same pair with the noise given as the RAW parameter of an Interval constraint (mfdgp.py:116):
  * tau = lo + (hi - lo) * sigmoid(raw_noise[0]) is evaluated inside the kernels and g_tau is the gradient w.r.t. the raw

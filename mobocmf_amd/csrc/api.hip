@@ -43,7 +43,9 @@ int launch_mirror_lower(const double* src, int64_t lds, double* dst, int64_t ldd
                         int64_t n_real, hipStream_t s);
 // layer-batched forms (blockIdx.z = layer, workspace pointers + z*zs doubles, user tensors as tables)
 int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
-                   hipStream_t s);
+                   double* zero0, double* zero1, hipStream_t s);
+int launch_pad_params_z(const double* const* LS, const double* const* m, int M, double* LSp, double* mp, int Mp, int nz,
+                        int64_t zs, hipStream_t s);
 int launch_trtri_z(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
                    int64_t ws_elems, int nz, int64_t zs, hipStream_t s);
 int launch_transpose_z(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, int nz,
@@ -350,16 +352,12 @@ int chain_forward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const 
         g.K = c.L + z * zs;
         TRY(launch_gram_fwd(g, s));
     }
-    TRY(launch_potrf_z(c.L, Mp, Mp, D.M, c.Dinv, c.Ld, io.info, n, zs, s));
-    TRY(launch_zero32_z(c.Linv, mm * 2, n, zs * 8, s));
+    // (the last launch of the factorisation also clears L^-1 and U, which are filled on and below the block diagonal only)
+    TRY(launch_potrf_z(c.L, Mp, Mp, D.M, c.Dinv, c.Ld, io.info, n, zs, c.Linv, c.U, s));
     TRY(launch_trtri_z(c.L, Mp, Mp, c.Dinv, c.Linv, c.T, c.ws, c.ws_elems, n, zs, s));
     TRY(launch_transpose_z(c.Linv, Mp, c.LinvT, Mp, Mp, Mp, n, zs, s));
-    for (int z = 0; z < n; ++z) {      // user tensors -> padded copies
-        TRY(launch_pad_tril(io.L_S[z], D.M, D.M, c.LSp + z * zs, Mp, s));
-        TRY(launch_pad_vec(io.m[z], D.M, c.mp + z * zs, Mp, s));
-    }
+    TRY(launch_pad_params_z(io.L_S, io.m, D.M, c.LSp, c.mp, Mp, n, zs, s));      // user tensors -> padded copies, all layers
     // U = L^-1 L_S (lower x lower), a = L^-1 m
-    TRY(launch_zero32_z(c.U, mm * 2, n, zs * 8, s));
     {
         GemmArgs ga = gemm_args(c.Linv, Mp, c.LSp, Mp, c.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
         ga.lower_out = 1;
@@ -760,7 +758,7 @@ int mobocmf_layers_chain_backward(int32_t n, const mobocmf_layer_desc* const* de
         if (!Zx[z] || !hyp[z] || !g_kl[z] || !g_hyp[z] || !g_m[z] || !g_LS[z] || (desc[z]->kind == 1 && (!zf[z] || !g_zf[z])))
             return MOBOCMF_BAD_ARG;
         zero[z] = had_panel[z] == 0;
-        acc[z] = 0;          // the chain halves report their own g_hyp / g_zf (the caller adds the panel halves')
+        acc[z] = had_panel[z] == 2 ? 1 : 0;      // 2: g_hyp / g_zf hold the PANEL half's share already -- add to it
     }
     Dims D = dims_of(desc[0]);
     ChainWs c = {};

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(128) void potrf_panel2_kernel(double* A, int64_t ld
             double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
             for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? v[c] : 0.0;
-            if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
+            // the first panel (re)sets the status word, later ones only report the first failure: no separate zero launch
+            if (lane == 0 && (jb == 0 || (fail && *info == 0))) *info = fail ? (int32_t)(j0 + fail) : 0;
         }
     } else if (bi == 0) {      // v[k + lag] = L^-T[lane][k] = L^-1[k][lane]: store transposed (one coalesced row per k)
         double* inv = Dinv + (int64_t)jb * NB * NB;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64) void potrf_panel_pad_kernel(double* A, int64_t 
         double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
 #pragma unroll
         for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? a[c] : 0.0;
-        if (lane == 0 && fail && *info == 0) *info = (int32_t)(j0 + fail);
+        if (lane == 0 && (jb == 0 || (fail && *info == 0))) *info = fail ? (int32_t)(j0 + fail) : 0;
         double x[NB];
         trinv64_pad_rows<NACT>(a, x, lane);
         double* irow = Dinv + (int64_t)jb * NB * NB + lane * NB;
@@ -325,11 +326,14 @@ int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
-// strict upper triangle <- 0, diagonal 64x64 blocks <- the factors kept in Ld
-__global__ void finish_l_kernel(double* A, int64_t ld, int n, const double* Ld, int64_t zs) {
+// strict upper triangle <- 0, diagonal 64x64 blocks <- the factors kept in Ld; z0 / z1 (n x n each, may be null) <- 0: the
+// buffers the triangular inverse and U = L^-1 L_S fill only on and below the block diagonal (no separate zero launches)
+__global__ void finish_l_kernel(double* A, int64_t ld, int n, const double* Ld, int64_t zs, double* z0, double* z1) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)n * n) return;
     A += blockIdx.z * zs; Ld += blockIdx.z * zs;
+    if (z0) z0[blockIdx.z * zs + idx] = 0.0;
+    if (z1) z1[blockIdx.z * zs + idx] = 0.0;
     int i = (int)(idx / n), j = (int)(idx % n);
     if (j > i) A[(int64_t)i * ld + j] = 0.0;
     else if (i / NB == j / NB) A[(int64_t)i * ld + j] = Ld[(int64_t)(i / NB) * NB * NB + (i % NB) * NB + (j % NB)];
@@ -349,15 +353,12 @@ __global__ void identity_blocks_kernel(double* Dinv, double* Ld, int b0, int b1,
 // Dinv and Ld: (Mp/64) x 64 x 64 doubles each.  M = real order: rows/columns >= M of A are identity padding, which the
 // factorisation leaves alone -- a 16-point problem padded to 128 costs 16 elimination steps, not 128.
 int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
-                   hipStream_t s) {
+                   double* zero0, double* zero1, hipStream_t s) {
     // nz layers (same M): layer z works on A + z*zs, Dinv + z*zs, Ld + z*zs (doubles) and reports through info[z]
     const int nblk = Mp / NB;
     const int nreal = (M + NB - 1) / NB;          // 64-blocks that hold real rows
     InfoZ iz = {};
-    for (int z = 0; z < nz; ++z) {
-        iz.p[z] = info[z];
-        if (launch_zero32(info[z], 1, s)) return MOBOCMF_HIP_ERROR;
-    }
+    for (int z = 0; z < nz; ++z) iz.p[z] = info[z];      // (re)set by the first panel
     for (int jb = 0; jb < nreal; ++jb) {
         int nact = M - jb * NB;
         nact = nact >= NB ? NB : (nact + 15) & ~15;
@@ -374,13 +375,13 @@ int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* L
     }
     int64_t n2 = (int64_t)Mp * Mp;
     hipLaunchKernelGGL(finish_l_kernel, dim3((unsigned)((n2 + 255) / 256), 1, nz), dim3(256), 0, s, A, ld, Mp,
-                       (const double*)Ld, zs);
+                       (const double*)Ld, zs, zero0, zero1);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
 int launch_potrf(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* info, hipStream_t s) {
     int32_t* one[1] = {info};
-    return launch_potrf_z(A, ld, Mp, M, Dinv, Ld, one, 1, 0, s);
+    return launch_potrf_z(A, ld, Mp, M, Dinv, Ld, one, 1, 0, nullptr, nullptr, s);
 }
 
 // ---------------------------------------------------------------------------------- triangular inverse

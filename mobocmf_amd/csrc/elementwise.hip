@@ -77,6 +77,24 @@ int launch_pad_vec(const double* src, int64_t n, double* dst, int64_t np, hipStr
     return CHECK_LAUNCH();
 }
 
+// the same for every layer of a chain batch in ONE launch: LSp + z*zs = tril(L_S[z]) padded, mp + z*zs = m[z] padded
+struct PadZ { const double* LS[MAX_ZL]; const double* m[MAX_ZL]; };
+__global__ void pad_params_z_kernel(PadZ t, int M, double* LSp, double* mp, int Mp, int64_t zs) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    const int z = blockIdx.z;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    LSp[z * zs + idx] = (i < M && j <= i) ? t.LS[z][(int64_t)i * M + j] : 0.0;
+    if (idx < Mp) mp[z * zs + idx] = idx < M ? t.m[z][idx] : 0.0;
+}
+int launch_pad_params_z(const double* const* LS, const double* const* m, int M, double* LSp, double* mp, int Mp, int nz,
+                        int64_t zs, hipStream_t s) {
+    PadZ t = {};
+    for (int z = 0; z < nz; ++z) { t.LS[z] = LS[z]; t.m[z] = m[z]; }
+    hipLaunchKernelGGL(pad_params_z_kernel, GRIDZ((int64_t)Mp * Mp, nz), 0, s, t, M, LSp, mp, Mp, zs);
+    return CHECK_LAUNCH();
+}
+
 // out[c][r] = in[r][c]   (rows x cols -> cols x rows), 32x32 LDS tiles
 __global__ void transpose_kernel(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols,
                                  int64_t zs) {
@@ -146,19 +164,22 @@ __global__ void kl_part_kernel(const double* L, const double* LSp, const double*
     s = block_sum(s, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
-__global__ void kl_final_kernel(const double* part, int np, int M, double* kl) {
+struct KlZ { double* p[MAX_ZL]; };      // per-layer KL outputs (user tensors: not strided)
+__global__ void kl_final_kernel(const double* part, int np, int M, KlZ kl, int64_t zs) {
     __shared__ double sh[4];
     double s = 0.0;
+    part += blockIdx.x * zs;
     for (int i = threadIdx.x; i < np; i += 256) s += part[i];
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) kl[0] = 0.5 * (s - (double)M);
+    if (threadIdx.x == 0) kl.p[blockIdx.x][0] = 0.5 * (s - (double)M);
 }
 int launch_kl_z(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* const* kl,
                 double* part, int nz, int64_t zs, hipStream_t s) {
     const int nb = (M + 3) / 4;
     hipLaunchKernelGGL(kl_part_kernel, dim3(nb, 1, nz), dim3(256), 0, s, L, LSp, U, a, M, Mp, part, zs);
-    for (int z = 0; z < nz; ++z)      // kl[z] is a user tensor
-        hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(256), 0, s, (const double*)(part + z * zs), nb, M, kl[z]);
+    KlZ kz = {};
+    for (int z = 0; z < nz; ++z) kz.p[z] = kl[z];      // kl[z] is a user tensor
+    hipLaunchKernelGGL(kl_final_kernel, dim3(nz), dim3(256), 0, s, (const double*)part, nb, M, kz, zs);
     return CHECK_LAUNCH();
 }
 int launch_kl(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* kl,
@@ -522,6 +543,114 @@ __global__ void final_sum_scaled_kernel(const double* part, int np, const double
     }
 }
 
+// ---- The whole ELBO of variational_elbo_mf.py:24-51 in TWO launches each way (was: two launches per fidelity + the tail,
+// and as many again in backward): blockIdx.y = layer (fidelity level), every block reduces its share of the layer's masked
+// expected log-likelihood; a one-block tail adds the partial sums, the KL tail and writes the results.  (A single launch
+// whose last-finishing block does the tail needs a device ticket and __threadfence() -- an L2 write-back + invalidate on
+// gfx950 -- in every block: see the note at adam_multi_kernel.)
+#define ELBO_BLOCKS 512
+#define ELBO_MAX_LAYERS 8
+struct ElboTable {
+    const double* mean[ELBO_MAX_LAYERS]; const double* var[ELBO_MAX_LAYERS]; const double* raw[ELBO_MAX_LAYERS];
+    double* gmean[ELBO_MAX_LAYERS]; double* gvar[ELBO_MAX_LAYERS]; double* graw[ELBO_MAX_LAYERS];
+    const double* kl[ELBO_MAX_LAYERS];
+    double lo[ELBO_MAX_LAYERS], hi[ELBO_MAX_LAYERS];
+    int div[ELBO_MAX_LAYERS];
+};
+__global__ void elbo_all_fwd_kernel(ElboTable t, const double* y, const double* fid, int64_t B, double* part) {
+    __shared__ double sh[4];
+    const int l = blockIdx.y;
+    double s = 0.0;
+    if (t.mean[l]) {
+        const double lo = t.lo[l], hi = t.hi[l], raw = t.raw[l][0];
+        const double tau = hi > lo ? lo + (hi - lo) / (1.0 + exp(-raw)) : raw, ltau = log(tau);
+        const int div = t.div[l];
+        const int64_t n = B * div;
+        const double level = (double)l;
+        const double* mean = t.mean[l];
+        const double* var = t.var[l];
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t b = i / div;
+            if (fid[b] == level) s += elp_term(y[b], mean[i], var[i], tau, ltau);
+        }
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[(int64_t)l * gridDim.x + blockIdx.x] = s;
+}
+// one block: the partial sums of every layer, the KL tail, the three results
+__global__ void elbo_all_fwd_tail_kernel(ElboTable t, int L, int nb, int nkl, double scale, const double* part, double* out) {
+    __shared__ double sh[4];
+    double data = 0.0;
+    for (int ll = 0; ll < L; ++ll) {
+        double p = 0.0;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) p += part[(int64_t)ll * nb + i];
+        p = block_sum(p, sh);
+        __syncthreads();
+        if (t.mean[ll]) data += p / t.div[ll];
+    }
+    if (threadIdx.x == 0) {
+        double kl = 0.0;
+        for (int j = 0; j < nkl; ++j) kl += t.kl[j][0];
+        out[0] = data - scale * kl;
+        out[1] = scale * kl;
+        out[2] = -(data - scale * kl);
+    }
+}
+// gradients: g_mean / g_var per layer row, g_raw (the noise parameter of each layer, chain rule of the Interval transform
+// included), gkl[0] = d / d(every KL) = scale * (g_skl - g_elbo)
+__global__ void elbo_all_bwd_kernel(ElboTable t, const double* y, const double* fid, int64_t B, const double* g_elbo,
+                                    double* part) {
+    __shared__ double sh[4];
+    const int l = blockIdx.y;
+    const double ge = g_elbo ? g_elbo[0] : 0.0;
+    double st = 0.0;
+    if (t.mean[l]) {
+        const double lo = t.lo[l], hi = t.hi[l], raw = t.raw[l][0];
+        const double tau = hi > lo ? lo + (hi - lo) / (1.0 + exp(-raw)) : raw;
+        const int div = t.div[l];
+        const int64_t n = B * div;
+        const double level = (double)l, g = ge / div;
+        const double* mean = t.mean[l];
+        const double* var = t.var[l];
+        double* gmean = t.gmean[l];
+        double* gvar = t.gvar[l];
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t b = i / div;
+            double gm = 0.0, gvv = 0.0;
+            if (fid[b] == level) {
+                const double dlt = y[b] - mean[i];
+                gm = g * dlt / tau;
+                gvv = -0.5 * g / tau;
+                st += 0.5 * ((dlt * dlt + var[i]) / (tau * tau) - 1.0 / tau);
+            }
+            gmean[i] = gm;
+            gvar[i] = gvv;
+        }
+    }
+    st = block_sum(st, sh);
+    if (threadIdx.x == 0) part[(int64_t)l * gridDim.x + blockIdx.x] = st;
+}
+__global__ void elbo_all_bwd_tail_kernel(ElboTable t, int L, int nb, double scale, const double* g_elbo, const double* g_skl,
+                                         const double* part, double* gkl) {
+    __shared__ double sh[4];
+    const double ge = g_elbo ? g_elbo[0] : 0.0;
+    for (int ll = 0; ll < L; ++ll) {
+        double p = 0.0;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) p += part[(int64_t)ll * nb + i];
+        p = block_sum(p, sh);
+        __syncthreads();
+        if (threadIdx.x == 0 && t.mean[ll] && t.graw[ll]) {
+            double chain = 1.0;
+            if (t.hi[ll] > t.lo[ll]) {
+                const double sg = 1.0 / (1.0 + exp(-t.raw[ll][0]));
+                chain = (t.hi[ll] - t.lo[ll]) * sg * (1.0 - sg);
+            }
+            t.graw[ll][0] = p / t.div[ll] * ge * chain;
+        }
+    }
+    if (threadIdx.x == 0) gkl[0] = scale * ((g_skl ? g_skl[0] : 0.0) - ge);
+}
+
 __global__ void acq_fwd_kernel(const double* mu_t, const double* var_t, double* mus, double* vars, int64_t T, int S) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -581,6 +710,9 @@ struct AdamTable {
     double* v[ADAM_MAX_TENSORS];
     int64_t n[ADAM_MAX_TENSORS];
 };
+// (The step count is advanced by a trailing one-thread launch.  Letting the last-finishing workgroup do it through a device
+// ticket -- here and in the ELBO reduction below -- was tried and withdrawn: together the two hand-overs cost 0.11 ms per C3
+// surrogate step and 1.05 ms per C5 step in a same-box A/B, far more than the two launches they saved.)
 __global__ void adam_multi_kernel(AdamTable t, double lr, double b1, double b2, double eps, const int64_t* steps_done) {
     const int64_t step = steps_done[0] + 1;
     const int ti = blockIdx.y;
@@ -773,7 +905,6 @@ int mobocmf_propagate_backward(const double* var, const double* eps, const doubl
     return CHECK_LAUNCH();
 }
 
-#define ELBO_BLOCKS 512
 int mobocmf_elbo_data_forward(const double* mean, const double* var, const double* y, const double* fid,
                               const double* tau, double level, int64_t n_rows, int32_t div, double* out, void* scratch,
                               size_t scratch_bytes, mobocmf_stream_t stream) {
@@ -819,6 +950,58 @@ int mobocmf_elbo_data_interval_backward(const double* mean, const double* var, c
                        g_out, g_mean, g_var, (double*)scratch);
     hipLaunchKernelGGL(final_sum_scaled_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, nb, g_out, 1.0 / div,
                        g_tau, tau, lo, hi);
+    return CHECK_LAUNCH();
+}
+
+static int elbo_blocks(int32_t L, const double* const* mean, const int32_t* div, int64_t B) {
+    int64_t nmax = 1;
+    for (int l = 0; l < L; ++l)
+        if (mean[l] && B * div[l] > nmax) nmax = B * div[l];
+    int64_t nb = (nmax + 1023) / 1024;
+    return (int)(nb < 1 ? 1 : (nb > ELBO_BLOCKS ? ELBO_BLOCKS : nb));
+}
+
+int mobocmf_elbo_forward(int32_t L, const double* const* mean, const double* const* var, const int32_t* div,
+                         const double* const* raw_noise, const double* lo, const double* hi, const double* y,
+                         const double* fid, int64_t B, int32_t n_kl, const double* const* kls, double scale, double* out3,
+                         void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
+    if (L < 1 || L > ELBO_MAX_LAYERS || n_kl < 0 || n_kl > ELBO_MAX_LAYERS || !mean || !var || !div || !raw_noise || !lo ||
+        !hi || !y || !fid || B < 0 || !out3 || !scratch || (n_kl && !kls))
+        return MOBOCMF_BAD_ARG;
+    if (scratch_bytes < (size_t)ELBO_MAX_LAYERS * ELBO_BLOCKS * sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    ElboTable t = {};
+    for (int l = 0; l < L; ++l) {
+        if (mean[l] && (!var[l] || !raw_noise[l] || div[l] < 1)) return MOBOCMF_BAD_ARG;
+        t.mean[l] = mean[l]; t.var[l] = var[l]; t.raw[l] = raw_noise[l]; t.lo[l] = lo[l]; t.hi[l] = hi[l]; t.div[l] = div[l];
+    }
+    for (int j = 0; j < n_kl; ++j) { if (!kls[j]) return MOBOCMF_BAD_ARG; t.kl[j] = kls[j]; }
+    const int nb = elbo_blocks(L, mean, div, B);
+    hipLaunchKernelGGL(elbo_all_fwd_kernel, dim3(nb, L), dim3(256), 0, (hipStream_t)stream, t, y, fid, B, (double*)scratch);
+    hipLaunchKernelGGL(elbo_all_fwd_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, L, nb, n_kl, scale,
+                       (const double*)scratch, out3);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_elbo_backward(int32_t L, const double* const* mean, const double* const* var, const int32_t* div,
+                          const double* const* raw_noise, const double* lo, const double* hi, const double* y,
+                          const double* fid, int64_t B, double scale, const double* g_elbo, const double* g_skl,
+                          double* const* g_mean, double* const* g_var, double* const* g_raw_noise, double* g_kl,
+                          void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
+    if (L < 1 || L > ELBO_MAX_LAYERS || !mean || !var || !div || !raw_noise || !lo || !hi || !y || !fid || B < 0 ||
+        !g_mean || !g_var || !g_raw_noise || !g_kl || !scratch)
+        return MOBOCMF_BAD_ARG;
+    if (scratch_bytes < (size_t)ELBO_MAX_LAYERS * ELBO_BLOCKS * sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    ElboTable t = {};
+    for (int l = 0; l < L; ++l) {
+        if (mean[l] && (!var[l] || !raw_noise[l] || div[l] < 1 || !g_mean[l] || !g_var[l])) return MOBOCMF_BAD_ARG;
+        t.mean[l] = mean[l]; t.var[l] = var[l]; t.raw[l] = raw_noise[l]; t.lo[l] = lo[l]; t.hi[l] = hi[l]; t.div[l] = div[l];
+        t.gmean[l] = g_mean[l]; t.gvar[l] = g_var[l]; t.graw[l] = g_raw_noise[l];
+    }
+    const int nb = elbo_blocks(L, mean, div, B);
+    hipLaunchKernelGGL(elbo_all_bwd_kernel, dim3(nb, L), dim3(256), 0, (hipStream_t)stream, t, y, fid, B, g_elbo,
+                       (double*)scratch);
+    hipLaunchKernelGGL(elbo_all_bwd_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, L, nb, scale, g_elbo, g_skl,
+                       (const double*)scratch, g_kl);
     return CHECK_LAUNCH();
 }
 

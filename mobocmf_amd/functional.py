@@ -226,7 +226,7 @@ class _ChainFn(torch.autograd.Function):
         P.saved = _poison(torch.empty(P.sb, dtype=torch.uint8, device=dev))
         scratch = scratch_buffer(P.cb, dev)
         kl = _empty((), device=dev)
-        token = torch.zeros(1, dtype=torch.float64, device=dev)
+        token = torch.empty(1, dtype=torch.float64, device=dev)      # never read: it only orders the autograd nodes
         rc = lib.mobocmf_layer_forward(ctypes.byref(desc), None, None, _ptr(Zx), _ptr(zf), _ptr(hyp), _ptr(m), _ptr(L_S),
                                        None, None, _ptr(kl), _ptr(P.info), _ptr(P.saved), P.sb, _ptr(scratch),
                                        scratch.numel(), _stream())
@@ -328,6 +328,8 @@ class _PanelFn(torch.autograd.Function):
         if P.frozen:
             return g_x, g_f, None, None, None, None, None
         P.bscratch = scratch
+        # the token gradient is a real tensor here: the CHAIN half may run on another stream, and the autograd engine
+        # orders the two streams through the tensors that flow between the nodes
         return g_x, g_f, None, g_zf, g_hyp, torch.zeros(1, dtype=torch.float64, device=dev), None
 
 
@@ -364,7 +366,7 @@ def layer_panel(P, token, x, f, Zx, zf, hyp):
 class ChainBatch:
     """Workspace + bookkeeping shared by ``layers_chain`` and the per-layer ``layer_panel_batched`` calls of one forward."""
     __slots__ = ("n", "kinds", "ds", "M", "branch", "jitters", "min_var", "blocks", "stride", "block_bytes", "infos",
-                 "kls", "had_panel", "token")
+                 "kls", "had_panel", "token", "panel_g")
 
     def chain_desc(self, z):
         return make_desc(self.kinds[z], self.ds[z], self.M, 1, 1, self.branch, False, self.jitters[z], self.min_var,
@@ -398,7 +400,9 @@ class _ChainsFn(torch.autograd.Function):
         CB.blocks = _poison(torch.empty(n * CB.stride, dtype=torch.uint8, device=dev))
         CB.kls = [_empty((), device=dev) for _ in range(n)]
         CB.had_panel = [0] * n
-        token = torch.zeros(1, dtype=torch.float64, device=dev)
+        CB.panel_g = [None] * n
+        ctx.set_materialize_grads(False)
+        token = torch.empty(1, dtype=torch.float64, device=dev)      # never read: it only orders the autograd nodes
         P = lambda i, none_ok=False: _table([0 if per[z][i] is None else per[z][i].data_ptr() for z in range(n)])
         rc = lib.mobocmf_layers_chain_forward(n, _desc_table(descs), P(0), P(1), P(2), P(3), P(4),
                                               _table([k.data_ptr() for k in CB.kls]),
@@ -421,13 +425,24 @@ class _ChainsFn(torch.autograd.Function):
         dev = per[0][0].device
         gk = [_prep(g) if g is not None else torch.zeros((), dtype=torch.float64, device=dev) for g in g_kls]
         new = lambda *s: _empty(*s, device=dev)
-        g_zf = [new(CB.M) if per[z][1] is not None else None for z in range(n)]
-        g_hyp = [new(per[z][2].numel()) for z in range(n)]
+        # a layer whose PANEL half ran left its share of g_hyp / g_zf in CB.panel_g: the chain accumulates into those buffers
+        # (had_panel = 2) instead of autograd adding two tensors per layer afterwards
+        had = list(CB.had_panel)
+        g_zf, g_hyp = [], []
+        for z in range(n):
+            pg = CB.panel_g[z]
+            if pg is not None:
+                had[z] = 2
+                g_hyp.append(pg[0])
+                g_zf.append(pg[1] if per[z][1] is not None else None)
+            else:
+                g_hyp.append(new(per[z][2].numel()))
+                g_zf.append(new(CB.M) if per[z][1] is not None else None)
         g_m = [new(CB.M) for _ in range(n)]
         g_LS = [new(CB.M, CB.M) for _ in range(n)]
         T = lambda ts: _table([0 if t is None else t.data_ptr() for t in ts])
         rc = lib.mobocmf_layers_chain_backward(n, _desc_table(ctx.descs), T([p[0] for p in per]), T([p[1] for p in per]),
-                                               T([p[2] for p in per]), T(gk), (ctypes.c_int32 * n)(*CB.had_panel),
+                                               T([p[2] for p in per]), T(gk), (ctypes.c_int32 * n)(*had),
                                                T(g_zf), T(g_hyp), T(g_m), T(g_LS), _ptr(CB.blocks), CB.stride,
                                                CB.blocks.numel(), _stream())
         _lib.check(rc, "mobocmf_layers_chain_backward")
@@ -506,7 +521,10 @@ class _PanelBatchedFn(torch.autograd.Function):
                                               scratch.numel(), _stream())
         _lib.check(rc, "mobocmf_layer_panel_backward")
         CB.had_panel[z] = 1
-        return g_x, g_f, None, g_zf, g_hyp, torch.zeros(1, dtype=torch.float64, device=dev), None, None, None, None
+        # the K_mn share of g_hyp / g_zf is handed to the chain node (which adds its K_mm share into the same buffers), and
+        # None for the token: the edge to the chain node orders the backward passes, no gradient has to flow through it
+        CB.panel_g[z] = (g_hyp, g_zf)
+        return g_x, g_f, None, None, None, None, None, None, None, None
 
 
 def layer_panel_batched(CB, z, x, f, Zx, zf, hyp, xdiv=1, want_dx=False):
@@ -724,6 +742,85 @@ def elbo_combine(data_terms, kls, scale):
         k = sum(kls) * scale if kls else 0.0
         return d - k, k
     return _ElboCombineFn.apply(scale, len(data_terms), *data_terms, *kls)
+
+
+class _ElboFusedFn(torch.autograd.Function):
+    """(elbo, scaled_kl, -elbo) of variational_elbo_mf.py:24-51 in one launch, one more in backward (mobocmf_elbo_forward)."""
+
+    @staticmethod
+    def forward(ctx, scale, B, specs, y, fid, n_kl, *tensors):
+        lib = _lib.require_device()
+        L = len(specs)
+        y, fid = _prep(y.reshape(-1)), _prep(fid.reshape(-1))
+        dev = y.device
+        means, vars_, raws, it = [None] * L, [None] * L, [None] * L, iter(tensors)
+        for l, sp in enumerate(specs):
+            if sp is not None:
+                means[l], vars_[l], raws[l] = _prep(next(it).reshape(-1)), _prep(next(it).reshape(-1)), _prep(next(it).reshape(-1))
+                if means[l].numel() != B * sp[0] or vars_[l].numel() != B * sp[0]:
+                    raise _lib.MobocmfError("elbo: layer %d holds %d rows, expected %d" % (l, means[l].numel(), B * sp[0]))
+        kls = [_prep(next(it).reshape(())) for _ in range(n_kl)]
+        if y.numel() != B or fid.numel() != B:
+            raise _lib.MobocmfError("elbo: target / fidelities shape mismatch")
+        out = _empty(3, device=dev)
+        scratch = scratch_buffer(8 * 512 * 8, dev)
+        T = lambda ts: _table([0 if t is None else t.data_ptr() for t in ts])
+        div = (ctypes.c_int32 * L)(*[1 if sp is None else sp[0] for sp in specs])
+        lo = (ctypes.c_double * L)(*[0.0 if sp is None else sp[1] for sp in specs])
+        hi = (ctypes.c_double * L)(*[0.0 if sp is None else sp[2] for sp in specs])
+        _lib.check(lib.mobocmf_elbo_forward(L, T(means), T(vars_), div, T(raws), lo, hi, _ptr(y), _ptr(fid), B, n_kl,
+                                            T(kls) if n_kl else None, float(scale), _ptr(out), _ptr(scratch),
+                                            scratch.numel(), _stream()), "mobocmf_elbo_forward")
+        ctx.set_materialize_grads(False)
+        ctx.meta = (float(scale), B, specs, n_kl, [None if t is None else t.shape for t in tensors])
+        ctx.save_for_backward(y, fid, *[t for l in range(L) if specs[l] is not None for t in (means[l], vars_[l], raws[l])])
+        elbo, skl, neg = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(neg)
+        return elbo, skl, neg
+
+    @staticmethod
+    def backward(ctx, g_elbo, g_skl, _g_neg):
+        lib = _lib.require_device()
+        scale, B, specs, n_kl, shapes = ctx.meta
+        L = len(specs)
+        y, fid = ctx.saved_tensors[:2]
+        it = iter(ctx.saved_tensors[2:])
+        dev = y.device
+        means, vars_, raws = [None] * L, [None] * L, [None] * L
+        gm, gv, gr = [None] * L, [None] * L, [None] * L
+        for l, sp in enumerate(specs):
+            if sp is not None:
+                means[l], vars_[l], raws[l] = next(it), next(it), next(it)
+                gm[l], gv[l], gr[l] = _empty_like(means[l]), _empty_like(vars_[l]), _empty_like(raws[l])
+        gkl = _empty(1, device=dev)
+        ge = None if g_elbo is None else _prep(g_elbo)
+        gs = None if g_skl is None else _prep(g_skl)
+        scratch = scratch_buffer(8 * 512 * 8, dev)
+        T = lambda ts: _table([0 if t is None else t.data_ptr() for t in ts])
+        div = (ctypes.c_int32 * L)(*[1 if sp is None else sp[0] for sp in specs])
+        lo = (ctypes.c_double * L)(*[0.0 if sp is None else sp[1] for sp in specs])
+        hi = (ctypes.c_double * L)(*[0.0 if sp is None else sp[2] for sp in specs])
+        _lib.check(lib.mobocmf_elbo_backward(L, T(means), T(vars_), div, T(raws), lo, hi, _ptr(y), _ptr(fid), B, scale,
+                                             _ptr(ge), _ptr(gs), T(gm), T(gv), T(gr), _ptr(gkl), _ptr(scratch),
+                                             scratch.numel(), _stream()), "mobocmf_elbo_backward")
+        grads, k = [], 0
+        for l, sp in enumerate(specs):
+            if sp is not None:
+                grads += [gm[l].reshape(shapes[k]), gv[l].reshape(shapes[k + 1]), gr[l].reshape(shapes[k + 2])]
+                k += 3
+        grads += [gkl[0]] * n_kl
+        return (None,) * 6 + tuple(grads)
+
+
+ELBO_MAX_LAYERS = 8
+
+
+def elbo_fused(layers, y, fid, kls, scale):
+    """``layers``: per fidelity level None or (mean, var, raw_noise, div, lo, hi) -- hi <= lo: ``raw_noise`` is the noise
+    itself.  Returns (elbo, scaled_kl, -elbo); the last one carries no gradient (the loss value a training step reports)."""
+    specs = [None if lay is None else (int(lay[3]), float(lay[4]), float(lay[5])) for lay in layers]
+    tensors = [t for lay in layers if lay is not None for t in lay[:3]]
+    return _ElboFusedFn.apply(float(scale), int(y.numel()), specs, y, fid, len(kls), *tensors, *kls)
 
 
 class _AcqMomentsFn(torch.autograd.Function):

@@ -19,27 +19,43 @@ class VariationalELBOMF(nn.Module):
         self.num_data = num_data
         self.num_fidelities = num_fidelities
 
+    last_neg_elbo = None      # -elbo of the last fused call (no gradient): the loss value a training step reports
+
     def forward(self, l_approximate_dist_f, target, fidelities, include_kl_term=True):
         assert target.shape[0] <= target.shape[1]        # (1, B), as the reference checks
         num_batch = target.shape[1]
         y = target.reshape(-1)
         fid = fidelities.reshape(-1).to(y.dtype)
-        data_terms = []
-        for i in range(min(self.num_fidelities, len(l_approximate_dist_f))):
+        n_lev = min(self.num_fidelities, len(l_approximate_dist_f))
+        layers = []
+        for i in range(n_lev):
             dist = l_approximate_dist_f[i]
             if dist is None:
+                # rows with fid != i contribute nothing (an empty mask gives 0, as the reference's skip at :33)
+                layers.append(None)
                 continue
             likelihood = getattr(self.model, self.model.name_hidden_layer_likelihood + str(i))
             mean, var = dist.mean.reshape(-1), dist.variance.reshape(-1)
-            # rows with fid != i contribute nothing (an empty mask gives 0, as the reference's skip at :33)
             c = likelihood.raw_noise_constraint
             if type(c) is gp.Interval and math.isfinite(c.upper_bound) and c.upper_bound > c.lower_bound:
-                data_terms.append(F.elbo_data(mean, var, y, fid, likelihood.raw_noise, float(i),
-                                              div=mean.numel() // num_batch, interval=(c.lower_bound, c.upper_bound)))
+                layers.append((mean, var, likelihood.raw_noise, mean.numel() // num_batch, c.lower_bound, c.upper_bound))
             else:
-                data_terms.append(F.elbo_data(mean, var, y, fid, likelihood.noise, float(i), div=mean.numel() // num_batch))
+                layers.append((mean, var, likelihood.noise, mean.numel() // num_batch, 0.0, 0.0))
+        if all(lay is None for lay in layers):
+            if not include_kl_term:
+                return 0.0
+            return F.elbo_combine([], self.model.variational_strategy.kl_terms(), num_batch / self.num_data)
+        kls = self.model.variational_strategy.kl_terms() if include_kl_term else []
+        if n_lev <= F.ELBO_MAX_LAYERS and len(kls) <= F.ELBO_MAX_LAYERS:
+            # data terms of every fidelity + the KL tail: one reduction launch + a one-block tail (the same in backward)
+            elbo, skl, neg = F.elbo_fused(layers, y, fid, kls, num_batch / self.num_data if include_kl_term else 0.0)
+            self.last_neg_elbo = neg
+            return (elbo, skl) if include_kl_term else elbo
+        self.last_neg_elbo = None
+        data_terms = [F.elbo_data(lay[0], lay[1], y, fid, lay[2], float(i), div=lay[3],
+                                  interval=(lay[4], lay[5]) if lay[5] > lay[4] else None)
+                      for i, lay in enumerate(layers) if lay is not None]
         # the tail -- sum of the data terms, sum of the layer KLs, batch/num_data scaling, the difference -- is one launch
         if not include_kl_term:
-            return F.elbo_combine(data_terms, [], 0.0)[0] if data_terms else 0.0
-        kls = self.model.variational_strategy.kl_terms()
+            return F.elbo_combine(data_terms, [], 0.0)[0]
         return F.elbo_combine(data_terms, kls, num_batch / self.num_data)

@@ -52,8 +52,12 @@ class GraphedELBOStep:
         res = self.elbo(out, self.y.T, self.fid)
         # d(-ELBO): the sign goes in as the upstream gradient (no negation node, no ones fill, no negation backward)
         res[0].backward(gradient=self._minus_one)
-        torch.neg(res[0].detach(), out=self.loss)
-        self.kl.copy_(res[1].detach())
+        neg = getattr(self.elbo, "last_neg_elbo", None)
+        if neg is not None:      # the fused ELBO launch wrote -elbo next to elbo: no negation / copy launches
+            self.loss, self.kl = neg, res[1].detach()
+        else:
+            torch.neg(res[0].detach(), out=self.loss)
+            self.kl.copy_(res[1].detach())
         self.model.clear_kl_cache()
 
     def _exchange(self):
