@@ -277,6 +277,29 @@ int mobocmf_softplus_pack(int32_t n_tensors, const double* const* raw, const int
 int mobocmf_softplus_pack_backward(int32_t n_tensors, const double* const* raw, const int32_t* sizes, const double* g_out,
                                    double* const* g_raw, mobocmf_stream_t stream);
 
+/* ---- Exact-GP comparison baselines (mobocmf/models/mfgp.py:24-141,145-184; mfgp_lin.py:101-189) on the layer's kernels.
+ * The reference inherits exact inference from GPyTorch's ExactGP; here the Gram matrices come from mobocmf_gram_forward,
+ * the multi-fidelity combination is one element-wise launch, the factorisation / triangular inverse are the variational
+ * layer's (blocked Cholesky + MFMA), the predictive moments its triangular product with the column-statistics epilogue.
+ *
+ * mobocmf_mf_kernel_combine: out[i][j] = s1[i] s2[j] Ks[i][j] + ntab[min(l1[i], l2[j])] Kn[i][j] (+ diag if i == j), i < n1,
+ *   j < n2; zero (identity on the diagonal when diag != 0) in the padding up to rows_p x cols_p.  Ks / Kn: the two ARD-RBF Gram
+ *   matrices (signal / noise kernel, ld), l1 / l2 int32 fidelity levels, s1 / s2 per-row / per-column signal factors (NULL = 1),
+ *   ntab[level] the noise factor (MFKernel: the level itself; MFKernel_lin: its rho polynomial).
+ * mobocmf_exact_gp_factor: K = the n x n training covariance with the noise on its diagonal; leaves L, L^-1, a = L^-1 y in
+ *   `state`, mll[0] = log N(y | 0, K), info = 0 or the failed pivot.
+ * mobocmf_exact_gp_predict: mean[j] = k_j^T K^-1 y, var[j] = kss[j] - k_j^T K^-1 k_j for the nt columns k_j of Kts [n x nt].
+ * Sizes from mobocmf_exact_gp_workspace_bytes (state for a given n; scratch for n and up to nt test points per call). */
+int mobocmf_mf_kernel_combine(int64_t n1, int64_t n2, const double* Ks, const double* Kn, int64_t ld, const double* s1,
+                              const double* s2, const int32_t* l1, const int32_t* l2, const double* ntab, double diag,
+                              double* out, int64_t ldo, int64_t rows_p, int64_t cols_p, mobocmf_stream_t stream);
+int mobocmf_exact_gp_workspace_bytes(int32_t n, int64_t nt, size_t* state_bytes, size_t* scratch_bytes);
+int mobocmf_exact_gp_factor(int32_t n, const double* K, int64_t ldk, const double* y, double* mll, int32_t* info, void* state,
+                            size_t state_bytes, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+int mobocmf_exact_gp_predict(int32_t n, int64_t nt, const double* Kts, int64_t ld, const double* kss, double* mean,
+                             double* var, const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
+                             mobocmf_stream_t stream);
+
 /* The f64 MFMA GEMM used by the layer (exposed for tests and for the roofline measurement of bench.py):
  * C[Mr x Nc] (+)= alpha * A[Mr x Kd] * B, B is [Kd x Nc] (trans_b = 0) or [Nc x Kd] (trans_b = 1).
  * Mr, Nc multiples of 128, Kd multiple of 16, leading dimensions even, pointers 16-byte aligned.

@@ -66,6 +66,10 @@ SYMBOLS = {
     "mobocmf_adam_step": [_P, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P],
     "mobocmf_gemm_f64": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32, _P],
     "mobocmf_gemm_f64_epilogue": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32] + [_P] * 8 + [_P],
+    "mobocmf_mf_kernel_combine": [_I64, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _D, _P, _I64, _I64, _I64, _P],
+    "mobocmf_exact_gp_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
+    "mobocmf_exact_gp_factor": [_I32, _P, _I64, _P, _P, _P, _P, _SZ, _P, _SZ, _P],
+    "mobocmf_exact_gp_predict": [_I32, _I64, _P, _I64, _P, _P, _P, _P, _SZ, _P, _SZ, _P],
     "mobocmf_gemm_colstat_rows": [_I32, _I32, _I64, _I64, ctypes.POINTER(_I32)],
     "mobocmf_set_tile_rows": [_I32, _I32],
     "mobocmf_syrk_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ)],

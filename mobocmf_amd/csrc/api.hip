@@ -39,6 +39,13 @@ int launch_symmetrize(const double* S, int Mp, double* G, hipStream_t s);
 int launch_gls_out(const double* X, const double* LSp, const double* gkl, int M, int Mp, double* gLS, hipStream_t s);
 int launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
 int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s);
+int launch_mf_combine(const double* Ks, const double* Kn, int64_t ld, const double* s1, const double* s2, const int32_t* l1,
+                      const int32_t* l2, const double* ntab, int64_t n1, int64_t n2, double diag, double* out, int64_t ldo,
+                      int64_t rows_p, int64_t cols_p, hipStream_t s);
+int launch_copy_pad_identity(const double* src, int64_t lds, int n, double* dst, int np, hipStream_t s);
+int launch_exact_gp_mll(const double* L, int64_t ld, const double* a, int n, double* mll, hipStream_t s);
+int launch_exact_gp_finish(const double* qpart, const double* mupart, int nparts, int64_t ntp, int64_t nt, const double* kss,
+                           double* mean, double* var, hipStream_t s);
 int launch_mirror_lower(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t row0, int64_t rows, int64_t cols,
                         int64_t n_real, hipStream_t s);
 // layer-batched forms (blockIdx.z = layer, workspace pointers + z*zs doubles, user tensors as tables)
@@ -868,6 +875,106 @@ int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* 
     }
     return MOBOCMF_OK;
 }
+
+}  // extern "C"
+
+// ---- Exact-GP comparison baselines on the layer's kernels ("exact-GP baselines reuse K1 / K3 / K4"):
+// the Gram matrices come from mobocmf_gram_forward (K1), the factorisation and the triangular inverse are the chain's
+// (K3), the predictive moments are the layer's A = L^-1 K product with the column-statistics epilogue (K4 / K5).
+namespace {
+struct ExactState { double *L, *Linv, *a, *yp; };
+struct ExactFactorWs { double *Dinv, *Ld, *T, *ws; int64_t ws_elems; };
+void carve_exact_state(Bump& b, int np, ExactState& S) {
+    const int64_t mm = (int64_t)np * np;
+    S.L = b.take(mm); S.Linv = b.take(mm); S.a = b.take(np); S.yp = b.take(np);
+}
+void carve_exact_factor(Bump& b, int np, ExactFactorWs& W) {
+    W.Dinv = b.take((int64_t)(np / NB) * NB * NB);
+    W.Ld = b.take((int64_t)(np / NB) * NB * NB);
+    W.T = b.take((int64_t)np * np);
+    W.ws_elems = (int64_t)16 * np * np;
+    W.ws = b.take(W.ws_elems);
+}
+struct ExactPredictWs { double *Kp, *A, *qpart, *mupart; };
+void carve_exact_predict(Bump& b, int np, int64_t ntp, ExactPredictWs& W) {
+    W.Kp = b.take((int64_t)np * ntp); W.A = b.take((int64_t)np * ntp);
+    W.qpart = b.take((int64_t)4 * (np / TILE) * ntp); W.mupart = b.take((int64_t)4 * (np / TILE) * ntp);
+}
+}  // namespace
+
+extern "C" {
+
+int mobocmf_mf_kernel_combine(int64_t n1, int64_t n2, const double* Ks, const double* Kn, int64_t ld, const double* s1,
+                              const double* s2, const int32_t* l1, const int32_t* l2, const double* ntab, double diag,
+                              double* out, int64_t ldo, int64_t rows_p, int64_t cols_p, mobocmf_stream_t stream) {
+    if (n1 < 1 || n2 < 1 || !Ks || !Kn || !l1 || !l2 || !ntab || !out || ld < n2 || rows_p < n1 || cols_p < n2 || ldo < cols_p)
+        return MOBOCMF_BAD_ARG;
+    return launch_mf_combine(Ks, Kn, ld, s1, s2, l1, l2, ntab, n1, n2, diag, out, ldo, rows_p, cols_p, (hipStream_t)stream);
+}
+
+int mobocmf_exact_gp_workspace_bytes(int32_t n, int64_t nt, size_t* state_bytes, size_t* scratch_bytes) {
+    if (n < 1 || nt < 0 || !state_bytes || !scratch_bytes) return MOBOCMF_BAD_ARG;
+    const int np = (int)round_up(n, TILE);
+    const int64_t ntp = round_up(nt > 0 ? nt : 1, TILE);
+    const size_t big = ~(size_t)0 >> 1;
+    Bump bs(nullptr, big), bf(nullptr, big), bp(nullptr, big);
+    ExactState S; ExactFactorWs F; ExactPredictWs P;
+    carve_exact_state(bs, np, S);
+    carve_exact_factor(bf, np, F);
+    carve_exact_predict(bp, np, ntp, P);
+    *state_bytes = bs.off;
+    *scratch_bytes = bf.off > bp.off ? bf.off : bp.off;
+    return MOBOCMF_OK;
+}
+
+/* K: the n x n training covariance INCLUDING the noise on its diagonal (ld ldk); y[n].  state <- L, L^-1, a = L^-1 y;
+ * mll[0] = log N(y | 0, K); info as in the layer calls (0 or the failed pivot). */
+int mobocmf_exact_gp_factor(int32_t n, const double* K, int64_t ldk, const double* y, double* mll, int32_t* info, void* state,
+                            size_t state_bytes, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
+    if (n < 1 || !K || ldk < n || !y || !mll || !info || !state || !scratch) return MOBOCMF_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int np = (int)round_up(n, TILE);
+    Bump bs(state, state_bytes), bf(scratch, scratch_bytes);
+    ExactState S; ExactFactorWs F;
+    carve_exact_state(bs, np, S);
+    carve_exact_factor(bf, np, F);
+    if (!bs.ok || !bf.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    // padded copy of K (identity on the padded diagonal), padded y
+    TRY(launch_copy_pad_identity(K, ldk, n, S.L, np, s));
+    TRY(launch_pad_vec(y, n, S.yp, np, s));
+    TRY(launch_potrf_z(S.L, np, np, n, F.Dinv, F.Ld, &info, 1, 0, S.Linv, nullptr, s));
+    TRY(launch_trtri(S.L, np, np, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
+    TRY(launch_gemv_rows(S.Linv, np, S.yp, S.a, np, np, 1.0, 0, s));
+    return launch_exact_gp_mll(S.L, np, S.a, n, mll, s);
+}
+
+/* Posterior moments of the latent function at nt points: Kts [n x nt] = k(train, test) (ld), kss[nt] = prior variances:
+ * mean = Kts^T K^-1 y = (L^-1 Kts)^T a,  var = kss - colsum((L^-1 Kts)^2)  -- the layer's triangular MFMA product with its
+ * column-statistics epilogue. */
+int mobocmf_exact_gp_predict(int32_t n, int64_t nt, const double* Kts, int64_t ld, const double* kss, double* mean,
+                             double* var, const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
+                             mobocmf_stream_t stream) {
+    if (n < 1 || nt < 1 || !Kts || ld < nt || !kss || !mean || !var || !state || !scratch) return MOBOCMF_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int np = (int)round_up(n, TILE);
+    const int64_t ntp = round_up(nt, TILE);
+    Bump bs((void*)state, state_bytes), bp(scratch, scratch_bytes);
+    ExactState S; ExactPredictWs P;
+    carve_exact_state(bs, np, S);
+    carve_exact_predict(bp, np, ntp, P);
+    if (!bs.ok || !bp.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
+    TRY(launch_zero32(P.Kp, (int64_t)np * ntp * 2, s));
+    TRY(launch_copy_block(Kts, ld, P.Kp, ntp, n, nt, s));
+    GemmArgs ga = gemm_args(S.Linv, np, P.Kp, ntp, P.A, ntp, np, ntp, np, TRI_LOWER_A, 1.0);
+    ga.epi = EPI_COLSTATS; ga.colsq_part = P.qpart; ga.coldot_part = P.mupart; ga.avec = S.a;
+    ga.Kreal = n;
+    TRY(launch_gemm(ga, false, 1, s));
+    return launch_exact_gp_finish(P.qpart, P.mupart, gemm_colstat_rows(ga), ntp, nt, kss, mean, var, s);
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
                      const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t accumulate,

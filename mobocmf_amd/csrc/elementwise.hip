@@ -459,6 +459,72 @@ int launch_mirror_lower(const double* src, int64_t lds_, double* dst, int64_t ld
     return CHECK_LAUNCH();
 }
 
+// ---- exact-GP comparison baselines (mobocmf/models/mfgp.py:145-184, mfgp_lin.py:101-189): the multi-fidelity kernels are
+// element-wise combinations of TWO ARD-RBF Gram matrices,  K[i][j] = s1[i] s2[j] Ks[i][j] + ntab[min(l1[i], l2[j])] Kn[i][j]
+// (+ diag on the diagonal): MFKernel has s = 1, ntab[t] = t; MFKernel_lin has s = cumulative products of rho and
+// ntab[t] = the noise factor of level t.  Output zero-padded to (rows_p x cols_p).
+__global__ void mf_combine_kernel(const double* Ks, const double* Kn, int64_t ld, const double* s1, const double* s2,
+                                  const int32_t* l1, const int32_t* l2, const double* ntab, int64_t n1, int64_t n2,
+                                  double diag, double* out, int64_t ldo, int64_t rows_p, int64_t cols_p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows_p * cols_p) return;
+    const int64_t i = idx / cols_p, j = idx % cols_p;
+    double v = 0.0;
+    if (i < n1 && j < n2) {
+        const int a = l1[i], b = l2[j];
+        v = (s1 ? s1[i] : 1.0) * (s2 ? s2[j] : 1.0) * Ks[i * ld + j] + ntab[a < b ? a : b] * Kn[i * ld + j];
+        if (i == j) v += diag;
+    } else if (i == j && diag != 0.0) {
+        v = 1.0;      // identity on the padded diagonal of a matrix that is factorised afterwards
+    }
+    out[i * ldo + j] = v;
+}
+int launch_mf_combine(const double* Ks, const double* Kn, int64_t ld, const double* s1, const double* s2, const int32_t* l1,
+                      const int32_t* l2, const double* ntab, int64_t n1, int64_t n2, double diag, double* out, int64_t ldo,
+                      int64_t rows_p, int64_t cols_p, hipStream_t s) {
+    hipLaunchKernelGGL(mf_combine_kernel, GRID1(rows_p * cols_p), 0, s, Ks, Kn, ld, s1, s2, l1, l2, ntab, n1, n2, diag, out,
+                       ldo, rows_p, cols_p);
+    return CHECK_LAUNCH();
+}
+// dst (np x np) = [[src (n x n), 0], [0, I]]: a matrix to factorise, identity on the padded diagonal
+__global__ void copy_pad_identity_kernel(const double* src, int64_t lds_, int n, double* dst, int np) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)np * np) return;
+    const int i = (int)(idx / np), j = (int)(idx % np);
+    dst[idx] = (i < n && j < n) ? src[(int64_t)i * lds_ + j] : (i == j ? 1.0 : 0.0);
+}
+int launch_copy_pad_identity(const double* src, int64_t lds_, int n, double* dst, int np, hipStream_t s) {
+    hipLaunchKernelGGL(copy_pad_identity_kernel, GRID1((int64_t)np * np), 0, s, src, lds_, n, dst, np);
+    return CHECK_LAUNCH();
+}
+// mll = -1/2 |a|^2 - sum_i log L_ii - n/2 log 2 pi   (a = L^-1 y; one block)
+__global__ void exact_gp_mll_kernel(const double* L, int64_t ld, const double* a, int n, double* mll) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += -0.5 * a[i] * a[i] - log(L[(int64_t)i * ld + i]);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) mll[0] = s - 0.5 * n * 1.8378770664093453;
+}
+int launch_exact_gp_mll(const double* L, int64_t ld, const double* a, int n, double* mll, hipStream_t s) {
+    hipLaunchKernelGGL(exact_gp_mll_kernel, dim3(1), dim3(256), 0, s, L, ld, a, n, mll);
+    return CHECK_LAUNCH();
+}
+// mean[j] = sum_p mupart[p][j], var[j] = kss[j] - sum_p qpart[p][j]   (j < nt)
+__global__ void exact_gp_finish_kernel(const double* qpart, const double* mupart, int nparts, int64_t ntp, int64_t nt,
+                                       const double* kss, double* mean, double* var) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nt) return;
+    double q = 0.0, m = 0.0;
+    for (int p = 0; p < nparts; ++p) { q += qpart[(int64_t)p * ntp + j]; m += mupart[(int64_t)p * ntp + j]; }
+    mean[j] = m;
+    var[j] = kss[j] - q;
+}
+int launch_exact_gp_finish(const double* qpart, const double* mupart, int nparts, int64_t ntp, int64_t nt, const double* kss,
+                           double* mean, double* var, hipStream_t s) {
+    hipLaunchKernelGGL(exact_gp_finish_kernel, GRID1(nt), 0, s, qpart, mupart, nparts, ntp, nt, kss, mean, var);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ public elementwise entry points
 __global__ void propagate_fwd_kernel(const double* mean, const double* var, const double* eps, double* f, int64_t n,
                                      int div) {

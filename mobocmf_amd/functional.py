@@ -1008,6 +1008,74 @@ def rff_eval(kind, x, fprev, W1, b1, Wf, W2, b2, theta, s0, s1=0.0, s2=0.0):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------
+# Exact-GP comparison baselines on the layer's kernels: Gram (mobocmf_gram_forward), the multi-fidelity
+# combination, the blocked Cholesky + triangular inverse of the chain, the triangular MFMA product with column statistics.
+# Evaluation only (no autograd): fitting the baselines' hyper-parameters differentiates the plain-torch statement.
+# ------------------------------------------------------------------------------------------------------------
+def mf_kernel_combine(Ks, Kn, s1, s2, l1, l2, ntab, diag=0.0):
+    """K[i][j] = s1[i] s2[j] Ks[i][j] + ntab[min(l1[i], l2[j])] Kn[i][j] (+ diag on the diagonal); l1 / l2 int32 levels."""
+    lib = _lib.require_device()
+    with torch.no_grad():
+        Ks, Kn, s1, s2, ntab = (_prep(t) for t in (Ks, Kn, s1, s2, ntab))
+        n1, n2 = Ks.shape
+        if tuple(Kn.shape) != (n1, n2) or l1.numel() != n1 or l2.numel() != n2 or l1.dtype != torch.int32 or l2.dtype != torch.int32:
+            raise _lib.MobocmfError("mf_kernel_combine: shape / dtype mismatch")
+        if int(max(l1.max(), l2.max())) >= ntab.numel() or int(min(l1.min(), l2.min())) < 0:
+            raise _lib.MobocmfError("mf_kernel_combine: fidelity level outside the noise-factor table")
+        l1, l2 = l1.contiguous(), l2.contiguous()
+        out = _empty(n1, n2, device=Ks.device)
+        _lib.check(lib.mobocmf_mf_kernel_combine(n1, n2, _ptr(Ks), _ptr(Kn), Ks.stride(0), _ptr(s1), _ptr(s2), _ptr(l1), _ptr(l2),
+                                                 _ptr(ntab), float(diag), _ptr(out), n2, n1, n2, _stream()),
+                   "mobocmf_mf_kernel_combine")
+    return out
+
+
+class ExactGPState:
+    """L, L^-1 and a = L^-1 y of an exact GP on n training points (mobocmf_exact_gp_factor)."""
+    __slots__ = ("n", "state", "mll", "info")
+
+
+def exact_gp_factor(K, y):
+    """Factorises the n x n training covariance (noise on its diagonal); returns the state with ``.mll`` = log N(y | 0, K)
+    and ``.info`` (0 or the failed pivot, device word)."""
+    lib = _lib.require_device()
+    with torch.no_grad():
+        K, y = _prep(K), _prep(y.reshape(-1))
+        n = K.shape[0]
+        if K.shape[1] != n or y.numel() != n:
+            raise _lib.MobocmfError("exact_gp_factor: K must be n x n and y of length n")
+        sb, cb = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(lib.mobocmf_exact_gp_workspace_bytes(n, 1, ctypes.byref(sb), ctypes.byref(cb)), "mobocmf_exact_gp_workspace_bytes")
+        st = ExactGPState()
+        st.n = n
+        st.state = _poison(torch.empty(sb.value, dtype=torch.uint8, device=K.device))
+        st.mll = _empty((), device=K.device)
+        st.info = torch.zeros((), dtype=torch.int32, device=K.device)
+        scratch = scratch_buffer(cb.value, K.device)
+        _lib.check(lib.mobocmf_exact_gp_factor(n, _ptr(K), K.stride(0), _ptr(y), _ptr(st.mll), _ptr(st.info), _ptr(st.state),
+                                               sb.value, _ptr(scratch), scratch.numel(), _stream()), "mobocmf_exact_gp_factor")
+    return st
+
+
+def exact_gp_predict(st, Kts, kss):
+    """Posterior mean and variance at the nt columns of Kts [n x nt] (prior variances kss)."""
+    lib = _lib.require_device()
+    with torch.no_grad():
+        Kts, kss = _prep(Kts), _prep(kss.reshape(-1))
+        n, nt = Kts.shape
+        if n != st.n or kss.numel() != nt:
+            raise _lib.MobocmfError("exact_gp_predict: shape mismatch")
+        sb, cb = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(lib.mobocmf_exact_gp_workspace_bytes(n, nt, ctypes.byref(sb), ctypes.byref(cb)), "mobocmf_exact_gp_workspace_bytes")
+        scratch = scratch_buffer(cb.value, Kts.device)
+        mean, var = _empty(nt, device=Kts.device), _empty(nt, device=Kts.device)
+        _lib.check(lib.mobocmf_exact_gp_predict(n, nt, _ptr(Kts), Kts.stride(0), _ptr(kss), _ptr(mean), _ptr(var), _ptr(st.state),
+                                                st.state.numel(), _ptr(scratch), scratch.numel(), _stream()),
+                   "mobocmf_exact_gp_predict")
+    return mean, var
+
+
 class _SoftplusPackFn(torch.autograd.Function):
     """softplus of several raw parameter tensors, concatenated: one launch forward, one backward (mobocmf_softplus_pack)."""
 

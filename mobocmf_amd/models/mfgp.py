@@ -1,7 +1,11 @@
 """Exact-GP multi-fidelity baselines -- host mirror of mobocmf/models/mfgp.py (``MFGP`` :24-141, ``MFKernel`` :145-184) and
-mobocmf/models/mfgp_lin.py (``MFGP_lin`` :23-97, ``MFKernel_lin`` :101-189).  SURVEY row N4 (last in priority): these are
-the COMPARISON baselines of the reference's experiments, not part of the MFDGP hot path, so they are plain float64 torch
-(they run on the GPU through torch's rocBLAS / rocSOLVER ops when their tensors live there; no HIP kernel of this package).
+mobocmf/models/mfgp_lin.py (``MFGP_lin`` :23-97, ``MFKernel_lin`` :101-189).  SURVEY row N4: the COMPARISON baselines of the
+reference's experiments.  Two statements of the same model live here: the plain float64 torch one (differentiable: ``fit()``
+and the acquisition optimisation use it; it also runs on the CPU), and -- when the model's tensors live on the GPU and no
+gradient is asked for -- the evaluation path on this package's kernels ("exact-GP baselines reuse K1 / K3 / K4"):
+the two ARD-RBF Gram matrices from mobocmf_gram_forward, the multi-fidelity combination in one element-wise launch, the
+layer's blocked Cholesky + triangular inverse, and the layer's triangular MFMA product with its column-statistics epilogue for
+the predictive moments (``marginal_log_likelihood()`` / ``predict()`` under ``torch.no_grad()``, ``hip=True`` forces it).
 
 Same surface as the reference classes: constructor ``(x_train, y_train, num_fidelities, type_lengthscale)`` with the
 fidelity in the LAST column of ``x_train`` (counted from 0), ``predict(x, fidelity)`` -> distribution with ``.mean`` /
@@ -21,6 +25,10 @@ from torch import nn
 from .. import gp
 from ..util.util import compute_dist, triu_indices
 from .mfdgp import TL
+
+
+class gp_NotPSD(RuntimeError):
+    pass
 
 
 def _rbf(x1, x2, lengthscale):
@@ -50,6 +58,13 @@ class MFKernel(gp.Kernel):
         self.cov_funct_noise = _scaled_rbf(d, init_lengthscale, 0.1, gp.Interval(1e-3, 1000.0), gp.Interval(1e-3, 100.0))
         self.cov_funct_signal = _scaled_rbf(d, init_lengthscale, 1.0, gp.Interval(1e-3, 1000.0), gp.Interval(1e-3, 100.0))
 
+    def hip_factors(self, x):
+        """(levels int32, signal factor or None) of rows x and the noise-factor table for functional.mf_kernel_combine."""
+        return x[:, self.input_dim - 1].round().to(torch.int32), None
+
+    def hip_noise_table(self, num_levels, device):
+        return torch.arange(num_levels, dtype=torch.float64, device=device)          # min(t, t') itself (mfgp.py:183)
+
     def forward(self, x1, x2, **params):
         d = self.input_dim - 1
         t1, t2 = x1[:, d:d + 1], x2[:, d:d + 1]
@@ -73,6 +88,21 @@ class MFKernel_lin(gp.Kernel):
         self.cov_funct_noise = _scaled_rbf(d, init_lengthscale, 0.1)
         self.cov_funct_signal = _scaled_rbf(d, init_lengthscale, 1.0)
         self.rho = nn.Parameter(0.5 * torch.ones(num_fidelities - 1))
+
+    def _cum(self):
+        return torch.cat([torch.ones(1, dtype=self.rho.dtype, device=self.rho.device), torch.cumprod(self.rho, 0)], 0)
+
+    def hip_factors(self, x):
+        lev = x[:, self.input_dim - 1].round().to(torch.int32)
+        return lev, self._cum().detach()[lev.long()]
+
+    def hip_noise_table(self, num_levels, device):
+        """Noise factor of min fidelity level t (counted from 0): [t + 1 >= 2] + sum_k [t + 1 >= k] rho[k - 2]^2 (:160-176)."""
+        t = torch.arange(num_levels, dtype=torch.float64, device=device) + 1.0
+        tab = (t >= 2).to(torch.float64)
+        for k in range(3, self.num_fidelities - 1):
+            tab = tab + (t >= k).to(torch.float64) * self.rho.detach()[k - 2] ** 2
+        return tab
 
     def forward(self, x1, x2, **params):
         d = self.input_dim - 1
@@ -115,14 +145,62 @@ class _ExactMFGP(nn.Module):
         return gp.MultivariateNormal(torch.zeros(x.shape[0], dtype=x.dtype, device=x.device),
                                      covariance_matrix=self.covar_module(x, x))
 
+    # ------------------------------------------------------------------ evaluation on the package's kernels
+    def _hip_wanted(self, hip, *tensors):
+        if hip is None:
+            hip = self.x_train.is_cuda and not torch.is_grad_enabled()
+        if hip and not all(t.is_cuda for t in (self.x_train,) + tensors):
+            raise RuntimeError("the HIP evaluation path needs the model and its inputs on the GPU (there is no CPU fallback)")
+        return hip
+
+    def _hip_cov(self, x1, x2, diag=0.0):
+        """k(x1, x2) (+ diag on the diagonal) through mobocmf_gram_forward x 2 + mobocmf_mf_kernel_combine."""
+        from .. import functional as F
+        cm, d = self.covar_module, self.input_dim
+        hs = torch.cat([cm.cov_funct_signal.outputscale.reshape(1), cm.cov_funct_signal.base_kernel.lengthscale.reshape(-1)]).detach()
+        hn = torch.cat([cm.cov_funct_noise.outputscale.reshape(1), cm.cov_funct_noise.base_kernel.lengthscale.reshape(-1)]).detach()
+        a, b = x1[:, :d].contiguous(), x2[:, :d].contiguous()
+        Ks, Kn = F.gram(0, a, None, b, None, hs), F.gram(0, a, None, b, None, hn)
+        l1, s1 = cm.hip_factors(x1)
+        l2, s2 = cm.hip_factors(x2)
+        return F.mf_kernel_combine(Ks.contiguous(), Kn.contiguous(), s1, s2, l1, l2, cm.hip_noise_table(self.num_fidelities, x1.device), diag)
+
+    def _hip_factor(self):
+        from .. import functional as F
+        with torch.no_grad():
+            K = self._hip_cov(self.x_train, self.x_train, diag=float(self.likelihood.noise))
+            st = F.exact_gp_factor(K, self.y_train)
+        if F.check_info(st.info) != 0:
+            raise gp_NotPSD("exact-GP training covariance not positive definite")
+        return st
+
+    def predict_hip(self, x, fidelity):
+        """``predict`` on the package's kernels: latent posterior mean / variance at fidelity ``fidelity`` (no gradient)."""
+        from .. import functional as F
+        with torch.no_grad():
+            t = fidelity * torch.ones((x.shape[0], 1), dtype=x.dtype, device=x.device)
+            xt = torch.cat([x, t], 1)
+            st = self._hip_factor()
+            Kts = self._hip_cov(self.x_train, xt)
+            cm = self.covar_module
+            lev, sf = cm.hip_factors(xt)
+            tab = cm.hip_noise_table(self.num_fidelities, x.device)
+            kss = (1.0 if sf is None else sf * sf) * cm.cov_funct_signal.outputscale.detach() + \
+                tab[lev.long()] * cm.cov_funct_noise.outputscale.detach()
+            mean, var = F.exact_gp_predict(st, Kts, kss * torch.ones(x.shape[0], dtype=x.dtype, device=x.device))
+        return gp.MultivariateNormal(mean, var)
+
     def _train_factor(self):
         n = self.x_train.shape[0]
         K = self.covar_module(self.x_train, self.x_train)
         K = K + self.likelihood.noise.reshape(()) * torch.eye(n, dtype=K.dtype, device=K.device)
         return torch.linalg.cholesky(K)
 
-    def marginal_log_likelihood(self):
-        """log p(y | X) of the exact GP (what gpytorch's ExactMarginalLogLikelihood x n evaluates)."""
+    def marginal_log_likelihood(self, hip=None):
+        """log p(y | X) of the exact GP (what gpytorch's ExactMarginalLogLikelihood x n evaluates).  ``hip``: None = the
+        package's kernels when the model is on the GPU and no gradient is recorded, else plain torch; True / False force."""
+        if self._hip_wanted(hip):
+            return self._hip_factor().mll
         L = self._train_factor()
         alpha = torch.cholesky_solve(self.y_train, L)
         n = self.y_train.shape[0]
@@ -140,11 +218,14 @@ class _ExactMFGP(nn.Module):
     def __call__(self, x):
         return self.forward(x) if self.training else self.posterior(x)
 
-    def predict(self, x, fidelity):
-        """mfgp.py:50-61: posterior of the latent function at fidelity ``fidelity``."""
+    def predict(self, x, fidelity, hip=None):
+        """mfgp.py:50-61: posterior of the latent function at fidelity ``fidelity`` (``hip`` as in marginal_log_likelihood;
+        the kernel path returns mean and marginal variances)."""
         if len(x.shape) > 2:
             assert x.shape[1] == 1
             x = x[:, 0, :]
+        if self._hip_wanted(hip, x) and not x.requires_grad:
+            return self.predict_hip(x, fidelity)
         self.eval()
         t = fidelity * torch.ones((x.shape[0], 1), dtype=x.dtype, device=x.device)
         result = self(torch.cat([x, t], 1))

@@ -1,0 +1,76 @@
+"""SURVEY 8(f) N4 on the GPU path: the exact-GP comparison baselines (mobocmf/models/mfgp.py:24-141,145-184;
+mfgp_lin.py:101-189) evaluated on this package's kernels -- Gram (mobocmf_gram_forward), multi-fidelity combination, the
+layer's blocked Cholesky + triangular inverse, the triangular MFMA product with column statistics -- against the plain
+float64 torch statement of the same model (CPU), which tests/test_baselines_cpu.py pins to numpy restatements of the
+reference's formulas."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _data(n, d, nf, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, d))
+    fid = (np.arange(n) % nf).astype(float)
+    y = np.sin(3 * x.sum(1)) + 0.3 * fid * np.cos(2 * x[:, 0]) + 0.05 * rng.standard_normal(n)
+    return torch.as_tensor(np.concatenate([x, fid[:, None]], 1)), torch.as_tensor(y)[:, None]
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("cls_name,n,d,nf", [("MFGP", 14, 2, 2), ("MFGP", 200, 5, 3), ("MFGP", 700, 8, 2), ("MFGP_lin", 14, 2, 2),
+                                              ("MFGP_lin", 333, 3, 5), ("MFGP_lin", 520, 1, 3)])
+def test_exact_gp_baselines_on_the_hip_kernels_match_torch(cls_name, n, d, nf):
+    from mobocmf_amd.models.mfgp import MFGP, MFGP_lin
+    from mobocmf_amd.models.mfdgp import TL
+    cls = MFGP if cls_name == "MFGP" else MFGP_lin
+    X, Y = _data(n, d, nf, seed=n + d)
+    ref = cls(X, Y, nf, type_lengthscale=TL.MEDIAN if n < 400 else TL.MEDIAN)
+    with torch.no_grad():      # off-default hyper-parameters: every factor of the kernels takes part
+        ref.covar_module.cov_funct_signal.outputscale = 0.8
+        ref.covar_module.cov_funct_noise.outputscale = 0.35
+        ref.covar_module.cov_funct_noise.base_kernel.lengthscale = 0.7 * ref.covar_module.cov_funct_signal.base_kernel.lengthscale.reshape(-1)
+        ref.likelihood.noise = 0.02
+        if cls is MFGP_lin:
+            ref.covar_module.rho.copy_(torch.linspace(0.6, 1.4, nf - 1))
+    gpu = copy.deepcopy(ref).to(DEV)
+    # kernel matrix
+    with torch.no_grad():
+        K_ref = ref.covar_module(ref.x_train, ref.x_train)
+        K_hip = gpu._hip_cov(gpu.x_train, gpu.x_train)
+        assert _rel(K_hip, K_ref) < 1e-12
+        # marginal likelihood: dispatches to the kernels on the GPU under no_grad
+        mll_ref = ref.marginal_log_likelihood(hip=False)
+        mll_hip = gpu.marginal_log_likelihood()
+        assert abs(float(mll_hip) - float(mll_ref)) < 1e-9 * max(1.0, abs(float(mll_ref)))
+        # predictive moments at every fidelity, a number of test points that is no multiple of the tile
+        Xt = torch.as_tensor(np.random.default_rng(1).random((37, d)))
+        for f in range(nf):
+            p_ref = ref.predict(Xt, f, hip=False)
+            p_hip = gpu.predict(Xt.to(DEV), f)
+            assert _rel(p_hip.mean, p_ref.mean) < 1e-8, f
+            assert float((p_hip.variance.cpu() - p_ref.variance).abs().max()) < 1e-8 * float(p_ref.variance.abs().max() + 1.0), f
+    # with gradients recorded the differentiable torch statement is used (fit(), acquisition optimisation) -- same value
+    mll_t = gpu.marginal_log_likelihood()
+    assert mll_t.requires_grad and abs(float(mll_t) - float(mll_ref)) < 1e-8 * max(1.0, abs(float(mll_ref)))
+
+
+def test_exact_gp_not_positive_definite_is_reported():
+    from mobocmf_amd import functional as F
+    K = torch.eye(40, dtype=torch.float64, device=DEV)
+    K[7, 7] = -1.0
+    st = F.exact_gp_factor(K, torch.ones(40, dtype=torch.float64, device=DEV))
+    assert F.check_info(st.info) == 8
+    K[7, 7] = 2.0
+    st = F.exact_gp_factor(K, torch.ones(40, dtype=torch.float64, device=DEV))
+    assert F.check_info(st.info) == 0
+    assert abs(float(st.mll) - (-0.5 * 39.5 - 0.5 * math.log(2.0) - 20 * math.log(2 * math.pi))) < 1e-12
