@@ -220,36 +220,97 @@ def coupled_acquisition(local_acq):
     return torch.cat(all_gather_ragged(local_acq), 0).sum(0)
 
 
+_gather_plans = {}
+
+
+def _gather_plan(k_obj, k_con, obj_index, con_index, device):
+    """Row bookkeeping of ``gather_with_local_grad``, negotiated ONCE per (world, local shard layout) and cached: per-rank
+    row counts, the padded row count of the per-step all-gather, and the permutations into global black-box order.  The
+    global indices are static for a whole training run, so their exchange and validation (a host sync) happen here, not at
+    every step.  Every rank enters the same two collectives whatever it holds; disagreements (some ranks pass indices,
+    others do not; indices that are no permutation) raise the same error on every rank instead of dead-locking."""
+    import torch.distributed as dist
+    r, w = world()
+    oi = None if obj_index is None else tuple(int(i) for i in obj_index)
+    ci = None if con_index is None else tuple(int(i) for i in con_index)
+    key = (r, w, k_obj, k_con, oi, ci, dist.get_backend())
+    plan = _gather_plans.get(key)
+    if plan is not None:
+        return plan
+    if (oi is not None and len(oi) != k_obj) or (ci is not None and len(ci) != k_con):
+        raise ValueError("gather_with_local_grad: one global index per local row")
+    cdev = torch.device("cpu") if (device.type == "cuda" and dist.get_backend() == "gloo") else device
+    meta = torch.empty(w, 4, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(meta, torch.tensor([[k_obj, k_con, int(oi is not None), int(ci is not None)]], dtype=torch.int64,
+                                                   device=cdev))
+    meta = meta.cpu()
+    ko, kc = meta[:, 0].tolist(), meta[:, 1].tolist()
+    has_o = {int(meta[q, 2]) for q in range(w) if ko[q] > 0}
+    has_c = {int(meta[q, 3]) for q in range(w) if kc[q] > 0}
+    if len(has_o) > 1 or len(has_c) > 1:
+        raise ValueError("gather_with_local_grad: either every rank passes the global indices of its rows or none does "
+                         "(objectives %s, constraints %s)" % (meta[:, 2].tolist(), meta[:, 3].tolist()))
+    use_o, use_c = has_o == {1}, has_c == {1}
+    kmax = max(a + b for a, b in zip(ko, kc))
+    order_o = order_c = None
+    if (use_o or use_c) and kmax > 0:
+        idx = torch.full((1, kmax), -1, dtype=torch.int64, device=cdev)
+        loc = (list(oi) if (use_o and oi is not None) else [-1] * k_obj) + (list(ci) if (use_c and ci is not None) else [-1] * k_con)
+        if loc:
+            idx[0, :len(loc)] = torch.tensor(loc, dtype=torch.int64, device=cdev)
+        allidx = torch.empty(w, kmax, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(allidx, idx)
+        allidx = allidx.cpu()
+        go = [int(v) for q in range(w) for v in allidx[q, :ko[q]]]
+        gc = [int(v) for q in range(w) for v in allidx[q, ko[q]:ko[q] + kc[q]]]
+        for name, used, g in (("objective", use_o, go), ("constraint", use_c, gc)):
+            if used and sorted(g) != list(range(len(g))):
+                raise ValueError("gather_with_local_grad: global %s indices of all ranks must be a permutation of 0..n-1, "
+                                 "got %s" % (name, g))
+        if use_o:
+            order_o = torch.argsort(torch.tensor(go, dtype=torch.int64)).to(device)
+        if use_c:
+            order_c = torch.argsort(torch.tensor(gc, dtype=torch.int64)).to(device)
+    plan = {"ko": ko, "kc": kc, "kmax": kmax, "order_o": order_o, "order_c": order_c, "cdev": cdev}
+    _gather_plans[key] = plan
+    return plan
+
+
 def gather_with_local_grad(fm, fv, cm, cv, obj_index=None, con_index=None):
     """omega-factor coupling of the conditioned training (blackbox_mfdgp_fitter.py:317-341) when the surrogates are
     sharded over ranks: every rank needs ALL models' (mean, var) at the 10 x~ points; its own rows keep their autograd
-    history, the other ranks' rows arrive as constants (one ragged all-gather per kind).  Ranks may hold different numbers
-    of objectives / constraints, none included.  ``obj_index`` / ``con_index``: the GLOBAL position of each local row
-    (the column of the Pareto front / the entry of the threshold vector it belongs to); the result is ordered by it.
-    Without them the rows come back in rank order.  World size 1: identity."""
+    history, the other ranks' rows arrive as constants.  ONE padded all-gather per call carries objectives and constraints
+    together (the row layout is negotiated once and cached, ``_gather_plan``).  Ranks may hold different numbers of
+    objectives / constraints, none included.  ``obj_index`` / ``con_index``: the GLOBAL position of each local row (the
+    column of the Pareto front / the entry of the threshold vector it belongs to); the result is ordered by it.  Without
+    them the rows come back in rank order.  World size 1: identity."""
+    import torch.distributed as dist
     r, w = world()
     if w == 1:
         return fm, fv, cm, cv
-
-    def mix(mean, var, index):
-        local = torch.stack([mean, var], 1)                       # (k, 2, T)
-        parts = all_gather_ragged(local)
-        parts[r] = local                                          # own rows: with gradient
-        allv = torch.cat(parts, 0)
-        if index is not None:
-            idx = torch.as_tensor(list(index), dtype=torch.int64, device=mean.device).reshape(-1)
-            if idx.numel() != mean.shape[0]:
-                raise ValueError("gather_with_local_grad: one global index per local row")
-            order = torch.cat(all_gather_ragged(idx), 0)
-            if sorted(order.tolist()) != list(range(order.numel())):
-                raise ValueError("gather_with_local_grad: global indices of all ranks must be a permutation of "
-                                 "0..n-1, got %s" % order.tolist())
-            allv = allv.index_select(0, torch.argsort(order))
-        return allv[:, 0], allv[:, 1]
-
-    fm, fv = mix(fm, fv, obj_index)
-    cm, cv = mix(cm, cv, con_index)
-    return fm, fv, cm, cv
+    k_obj, k_con = fm.shape[0], cm.shape[0]
+    plan = _gather_plan(k_obj, k_con, obj_index, con_index, fm.device)
+    T = fm.shape[1] if k_obj else cm.shape[1]
+    dev, cdev, kmax = fm.device, plan["cdev"], plan["kmax"]
+    if kmax == 0:
+        return fm, fv, cm, cv
+    local = torch.cat([torch.stack([fm, fv], 1), torch.stack([cm, cv], 1)], 0)        # (k_obj + k_con, 2, T), with gradient
+    pad = torch.zeros(kmax, 2, T, dtype=local.dtype, device=cdev)
+    pad[:local.shape[0]] = local.detach().to(cdev)
+    out = torch.empty(w * kmax, 2, T, dtype=local.dtype, device=cdev)
+    dist.all_gather_into_tensor(out, pad)
+    out = out.to(dev)
+    objs, cons = [], []
+    for q in range(w):
+        rows = local if q == r else out[q * kmax:(q + 1) * kmax]                       # own rows: with gradient
+        objs.append(rows[:plan["ko"][q]])
+        cons.append(rows[plan["ko"][q]:plan["ko"][q] + plan["kc"][q]])
+    allo, allc = torch.cat(objs, 0), torch.cat(cons, 0)
+    if plan["order_o"] is not None:
+        allo = allo.index_select(0, plan["order_o"])
+    if plan["order_c"] is not None:
+        allc = allc.index_select(0, plan["order_c"])
+    return allo[:, 0], allo[:, 1], allc[:, 0], allc[:, 1]
 
 
 # ---------------------------------------------------------------------------------------------------------------

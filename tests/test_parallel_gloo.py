@@ -86,9 +86,19 @@ def _ragged_worker(rank, world, port, q):
         parallel.gather_with_local_grad(fm, fm, cm, cm, [0] * len(obj_idx), con_idx)   # not a permutation
     except ValueError as err:
         bad = str(err)
+    # one rank passes indices, the other does not: the SAME error on both ranks, no rank left waiting in a collective
+    mismatch = None
+    try:
+        parallel.gather_with_local_grad(fm, fm, cm, cm, obj_idx if rank == 0 else None, con_idx)
+    except ValueError as err:
+        mismatch = "either every rank" in str(err)
+    # the negotiated layout is cached: a second step costs one collective and gives the same rows
+    n_plans = len(parallel._gather_plans)
+    bfm, _, _, _ = parallel.gather_with_local_grad(fm, fm * 2, cm, cm * 3, obj_idx, con_idx)
+    cached = len(parallel._gather_plans) == n_plans and torch.equal(bfm.detach(), afm.detach())
     q.put((rank, afm[:, 0].tolist(), afv[:, 0].tolist(), acm[:, 0].tolist(), acv[:, 0].tolist(), fm.grad[:, 0].tolist(),
            None if cm.grad is None else cm.grad.reshape(-1).tolist(), [tuple(p.shape) for p in parts], acq.tolist(),
-           x.tolist(), bad is not None))
+           x.tolist(), bad is not None and bool(mismatch) and cached))
     dist.barrier()
     dist.destroy_process_group()
 
