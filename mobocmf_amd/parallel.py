@@ -228,7 +228,9 @@ def _gather_plan(k_obj, k_con, obj_index, con_index, device):
     row counts, the padded row count of the per-step all-gather, and the permutations into global black-box order.  The
     global indices are static for a whole training run, so their exchange and validation (a host sync) happen here, not at
     every step.  Every rank enters the same two collectives whatever it holds; disagreements (some ranks pass indices,
-    others do not; indices that are no permutation) raise the same error on every rank instead of dead-locking."""
+    others do not; indices that are no permutation) raise the same error on every rank instead of dead-locking.
+    Contract: the negotiation is collective, so all ranks must meet a NEW layout in the same call (they do: the layout is
+    fixed by the sharding of the black-boxes for a whole run)."""
     import torch.distributed as dist
     r, w = world()
     oi = None if obj_index is None else tuple(int(i) for i in obj_index)

@@ -89,7 +89,8 @@ def _ragged_worker(rank, world, port, q):
     # one rank passes indices, the other does not: the SAME error on both ranks, no rank left waiting in a collective
     mismatch = None
     try:
-        parallel.gather_with_local_grad(fm, fm, cm, cm, obj_idx if rank == 0 else None, con_idx)
+        # (a layout neither rank has negotiated before: the row layout is negotiated collectively on first use and cached)
+        parallel.gather_with_local_grad(fm[:1], fm[:1], cm[:0], cm[:0], [0] if rank == 0 else None, [])
     except ValueError as err:
         mismatch = "either every rank" in str(err)
     # the negotiated layout is cached: a second step costs one collective and gives the same rows
