@@ -21,12 +21,14 @@ int launch_kl(const double* L, const double* LSp, const double* U, const double*
               double* part, hipStream_t s);
 int launch_moments_finish(const double* qpart, const double* mupart, const double* rpart, int nrb, int64_t Np, int64_t N,
                           const double* knn, int branch, double min_var, double* q, double* r, double* varraw,
-                          double* mean, double* var, hipStream_t s);
+                          double* mean, double* var, int32_t* zero_word, hipStream_t s);
 int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
                             const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
-                            double* gv, double* gv2, double* cgv, int32_t* nclamped, hipStream_t s);
+                            double* gv, double* gv2, double* cgv, int32_t* nclamped, int zeroed, hipStream_t s);
 int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, int nslab_diag, double* out, int Mp, const int32_t* flag,
                             const double* fallback, hipStream_t s);
+int launch_reduce_slabs_sym2(const double* slabs, const double* slabs2, int64_t slab_stride, int nslab, int nslab_diag,
+                             double* out, double* out2, int Mp, const int32_t* flag, hipStream_t s);
 int launch_dutot(const double* X, const double* U, const double* da, const double* a, const double* gkl, int Mp,
                  double* dU, double* da_tot, hipStream_t s);
 int launch_y_combine(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
@@ -174,6 +176,26 @@ int weighted_syrk(const double* A, int64_t lda, const double* w, int Mp, int64_t
     return launch_reduce_slabs_sym(slabs, mm, nsl, (nsl > 1 && sD > 0) ? sD : nsl, H, Mp, skip, fallback, s);
 }
 
+// H = A diag(w) A^T and Hc = A diag(w2) A^T, where Hc differs from H only if *flag != 0 (w2 = w except in clamped columns):
+// ONE dual launch (the twin half of the grid exits at once when the flag is zero) + ONE reduction writing both.
+int weighted_syrk_pair(const double* A, int64_t lda, const double* w, const double* w2, int Mp, int64_t Np, double* slabs,
+                       double* slabs2, double* H, double* Hc, const int32_t* flag, hipStream_t s) {
+    const int64_t mm = (int64_t)Mp * Mp;
+    GemmArgs ga = gemm_args(A, lda, A, lda, slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
+    ga.bscale = w; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm;
+    int sD = 0;
+    const int sF = syrk_splitk(Mp, Np, &sD);
+    const int nsl = gemm_nt_slabs(ga, sF);
+    if (nsl <= 1) {      // small problem (no k-slicing): the plain pair of launches
+        TRY(weighted_syrk(A, lda, w, Mp, Np, slabs, H, nullptr, nullptr, s));
+        return weighted_syrk(A, lda, w2, Mp, Np, slabs, Hc, flag, H, s);
+    }
+    ga.splitk_diag = sD;
+    ga.dual_flag = flag; ga.bscale2 = w2; ga.C2 = slabs2;
+    TRY(launch_gemm(ga, true, nsl, s));
+    return launch_reduce_slabs_sym2(slabs, slabs2, mm, nsl, sD > 0 ? sD : nsl, H, Hc, Mp, flag, s);
+}
+
 bool valid_desc(const mobocmf_layer_desc* d) {
     return d && (d->kind == 0 || d->kind == 1) && d->d >= 1 && d->d <= MOBOCMF_MAX_D && d->M >= 1 && d->xdiv >= 1 &&
            d->xdiv <= MOBOCMF_MAX_XDIV && d->Np >= 1 && d->Np % d->xdiv == 0 && (d->branch == 0 || d->branch == 1) && d->phase >= 0 &&
@@ -226,7 +248,7 @@ struct ChainWs {
 // forward SCRATCH, not in the state kept for backward -- one M x N' panel less per layer (268 MB at C3, 8.6 GB at C4)
 struct PanelSaved { double *A, *C, *knn, *q, *r, *varraw; };
 struct PanelFwd { double *K, *qpart, *mupart, *rpart; };
-struct PanelBwd { double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *dapart, *hyp_part, *df_part, *dzf_part, *dx_part; int64_t slab_elems; };
+struct PanelBwd { double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *slabs2, *dapart, *hyp_part, *df_part, *dzf_part, *dx_part; int64_t slab_elems; };
 
 void carve_chain_state(Bump& b, const Dims& D, ChainWs& S) {
     int64_t mm = (int64_t)D.Mp * D.Mp;
@@ -272,6 +294,7 @@ void carve_panel_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, PanelB
     S.dA = b.take(mn); S.dK = b.take(mn);
     S.slab_elems = syrk_slab_elems(D.Mp, D.Np);
     S.slabs = b.take(S.slab_elems);
+    S.slabs2 = d->branch == 0 ? b.take(S.slab_elems) : nullptr;      // the clamped-column twin of the syrk (training branch)
     S.dapart = b.take((D.Np <= 8192 ? D.Np / 16 : D.Np / 64) * (int64_t)D.Mp);   // row-dot partials of the dA epilogue (gemm_rowdot_parts)
     S.hyp_part = b.take((int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H);
     S.df_part = S.dzf_part = nullptr;
@@ -382,7 +405,7 @@ int chain_forward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const 
 // PANEL half, forward: K_mn, A = L^-1 K (+ q, mean partials), C = U^T A (+ r partials), moments
 int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& c, const PanelSaved& P, const PanelFwd& F,
                   const double* x, const double* f, const double* Zx, const double* zf, const double* hyp, double* mean,
-                  double* var, hipStream_t s) {
+                  double* var, bool block_layout, hipStream_t s) {
     const int Mp = D.Mp;
     const int64_t Np = D.Np;
     GramArgs g = {};
@@ -406,15 +429,16 @@ int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& 
     gc.rm = ga.rm; gc.pair_mode = ga.pair_mode;
     TRY(launch_gemm(gc, false, 1, s));
     probe_at(2, D.N, s);
+    // chain-block layout: the clamped-column counter of the backward lives in the block and is cleared here
     TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, gemm_colstat_rows(ga), Np, D.N, P.knn, desc->branch, desc->min_var, P.q, P.r,
-                              P.varraw, mean, var, s));
+                              P.varraw, mean, var, block_layout ? (int32_t*)c.flag : nullptr, s));
     return MOBOCMF_OK;
 }
 
 // PANEL half, backward: dA, the weighted syrk(s) H / Hc and da (unless the parameters are constants), dK, Gram backward of
 // K_mn and k_nn.  Writes g_f, g_x and -- overwriting -- the K_mn share of g_hyp / g_zf.
 int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& c, const PanelSaved& P, const PanelBwd& B,
-                   bool inputs_only, const double* x, const double* f, const double* Zx, const double* zf,
+                   bool inputs_only, bool block_layout, const double* x, const double* f, const double* Zx, const double* zf,
                    const double* hyp, const double* g_mean, const double* g_var, double* g_f, double* g_zf, double* g_hyp,
                    double* g_x, hipStream_t s) {
     const int Mp = D.Mp;
@@ -422,7 +446,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     int32_t* nclamped = (int32_t*)c.flag;
     double* Hc = desc->branch != 0 ? c.H : c.Hc;
     TRY(launch_moments_bwd_prep(g_mean, g_var, P.knn, P.q, P.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
-                                B.gv2, B.cgv, nclamped, s));
+                                B.gv2, B.cgv, nclamped, block_layout ? 1 : 0, s));
     // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
     {
         GemmArgs ga = gemm_args(c.U, Mp, P.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
@@ -442,9 +466,9 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     // (skip_if_zero) when no column is clamped.
     if (!inputs_only) {
         probe_at(5, D.N, s);
-        TRY(weighted_syrk(P.A, Np, B.gv, Mp, Np, B.slabs, c.H, nullptr, nullptr, s));
+        if (desc->branch == 0) TRY(weighted_syrk_pair(P.A, Np, B.gv, B.cgv, Mp, Np, B.slabs, B.slabs2, c.H, Hc, nclamped, s));
+        else TRY(weighted_syrk(P.A, Np, B.gv, Mp, Np, B.slabs, c.H, nullptr, nullptr, s));
         probe_at(6, D.N, s);
-        if (desc->branch == 0) TRY(weighted_syrk(P.A, Np, B.cgv, Mp, Np, B.slabs, Hc, nclamped, c.H, s));
     }
     // dK = L^-T dA
     {
@@ -669,7 +693,7 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
         TRY(chain_forward(1, c, 0, io, D, s));
     }
     if (!do_panel) return MOBOCMF_OK;
-    return panel_forward(desc, D, c, P, F, x, f, Zx, zf, hyp, mean, var, s);
+    return panel_forward(desc, D, c, P, F, x, f, Zx, zf, hyp, mean, var, false, s);
 }
 
 int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
@@ -693,7 +717,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     if (!carve_single_saved(saved, saved_bytes, D, c, P) || !carve_single_bwd(scratch, scratch_bytes, D, desc, c, B))
         return MOBOCMF_WORKSPACE_TOO_SMALL;
     if (do_panel)
-        TRY(panel_backward(desc, D, c, P, B, inputs_only, x, f, Zx, zf, hyp, g_mean, g_var, g_f, g_zf, g_hyp, g_x, s));
+        TRY(panel_backward(desc, D, c, P, B, inputs_only, false, x, f, Zx, zf, hyp, g_mean, g_var, g_f, g_zf, g_hyp, g_x, s));
     if (!do_chain) return MOBOCMF_OK;
     ChainIO io = {};
     io.desc = &desc; io.Zx = &Zx; io.zf = &zf; io.hyp = &hyp; io.m = &m; io.L_S = &L_S;
@@ -791,7 +815,7 @@ int mobocmf_layer_panel_forward(const mobocmf_layer_desc* desc, const double* x,
     carve_panel_saved(bs, D, P);
     carve_panel_fwd(bf, D, F);
     if (!bs.ok || !bf.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
-    return panel_forward(desc, D, c, P, F, x, f, Zx, zf, hyp, mean, var, (hipStream_t)stream);
+    return panel_forward(desc, D, c, P, F, x, f, Zx, zf, hyp, mean, var, true, (hipStream_t)stream);
 }
 
 int mobocmf_layer_panel_backward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,
@@ -812,8 +836,8 @@ int mobocmf_layer_panel_backward(const mobocmf_layer_desc* desc, const double* x
     carve_panel_saved(bs, D, P);
     carve_panel_bwd(bb, D, desc, B);
     if (!bs.ok || !bb.ok) return MOBOCMF_WORKSPACE_TOO_SMALL;
-    return panel_backward(desc, D, c, P, B, desc->phase == MOBOCMF_PHASE_PANEL_INPUTS, x, f, Zx, zf, hyp, g_mean, g_var, g_f,
-                          g_zf, g_hyp, g_x, (hipStream_t)stream);
+    return panel_backward(desc, D, c, P, B, desc->phase == MOBOCMF_PHASE_PANEL_INPUTS, true, x, f, Zx, zf, hyp, g_mean, g_var,
+                          g_f, g_zf, g_hyp, g_x, (hipStream_t)stream);
 }
 
 int mobocmf_predictive_covariance_workspace_bytes(const mobocmf_layer_desc* desc, size_t* scratch_bytes) {
@@ -1096,7 +1120,7 @@ int mobocmf_debug_touch_workspaces(const mobocmf_layer_desc* desc, void* saved, 
     };
     auto panel_bwd = [&](PanelBwd& B) {
         touch(B.gmu, D.Np, &n); touch(B.gv, D.Np, &n); touch(B.gv2, D.Np, &n); touch(B.cgv, D.Np, &n);
-        touch(B.dA, mn, &n); touch(B.dK, mn, &n); touch(B.slabs, B.slab_elems, &n);
+        touch(B.dA, mn, &n); touch(B.dK, mn, &n); touch(B.slabs, B.slab_elems, &n); touch(B.slabs2, B.slab_elems, &n);
         touch(B.dapart, (D.Np <= 8192 ? D.Np / 16 : D.Np / 64) * (int64_t)D.Mp, &n);
         touch(B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H, &n);
         if (desc->kind == 1) { touch(B.df_part, (int64_t)D.ggrid_mn.y * D.Np, &n); touch(B.dzf_part, (int64_t)D.ggrid_mn.x * D.Mp, &n); }

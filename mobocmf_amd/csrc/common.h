@@ -62,6 +62,12 @@ struct GemmArgs {
                                    // NEXT launch must stay cacheable -- streaming A cost the step 4 % although the
                                    // kernel alone got 6 % faster)
     const int32_t* skip_if_zero;   // device word: the whole launch is a no-op when it is 0 (rarely needed passes)
+    // Dual launch (k-sliced A B^T only): the grid is doubled; the second half computes the SAME product with the contraction
+    // weights bscale2 into the slabs at C2 -- but only if *dual_flag != 0, otherwise its workgroups exit at once.  One launch
+    // instead of a real one plus a conditional one that is a no-op nearly always (the clamped-column syrk of the backward).
+    const int32_t* dual_flag;
+    const double* bscale2;
+    double* C2;
     // epilogues
     int epi;
     double* colsq_part;    // EPI_COLSTATS: [2*Mr/TILE][Nc] partial column sums of C^2 (two wavefront rows per row block)

@@ -192,8 +192,9 @@ int launch_kl(const double* L, const double* LSp, const double* U, const double*
 // q = sum_rb qpart, mean = sum_rb mupart, r = sum_rb rpart; var_raw = (branch ? knn - q : max(knn - q, 0)) + r
 __global__ void moments_finish_kernel(const double* qpart, const double* mupart, const double* rpart, int nrb,
                                       int64_t Np, int64_t N, const double* knn, int branch, double min_var, double* q,
-                                      double* r, double* varraw, double* mean, double* var) {
+                                      double* r, double* varraw, double* mean, double* var, int32_t* zero_word) {
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0 && zero_word) zero_word[0] = 0;      // the backward's clamped-column counter (no zero launch there)
     if (n >= Np) return;
     double qs = 0, ms = 0, rs = 0;
     for (int b = 0; b < nrb; ++b) {
@@ -214,9 +215,9 @@ __global__ void moments_finish_kernel(const double* qpart, const double* mupart,
 }
 int launch_moments_finish(const double* qpart, const double* mupart, const double* rpart, int nrb, int64_t Np, int64_t N,
                           const double* knn, int branch, double min_var, double* q, double* r, double* varraw,
-                          double* mean, double* var, hipStream_t s) {
+                          double* mean, double* var, int32_t* zero_word, hipStream_t s) {
     hipLaunchKernelGGL(moments_finish_kernel, GRID1(Np), 0, s, qpart, mupart, rpart, nrb, Np, N, knn, branch, min_var, q,
-                       r, varraw, mean, var);
+                       r, varraw, mean, var, zero_word);
     return CHECK_LAUNCH();
 }
 
@@ -240,8 +241,10 @@ __global__ void moments_bwd_prep_kernel(const double* g_mean, const double* g_va
 }
 int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
                             const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
-                            double* gv, double* gv2, double* cgv, int32_t* nclamped, hipStream_t s) {
-    if (launch_zero32(nclamped, 1, s)) return MOBOCMF_HIP_ERROR;
+                            double* gv, double* gv2, double* cgv, int32_t* nclamped, int zeroed, hipStream_t s) {
+    // zeroed: the forward's moments_finish cleared the counter (a second backward over the same forward then adds to a
+    // non-zero count, which reads the same: only zero / non-zero matters)
+    if (!zeroed && launch_zero32(nclamped, 1, s)) return MOBOCMF_HIP_ERROR;
     hipLaunchKernelGGL(moments_bwd_prep_kernel, GRID1(Np), 0, s, g_mean, g_var, knn, q, varraw, branch, min_var, N, Np,
                        gmu, gv, gv2, cgv, nclamped);
     return CHECK_LAUNCH();
@@ -268,6 +271,32 @@ __global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride
     for (int z = 0; z < ns; ++z) v += p[z * slab_stride];
     out[idx] = v;
     if (j / TILE < i / TILE) out[(int64_t)j * Mp + i] = v;     // strictly-upper tiles mirror the lower ones
+}
+// the pair of a dual syrk launch: out = sum of slabs (always), out2 = sum of slabs2 if *flag != 0, else = out
+__global__ void reduce_slabs_sym2_kernel(const double* slabs, const double* slabs2, int64_t slab_stride, int nslab,
+                                         int nslab_diag, double* out, double* out2, int Mp, const int32_t* flag) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mp * Mp) return;
+    int i = (int)(idx / Mp), j = (int)(idx % Mp);
+    if (j / TILE > i / TILE) return;
+    const int64_t off = j > i ? (int64_t)j * Mp + i : (int64_t)i * Mp + j;
+    const int ns = (i / TILE == j / TILE) ? nslab_diag : nslab;
+    double v = 0.0;
+    for (int z = 0; z < ns; ++z) v += slabs[off + z * slab_stride];
+    double v2 = v;
+    if (*flag != 0) {
+        v2 = 0.0;
+        for (int z = 0; z < ns; ++z) v2 += slabs2[off + z * slab_stride];
+    }
+    out[idx] = v;
+    out2[idx] = v2;
+    if (j / TILE < i / TILE) { out[(int64_t)j * Mp + i] = v; out2[(int64_t)j * Mp + i] = v2; }
+}
+int launch_reduce_slabs_sym2(const double* slabs, const double* slabs2, int64_t slab_stride, int nslab, int nslab_diag,
+                             double* out, double* out2, int Mp, const int32_t* flag, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_slabs_sym2_kernel, GRID1((int64_t)Mp * Mp), 0, s, slabs, slabs2, slab_stride, nslab, nslab_diag,
+                       out, out2, Mp, flag);
+    return CHECK_LAUNCH();
 }
 int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, int nslab_diag, double* out, int Mp,
                             const int32_t* flag, const double* fallback, hipStream_t s) {

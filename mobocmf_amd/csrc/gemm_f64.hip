@@ -131,6 +131,15 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
     //  * no split-K: the row blocks that re-read the same 128-column panel of B run back to back on one XCD;
     //  * split-K: all tiles of one k-slice (they share the slice's rows of A and B) run back to back on one XCD.
     int64_t id = blockIdx.x;
+    if (g.dual_flag) {      // dual launch: the second half of the grid is the conditional twin (common.h)
+        const int64_t half = (int64_t)(gridDim.x >> 1);
+        if (id >= half) {
+            if (*g.dual_flag == 0) return;
+            id -= half;
+            g.bscale = g.bscale2;
+            g.C = g.C2;
+        }
+    }
     int rb, z = 0, sk_eff = splitk;      // sk_eff: k slices of THIS tile
     int64_t cb;
     if (g.batched) {
@@ -705,7 +714,7 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         int64_t ntile = g.lower_out ? (int64_t)nrb * (nrb + 1) / 2 : (int64_t)nrb * ncb;
         if (g.lower_out && g.splitk_diag > 0) ntile = 0;      // two classes: counted below
         const int64_t nblk = ntile ? ntile * splitk : (int64_t)nrb * (nrb - 1) / 2 * splitk + (int64_t)nrb * g.splitk_diag;
-        grid = dim3((unsigned)nblk, 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
+        grid = dim3((unsigned)(g.dual_flag ? 2 * nblk : nblk), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
     } else {
         // pairing balances the work per workgroup; it only pays when the pairs still fill the chip (table above), otherwise
         // the longest single tile is the critical path and pairing lengthens it

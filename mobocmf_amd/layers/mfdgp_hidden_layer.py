@@ -37,6 +37,7 @@ class UnwhitenedVariationalStrategy(nn.Module):
         # the memoised KL is a graph tensor: never copied / pickled (deepcopy + dill of the fitter must work)
         state = self.__dict__.copy()
         state["_kl_cache"] = None
+        state.pop("_Zx_contig", None)
         return state
 
     @property
@@ -81,7 +82,18 @@ class MFDGUnwhitenedVariationalStrategy(UnwhitenedVariationalStrategy):
 
     @property
     def Zx(self):
-        return self._inducing_points[:, :-1] if self.previous_layer is not None else self._inducing_points
+        """The x columns of Z~ as a CONTIGUOUS tensor (the C-ABI takes dense rows): the column slice of the stored
+        (M, d + 1) matrix is copied once and reused while that matrix is unchanged (same storage, same version counter) --
+        not twice per forward."""
+        if self.previous_layer is None:
+            return self._inducing_points
+        Z = self._inducing_points
+        tag = (Z.data_ptr(), Z._version, Z.device)
+        c = self.__dict__.get("_Zx_contig")
+        if c is None or c[0] != tag:
+            c = (tag, Z.detach()[:, :-1].contiguous())
+            self.__dict__["_Zx_contig"] = c
+        return c[1]
 
     @property
     def zf(self):

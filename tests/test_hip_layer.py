@@ -116,16 +116,18 @@ def test_clamp_branch_and_min_variance_gradients():
     _close(mg.grad, m.grad, 1e-6, "g_m")
 
 
-@pytest.mark.parametrize("kind", [0, 1])
-def test_clamped_columns_take_the_separate_syrk_path(kind):
+@pytest.mark.parametrize("kind,d,M,nbase,ls", [(0, 2, 8, 40, 0.15), (1, 2, 8, 40, 0.15), (0, 8, 400, 600, 0.3), (1, 8, 400, 600, 0.3)],
+                         ids=["kind0_small", "kind1_small", "kind0_ksliced_dual_launch", "kind1_ksliced_dual_launch"])
+def test_clamped_columns_take_the_separate_syrk_path(kind, d, M, nbase, ls):
     """clamp(k_nn - q, 0) active in SOME columns (forced robustly with a negative jitter on a well-conditioned
-    K_mm: q > k_nn at the inducing rows): the backward must then use Hc = A diag(c gv) A^T != H."""
+    K_mm: q > k_nn at the inducing rows): the backward must then use Hc = A diag(c gv) A^T != H -- through the small
+    operands' pair of launches and through the k-sliced DUAL launch (H and Hc slabs from one grid, M > 384)."""
     from mobocmf_amd import functional as F
-    d, M, nbase, jit = 2, 8, 40, -2e-3
+    jit = -2e-3
     x, f, Zx, zf, hyp, m, L_S = _mk(kind, d, M, nbase, 1, seed=21)
     for k in ("ls", "ls1", "ls2"):
         if k in hyp:
-            hyp[k] = hyp[k] * 0.0 + 0.15                      # short lengthscale: K_mm ~ diagonal, PD with jitter < 0
+            hyp[k] = hyp[k] * 0.0 + ls                        # short lengthscale: K_mm ~ diagonal, PD with jitter < 0
     x = torch.cat([Zx, x[M:]], 0)                             # first M data rows sit on the inducing inputs
     if kind == 1:
         f = torch.cat([zf, f[M:]], 0)
