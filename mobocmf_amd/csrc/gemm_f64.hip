@@ -702,6 +702,9 @@ int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
         return launch_small_panel<EPI_STORE>(g, s);
     }
     if (B_T && splitk <= 1 && small_gemm_ok(g, true)) return launch_small_gemm(g, true, s);   // small weighted syrk
+    // batched small products (the 128 / 256-wide merges of the blocked triangular inverse): a handful of tiles each, pure
+    // latency on the 128 x 128 x 16 pipeline (19-23 us per launch at M = 512), ~7 us on the small-operand kernel
+    if (!B_T && g.batched > 1 && splitk <= 1 && small_gemm_ok(g, false)) return launch_small_gemm(g, false, s);
     const int rm = tile_rows(g, B_T, splitk);
     int nrb = g.Mr / rm;
     int64_t ncb = g.Nc / BN;
@@ -819,9 +822,14 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int64_t r0 = (int64_t)blockIdx.y * 16, c0 = (int64_t)blockIdx.x * 16;
     if (g.lower_out && c0 / BM > r0 / BM) return;        // same contract as the tiled kernel: lower 128-tiles only
-    g.A += blockIdx.z * g.zsA;                            // layer batching (blockIdx.z = layer)
-    g.B += blockIdx.z * g.zsB;
-    g.C += blockIdx.z * g.zsC;
+    {   // blockIdx.z = batch * layers + layer, as in the tiled kernel (batched merges of the triangular inverse, layer
+        // batching of the chains, or both)
+        const int nzl = g.zlayers > 1 ? g.zlayers : 1;
+        const int zl = (int)blockIdx.z % nzl, zb = (int)blockIdx.z / nzl;
+        g.A += zb * g.strideA + zl * g.zsA;
+        g.B += zb * g.strideB + zl * g.zsB;
+        g.C += zb * g.strideC + zl * g.zsC;
+    }
     int64_t k0 = 0, k1 = g.Kd;
     if (g.tri & TRI_LOWER_A) k1 = k1 < r0 + 16 ? k1 : r0 + 16;
     if (g.tri & TRI_UPPER_A) k0 = k0 > r0 ? k0 : r0;
@@ -884,15 +892,19 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
 // (8 dependent steps = ~28 us for a 128 x 128 x 128 product).  Here a workgroup pulls its whole 128 x 128 block of A and
 // 128 x 16 block of B into LDS at once (149 KB of the CU's 160 KB: every load of the block is in flight together),
 // then multiplies out of LDS.
-#define SP_LDA 129
-#define SP_LDB 17
-#define SP_LDS_BYTES ((BM * SP_LDA + BM * SP_LDB) * 8)
+#define SP_LDT 132     // leading dimension of the TRANSPOSED A image [k][row] (16-byte aligned rows of 4, padded)
+#define SP_LDB 18
+#define SP_LDS_BYTES ((BM * SP_LDT + BM * SP_LDB) * 8)
+// Thread tile 4 rows x 2 columns: per k one 32-byte run of the transposed A image (two ds_read_b128) and one 16-byte pair of
+// B feed eight FMAs -- three LDS instructions per eight FMAs where one output column per thread needed nine (the loop is
+// LDS-issue bound: 128 x 16 outputs per workgroup, K = 128, everything resident in LDS).
 template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_panel_kernel(GemmArgs g) {
     extern __shared__ double sp_smem[];
-    double* As = sp_smem;                    // [128][SP_LDA]
-    double* Bs = sp_smem + BM * SP_LDA;      // [128][SP_LDB]
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double* AsT = sp_smem;                   // [128 k][SP_LDT rows]
+    double* Bs = sp_smem + BM * SP_LDT;      // [128 k][SP_LDB cols]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // staging map: 16 k x 16 rows
+    const int tc = threadIdx.x & 7, tr = threadIdx.x >> 3;        // compute map: columns 2 tc, 2 tc + 1; rows 4 tr .. 4 tr + 3
     const int rb = blockIdx.y;
     const int64_t r0 = (int64_t)rb * BM, c0 = (int64_t)blockIdx.x * 16;
     int64_t k0 = 0, k1 = g.Kd;               // multiples of 128 (Mr, Kd are)
@@ -901,9 +913,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // B's rows >= Kreal are zero padding (a 16-point problem padded to 128): the contraction stops at the real size
     const int64_t kend = g.Kreal > 0 ? ((g.Kreal + 15) & ~(int64_t)15) : g.Kd;
     if (k1 > kend) k1 = kend;
-    double acc[8];
+    double acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+    for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = 0.0;
     for (int64_t kc = k0; kc < k1; kc += BM) {
         const int kn = (int)(k1 - kc < BM ? k1 - kc : BM);      // multiple of 16: K steps of this chunk that matter
         double va[8][8], vb[8];               // every load of the block in flight before the first use
@@ -923,69 +935,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int64_t kk = kc + c * 16 + tx;
                 double v = va[i][c];
                 if (((g.tri & TRI_LOWER_A) && kk > row) || ((g.tri & TRI_UPPER_A) && kk < row)) v = 0.0;
-                As[(ty + 16 * i) * SP_LDA + c * 16 + tx] = v;
+                AsT[(c * 16 + tx) * SP_LDT + ty + 16 * i] = v;
             }
             Bs[(ty + 16 * i) * SP_LDB + tx] = vb[i];
         }
         __syncthreads();
+        const double* ap = AsT + 4 * tr;
+        const double* bp = Bs + 2 * tc;
 #pragma unroll 8
         for (int q = 0; q < kn; ++q) {
-            const double b = Bs[q * SP_LDB + tx];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += As[(ty + 16 * i) * SP_LDA + q] * b;
+            const v2f64 a01 = *(const v2f64*)(ap + q * SP_LDT), a23 = *(const v2f64*)(ap + q * SP_LDT + 2);
+            const v2f64 b = *(const v2f64*)(bp + q * SP_LDB);
+            acc[0][0] += a01[0] * b[0]; acc[0][1] += a01[0] * b[1];
+            acc[1][0] += a01[1] * b[0]; acc[1][1] += a01[1] * b[1];
+            acc[2][0] += a23[0] * b[0]; acc[2][1] += a23[0] * b[1];
+            acc[3][0] += a23[1] * b[0]; acc[3][1] += a23[1] * b[1];
         }
         __syncthreads();
     }
-    const int64_t col = c0 + tx;
+    const int64_t col = c0 + 2 * tc, row0 = r0 + 4 * tr;
     if (EPI == EPI_DA) {
-        const double gm = g.gmu[col], cg = g.cgv[col];
-        const double cs = g.alpha * (g.bscale ? g.bscale[col] : 1.0);
+        const v2f64 gm = *(const v2f64*)(g.gmu + col), cg = *(const v2f64*)(g.cgv + col);
+        v2f64 cs = (v2f64){g.alpha, g.alpha};
+        if (g.bscale) { const v2f64 bs = *(const v2f64*)(g.bscale + col); cs[0] *= bs[0]; cs[1] *= bs[1]; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int64_t row = r0 + ty + 16 * i;
-            const double av = g.Aaux[row * g.ldc + col];
-            g.C[row * g.ldc + col] = cs * acc[i] + g.avec[row] * gm - 2.0 * av * cg;
-            if (g.rowdot_part) {       // the 16 lanes tx of a row hold its 16 columns
-                double v = av * gm;
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + i;
+            const v2f64 av = *(const v2f64*)(g.Aaux + row * g.ldc + col);
+            const double ar = g.avec[row];
+            v2f64 o;
+            o[0] = cs[0] * acc[i][0] + ar * gm[0] - 2.0 * av[0] * cg[0];
+            o[1] = cs[1] * acc[i][1] + ar * gm[1] - 2.0 * av[1] * cg[1];
+            *(v2f64*)(g.C + row * g.ldc + col) = o;
+            if (g.rowdot_part) {       // the 8 lanes tc of a row hold its 16 columns
+                double v = av[0] * gm[0] + av[1] * gm[1];
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
-                if (tx == 0) g.rowdot_part[(int64_t)blockIdx.x * g.Mr + row] = v;
+                if (tc == 0) g.rowdot_part[(int64_t)blockIdx.x * g.Mr + row] = v;
             }
         }
         return;
     }
-    double sq = 0.0, dt = 0.0;
+    double sq[2] = {0.0, 0.0}, dt[2] = {0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t row = r0 + ty + 16 * i;
-        double v = g.alpha * acc[i];
-        if (g.accumulate) v += g.C[row * g.ldc + col];
-        g.C[row * g.ldc + col] = v;
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + i;
+        v2f64 v = (v2f64){g.alpha * acc[i][0], g.alpha * acc[i][1]};
+        if (g.accumulate) { const v2f64 old = *(const v2f64*)(g.C + row * g.ldc + col); v[0] += old[0]; v[1] += old[1]; }
+        *(v2f64*)(g.C + row * g.ldc + col) = v;
         if (EPI == EPI_COLSTATS) {
-            sq += v * v;
-            if (g.coldot_part) dt += g.avec[row] * v;
+            sq[0] += v[0] * v[0]; sq[1] += v[1] * v[1];
+            if (g.coldot_part) { const double ar = g.avec[row]; dt[0] += ar * v[0]; dt[1] += ar * v[1]; }
         }
     }
     if (EPI == EPI_COLSTATS) {
-        double* red = sp_smem;               // [2][16][17]; the operand blocks are dead after the last barrier
-        red[(0 * 16 + ty) * 17 + tx] = sq;
-        red[(1 * 16 + ty) * 17 + tx] = dt;
+        // column sums: over the 8 row groups of a wavefront (lane bits 3..5), then over the 4 wavefronts through LDS
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            sq[b] += __shfl_xor(sq[b], 8); sq[b] += __shfl_xor(sq[b], 16); sq[b] += __shfl_xor(sq[b], 32);
+            dt[b] += __shfl_xor(dt[b], 8); dt[b] += __shfl_xor(dt[b], 16); dt[b] += __shfl_xor(dt[b], 32);
+        }
+        double* red = sp_smem;               // [2][4 waves][16 cols]; the operand blocks are dead after the last barrier
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane < 8) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                red[(0 * 4 + wave) * 16 + 2 * tc + b] = sq[b];
+                red[(1 * 4 + wave) * 16 + 2 * tc + b] = dt[b];
+            }
+        }
         __syncthreads();
-        if (ty == 0) {
+        if (threadIdx.x < 16) {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                s0 += red[(0 * 16 + q) * 17 + tx];
-                s1 += red[(1 * 16 + q) * 17 + tx];
+            for (int w = 0; w < 4; ++w) {
+                s0 += red[(0 * 4 + w) * 16 + threadIdx.x];
+                s1 += red[(1 * 4 + w) * 16 + threadIdx.x];
             }
+            const int64_t cc = c0 + threadIdx.x;
             // same partial layout as the tiled kernel (two rows per 128-row block): the second one is zero here
-            g.colsq_part[(int64_t)(2 * rb) * g.Nc + col] = s0;
-            g.colsq_part[(int64_t)(2 * rb + 1) * g.Nc + col] = 0.0;
+            g.colsq_part[(int64_t)(2 * rb) * g.Nc + cc] = s0;
+            g.colsq_part[(int64_t)(2 * rb + 1) * g.Nc + cc] = 0.0;
             if (g.coldot_part) {
-                g.coldot_part[(int64_t)(2 * rb) * g.Nc + col] = s1;
-                g.coldot_part[(int64_t)(2 * rb + 1) * g.Nc + col] = 0.0;
+                g.coldot_part[(int64_t)(2 * rb) * g.Nc + cc] = s1;
+                g.coldot_part[(int64_t)(2 * rb + 1) * g.Nc + cc] = 0.0;
             }
         }
     }
@@ -1022,12 +1056,13 @@ int gemm_rowdot_parts(const GemmArgs& g) {
 static bool small_gemm_ok(const GemmArgs& g, bool B_T) {
     const int L = small_gemm_limit();
     if (g.Mr > L || g.Nc > L || g.Kd > L) return false;
-    return (!g.batched || (g.batched == 1 && g.zlayers > 1)) && g.epi == EPI_STORE && (B_T || (!g.bscale && !g.skip_if_zero)) && g.Mr <= 512 && g.Nc <= 512 &&
+    return g.epi == EPI_STORE && (B_T || (!g.bscale && !g.skip_if_zero)) && g.Mr <= 512 && g.Nc <= 512 &&
            g.Kd <= 512 && g.Mr % 16 == 0 && g.Nc % 16 == 0 && g.Kd % 16 == 0;
 }
 
 static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
-    const dim3 grid((unsigned)(g.Nc / 16), (unsigned)(g.Mr / 16), (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
+    const dim3 grid((unsigned)(g.Nc / 16), (unsigned)(g.Mr / 16),
+                    (unsigned)((g.batched > 1 ? g.batched : 1) * (g.zlayers > 1 ? g.zlayers : 1)));
     if (B_T) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, s, g);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
