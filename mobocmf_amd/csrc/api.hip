@@ -53,6 +53,8 @@ int launch_mirror_lower(const double* src, int64_t lds, double* dst, int64_t ldd
 // layer-batched forms (blockIdx.z = layer, workspace pointers + z*zs doubles, user tensors as tables)
 int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
                    double* zero0, double* zero1, hipStream_t s);
+int launch_chain_outputs_z(const double* X, const double* LSp, const double* LinvT, const double* da_tot, int M, int Mp,
+                           const double* const* gkl, double* const* gLS, double* const* gm, int nz, int64_t zs, hipStream_t s);
 int launch_pad_params_z(const double* const* LS, const double* const* m, int M, double* LSp, double* mp, int Mp, int nz,
                         int64_t zs, hipStream_t s);
 int launch_trtri_z(const double* L, int64_t ld, int Mp, const double* Dinv, double* Linv, double* T, double* ws,
@@ -541,17 +543,13 @@ int chain_backward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const
         g4.Kreal = D.M;
         TRY(chain_gemm(g4, true, c, n, zs, s));
     }
-    // g_m = L^-T da_tot  (user tensors: one launch per layer)
-    for (int z = 0; z < n; ++z)
-        TRY(launch_gemv_rows(c.LinvT + z * zs, Mp, c.da_tot + z * zs, io.g_m[z], D.M, Mp, 1.0, 0, s));
-    // g_LS = tril(L^-T dU_tot) - gkl diag(1/LS_ii)
+    // g_LS = tril(L^-T dU_tot) - gkl diag(1/LS_ii) and g_m = L^-T da_tot: the user tensors of all layers in one launch
     {
         GemmArgs ga = gemm_args(c.LinvT, Mp, dU, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
         ga.lower_out = 1;
         ga.Kreal = D.M;
         TRY(chain_gemm(ga, false, c, n, zs, s));
-        for (int z = 0; z < n; ++z)
-            TRY(launch_gls_out(T1 + z * zs, c.LSp + z * zs, io.g_kl[z], D.M, Mp, io.g_LS[z], s));
+        TRY(launch_chain_outputs_z(T1, c.LSp, c.LinvT, c.da_tot, D.M, Mp, io.g_kl, io.g_LS, io.g_m, n, zs, s));
     }
     // dL
     {
@@ -576,7 +574,10 @@ int chain_backward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const
         TRY(chain_gemm(gc, false, c, n, zs, s));
         TRY(launch_symmetrize_z(T2, Mp, Gm, n, zs, s));
     }
-    // Gram backward of K_mm (both arguments are Z~): per layer
+    // Gram backward of K_mm (both arguments are Z~): one launch per layer (kernel kind, user tensors), then the partial
+    // sums of all layers in one
+    SumTask tk[2 * MAX_ZL];
+    int nt = 0;
     for (int z = 0; z < n; ++z) {
         const mobocmf_layer_desc* d = io.desc[z];
         GramArgs g = kmm_gram(d, D, io.Zx[z], io.zf[z], io.hyp[z]);
@@ -585,14 +586,11 @@ int chain_backward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const
         g.dx_part = nullptr;
         TRY(launch_gram_bwd(g, false, s));
         const int H = hyp_len(d->kind, d->d);
-        SumTask tk[2];
-        int nt = 0;
         tk[nt++] = {g.hyp_part, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, H, nullptr, 0, 0, io.g_hyp[z], H, acc[z]};
         if (d->kind == 1)      // both arguments of K_mm are Z~: the row-side and the column-side partials land in g_zf
             tk[nt++] = {g.df_part, D.ggrid_mm.y, Mp, g.dzf_part, D.ggrid_mm.x, Mp, io.g_zf[z], D.M, acc[z]};
-        TRY(launch_sum_partials_multi(tk, nt, s));
     }
-    return MOBOCMF_OK;
+    return launch_sum_partials_multi(tk, nt, s);
 }
 
 bool same_chain_shape(int n, const mobocmf_layer_desc* const* d) {

@@ -448,6 +448,44 @@ int launch_gls_out(const double* X, const double* LSp, const double* gkl, int M,
     return CHECK_LAUNCH();
 }
 
+// Both user-tensor outputs of the chain backward for every layer in ONE launch (blockIdx.y = layer):
+//   g_LS[z] (M x M, ld M) = tril(X_z) - gkl_z diag(1 / LS_ii)      (blocks [0, nb_ls))
+//   g_m[z]  (M)           = L^-T_z da_tot_z                         (blocks [nb_ls, ...): one wavefront per row)
+struct ChainOutZ { const double* gkl[MAX_ZL]; double* gLS[MAX_ZL]; double* gm[MAX_ZL]; };
+__global__ void chain_outputs_z_kernel(const double* X, const double* LSp, const double* LinvT, const double* da_tot, int M,
+                                       int Mp, ChainOutZ t, int nb_ls, int64_t zs) {
+    const int z = blockIdx.y;
+    X += z * zs; LSp += z * zs; LinvT += z * zs; da_tot += z * zs;
+    if ((int)blockIdx.x < nb_ls) {
+        const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= (int64_t)M * M) return;
+        const int i = (int)(idx / M), j = (int)(idx % M);
+        double v = 0.0;
+        if (j <= i) {
+            v = X[(int64_t)i * Mp + j];
+            if (i == j && t.gkl[z]) v -= t.gkl[z][0] / LSp[(int64_t)i * Mp + i];
+        }
+        t.gLS[z][idx] = v;
+        return;
+    }
+    const int row = ((int)blockIdx.x - nb_ls) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const double* p = LinvT + (int64_t)row * Mp;
+    double sacc = 0.0;
+    for (int j = lane; j < Mp; j += 64) sacc += p[j] * da_tot[j];
+    sacc = wave_sum(sacc);
+    if (lane == 0) t.gm[z][row] = sacc;
+}
+int launch_chain_outputs_z(const double* X, const double* LSp, const double* LinvT, const double* da_tot, int M, int Mp,
+                           const double* const* gkl, double* const* gLS, double* const* gm, int nz, int64_t zs, hipStream_t s) {
+    ChainOutZ t = {};
+    for (int z = 0; z < nz; ++z) { t.gkl[z] = gkl[z]; t.gLS[z] = gLS[z]; t.gm[z] = gm[z]; }
+    const int nb_ls = (int)(((int64_t)M * M + 255) / 256), nb_m = (M + 3) / 4;
+    hipLaunchKernelGGL(chain_outputs_z_kernel, dim3((unsigned)(nb_ls + nb_m), (unsigned)nz), dim3(256), 0, s, X, LSp, LinvT, da_tot,
+                       M, Mp, t, nb_ls, zs);
+    return CHECK_LAUNCH();
+}
+
 __global__ void copy_block_kernel(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * cols) return;

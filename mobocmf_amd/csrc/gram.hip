@@ -391,12 +391,32 @@ __global__ void group_sum_kernel(const double* in, double* out, int64_t nout, in
     out[j] = accumulate ? out[j] + v : v;
 }
 
-#define SUM_MULTI_MAX 4
-struct SumTasksArg { SumTask t[SUM_MULTI_MAX]; int blk0[SUM_MULTI_MAX + 1]; int n; };
+#define SUM_MULTI_MAX 8
+// Several reductions in ONE launch: consecutive block ranges belong to consecutive tasks; a task with many partials per
+// output and few outputs is reduced "wide" (one block per output, threads stride over the partials), the others one
+// thread per output.  (Each separate launch is 3-5 us of pure latency on the step's critical path.)
+struct SumTasksArg { SumTask t[SUM_MULTI_MAX]; int blk0[SUM_MULTI_MAX + 1]; int wide[SUM_MULTI_MAX]; int n; };
 __global__ void sum_partials_multi_kernel(SumTasksArg T) {
+    __shared__ double sh[4];
     int k = 0;
     while (k + 1 < T.n && (int)blockIdx.x >= T.blk0[k + 1]) ++k;
     const SumTask& t = T.t[k];
+    if (T.wide[k]) {
+        const int64_t j = (int64_t)(blockIdx.x - T.blk0[k]);
+        double v = 0.0;
+        for (int64_t p = threadIdx.x; p < t.P; p += 256) v += t.part[p * t.stride + j];
+        if (t.part2)
+            for (int64_t p = threadIdx.x; p < t.P2; p += 256) v += t.part2[p * t.stride2 + j];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            v = sh[0] + sh[1] + sh[2] + sh[3];
+            t.out[j] = t.accumulate ? t.out[j] + v : v;
+        }
+        return;
+    }
     const int64_t j = (int64_t)(blockIdx.x - T.blk0[k]) * blockDim.x + threadIdx.x;
     if (j >= t.len) return;
     double v = 0.0;
@@ -410,32 +430,29 @@ int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* o
                         int accumulate, hipStream_t s);
 
 int launch_sum_partials_multi(const SumTask* tasks, int n, hipStream_t s) {
-    bool small = n <= SUM_MULTI_MAX;
-    for (int i = 0; i < n; ++i) small = small && tasks[i].P <= 64 && (!tasks[i].part2 || tasks[i].P2 <= 64);
-    if (!small) {     // many partials per output: the separate launches pick the wide (one block per output) reduction
-        for (int i = 0; i < n; ++i) {
-            int rc = launch_sum_partials(tasks[i].part, tasks[i].P, tasks[i].stride, tasks[i].out, tasks[i].len, 1.0,
-                                         tasks[i].accumulate, s);
+    if (n > SUM_MULTI_MAX) {
+        for (int i = 0; i < n; i += SUM_MULTI_MAX) {
+            int rc = launch_sum_partials_multi(tasks + i, n - i < SUM_MULTI_MAX ? n - i : SUM_MULTI_MAX, s);
             if (rc) return rc;
-            if (tasks[i].part2) {
-                rc = launch_sum_partials(tasks[i].part2, tasks[i].P2, tasks[i].stride2, tasks[i].out, tasks[i].len, 1.0, 1, s);
-                if (rc) return rc;
-            }
         }
         return MOBOCMF_OK;
     }
     SumTasksArg T = {};
-    int nb = 0, m = 0;
+    int64_t nb = 0;
+    int m = 0;
     for (int i = 0; i < n; ++i) {
         if (tasks[i].len <= 0) continue;
         T.t[m] = tasks[i];
-        T.blk0[m] = nb;
-        nb += (int)((tasks[i].len + 255) / 256);
+        T.blk0[m] = (int)nb;
+        const int64_t pmax = tasks[i].P > (tasks[i].part2 ? tasks[i].P2 : 0) ? tasks[i].P : tasks[i].P2;
+        T.wide[m] = (pmax >= 64 && tasks[i].len <= 4096) ? 1 : 0;
+        nb += T.wide[m] ? tasks[i].len : (tasks[i].len + 255) / 256;
         ++m;
     }
-    T.blk0[m] = nb;
+    T.blk0[m] = (int)nb;
     T.n = m;
     if (m == 0) return MOBOCMF_OK;
+    if (nb > 0x7fffffff) return MOBOCMF_BAD_ARG;
     hipLaunchKernelGGL(sum_partials_multi_kernel, dim3((unsigned)nb), dim3(256), 0, s, T);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
