@@ -355,6 +355,10 @@ int mobocmf_set_tuning(int32_t small_gemm_max, int32_t small_panel_max);
 #define MOBOCMF_PROBE_EVENTS 11
 int mobocmf_set_probe_events(void* const* events, int32_t n, int64_t Np);
 
+/* Columns the 64-wide Cholesky panel kernel eliminates per hand-over between its two wavefronts: 4 (default) or 1 (the
+ * round-2 kernel).  Process-wide A/B and test knob, like mobocmf_set_tuning. */
+int mobocmf_set_potrf_cols(int32_t cols);
+
 /* Host-side, synchronising: copies the device word and returns MOBOCMF_OK or MOBOCMF_NOT_PD (pivot in *pivot). */
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream);
 

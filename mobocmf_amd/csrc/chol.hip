@@ -7,6 +7,7 @@
 // blocked triangular inverse).  The trailing update A22 -= L21 L21^T runs on the f64 MFMA.
 // Reference behaviour replaced: gpytorch psd_safe_cholesky(K_mm) -> torch.linalg.cholesky_ex.
 #include "common.h"
+#include <atomic>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -139,6 +140,132 @@ __global__ __launch_bounds__(128) void potrf_panel2_kernel(double* A, int64_t ld
     } else {
 #pragma unroll
         for (int c = 0; c < NB; ++c) prow[c] = v[c + P2_LAG];
+    }
+}
+
+// ---- Four columns per hand-over (potrf_panel4_kernel).  The two-role scheme of potrf_panel2_kernel with the elimination
+// advancing FOUR columns per iteration: the 4 x 4 pivot block is broadcast out of wavefront 0's registers, factorised
+// redundantly in every lane (T, reciprocal diagonal), published, and each lane -- of either role -- turns its four entries
+// v[i..i+3] into the four multipliers m = v T^-T by forward substitution and subtracts m L[k][i..i+3]^T from the columns
+// k > i + 3.  Same flops and LDS traffic as one column at a time, but ONE publish / barrier / read-back round trip per four
+// columns instead of four: the panel is bound by that round trip (~1000 cycles per column with one column per round).
+// Wavefront 1 lags ONE iteration (four columns) behind; as in potrf_panel2_kernel both roles are the same straight-line
+// code on shifted registers (v[c + 4]) and shifted LDS pointers, idle iterations run on zero padding.
+#define P4_LAG 4
+#define P4_STEPS (NB / 4)
+__global__ __launch_bounds__(128) void potrf_panel4_kernel(double* A, int64_t ld, int jb, double* Dinv, double* Ld,
+                                                           InfoZ infoz, int64_t zs) {
+    __shared__ __attribute__((aligned(16))) double LTp[NB + 2 * P4_LAG][NB];      // columns -4 .. NB + 4 of the image [col][row]
+    __shared__ __attribute__((aligned(16))) double Tp[P4_STEPS + 2][16];          // steps -1 .. 16: T10 T20 T21 T30 T31 T32 r0 r1 r2 r3
+    __shared__ __attribute__((aligned(16))) double sinkT[16];
+    __shared__ __attribute__((aligned(16))) double sinkcol[4 * NB + 96];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar role
+    const int bi = blockIdx.x;
+    A += blockIdx.y * zs; Dinv += blockIdx.y * zs; Ld += blockIdx.y * zs;      // layer batching
+    int32_t* info = infoz.p[blockIdx.y];
+    const int64_t j0 = (int64_t)jb * NB;
+    const int lag = wave * P4_LAG;
+    double (*LT)[NB] = LTp + P4_LAG;
+    for (int e = threadIdx.x; e < P4_LAG * NB; e += 128) { (&LTp[0][0])[e] = 0.0; (&LT[NB][0])[e] = 0.0; }
+    if (threadIdx.x < 16) { Tp[0][threadIdx.x] = 0.0; Tp[P4_STEPS + 1][threadIdx.x] = 0.0; }
+    double v[NB + P4_LAG];
+    double* prow = A + (j0 + (int64_t)bi * NB + lane) * ld + j0;      // wavefront 1: its block's row
+    {
+        const bool ident = wave == 1 && bi == 0;
+        const double* src = wave == 0 ? A + (j0 + lane) * ld + j0 : prow;
+#pragma unroll
+        for (int c = 0; c < NB + P4_LAG; ++c) v[c] = 0.0;
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) v[c] = src[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) v[c + P4_LAG] = ident ? (c == lane ? 1.0 : 0.0) : src[c];
+        }
+    }
+    const double* LTw = &LT[0][0] - lag * NB - lag;      // LTw[c*NB + k] = LT[c - lag][k - lag]
+    const double* Tw = &Tp[1][0] - (lag / 4) * 16;       // Tw[16*it + e]: step it - lag/4
+    double* pubcol = wave == 0 ? &LT[0][0] + lane : sinkcol + lane;      // + c*NB for wavefront 0 (stride 0 rows for the sink)
+    const int pubstride = wave == 0 ? NB : 0;
+    int fail = 0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < P4_STEPS + 1; ++it) {
+        const int i = 4 * it;
+        // ---- the pivot block out of wavefront 0's registers (wavefront 1 computes on its own numbers and discards the result)
+        const int l0 = i & 63, l1 = (i + 1) & 63, l2 = (i + 2) & 63, l3 = (i + 3) & 63;
+        const double p00 = bcast(v[i], l0);
+        const double p10 = bcast(v[i], l1), p11 = bcast(v[i + 1], l1);
+        const double p20 = bcast(v[i], l2), p21 = bcast(v[i + 1], l2), p22 = bcast(v[i + 2], l2);
+        const double p30 = bcast(v[i], l3), p31 = bcast(v[i + 1], l3), p32 = bcast(v[i + 2], l3), p33 = bcast(v[i + 3], l3);
+        const double r0 = rsqrt_nr(p00);
+        const double T10 = p10 * r0, T20 = p20 * r0, T30 = p30 * r0;
+        const double q11 = __builtin_fma(-T10, T10, p11);
+        const double r1 = rsqrt_nr(q11);
+        const double T21 = __builtin_fma(-T20, T10, p21) * r1, T31 = __builtin_fma(-T30, T10, p31) * r1;
+        const double q22 = __builtin_fma(-T21, T21, __builtin_fma(-T20, T20, p22));
+        const double r2 = rsqrt_nr(q22);
+        const double T32 = __builtin_fma(-T31, T21, __builtin_fma(-T30, T20, p32)) * r2;
+        const double q33 = __builtin_fma(-T32, T32, __builtin_fma(-T31, T31, __builtin_fma(-T30, T30, p33)));
+        const double r3 = rsqrt_nr(q33);
+        if (it < P4_STEPS) {
+            int f = 0;
+            f = !(q33 > 0.0) ? i + 4 : f;
+            f = !(q22 > 0.0) ? i + 3 : f;
+            f = !(q11 > 0.0) ? i + 2 : f;
+            f = !(p00 > 0.0) ? i + 1 : f;
+            fail = (fail == 0) ? f : fail;
+        }
+        {   // published branch-free (a basic block inside this loop makes LLVM sink the updates: see potrf_panel2_kernel):
+            // lane e < 10 stores entry e, every other lane stores into its own slot of the sink
+            double* tw = (wave == 0 && it < P4_STEPS) ? &Tp[1 + it][0] : sinkT;
+            double tv = T10;
+            tv = lane == 1 ? T20 : tv; tv = lane == 2 ? T21 : tv; tv = lane == 3 ? T30 : tv; tv = lane == 4 ? T31 : tv;
+            tv = lane == 5 ? T32 : tv; tv = lane == 6 ? r0 : tv; tv = lane == 7 ? r1 : tv; tv = lane == 8 ? r2 : tv;
+            tv = lane == 9 ? r3 : tv;
+            double* dst = lane < 10 ? tw + lane : sinkcol + 16 + lane;
+            *dst = tv;
+        }
+        // ---- both roles: the step's T from LDS (wavefront 0 reads back what it has just published)
+        const double* t = Tw + 16 * it;
+        const double a10 = t[0], a20 = t[1], a21 = t[2], a30 = t[3], a31 = t[4], a32 = t[5];
+        const double s0 = t[6], s1 = t[7], s2 = t[8], s3 = t[9];
+        const double m0 = v[i] * s0;
+        const double m1 = __builtin_fma(-m0, a10, v[i + 1]) * s1;
+        const double m2 = __builtin_fma(-m1, a21, __builtin_fma(-m0, a20, v[i + 2])) * s2;
+        const double m3 = __builtin_fma(-m2, a32, __builtin_fma(-m1, a31, __builtin_fma(-m0, a30, v[i + 3]))) * s3;
+        v[i] = m0; v[i + 1] = m1; v[i + 2] = m2; v[i + 3] = m3;
+        pubcol[(i + 0) * pubstride] = lane >= i + 0 ? m0 : 0.0;
+        pubcol[(i + 1) * pubstride] = lane >= i + 1 ? m1 : 0.0;
+        pubcol[(i + 2) * pubstride] = lane >= i + 2 ? m2 : 0.0;
+        pubcol[(i + 3) * pubstride] = lane >= i + 3 ? m3 : 0.0;
+#pragma unroll
+        for (int k = i + 4; k + 1 < NB + P4_LAG; k += 2) {
+            const v2f64c c0 = *(const v2f64c*)&LTw[(i + 0) * NB + k];
+            const v2f64c c1 = *(const v2f64c*)&LTw[(i + 1) * NB + k];
+            const v2f64c c2 = *(const v2f64c*)&LTw[(i + 2) * NB + k];
+            const v2f64c c3 = *(const v2f64c*)&LTw[(i + 3) * NB + k];
+            v[k] -= m0 * c0[0] + m1 * c1[0] + m2 * c2[0] + m3 * c3[0];
+            v[k + 1] -= m0 * c0[1] + m1 * c1[1] + m2 * c2[1] + m3 * c3[1];
+        }
+        __syncthreads();          // this iteration's T and columns of L are in LDS for wavefront 1's next iteration
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wave == 0) {
+        if (bi == 0) {
+            double* wrow = Ld + (int64_t)jb * NB * NB + lane * NB;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) wrow[c] = (c <= lane) ? v[c] : 0.0;
+            if (lane == 0 && (jb == 0 || (fail && *info == 0))) *info = fail ? (int32_t)(j0 + fail) : 0;
+        }
+    } else if (bi == 0) {      // v[k + lag] = L^-T[lane][k] = L^-1[k][lane]: store transposed (one coalesced row per k)
+        double* inv = Dinv + (int64_t)jb * NB * NB;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) inv[k * NB + lane] = (k >= lane) ? v[k + P4_LAG] : 0.0;
+    } else {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) prow[c] = v[c + P4_LAG];
     }
 }
 
@@ -350,6 +477,14 @@ __global__ void identity_blocks_kernel(double* Dinv, double* Ld, int b0, int b1,
     Ld[(int64_t)b0 * NB * NB + idx] = v;
 }
 
+// columns per hand-over of the 64-wide panel kernel: 4 (potrf_panel4_kernel, default) or 1 (potrf_panel2_kernel); A/B knob
+static std::atomic<int> g_potrf_cols{4};
+extern "C" int mobocmf_set_potrf_cols(int32_t c) {
+    if (c != 1 && c != 4) return MOBOCMF_BAD_ARG;
+    g_potrf_cols.store(c, std::memory_order_relaxed);
+    return MOBOCMF_OK;
+}
+
 // Dinv and Ld: (Mp/64) x 64 x 64 doubles each.  M = real order: rows/columns >= M of A are identity padding, which the
 // factorisation leaves alone -- a 16-point problem padded to 128 costs 16 elimination steps, not 128.
 int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
@@ -364,7 +499,9 @@ int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* L
         nact = nact >= NB ? NB : (nact + 15) & ~15;
         const dim3 grid(nreal - jb, nz);          // blocks below the real rows are zero in these columns and stay zero
         if (nact == 16) hipLaunchKernelGGL(potrf_panel_pad_kernel<16>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
-        else hipLaunchKernelGGL(potrf_panel2_kernel, grid, dim3(128), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
+        else if (g_potrf_cols.load(std::memory_order_relaxed) == 1)
+            hipLaunchKernelGGL(potrf_panel2_kernel, grid, dim3(128), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
+        else hipLaunchKernelGGL(potrf_panel4_kernel, grid, dim3(128), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
         int nt = nreal - jb - 1;
         if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt, nz), dim3(256), 0, s, A, ld, jb, zs);
     }

@@ -953,6 +953,11 @@ def set_tile_rows(rows=0, pair_mode=0):
     _lib.check(_lib.load().mobocmf_set_tile_rows(int(rows), int(pair_mode)), "mobocmf_set_tile_rows")
 
 
+def set_potrf_cols(cols=4):
+    """Columns per hand-over of the Cholesky panel kernel: 4 (default) or 1 (mobocmf_set_potrf_cols)."""
+    _lib.check(_lib.load().mobocmf_set_potrf_cols(int(cols)), "mobocmf_set_potrf_cols")
+
+
 def gemm_f64_epilogue(A, B, C, tri, epi, alpha=1.0, stream_out=False, colsq_part=None, coldot_part=None, avec=None,
                       bscale=None, gmu=None, cgv=None, Aaux=None, rowdot_part=None):
     """The GEMM with the epilogue the layer launches it with (mobocmf_gemm_f64_epilogue): tests and per-variant timing."""

@@ -28,7 +28,10 @@ def test_tiny_and_ragged_shapes(kind, d, M, nbase, xdiv):
     fg, zfg, mg, LSg = g(f), g(zf), g(m), g(L_S)
     hg = _pack(kind, {k: v.detach() for k, v in hyp.items()}).to(DEV).requires_grad_(True)
     mean, var, kl = F.layer_forward(x.detach().to(DEV), fg, Zx.to(DEV), zfg, hg, mg, LSg, kind, xdiv=xdiv)
-    _close(mean, mean_o, 1e-9, "mean")
+    # 5e-9: K_mm of these random inducing sets has cond ~ 1e7 .. 1e9; two backward-stable Cholesky factorisations (this
+    # one, the oracle's LAPACK one) then differ by cond * eps in a = L^-1 m -- the 4-column and the 1-column panel kernels
+    # give 1.1e-9 and 0.8e-9 on the (0, 3, 80, 64, 1) case at equal backward error 2e-16 (profiles/r03_chol_accuracy.txt)
+    _close(mean, mean_o, 5e-9, "mean")
     _close(var, var_o, 1e-8, "var")
     _close(kl, kl_o, 1e-9, "kl")
     (mean.sum() + 0.5 * var.sum() + kl).backward()

@@ -22,6 +22,9 @@ cp(F + "/C5_step_timeline.txt", "C5_step_timeline.txt")
 cp(F + "/gemm_variants_kernel_summary.md", "gemm_variants_isolated_rocprof_summary.md")
 cp(glob.glob(F + "/rk/*/*kernel_stats.csv")[0], "gemm_variants_isolated_kernel_stats.csv")
 cp(F + "/pmc_gemm.json", "pmc_gemm.json")
+for name in ("instep_clock.md", "tile_sweep.txt", "C2_step_timeline.txt", "C1_step_timeline.txt"):
+    if os.path.exists(F + "/" + name):
+        cp(F + "/" + name, name)
 if os.path.exists(F + "/gemm_stamps.txt"):
     open(os.path.join(P, R + "_gemm_stamps.txt"), "w").write(clean(F + "/gemm_stamps.txt"))
 if os.path.exists(F + "/gemm_instep_vs_isolated.txt"):
