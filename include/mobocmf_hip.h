@@ -183,6 +183,12 @@ int mobocmf_rff_eval(int32_t kind, int32_t d, int32_t F, int64_t n, const double
 /* f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n],  n < n_out  (mfdgp_hidden_layer.py:263-274). */
 int mobocmf_propagate_forward(const double* mean, const double* var, const double* eps, double* f_out, int64_t n_out,
                               int32_t div, mobocmf_stream_t stream);
+/* The same with eps ~ N(0, 1) drawn inside the launch (the reference draws it with torch.normal, mfdgp_hidden_layer.py:274):
+ * counter-based Philox4x32-10 keyed by (seed, call counter, row index), Box-Muller in float64.  rng_state = 3 device int64
+ * {seed, calls, ticket} owned by the caller (ticket zero before the first call; every call leaves it zero and advances
+ * `calls` by one, so a captured step replays with fresh eps).  eps_out[n_out] receives the draw (the backward pass needs it). */
+int mobocmf_propagate_rng_forward(const double* mean, const double* var, int64_t* rng_state, double* f_out, double* eps_out,
+                                  int64_t n_out, int32_t div, mobocmf_stream_t stream);
 /* g_mean[n_out/div], g_var[n_out/div] from g_f[n_out]. */
 int mobocmf_propagate_backward(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
                                int64_t n_out, int32_t div, mobocmf_stream_t stream);

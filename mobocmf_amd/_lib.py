@@ -48,6 +48,7 @@ SYMBOLS = {
     "mobocmf_predictive_covariance_workspace_bytes": [ctypes.POINTER(LayerDesc), ctypes.POINTER(_SZ)],
     "mobocmf_predictive_covariance": [ctypes.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _I64, _P, _SZ, _P, _SZ, _P],
     "mobocmf_propagate_forward": [_P, _P, _P, _P, _I64, _I32, _P],
+    "mobocmf_propagate_rng_forward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_propagate_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_elbo_data_forward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _SZ, _P],
     "mobocmf_elbo_data_backward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _P, _P, _P, _SZ, _P],

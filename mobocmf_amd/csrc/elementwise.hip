@@ -600,6 +600,50 @@ __global__ void propagate_fwd_kernel(const double* mean, const double* var, cons
     int64_t b = i / div;
     f[i] = mean[b] + sqrt(var[b]) * eps[i];
 }
+// ---- the same with eps drawn INSIDE the launch (mfdgp_hidden_layer.py:272-274 draws it with torch.normal): counter-based
+// Philox4x32-10 keyed by (seed, call counter, row) + Box-Muller in float64.  rng_state = {seed, calls, ticket} (device int64
+// x 3, owned by the layer): every block reads `calls`, the block that takes the last ticket advances it -- a captured step
+// replays with fresh eps and without torch's generator (whose graph support costs two fill launches per replay and one
+// launch for the draw).  eps is written out for the backward pass.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t call, uint64_t idx) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)call, (uint32_t)(call >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    // two uniforms in (0, 1) with 53 random bits each, then Box-Muller (the cosine branch)
+    const double u1 = ((double)(((uint64_t)(r[0] >> 5) << 26) | (uint64_t)(r[1] >> 6)) + 0.5) * 1.1102230246251565e-16;
+    const double u2 = ((double)(((uint64_t)(r[2] >> 5) << 26) | (uint64_t)(r[3] >> 6)) + 0.5) * 1.1102230246251565e-16;
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+__global__ void propagate_rng_fwd_kernel(const double* mean, const double* var, int64_t* rng_state, double* f, double* eps_out,
+                                         int64_t n, int div) {
+    const uint64_t seed = (uint64_t)rng_state[0], call = (uint64_t)__atomic_load_n(&rng_state[1], __ATOMIC_RELAXED);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int64_t b = i / div;
+        const double e = philox_normal(seed, call, (uint64_t)i);
+        eps_out[i] = e;
+        f[i] = mean[b] + sqrt(var[b]) * e;
+    }
+    __syncthreads();      // every thread of the block has read `calls`
+    if (threadIdx.x == 0) {
+        const unsigned long long t = atomicAdd((unsigned long long*)&rng_state[2], 1ull);
+        if (t == (unsigned long long)gridDim.x - 1) {      // every block has read `calls`: advance it for the next launch
+            __atomic_store_n(&rng_state[2], (int64_t)0, __ATOMIC_RELAXED);
+            __atomic_store_n(&rng_state[1], (int64_t)(call + 1), __ATOMIC_RELAXED);
+        }
+    }
+}
 __global__ void propagate_bwd_kernel(const double* var, const double* eps, const double* gf, double* gmean, double* gvar,
                                      int64_t nbase, int div) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1026,6 +1070,14 @@ int mobocmf_propagate_forward(const double* mean, const double* var, const doubl
     if (n_out < 0 || div < 1) return MOBOCMF_BAD_ARG;
     if (n_out == 0) return MOBOCMF_OK;
     hipLaunchKernelGGL(propagate_fwd_kernel, GRID1(n_out), 0, (hipStream_t)stream, mean, var, eps, f_out, n_out, div);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_propagate_rng_forward(const double* mean, const double* var, int64_t* rng_state, double* f_out, double* eps_out,
+                                  int64_t n_out, int32_t div, mobocmf_stream_t stream) {
+    if (n_out < 1 || div < 1 || !mean || !var || !rng_state || !f_out || !eps_out) return MOBOCMF_BAD_ARG;
+    hipLaunchKernelGGL(propagate_rng_fwd_kernel, GRID1(n_out), 0, (hipStream_t)stream, mean, var, rng_state, f_out, eps_out,
+                       n_out, div);
     return CHECK_LAUNCH();
 }
 

@@ -632,6 +632,38 @@ class _PropagateFn(torch.autograd.Function):
         return gm, gv, None, None
 
 
+class _PropagateRngFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, var, rng_state, n_out, div):
+        lib = _lib.require_device()
+        mean, var = _prep(mean.reshape(-1)), _prep(var.reshape(-1))
+        if mean.numel() * div != n_out or rng_state.dtype != torch.int64 or rng_state.numel() != 3 or not rng_state.is_cuda:
+            raise _lib.MobocmfError("propagate_rng: n_out must be mean.numel()*div and rng_state three int64 on the GPU")
+        out, eps = _empty(n_out, device=mean.device), _empty(n_out, device=mean.device)
+        _lib.check(lib.mobocmf_propagate_rng_forward(_ptr(mean), _ptr(var), _ptr(rng_state), _ptr(out), _ptr(eps), n_out, div,
+                                                     _stream()), "mobocmf_propagate_rng_forward")
+        ctx.save_for_backward(var, eps)
+        ctx.div = div
+        ctx.mark_non_differentiable(eps)
+        return out, eps
+
+    @staticmethod
+    def backward(ctx, g, _g_eps):
+        lib = _lib.require_device()
+        var, eps = ctx.saved_tensors
+        g = _prep(g)
+        gm, gv = _empty_like(var), _empty_like(var)
+        _lib.check(lib.mobocmf_propagate_backward(_ptr(var), _ptr(eps), _ptr(g), _ptr(gm), _ptr(gv), eps.numel(),
+                                                  ctx.div, _stream()), "mobocmf_propagate_backward")
+        return gm, gv, None, None, None
+
+
+def propagate_rng(mean, var, rng_state, n_out, div=1):
+    """f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n] with eps ~ N(0, 1) drawn inside the launch (Philox4x32-10 keyed by
+    rng_state = int64 [seed, calls, ticket] on the device; every call advances ``calls``).  Returns (f~, eps)."""
+    return _PropagateRngFn.apply(mean, var, rng_state, int(n_out), int(div))
+
+
 def propagate(mean, var, eps, div=1):
     """f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n]   (mfdgp_hidden_layer.py:263-274)."""
     return _PropagateFn.apply(mean, var, eps, div)

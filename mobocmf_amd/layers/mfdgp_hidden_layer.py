@@ -233,6 +233,22 @@ class MFDGPHiddenLayer(nn.Module):
     def eval_mode(self):
         self._eval_mode = True
 
+    def __getstate__(self):
+        # a copy / unpickled layer draws its own seed on first use (two copies must not replay one eps stream)
+        state = self.__dict__.copy()
+        state.pop("_rng_state", None)
+        return state
+
+    def _rng(self, device):
+        """int64 [seed, calls, ticket] of this layer's training-sample stream on ``device`` (functional.propagate_rng): the
+        seed is drawn once from torch's global CPU generator (torch.manual_seed governs it), the counters live on the device."""
+        st = self.__dict__.get("_rng_state")
+        if st is None or st.device != device:
+            seed = int(torch.randint(1, 2 ** 62, (), dtype=torch.int64))
+            st = torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)
+            self.__dict__["_rng_state"] = st
+        return st
+
     # ------------------------------------------------------------------ the hot path
     def _moments(self, x, f, xdiv, want_dx):
         """(mean, var, kl) for layer rows X~ = [x[n/xdiv], f[n]] through the HIP library."""
@@ -367,9 +383,13 @@ class MFDGPHiddenLayer(nn.Module):
             elif eps is not None:
                 e = eps.reshape(-1)
             else:
-                # reference draws float32 N(0,1) on the CPU RNG; here float64 on the device RNG
-                e = torch.randn(n_rows, dtype=mean_p.dtype, device=mean_p.device)
-            f = F.propagate(mean_p, var_p, e, fdiv)
+                e = None
+            if e is None:
+                # the reference draws float32 N(0,1) on the CPU RNG; here float64, inside the propagation launch
+                # (counter-based Philox keyed by this layer's seed + call counter: capturable, fresh at every replay)
+                f, _ = F.propagate_rng(mean_p, var_p, self._rng(mean_p.device), n_rows, fdiv)
+            else:
+                f = F.propagate(mean_p, var_p, e, fdiv)
         else:
             f = inp.reshape(-1)
             if f.numel() != n_rows:

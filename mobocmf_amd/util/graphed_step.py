@@ -40,15 +40,16 @@ class GraphedELBOStep:
         self.fixed_eps = fixed_eps     # list (eps[l] for layer l >= 1) reused every step: deterministic tests
         model.set_check_pd(False)      # no host sync inside the step; call check() when a verdict is needed
         model.clear_kl_cache()         # an older graph would pin AccumulateGrad nodes to another stream (capture-illegal)
+        for layer in model._layers():  # the layers' eps streams get their seeds here, in a fixed order, eager or captured
+            layer._rng(x.device)
         if use_graph:
             self._capture(warmup)
 
     def _fwd_bwd(self):
         self.optimizer.zero_grad(set_to_none=True)
-        n = self.x.shape[0] * self.S
-        eps = self.fixed_eps if self.fixed_eps is not None else \
-            [None] + [torch.randn(n, dtype=torch.float64, device=self.x.device) for _ in range(1, self.L)]
-        out = self.model(self.x, eps=eps)
+        # eps: explicit (deterministic tests) or drawn inside the layers' propagation launches (no torch generator in the
+        # captured graph: its replay support costs two fill launches per replay, the draw a third)
+        out = self.model(self.x, eps=self.fixed_eps)
         res = self.elbo(out, self.y.T, self.fid)
         # d(-ELBO): the sign goes in as the upstream gradient (no negation node, no ones fill, no negation backward)
         res[0].backward(gradient=self._minus_one)
@@ -89,6 +90,9 @@ class GraphedELBOStep:
         with torch.cuda.stream(self.stream):
             # the side-stream warm-up also sizes the per-stream scratch arena and the optimizer state
             snapshot = [p.detach().clone() for p in self.model.parameters()]
+            # the layers' eps streams (seed, call counter): warm-up draws must not count either -- the first replay then
+            # draws exactly what the first eager step would have drawn
+            self._rng_snapshot = [(l, l._rng(self.x.device).clone()) for l in self.model._layers()]
             for _ in range(warmup):
                 self._eager()
             self._reset_after_warmup(snapshot)
@@ -109,6 +113,8 @@ class GraphedELBOStep:
         with torch.no_grad():           # warm-up steps must not count as training
             for p, s0 in zip(self.model.parameters(), snapshot):
                 p.copy_(s0)
+            for layer, st in getattr(self, "_rng_snapshot", []):
+                layer._rng(st.device).copy_(st)
             for st in self.optimizer.state.values():
                 for v in st.values():
                     if torch.is_tensor(v):
@@ -218,6 +224,8 @@ class GraphedConditionedStep(GraphedELBOStep):
         self.x = fitter.pareto_set            # (only its device is used by the base class)
         self.model.set_check_pd(False)
         self.model.clear_kl_cache()
+        for layer in self.model._layers():
+            layer._rng(dev)
         if use_graph:
             self._capture(warmup)
 

@@ -110,11 +110,13 @@ def test_graphed_conditioned_step_equals_eager():
             ls.append(float(step.loss))
         step.check()
         traj.append(ls)
-    # eps differs between the runs (graph-safe Philox offsets), so only the first-order behaviour is compared: both
-    # descend from the same start within sampling noise
+    # eps is drawn inside the layers' propagation launches from (seed, call counter): the seeds of both runs come from the
+    # same torch.manual_seed state and the captured step's warm-up draws are rolled back, so the replayed trajectory IS the
+    # eager one
     assert all(np.isfinite(v) for v in traj[0] + traj[1])
     assert traj[0][-1] < traj[0][0] and traj[1][-1] < traj[1][0]
-    assert abs(traj[0][0] - traj[1][0]) < 0.2 * abs(traj[0][0])
+    for a, b in zip(*traj):
+        assert abs(a - b) < 1e-9 * abs(a), (traj[0], traj[1])
 
 
 def test_jesmoc_next_point_flow():

@@ -208,3 +208,43 @@ def test_softplus_pack_matches_torch():
     for a, b in zip(raws, ref_in):
         assert a.grad.shape == b.grad.shape and rel(a.grad.reshape(-1), b.grad.reshape(-1)) < 1e-14
 
+
+
+def test_propagate_rng_draws_standard_normals_and_advances():
+    """mobocmf_propagate_rng_forward (eps of mfdgp_hidden_layer.py:272-274 drawn inside the propagation launch, Philox4x32-10 +
+    Box-Muller): f = mean + sqrt(var) eps holds exactly for the returned eps; eps has the moments of N(0, 1) and no serial
+    correlation; a call advances the counter (fresh draw), the same (seed, calls) reproduces the draw; gradients equal
+    those of the explicit-eps entry point."""
+    from mobocmf_amd import functional as F
+    nb, div = 250_000, 8
+    n = nb * div
+    g = torch.Generator(device=DEV).manual_seed(1)
+    mean = torch.randn(nb, dtype=torch.float64, device=DEV, generator=g).requires_grad_(True)
+    var = (torch.rand(nb, dtype=torch.float64, device=DEV, generator=g) + 0.1).requires_grad_(True)
+    st = torch.tensor([123456789, 0, 0], dtype=torch.int64, device=DEV)
+    f1, e1 = F.propagate_rng(mean, var, st, n, div)
+    assert st.tolist() == [123456789, 1, 0]
+    ref = mean.detach().repeat_interleave(div) + var.detach().sqrt().repeat_interleave(div) * e1
+    assert float((f1.detach() - ref).abs().max()) <= 1e-15 * float(ref.abs().max())      # (the kernel fuses the multiply-add)
+    e = e1.double()
+    m1, m2 = float(e.mean()), float(e.var())
+    skew, kurt = float((e ** 3).mean()), float((e ** 4).mean())
+    assert abs(m1) < 5.0 / n ** 0.5 and abs(m2 - 1.0) < 5.0 * (2.0 / n) ** 0.5
+    assert abs(skew) < 5.0 * (15.0 / n) ** 0.5 and abs(kurt - 3.0) < 5.0 * (96.0 / n) ** 0.5
+    assert abs(float((e[1:] * e[:-1]).mean())) < 5.0 / n ** 0.5            # neighbouring rows
+    assert abs(float((e[div:] * e[:-div]).mean())) < 5.0 / n ** 0.5        # neighbouring base rows
+    assert float(e.abs().max()) < 7.0 and float((e.abs() > 3.0).double().mean()) == pytest.approx(0.0027, abs=2e-4)
+    f2, e2 = F.propagate_rng(mean, var, st, n, div)                            # the next call: another draw
+    assert st.tolist() == [123456789, 2, 0] and abs(float((e1 * e2).mean())) < 5.0 / n ** 0.5 and not torch.equal(e1, e2)
+    st.copy_(torch.tensor([123456789, 0, 0]))                                  # same (seed, calls): the same draw
+    f3, e3 = F.propagate_rng(mean, var, st, n, div)
+    assert torch.equal(e3, e1) and torch.equal(f3, f1)
+    st2 = torch.tensor([987654321, 0, 0], dtype=torch.int64, device=DEV)       # another seed: another stream
+    _, e4 = F.propagate_rng(mean, var, st2, n, div)
+    assert abs(float((e1 * e4).mean())) < 5.0 / n ** 0.5
+    w = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    (f3 * w).sum().backward()
+    gm, gv = mean.grad.clone(), var.grad.clone()
+    mean.grad = var.grad = None
+    (F.propagate(mean, var, e1, div) * w).sum().backward()
+    assert torch.equal(mean.grad, gm) and torch.equal(var.grad, gv)
