@@ -368,6 +368,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = median")
     ap.add_argument("--tile-rows", type=int, default=0, help="A/B knob: tile height of the panel products (0 automatic, 64, 128)")
     ap.add_argument("--potrf-cols", type=int, default=0, help="A/B knob: columns per hand-over of the Cholesky panel kernel (4 | 1)")
+    ap.add_argument("--dense-backward", action="store_true",
+                    help="A/B knob: do not skip the column blocks of a layer backward whose upstream gradients are all zero")
     ap.add_argument("--launch", action="store_true", help="go through the rank launcher even for --gpus 1")
     args = ap.parse_args()
     if args.no_overlap:
@@ -401,6 +403,9 @@ def main():
     if args.tile_rows:
         from mobocmf_amd import functional as F_
         F_.set_tile_rows(args.tile_rows)
+    if args.dense_backward:
+        from mobocmf_amd import functional as F_
+        F_.set_sparse_backward(False)
     if args.potrf_cols:
         from mobocmf_amd import functional as F_
         F_.set_potrf_cols(args.potrf_cols)

@@ -338,6 +338,22 @@ int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, i
  * like mobocmf_set_tuning: size sweeps, tests, A/B timing. */
 int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode);
 
+/* Zero-gradient column blocks of the layer backward.  The backward of a layer is linear in its upstream gradients
+ * (g_mean, g_var), column by column of the N' side: a 128-column block in which both are exactly zero contributes exactly
+ * zero to every product of the backward (dA, the weighted syrk H, da, dK, the Gram backward).  The top layer of a
+ * multi-fidelity model is such a case by construction: the reference's ELBO scores each row at ITS fidelity only
+ * (variational_elbo_mf.py:33-38), so autograd hands the top layer zeros for every row of another fidelity -- and then
+ * multiplies them through (GPyTorch has no notion of it).  With on != 0 (the default) mobocmf_layer_backward /
+ * mobocmf_panels_backward find those blocks on the device (no host read) and leave them out; results are the same numbers
+ * (sums over fewer exact zeros).  on = 0: the dense backward, for A/B timing and the parity tests.  Process-wide. */
+int mobocmf_set_sparse_backward(int32_t on);
+
+/* Tests / tools: a DEVICE array of one int32 per 128 columns that mobocmf_gemm_f64 (column blocks of C: inactive blocks
+ * are left unwritten, their row-dot partials zeroed) and mobocmf_syrk_weighted_f64 (128-wide blocks of the contraction:
+ * inactive ones are left out) apply to their next launches; NULL (default) = dense.  The array must outlive those
+ * launches.  Process-wide. */
+int mobocmf_set_block_activity(const int32_t* act);
+
 /* The weighted symmetric rank-k update of the layer backward, H[Mr x Mr] = A diag(w) A^T with A [Mr x Kd] (k contiguous,
  * lda even) and w [Kd]: k-sliced over one round of resident workgroups into slabs (workspace), the slabs added and the
  * result written as the FULL symmetric matrix.  Both M x M contractions over N' of the reference's autograd backward

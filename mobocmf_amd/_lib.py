@@ -73,6 +73,8 @@ SYMBOLS = {
     "mobocmf_exact_gp_predict": [_I32, _I64, _P, _I64, _P, _P, _P, _P, _SZ, _P, _SZ, _P],
     "mobocmf_gemm_colstat_rows": [_I32, _I32, _I64, _I64, ctypes.POINTER(_I32)],
     "mobocmf_set_tile_rows": [_I32, _I32],
+    "mobocmf_set_sparse_backward": [_I32],
+    "mobocmf_set_block_activity": [_P],
     "mobocmf_set_potrf_cols": [_I32],
     "mobocmf_syrk_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ)],
     "mobocmf_syrk_weighted_f64": [_I32, _I64, _P, _I64, _P, _P, _P, _I64, _P],

@@ -24,7 +24,7 @@ int launch_moments_finish(const double* qpart, const double* mupart, const doubl
                           double* mean, double* var, int32_t* zero_word, hipStream_t s);
 int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
                             const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
-                            double* gv, double* gv2, double* cgv, int32_t* nclamped, int zeroed, hipStream_t s);
+                            double* gv, double* gv2, double* cgv, int32_t* nclamped, int zeroed, int32_t* blkact, hipStream_t s);
 int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab, int nslab_diag, double* out, int Mp, const int32_t* flag,
                             const double* fallback, hipStream_t s);
 int launch_reduce_slabs_sym2(const double* slabs, const double* slabs2, int64_t slab_stride, int nslab, int nslab_diag,
@@ -90,6 +90,10 @@ static inline void probe_at(int i, int64_t N, hipStream_t s) {
 // CU and the triangular operand resolved in 64-row blocks).  0 = automatic: launch_gemm picks it from the shape
 // (gemm_f64.hip tile_rows); 64 / 128 force it for every panel product (mobocmf_set_tile_rows: sweeps, tests, A/B timing).
 static std::atomic<int> g_tile_rows{0}, g_pair_mode{0};
+static std::atomic<int> g_sparse_bwd{1};      // skip column blocks whose upstream gradients are all zero (mobocmf_set_sparse_backward)
+// the standalone product entry points (mobocmf_gemm_f64 / mobocmf_syrk_weighted_f64) take this device array as their
+// column-block / K-block activity (mobocmf_set_block_activity; NULL = dense): how the tests drive the skipping directly
+static std::atomic<const int32_t*> g_block_activity{nullptr};
 static int panel_tile_rows(int, int64_t) { return g_tile_rows.load(std::memory_order_relaxed); }
 
 #define TRY(x)              \
@@ -166,10 +170,11 @@ int64_t syrk_slab_elems(int Mp, int64_t Np) {
 }
 // H (full, symmetric) = A diag(w) A^T; skip (device word, may be NULL): *skip == 0 -> nothing is computed and H = fallback
 int weighted_syrk(const double* A, int64_t lda, const double* w, int Mp, int64_t Np, double* slabs, double* H,
-                  const int32_t* skip, const double* fallback, hipStream_t s) {
+                  const int32_t* skip, const double* fallback, const int32_t* kact, hipStream_t s) {
     const int64_t mm = (int64_t)Mp * Mp;
     GemmArgs ga = gemm_args(A, lda, A, lda, slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
     ga.bscale = w; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm; ga.skip_if_zero = skip;
+    ga.kact = kact;      // w is zero throughout the inactive 128-column blocks: the contraction leaves them out
     int sD = 0;
     const int sF = syrk_splitk(Mp, Np, &sD);
     const int nsl = gemm_nt_slabs(ga, sF);      // 1: a small problem goes through whole, no k-slicing
@@ -181,7 +186,7 @@ int weighted_syrk(const double* A, int64_t lda, const double* w, int Mp, int64_t
 // H = A diag(w) A^T and Hc = A diag(w2) A^T, where Hc differs from H only if *flag != 0 (w2 = w except in clamped columns):
 // ONE dual launch (the twin half of the grid exits at once when the flag is zero) + ONE reduction writing both.
 int weighted_syrk_pair(const double* A, int64_t lda, const double* w, const double* w2, int Mp, int64_t Np, double* slabs,
-                       double* slabs2, double* H, double* Hc, const int32_t* flag, hipStream_t s) {
+                       double* slabs2, double* H, double* Hc, const int32_t* flag, const int32_t* kact, hipStream_t s) {
     const int64_t mm = (int64_t)Mp * Mp;
     GemmArgs ga = gemm_args(A, lda, A, lda, slabs, Mp, Mp, Mp, Np, TRI_NONE, 1.0);
     ga.bscale = w; ga.lower_out = 1; ga.sym_out = 1; ga.slab_stride = mm;
@@ -189,11 +194,11 @@ int weighted_syrk_pair(const double* A, int64_t lda, const double* w, const doub
     const int sF = syrk_splitk(Mp, Np, &sD);
     const int nsl = gemm_nt_slabs(ga, sF);
     if (nsl <= 1) {      // small problem (no k-slicing): the plain pair of launches
-        TRY(weighted_syrk(A, lda, w, Mp, Np, slabs, H, nullptr, nullptr, s));
-        return weighted_syrk(A, lda, w2, Mp, Np, slabs, Hc, flag, H, s);
+        TRY(weighted_syrk(A, lda, w, Mp, Np, slabs, H, nullptr, nullptr, kact, s));
+        return weighted_syrk(A, lda, w2, Mp, Np, slabs, Hc, flag, H, kact, s);
     }
     ga.splitk_diag = sD;
-    ga.dual_flag = flag; ga.bscale2 = w2; ga.C2 = slabs2;
+    ga.dual_flag = flag; ga.bscale2 = w2; ga.C2 = slabs2; ga.kact = kact;
     TRY(launch_gemm(ga, true, nsl, s));
     return launch_reduce_slabs_sym2(slabs, slabs2, mm, nsl, sD > 0 ? sD : nsl, H, Hc, Mp, flag, s);
 }
@@ -250,7 +255,7 @@ struct ChainWs {
 // forward SCRATCH, not in the state kept for backward -- one M x N' panel less per layer (268 MB at C3, 8.6 GB at C4)
 struct PanelSaved { double *A, *C, *knn, *q, *r, *varraw; };
 struct PanelFwd { double *K, *qpart, *mupart, *rpart; };
-struct PanelBwd { double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *slabs2, *dapart, *hyp_part, *df_part, *dzf_part, *dx_part; int64_t slab_elems; };
+struct PanelBwd { double *gmu, *gv, *gv2, *cgv, *dA, *dK, *slabs, *slabs2, *dapart, *hyp_part, *df_part, *dzf_part, *dx_part; int64_t slab_elems; int32_t* blkact; };
 
 void carve_chain_state(Bump& b, const Dims& D, ChainWs& S) {
     int64_t mm = (int64_t)D.Mp * D.Mp;
@@ -293,6 +298,7 @@ void carve_chain_bwd(Bump& b, const Dims& D, ChainWs& S) {
 void carve_panel_bwd(Bump& b, const Dims& D, const mobocmf_layer_desc* d, PanelBwd& S) {
     int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
     S.gmu = b.take(D.Np); S.gv = b.take(D.Np); S.gv2 = b.take(D.Np); S.cgv = b.take(D.Np);
+    S.blkact = (int32_t*)b.take((D.Np / TILE + 1) / 2);      // one word per 128 columns (moments_bwd_prep)
     S.dA = b.take(mn); S.dK = b.take(mn);
     S.slab_elems = syrk_slab_elems(D.Mp, D.Np);
     S.slabs = b.take(S.slab_elems);
@@ -447,14 +453,19 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     const int64_t Np = D.Np, mm = (int64_t)Mp * Mp;
     int32_t* nclamped = (int32_t*)c.flag;
     double* Hc = desc->branch != 0 ? c.H : c.Hc;
+    // act: one word per 128 columns, zero where every upstream gradient of the block is exactly zero (the top layer of a
+    // multi-fidelity model only gets gradient from the rows scored at ITS fidelity): those blocks' shares of dA, H, da,
+    // dK and the Gram backward are exactly zero and are not computed
+    const int32_t* act = g_sparse_bwd.load(std::memory_order_relaxed) ? B.blkact : nullptr;
     TRY(launch_moments_bwd_prep(g_mean, g_var, P.knn, P.q, P.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
-                                B.gv2, B.cgv, nclamped, block_layout ? 1 : 0, s));
+                                B.gv2, B.cgv, nclamped, block_layout ? 1 : 0, (int32_t*)act, s));
     // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
     {
         GemmArgs ga = gemm_args(c.U, Mp, P.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
         ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = c.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = P.A;
         ga.Kreal = D.M;
         ga.rowdot_part = inputs_only ? nullptr : B.dapart;      // da = A gmu rides in the epilogue (it reads A anyway)
+        ga.colact = act;
         ga.rm = panel_tile_rows(Mp, Np);
         ga.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
         probe_at(3, D.N, s);
@@ -468,8 +479,8 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     // (skip_if_zero) when no column is clamped.
     if (!inputs_only) {
         probe_at(5, D.N, s);
-        if (desc->branch == 0) TRY(weighted_syrk_pair(P.A, Np, B.gv, B.cgv, Mp, Np, B.slabs, B.slabs2, c.H, Hc, nclamped, s));
-        else TRY(weighted_syrk(P.A, Np, B.gv, Mp, Np, B.slabs, c.H, nullptr, nullptr, s));
+        if (desc->branch == 0) TRY(weighted_syrk_pair(P.A, Np, B.gv, B.cgv, Mp, Np, B.slabs, B.slabs2, c.H, Hc, nclamped, act, s));
+        else TRY(weighted_syrk(P.A, Np, B.gv, Mp, Np, B.slabs, c.H, nullptr, nullptr, act, s));
         probe_at(6, D.N, s);
     }
     // dK = L^-T dA
@@ -478,6 +489,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
         ga.Kreal = D.M;
         ga.rm = panel_tile_rows(Mp, Np);
         ga.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
+        ga.colact = act;      // inactive column blocks of dK stay unwritten: the Gram backward below does not read them
         probe_at(7, D.N, s);
         TRY(launch_gemm(ga, false, 1, s));
         probe_at(8, D.N, s);
@@ -486,7 +498,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     GramArgs g = {};
     g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
     g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase;
-    g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv;
+    g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv; g.colact = act;
     g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
     TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
     probe_at(10, D.N, s);
@@ -1034,6 +1046,7 @@ int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, 
     g.bscale = epi == EPI_DA ? bscale : nullptr; g.gmu = gmu; g.cgv = cgv; g.Aaux = Aaux; g.rowdot_part = rowdot_part;
     g.rm = panel_tile_rows(Mr, Nc);
     g.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
+    g.colact = g_block_activity.load(std::memory_order_relaxed);
     return launch_gemm(g, false, 1, (hipStream_t)stream);
 }
 
@@ -1063,7 +1076,18 @@ int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t l
                               void* workspace, int64_t workspace_bytes, mobocmf_stream_t stream) {
     if (!A || !w || !H || !workspace || Mr <= 0 || Kd <= 0 || Mr % TILE || Kd % TILE || (lda & 1)) return MOBOCMF_BAD_ARG;
     if (workspace_bytes < syrk_slab_elems(Mr, Kd) * (int64_t)sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
-    return weighted_syrk(A, lda, w, Mr, Kd, (double*)workspace, H, nullptr, nullptr, (hipStream_t)stream);
+    return weighted_syrk(A, lda, w, Mr, Kd, (double*)workspace, H, nullptr, nullptr, g_block_activity.load(std::memory_order_relaxed),
+                         (hipStream_t)stream);
+}
+
+int mobocmf_set_sparse_backward(int32_t on) {
+    g_sparse_bwd.store(on ? 1 : 0, std::memory_order_relaxed);
+    return MOBOCMF_OK;
+}
+
+int mobocmf_set_block_activity(const int32_t* act) {
+    g_block_activity.store(act, std::memory_order_relaxed);
+    return MOBOCMF_OK;
 }
 
 int mobocmf_set_probe_events(void* const* events, int32_t n, int64_t Np) {

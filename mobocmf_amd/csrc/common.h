@@ -68,6 +68,14 @@ struct GemmArgs {
     const int32_t* dual_flag;
     const double* bscale2;
     double* C2;
+    // Column-block activity (one int32 per 128 columns of the N' side; moments_bwd_prep writes it): block j is inactive when
+    // every upstream gradient of its columns is exactly zero, i.e. the block's share of every backward product is exactly
+    // zero.  A B form (colact): an inactive column block of C is NOT computed (its tiles exit at once; an EPI_DA tile still
+    // zeroes its row-dot partials) -- consumers of C must not read those columns.  k-sliced A B^T form (kact): the
+    // contraction runs over the active 128-column blocks of K only (compacted in the kernel's prologue); the slices split
+    // the ACTIVE steps evenly.  NULL = dense.
+    const int32_t* colact;
+    const int32_t* kact;
     // epilogues
     int epi;
     double* colsq_part;    // EPI_COLSTATS: [2*Mr/TILE][Nc] partial column sums of C^2 (two wavefront rows per row block)
@@ -126,6 +134,7 @@ struct GramArgs {
     double* df_part;      // [gridDim.y][Np]        (kind 1)
     double* dzf_part;     // [gridDim.x][Mp]        (kind 1)
     double* dx_part;      // [gridDim.y][nbase*d]   (want_dx)
+    const int32_t* colact; // per 128 columns of G (GemmArgs.colact): inactive blocks of G were never written and count as zero
 };
 
 // ------------------------------------------------------------------ hyper-parameter packing

@@ -224,9 +224,10 @@ int launch_moments_finish(const double* qpart, const double* mupart, const doubl
 // backward prep: gmu (padded), gv = g_var * [varraw > min_var], gv2 = 2*gv, cgv = gv * [branch || knn - q > 0]
 __global__ void moments_bwd_prep_kernel(const double* g_mean, const double* g_var, const double* knn, const double* q,
                                         const double* varraw, int branch, double min_var, int64_t N, int64_t Np,
-                                        double* gmu, double* gv, double* gv2, double* cgv, int32_t* nclamped) {
+                                        double* gmu, double* gv, double* gv2, double* cgv, int32_t* nclamped, int32_t* blkact) {
+    // 256 threads = two 128-column blocks; Np is a multiple of 128
+    __shared__ int any_w[4];
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Np) return;
     double gm = 0.0, g = 0.0, c = 0.0;
     if (n < N) {
         gm = g_mean ? g_mean[n] : 0.0;
@@ -234,19 +235,33 @@ __global__ void moments_bwd_prep_kernel(const double* g_mean, const double* g_va
         c = (branch || knn[n] - q[n] > 0.0) ? g : 0.0;
         if (c != g) atomicAdd(nclamped, 1);                      // columns where clamp(k_nn - q, 0) is active (rare)
     }
-    gmu[n] = gm;
-    gv[n] = g;
-    gv2[n] = 2.0 * g;
-    cgv[n] = c;
+    if (n < Np) {
+        gmu[n] = gm;
+        gv[n] = g;
+        gv2[n] = 2.0 * g;
+        cgv[n] = c;
+    }
+    if (blkact) {
+        // a column block is ACTIVE if any upstream gradient of its columns is non-zero (NaN counts: it compares unequal);
+        // the backward products skip inactive blocks, whose share is exactly zero (GemmArgs.colact / kact)
+        const bool any = !(gm == 0.0) || !(g == 0.0);      // c is g or 0
+        const unsigned long long b = __ballot(any);
+        if ((threadIdx.x & 63) == 0) any_w[threadIdx.x >> 6] = b != 0ull ? 1 : 0;
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int64_t blk = (int64_t)blockIdx.x * 2 + threadIdx.x;
+            if (blk * 128 < Np) blkact[blk] = any_w[2 * threadIdx.x] | any_w[2 * threadIdx.x + 1];
+        }
+    }
 }
 int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const double* knn, const double* q,
                             const double* varraw, int branch, double min_var, int64_t N, int64_t Np, double* gmu,
-                            double* gv, double* gv2, double* cgv, int32_t* nclamped, int zeroed, hipStream_t s) {
+                            double* gv, double* gv2, double* cgv, int32_t* nclamped, int zeroed, int32_t* blkact, hipStream_t s) {
     // zeroed: the forward's moments_finish cleared the counter (a second backward over the same forward then adds to a
     // non-zero count, which reads the same: only zero / non-zero matters)
     if (!zeroed && launch_zero32(nclamped, 1, s)) return MOBOCMF_HIP_ERROR;
     hipLaunchKernelGGL(moments_bwd_prep_kernel, GRID1(Np), 0, s, g_mean, g_var, knn, q, varraw, branch, min_var, N, Np,
-                       gmu, gv, gv2, cgv, nclamped);
+                       gmu, gv, gv2, cgv, nclamped, blkact);
     return CHECK_LAUNCH();
 }
 

@@ -33,6 +33,7 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 #define BM 128
 #define BN 128
 #define BK 16
+#define KL_MAX 1024   // active K blocks one k-slice of an A B^T product can hold (GemmArgs.kact; launch_gemm checks)
 #define TILE_ELEMS (BM * BK)   // 2048 doubles = 16 KiB per operand tile
 
 // Cross-lane sums without the LDS crossbar (ds_bpermute round trips): DPP moves inside a 16-lane row, permlane swaps across
@@ -124,6 +125,8 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
     constexpr int A_ELEMS = RM * BK;          // A image [RM rows][16 k]
     constexpr int STAGE_ELEMS = A_ELEMS + TILE_ELEMS;
     __shared__ __attribute__((aligned(16))) double lds[2 * STAGE_ELEMS];   // [buf][A | B]
+    __shared__ int kl[B_T ? KL_MAX : 1];      // A B^T over active K blocks (GemmArgs.kact): block ids of this slice
+    __shared__ int kl_wsum[4];
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     STAMP(0);
     STAMP_ID();
@@ -237,6 +240,20 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
 
+    if constexpr (!B_T) {
+        // inactive column block (GemmArgs.colact): its share of the product is exactly zero and is not computed
+        if (g.colact && g.colact[cb] == 0) {
+            if (EPI == EPI_DA && g.rowdot_part) {      // the row-dot partials are summed over ALL column blocks: zeros
+                for (int part = 0; part < nparts; ++part) {
+                    const int rbp = part == 0 ? rb_first : nrb - 1 - rb_first;
+                    for (int i = tid; i < 2 * RM; i += 256)
+                        g.rowdot_part[((int64_t)cb * 2 + i / RM) * g.Mr + (int64_t)rbp * RM + i % RM] = 0.0;
+                }
+            }
+            return;
+        }
+    }
+
     // ---- LDS-DMA staging maps (one instruction = 64 lanes x 16 B = 1 KiB of the image)
     // A / B_T image: lane -> (row = 8*wave + l/8 (+32 per round), physical chunk l%8); source chunk swizzled
     const int a_row = tid >> 3;
@@ -302,12 +319,54 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
         int64_t e = (cb + 1) * BN;
         if (k1 > e) k1 = e;
     }
+    bool compact = false;      // K steps of this slice come from the active-block list kl[] (GemmArgs.kact)
+    int64_t ct0 = 0;           // compact: index of the slice's first step among all active steps
+    int co0 = 0;               //          ordinal of the active block kl[0]
     if (!g.batched && splitk > 1) {   // slice the tile's own non-zero k range
-        int64_t nkt = k1 > k0 ? (k1 - k0) / BK : 0;
-        int64_t per = (nkt + sk_eff - 1) / sk_eff;
-        int64_t b = k0 + z * per * BK, e = b + per * BK;
-        k0 = b < k1 ? b : k1;
-        k1 = e < k1 ? e : k1;
+        bool sliced = false;
+        if constexpr (B_T) {
+            if (g.kact) {
+                // Active 128-column blocks of K, in ascending order: every thread counts a run of blocks, a workgroup scan
+                // gives each run its first ordinal; the slice takes steps [z per, (z+1) per) of the 8 nact active steps.
+                const int nb = (int)(g.Kd / 128), run = (nb + 255) / 256;
+                const int rb0 = tid * run < nb ? tid * run : nb, rb1 = rb0 + run < nb ? rb0 + run : nb;
+                int cnt = 0;
+                for (int b = rb0; b < rb1; ++b) cnt += g.kact[b] != 0 ? 1 : 0;
+                int inc = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(inc, off);
+                    if (lane >= off) inc += v;
+                }
+                if (lane == 63) kl_wsum[wave] = inc;
+                __syncthreads();
+                int ord = inc - cnt;
+                for (int w = 0; w < wave; ++w) ord += kl_wsum[w];
+                const int64_t nkt = (int64_t)(kl_wsum[0] + kl_wsum[1] + kl_wsum[2] + kl_wsum[3]) * (128 / BK);
+                const int64_t per = (nkt + sk_eff - 1) / sk_eff;
+                const int64_t tb = z * per < nkt ? z * per : nkt, te = tb + per < nkt ? tb + per : nkt;
+                ct0 = tb;
+                co0 = (int)(tb / (128 / BK));
+                const int co1 = te > tb ? (int)((te - 1) / (128 / BK)) : co0 - 1;
+                for (int b = rb0; b < rb1; ++b)
+                    if (g.kact[b] != 0) {
+                        if (ord >= co0 && ord <= co1 && ord - co0 < KL_MAX) kl[ord - co0] = b;
+                        ++ord;
+                    }
+                __syncthreads();
+                compact = true;
+                sliced = true;
+                k0 = 0;
+                k1 = (te - tb) * BK;      // only the step COUNT matters below: offsets come from KOFF
+            }
+        }
+        if (!sliced) {
+            int64_t nkt = k1 > k0 ? (k1 - k0) / BK : 0;
+            int64_t per = (nkt + sk_eff - 1) / sk_eff;
+            int64_t b = k0 + z * per * BK, e = b + per * BK;
+            k0 = b < k1 ? b : k1;
+            k1 = e < k1 ? e : k1;
+        }
     }
     const double* Ag = Ag0 + (int64_t)rb * RM * g.lda;
 
@@ -319,7 +378,16 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
 
     const int64_t nk = (k1 > k0) ? (k1 - k0) / BK : 0;
 #define KSTEP(KT) (rev ? nk - 1 - (KT) : (KT))   /* iteration -> K step of the tile */
-    if (nk > 0) stage(Ag, k0 + KSTEP(0) * BK, 0);
+    // iteration -> offset along K
+    auto koff = [&](int64_t kt) -> int64_t {
+        if (B_T && compact) {
+            const int64_t t = ct0 + kt;
+            return (int64_t)kl[(int)(t / (128 / BK)) - co0] * 128 + (t % (128 / BK)) * BK;
+        }
+        return k0 + KSTEP(kt) * BK;
+    };
+#define KOFF(KT) koff(KT)
+    if (nk > 0) stage(Ag, KOFF(0), 0);
 
     // LDS-DMA data is ordered for other wavefronts' ds_reads only by the issuing wavefront's vmcnt wait followed by
     // a barrier; the waits are written out (hipcc adds them only when it sees the DMA in the same scheduling scope)
@@ -327,7 +395,7 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
     __syncthreads();
     STAMP(1 + 4 * part);      // first stage landed
     v4f64 w_nxt = (v4f64){1.0, 1.0, 1.0, 1.0};
-    if (B_T && g.bscale && nk > 0) w_nxt = *(const v4f64*)(g.bscale + k0 + 4 * lk);
+    if (B_T && g.bscale && nk > 0) w_nxt = *(const v4f64*)(g.bscale + KOFF(0) + 4 * lk);
     // Software pipeline of one K step over 8 groups g = (kpair p, row tile mt): the A fragments of group g+1
     // (4 x ds_read_b128) and, at a kpair boundary, the B fragments of the next kpair are read while the 32 MFMAs of
     // group g issue.  sched_barrier(0) pins the group boundaries so the register allocator sees two fragment sets, not
@@ -372,8 +440,9 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
 #define STAGE_NEXT                                                                                          \
         if (kt + 1 < nk) {                                                                                  \
             /* the weight load is issued BEFORE the DMA: waiting for it never drains the DMA (vmcnt is in order) */ \
-            if (B_T && g.bscale) w_nxt = *(const v4f64*)(g.bscale + k0 + (kt + 1) * BK + 4 * lk);           \
-            stage(Ag, k0 + KSTEP(kt + 1) * BK, buf ^ 1);                                                    \
+            const int64_t knext = KOFF(kt + 1);                                                             \
+            if (B_T && g.bscale) w_nxt = *(const v4f64*)(g.bscale + knext + 4 * lk);                        \
+            stage(Ag, knext, buf ^ 1);                                                                      \
         }                                                                                                   \
         STEP_STAMP(1);
 // The standard K step: all four row groups, MMA = MMA_ALL or the skipping MMA_IF.
@@ -489,6 +558,7 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
     }
 #undef STAGE_LOOP
 #undef KSTEP
+#undef KOFF
 #undef KSTEP_STD
 #undef STAGE_NEXT
 #undef KSTEP_LE
@@ -693,8 +763,18 @@ static int tile_rows(const GemmArgs& g, bool B_T, int splitk) {
     return pairs128 >= 512 ? BM : 64;
 }
 
-int launch_gemm(const GemmArgs& g, bool B_T, int splitk, hipStream_t s) {
+int launch_gemm(const GemmArgs& g0, bool B_T, int splitk, hipStream_t s) {
+    GemmArgs g = g0;
     if (g.Mr % BM || g.Nc % BN || g.Kd % BK) return MOBOCMF_BAD_ARG;
+    // block activity is honoured where the kernels implement it, and ignored (dense product: the same result) elsewhere
+    if (B_T || g.batched || splitk > 1) g.colact = nullptr;
+    if (g.kact) {
+        const int sk_min = (g.lower_out && g.splitk_diag > 0 && g.splitk_diag < splitk) ? g.splitk_diag : splitk;
+        const int64_t nb = g.Kd / 128;
+        if (!B_T || g.batched || splitk <= 1 || g.zlayers > 1 || g.Kd % 128 || (g.tri & (TRI_LOWER_B | TRI_UPPER_B)) ||
+            (nb + sk_min - 1) / sk_min + 2 > KL_MAX)
+            g.kact = nullptr;
+    }
     if (!B_T && ((g.ldc & 1) || ((uintptr_t)g.C & 15))) return MOBOCMF_BAD_ARG;   // 16-byte epilogue accesses (A B form)
     if (small_panel_ok(g, B_T, splitk)) {
         if (g.epi == EPI_COLSTATS) return launch_small_panel<EPI_COLSTATS>(g, s);
@@ -907,6 +987,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tc = threadIdx.x & 7, tr = threadIdx.x >> 3;        // compute map: columns 2 tc, 2 tc + 1; rows 4 tr .. 4 tr + 3
     const int rb = blockIdx.y;
     const int64_t r0 = (int64_t)rb * BM, c0 = (int64_t)blockIdx.x * 16;
+    if (g.colact && g.colact[c0 >> 7] == 0) {      // inactive column block (GemmArgs.colact): not computed
+        if (EPI == EPI_DA && g.rowdot_part && threadIdx.x < BM) g.rowdot_part[(int64_t)blockIdx.x * g.Mr + r0 + threadIdx.x] = 0.0;
+        return;
+    }
     int64_t k0 = 0, k1 = g.Kd;               // multiples of 128 (Mr, Kd are)
     if (g.tri & TRI_LOWER_A) k1 = k1 < r0 + BM ? k1 : r0 + BM;
     if (g.tri & TRI_UPPER_A) k0 = r0;

@@ -186,6 +186,18 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
     const int xdiv = XD ? XD : g.xdiv;
     const int64_t c0 = n0 * xdiv;
     const bool real = n0 < g.nbase;
+    // Columns in inactive 128-column blocks of G (GramArgs.colact) were never written and count as exact zeros.  amask: bit s
+    // set = replica column c0 + s is live.  XD > 0 divides 128: a base row's replicas share one block (all or nothing).
+    static_assert(XD == 0 || 128 % XD == 0, "replica runs must not straddle a column block");
+    unsigned long long amask = ~0ull;
+    if (g.colact && real) {
+        if (XD) amask = g.colact[c0 >> 7] != 0 ? ~0ull : 0ull;
+        else {
+            amask = 0ull;
+            for (int s = 0; s < xdiv; ++s) amask |= (unsigned long long)(g.colact[(c0 + s) >> 7] != 0 ? 1 : 0) << s;
+        }
+    }
+    const bool live = real && amask != 0ull;      // no live column: the thread only writes its zero partials
     double fr[XD ? XD : 1], dfa[XD ? XD : 1];   // XD > 0: f and the df accumulators live in registers
     if (XD) {
 #pragma unroll
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
         const int m = m0 + mm;
         if (m >= g.M) break;   // uniform across the block
         double dzf_loc = 0.0;
-        if (real) {
+        if (live) {
             const double* grow = g.G + (int64_t)m * g.ldk;
             double d1 = 0.0, d2 = 0.0;
 #pragma unroll
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
             double W1 = 0.0, W2 = 0.0;
             if (KIND == 0) {
                 double Gsum = 0.0;
-                for (int s = 0; s < xdiv; ++s) Gsum += grow[c0 + s];
+                for (int s = 0; s < xdiv; ++s) Gsum += ((amask >> s) & 1ull) ? grow[c0 + s] : 0.0;
                 s_a1 += Gsum * E1;
                 W1 = Gsum * a1 * E1;
             } else {
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(GT) void gram_bwd_kernel(GramArgs g) {
                 } else {
                     for (int s = 0; s < xdiv; ++s) {
                         double acc = 0.0;
-                        body(grow[c0 + s], g.f[c0 + s], acc);
+                        body(((amask >> s) & 1ull) ? grow[c0 + s] : 0.0, g.f[c0 + s], acc);
                         dfs[s * GT + tid] += acc;
                     }
                 }

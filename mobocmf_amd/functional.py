@@ -979,6 +979,22 @@ def gemm_colstat_rows(Mr, Nc, Kd, tri=0):
     return rows.value
 
 
+def set_sparse_backward(on=True):
+    """Skip the 128-column blocks of a layer backward whose upstream gradients are all exactly zero (default on;
+    mobocmf_set_sparse_backward).  Off = the dense backward: A/B timing and the parity tests."""
+    _lib.check(_lib.load().mobocmf_set_sparse_backward(1 if on else 0), "mobocmf_set_sparse_backward")
+
+
+def set_block_activity(act=None):
+    """Tests / tools: int32 CUDA tensor (one word per 128 columns) that the standalone gemm_f64 / syrk_weighted calls apply
+    until it is cleared with None (mobocmf_set_block_activity).  The caller keeps the tensor alive."""
+    ptr = 0
+    if act is not None:
+        assert act.dtype == torch.int32 and act.is_cuda and act.is_contiguous()
+        ptr = act.data_ptr()
+    _lib.check(_lib.load().mobocmf_set_block_activity(ctypes.c_void_p(ptr)), "mobocmf_set_block_activity")
+
+
 def set_tile_rows(rows=0, pair_mode=0):
     """Tile height of the M x N' panel products: 0 automatic, 64 or 128; row-block pairing 0 automatic, 1 never, 2 always
     (mobocmf_set_tile_rows)."""
