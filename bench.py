@@ -45,7 +45,7 @@ def algorithmic_flops(cfg):
     return 3.0 * tot
 
 
-def build_graphed(cfg, outputs, device, use_graph, shard_rows=False):
+def build_graphed(cfg, outputs, device, use_graph, shard_rows=False, prune_rows=True):
     """One GraphedELBOStep (HIP-graph replay of the whole step) per surrogate, each on its own stream.
     shard_rows: every rank holds the SAME surrogates and 1/W of their batch rows (SURVEY 8(e) level 2)."""
     from mobocmf_amd.mlls import VariationalELBOMF
@@ -65,7 +65,7 @@ def build_graphed(cfg, outputs, device, use_graph, shard_rows=False):
             from mobocmf_amd.util.blackbox_mfdgp_fitter import BlackBoxMFDGPFitter
             perm = BlackBoxMFDGPFitter.shuffled_rows(cfg["N"], device)
             x, y, fid = x[perm].contiguous(), y[perm].contiguous(), fid[perm].contiguous()
-        steps.append(GraphedELBOStep(model, elbo, x, y, fid, lr=1e-3, use_graph=use_graph))
+        steps.append(GraphedELBOStep(model, elbo, x, y, fid, lr=1e-3, use_graph=use_graph, prune_rows=prune_rows))
     return steps
 
 
@@ -102,10 +102,46 @@ def one_step(sur, cfg, gens, streams):
     return losses
 
 
-def executed_gemm_flops(cfg):
+def panel_columns(cfg, layer_rows=None):
+    """N' of every layer's M x N' panel work in the step: base rows the layer is evaluated on (all N, or the prefix of rows
+    that can reach the loss -- GraphedELBOStep.layer_rows) times the samples per row (1 for layer 0, S above)."""
+    rows = layer_rows if layer_rows is not None else [cfg["N"]] * cfg["L"]
+    return [rows[l] * (1 if l == 0 else cfg["S"]) for l in range(cfg["L"])]
+
+
+def executed_gemm_flops(cfg, layer_rows=None, active_frac=None):
     """Flops the step really executes in its N'-sized contractions: per layer 4 triangular products (A = L^-1 K, C = U^T A,
-    dA, dK: M^2 N' each) + the weighted syrk H = A diag(gv) A^T (M^2 N') = 5 M^2 N' (DESIGN.md section 1)."""
-    return sum(5.0 * cfg["M"] ** 2 * (cfg["N"] if l == 0 else cfg["N"] * cfg["S"]) for l in range(cfg["L"]))
+    dA, dK: M^2 N' each) + the weighted syrk H = A diag(gv) A^T (M^2 N') = 5 M^2 N' (DESIGN.md section 1).  layer_rows: the
+    layers' row counts (dead rows pruned); active_frac[l]: share of layer l's column blocks with non-zero upstream gradient
+    (the three backward products run over those only)."""
+    cols = panel_columns(cfg, layer_rows)
+    act = active_frac if active_frac is not None else [1.0] * cfg["L"]
+    return sum((2.0 + 3.0 * act[l]) * cfg["M"] ** 2 * cols[l] for l in range(cfg["L"]))
+
+
+def backward_active_fractions(cfg, fid, layer_rows, sparse):
+    """Share of each layer's 128-column blocks that carry upstream gradient: rows scored at the layer's own fidelity plus the
+    rows the next layer propagates gradient back to."""
+    import numpy as np
+    fid = np.asarray(fid).reshape(-1)
+    L, N = cfg["L"], fid.size
+    out = []
+    need = np.zeros(N, dtype=bool)
+    for l in reversed(range(L)):
+        n_l = layer_rows[l] if layer_rows is not None else N
+        on = (fid == l)
+        on = on | need
+        need = on.copy()
+        if not sparse:
+            out.append(1.0)
+            continue
+        mult = 1 if l == 0 else cfg["S"]
+        cols = np.repeat(on[:n_l], mult)
+        nb = (cols.size + 127) // 128
+        pad = np.zeros(nb * 128, dtype=bool)
+        pad[:cols.size] = cols
+        out.append(float(pad.reshape(nb, 128).any(1).sum()) / nb)
+    return out[::-1]
 
 
 def _file_sha16(path):
@@ -114,7 +150,7 @@ def _file_sha16(path):
         return hashlib.sha256(fh.read()).hexdigest()[:16]
 
 
-def measure_gemm_variants(cfg, device, iters=20):
+def measure_gemm_variants(cfg, device, iters=20, n_cols=None):
     """Average duration (HIP events on the launch stream, each variant alone on an idle chip) of the four triangular
     M x N' products of the top layer, launched exactly as mobocmf_layer_forward / _backward launch them:
       A = L^-1 K  (lower-triangular, column-statistics epilogue: q and mean partials)
@@ -124,7 +160,8 @@ def measure_gemm_variants(cfg, device, iters=20):
     Algorithmic flops per launch: M^2 N' (triangular product)."""
     from mobocmf_amd import functional as F
     Mp = (cfg["M"] + 127) // 128 * 128
-    Np = (cfg["N"] * cfg["S"] + 127) // 128 * 128
+    n_cols = cfg["N"] * cfg["S"] if n_cols is None else n_cols
+    Np = (n_cols + 127) // 128 * 128
     nrb = Mp // 128
     g = torch.Generator(device=device)
     g.manual_seed(7)
@@ -145,7 +182,7 @@ def measure_gemm_variants(cfg, device, iters=20):
         ("dA (lower, dA epilogue + row dots)", lambda: F.gemm_f64_epilogue(Lw, B, C, 1, 2, alpha=2.0, avec=avec, bscale=gv, gmu=gmu, cgv=cgv, Aaux=A2, rowdot_part=rdp)),
         ("dK = L^-T dA (upper, plain store)", lambda: F.gemm_f64_epilogue(Up, B, C, 2, 0)),
     ]
-    flops = float(cfg["M"]) ** 2 * cfg["N"] * cfg["S"]
+    flops = float(cfg["M"]) ** 2 * n_cols
     out = []
     for name, fn in variants:
         # the chip needs a few hundred ms of load before its clock settles (a variant timed cold reads ~15 % slow); the
@@ -168,12 +205,12 @@ def measure_gemm_variants(cfg, device, iters=20):
     return out, flops, (Mp, Np)
 
 
-def measure_dominant_kernel(cfg, device, iters=20):
+def measure_dominant_kernel(cfg, device, iters=20, n_cols=None, layer=None):
     """`roofline` of the bench line: the dominant kernel of the step is the triangular f64 MFMA GEMM; the record carries
     the instantiation with the largest share of the step (A = L^-1 K with the column-statistics epilogue) and, under
-    `variants`, all four top-layer launches with their own times, plus their flop-weighted (= time-weighted, equal flops)
-    fraction."""
-    var, flops, (Mp, Np) = measure_gemm_variants(cfg, device, iters)
+    `variants`, all four launches of that layer with their own times, plus their flop-weighted (= time-weighted, equal
+    flops) fraction.  n_cols: N' of the layer with the widest panel in the step as it runs (dead rows pruned)."""
+    var, flops, (Mp, Np) = measure_gemm_variants(cfg, device, iters, n_cols)
     head = var[0]
     traffic, traffic_src = None, None
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/): static, valid only for the kernel source
@@ -196,7 +233,7 @@ def measure_dominant_kernel(cfg, device, iters=20):
     return {"bound": "mfma", "achieved": head["achieved"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": head["frac"], "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "gemm_f64_kernel<NN, triangular, colstats> -- %s, %dx%dx%d" % (head["kernel"], Mp, Np, Mp),
-            "kernel_ms": head["kernel_ms"], "flops_per_launch": flops, "variants": var,
+            "kernel_ms": head["kernel_ms"], "flops_per_launch": flops, "variants": var, "layer": layer,
             "weighted_frac": len(var) * flops / (tot * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             "timing": "HIP events on the launch stream, %d launches per variant after 0.25 s of the same launches (settled "
                       "clock), each variant alone on the chip" % iters}
@@ -208,7 +245,7 @@ PROBE_SPANS = (("Gram forward K_mn", 9, 0), ("A = L^-1 K (lower, colstats q+mean
                ("Gram backward of K_mn", 8, 10))
 
 
-def measure_instep_kernels(gstep, cfg, steps=6, skip=2):
+def measure_instep_kernels(gstep, cfg, steps=6, skip=2, n_cols=None):
     """Durations of the top layer's grid-filling launches INSIDE a training step of one surrogate (the other surrogates
     idle): the library records caller-created HIP events around them (mobocmf_set_probe_events) while the step is issued
     eagerly on the surrogate's own stream -- the same launch sequence the captured graph replays.  Mean over the last
@@ -218,7 +255,7 @@ def measure_instep_kernels(gstep, cfg, steps=6, skip=2):
     from mobocmf_amd import _lib
     lib = _lib.load()
     n_ev = 11
-    Np_top = cfg["N"] * cfg["S"]
+    Np_top = cfg["N"] * cfg["S"] if n_cols is None else n_cols      # the library fires the probes in the layer of this N'
     acc = {name: [] for name, _, _ in PROBE_SPANS}
     try:
         for k in range(steps):
@@ -370,6 +407,10 @@ def main():
     ap.add_argument("--potrf-cols", type=int, default=0, help="A/B knob: columns per hand-over of the Cholesky panel kernel (4 | 1)")
     ap.add_argument("--dense-backward", action="store_true",
                     help="A/B knob: do not skip the column blocks of a layer backward whose upstream gradients are all zero")
+    ap.add_argument("--no-prune-rows", action="store_true",
+                    help="A/B knob: evaluate every layer at every row (the reference's layout) instead of the rows that reach the loss")
+    ap.add_argument("--no-dense-leg", action="store_true",
+                    help="skip the second timing of the step in the reference's layout (every layer at every row, dense backward)")
     ap.add_argument("--launch", action="store_true", help="go through the rank launcher even for --gpus 1")
     args = ap.parse_args()
     if args.no_overlap:
@@ -428,7 +469,7 @@ def main():
     if rows and args.eager:
         raise SystemExit("--shard rows runs through RowShardedELBOStep (graph | all-reduce | graph)")
     if not args.eager:
-        gsteps = build_graphed(cfg, outputs, device, use_graph=True, shard_rows=rows)
+        gsteps = build_graphed(cfg, outputs, device, use_graph=True, shard_rows=rows, prune_rows=not args.no_prune_rows)
         sur = [(g.model, g.elbo, g.optimizer, (g.x, g.y, g.fid)) for g in gsteps]
 
         def one_step(*_a):
@@ -489,6 +530,47 @@ def main():
     exchange_ms = (time.perf_counter() - t1) * 1e3
     finite = finite and bool(torch.isfinite(gathered).all())
 
+    layer_rows = gsteps[0].layer_rows if (not args.eager and not rows) else None
+    sparse = not args.dense_backward
+    fid0 = synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=8, N=cfg["N"], S=1, seed=0)["fid"]
+    if layer_rows is not None:
+        import numpy as np
+        fid0 = np.sort(np.asarray(fid0).reshape(-1))[::-1]
+    act = backward_active_fractions(cfg, fid0, layer_rows, sparse)
+    cols = panel_columns(cfg, layer_rows)
+    dom = max(range(cfg["L"]), key=lambda l: cols[l])
+
+    # the same step in the reference's layout -- every layer at every row, dense backward -- timed beside it (one GPU only)
+    dense_leg = None
+    if world == 1 and not args.eager and not rows and not args.no_dense_leg and (layer_rows is not None or sparse):
+        from mobocmf_amd import functional as F_
+        F_.set_sparse_backward(False)
+        try:
+            dsteps = build_graphed(cfg, outputs, device, use_graph=True, prune_rows=False)
+        finally:
+            F_.set_sparse_backward(sparse)
+        for _ in range(args.warmup):
+            for g in dsteps:
+                g.step()
+        d_el = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                for g in dsteps:
+                    g.step()
+            torch.cuda.synchronize()
+            d_el.append(time.perf_counter() - t0)
+        d_med = sorted(d_el)[1]
+        dense_leg = {"value": n_out * args.steps / d_med, "unit": "ELBO steps/s", "ms_per_step": d_med / args.steps * 1e3,
+                     "repeat_values": [n_out * args.steps / e for e in d_el],
+                     "step_flops_executed_gemm": executed_gemm_flops(cfg),
+                     "what": "the same surrogates, every layer evaluated at every row and the backward dense: the reference's "
+                             "op layout (mfdgp.py:174-196 + variational_elbo_mf.py:33-38 masking afterwards)"}
+        for g in dsteps:
+            g.retire()
+        del dsteps
+
     if rank == 0:
         n_sur = n_out if rows else n_out * world
         value = n_sur * args.steps / elapsed
@@ -501,14 +583,22 @@ def main():
             "config": {"workload": "%s: synthetic d=%d, %d fidelities, M=%d, N=%d, S=%d, %d surrogates per GPU "
                                    "(2 objectives + 1 constraint), full batch, Adam" %
                                    (args.config, cfg["d"], cfg["L"], cfg["M"], cfg["N"], cfg["S"], n_out),
+                       "dead_rows": "pruned (layer l on the rows of fidelity >= l)" if layer_rows is not None else "kept (every layer at every row)",
+                       "backward": "skips zero-gradient column blocks" if sparse else "dense",
                        "surrogates_per_gpu": n_out, "parallelism": ("row-sharded x%d + grad all-reduce" if rows else "surrogate-per-rank x%d") % world},
             "per_surrogate_steps_per_s": value / n_sur,
             "repeat_values": [n_sur * args.steps / e for e in elapsed_all],
             "repeat_spread": (max(elapsed_all) - min(elapsed_all)) / elapsed,
             "step_flops_algorithmic": algorithmic_flops(cfg),
-            "step_flops_executed_gemm": executed_gemm_flops(cfg),
+            "step_flops_executed_gemm": executed_gemm_flops(cfg, layer_rows, act),
             # executed GEMM flops per second over the FP64 peak: what the chip really sustains over the whole step
-            "step_executed_fp64_frac": executed_gemm_flops(cfg) * value / world / (FP64_PEAK_TFLOPS * 1e12),
+            "step_executed_fp64_frac": executed_gemm_flops(cfg, layer_rows, act) * value / world / (FP64_PEAK_TFLOPS * 1e12),
+            # work the step does NOT do because it cannot reach the loss (same ELBO, same gradients -- tests/, parity below)
+            "dead_work": {"layer_rows": layer_rows, "panel_columns": cols, "backward_active_fraction": act,
+                          "dominant_layer": dom,
+                          "what": "layer l runs on the rows of fidelity >= l (batch ordered once by descending fidelity); a "
+                                  "layer backward skips 128-column blocks whose upstream gradients are all zero"},
+            "reference_layout": dense_leg,
             # SURVEY 8(d)'s F_step prices the reference's solve-based op sequence (~1.9x the flops executed here): a
             # speed-up-adjusted figure, NOT a roofline fraction
             "step_algorithmic_fp64_frac": algorithmic_flops(cfg) * value / world / (FP64_PEAK_TFLOPS * 1e12),
@@ -517,13 +607,13 @@ def main():
             "finite": finite, "step_issue": "eager" if args.eager else "hip-graph replay",
         }
         if not args.no_roofline:
-            line["roofline"] = measure_dominant_kernel(cfg, device)
+            line["roofline"] = measure_dominant_kernel(cfg, device, n_cols=cols[dom], layer=dom)
             if not args.eager and not rows:
-                ins = measure_instep_kernels(gsteps[0], cfg)
+                ins = measure_instep_kernels(gsteps[0], cfg, n_cols=cols[dom])
                 iso = {v["kernel"]: v["kernel_ms"] for v in line["roofline"]["variants"]}
                 line["per_kernel_instep_ms"] = {
                     "kernels": ins, "instep_over_isolated": {k: ins[k] / iso[k] for k in ins if k in iso},
-                    "how": "top layer of ONE surrogate, step issued eagerly on its own stream (the launch sequence the graph "
+                    "how": "widest layer of ONE surrogate, step issued eagerly on its own stream (the launch sequence the graph "
                            "replays), HIP events recorded by the library around each launch (mobocmf_set_probe_events), mean "
                            "of 4 steps; `instep_over_isolated` divides by the same launch timed alone (roofline.variants)"}
         if world == 1 and not args.no_cpu_baseline:

@@ -192,6 +192,11 @@ int mobocmf_propagate_rng_forward(const double* mean, const double* var, int64_t
 /* g_mean[n_out/div], g_var[n_out/div] from g_f[n_out]. */
 int mobocmf_propagate_backward(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
                                int64_t n_out, int32_t div, mobocmf_stream_t stream);
+/* Prefix propagation: the previous layer holds n_prev >= n_out/div rows of which only the FIRST n_out/div were propagated
+ * (the next layer is evaluated on a prefix of the batch -- the rows that can reach the loss, see mobocmf_elbo_forward);
+ * g_mean / g_var [n_prev] get zeros beyond the prefix. */
+int mobocmf_propagate_backward_prefix(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
+                                      int64_t n_out, int32_t div, int64_t n_prev, mobocmf_stream_t stream);
 
 /* out[0] = (1/div) * sum_{n : fid[n/div] == level} -0.5 * (((y[n/div]-mean[n])^2 + var[n]) / tau + log tau + log 2pi)
  * tau is a device scalar.  n < n_rows. */
@@ -226,17 +231,21 @@ int mobocmf_elbo_combine_backward(const double* g_elbo, const double* g_skl, dou
  * to y[i / div[l]]; averaged over the div[l] samples of a row), noise tau_l = lo[l] + (hi[l] - lo[l]) sigmoid(raw_noise[l][0])
  * (hi[l] <= lo[l]: raw_noise[l][0] is tau itself); n_kl KL scalars; scale = batch / num_data:
  *   out3[0] = sum data terms - scale * sum kls,  out3[1] = scale * sum kls,  out3[2] = -out3[0]  (the loss).
+ * rows (HOST array of L entries, or NULL = B everywhere): layer l holds only the FIRST rows[l] <= B rows of the batch
+ * (rows[l] * div[l] entries).  The reference evaluates every layer at every row and then masks (:33-38); a row of fidelity
+ * f reaches the loss only through layers 0..f, so with the batch ordered by descending fidelity layer l needs the prefix
+ * of rows with fidelity >= l and nothing else (mobocmf_amd.util.graphed_step orders the batch this way once).
  * Arrays of pointers / per-layer values are HOST arrays of L (n_kl) entries, L, n_kl <= 8.  scratch >= 8 * 512 * 8 bytes.  Backward: g_mean[l] / g_var[l] (B * div[l]), g_raw_noise[l] (w.r.t. the RAW parameter; may be
  * NULL per layer), g_kl[0] = the gradient w.r.t. every KL = scale * (g_skl - g_elbo); g_elbo / g_skl device scalars or NULL. */
 int mobocmf_elbo_forward(int32_t L, const double* const* mean, const double* const* var, const int32_t* div,
                          const double* const* raw_noise, const double* lo, const double* hi, const double* y,
-                         const double* fid, int64_t B, int32_t n_kl, const double* const* kls, double scale, double* out3,
-                         void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+                         const double* fid, int64_t B, const int64_t* rows, int32_t n_kl, const double* const* kls, double scale,
+                         double* out3, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
 int mobocmf_elbo_backward(int32_t L, const double* const* mean, const double* const* var, const int32_t* div,
                           const double* const* raw_noise, const double* lo, const double* hi, const double* y,
-                          const double* fid, int64_t B, double scale, const double* g_elbo, const double* g_skl,
-                          double* const* g_mean, double* const* g_var, double* const* g_raw_noise, double* g_kl,
-                          void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+                          const double* fid, int64_t B, const int64_t* rows, double scale, const double* g_elbo,
+                          const double* g_skl, double* const* g_mean, double* const* g_var, double* const* g_raw_noise,
+                          double* g_kl, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
 
 /* The same pair with the noise given as the RAW parameter of an Interval constraint (mfdgp.py:116):
  * tau = lo + (hi - lo) * sigmoid(raw_noise[0]) is evaluated inside the kernels and g_tau is the gradient w.r.t. the raw

@@ -50,12 +50,13 @@ SYMBOLS = {
     "mobocmf_propagate_forward": [_P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_propagate_rng_forward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_propagate_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
+    "mobocmf_propagate_backward_prefix": [_P, _P, _P, _P, _P, _I64, _I32, _I64, _P],
     "mobocmf_elbo_data_forward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _SZ, _P],
     "mobocmf_elbo_data_backward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _P, _P, _P, _SZ, _P],
     "mobocmf_elbo_data_interval_forward": [_P, _P, _P, _P, _P, _D, _D, _D, _I64, _I32, _P, _P, _SZ, _P],
     "mobocmf_elbo_data_interval_backward": [_P, _P, _P, _P, _P, _D, _D, _D, _I64, _I32, _P, _P, _P, _P, _P, _SZ, _P],
-    "mobocmf_elbo_forward": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _D, _P, _P, _SZ, _P],
-    "mobocmf_elbo_backward": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _D, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mobocmf_elbo_forward": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _P, _D, _P, _P, _SZ, _P],
+    "mobocmf_elbo_backward": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _D, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mobocmf_acq_moments_forward": [_P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_acq_moments_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_jes_forward": [_P, _P, _P, _I64, _P],

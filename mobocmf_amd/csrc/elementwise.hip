@@ -659,10 +659,16 @@ __global__ void propagate_rng_fwd_kernel(const double* mean, const double* var, 
         }
     }
 }
+// rows b >= nbase of the previous layer (up to nprev) fed nothing forward (prefix propagation): zero gradient
 __global__ void propagate_bwd_kernel(const double* var, const double* eps, const double* gf, double* gmean, double* gvar,
-                                     int64_t nbase, int div) {
+                                     int64_t nbase, int div, int64_t nprev) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbase) return;
+    if (b >= nprev) return;
+    if (b >= nbase) {
+        gmean[b] = 0.0;
+        gvar[b] = 0.0;
+        return;
+    }
     double sm = 0.0, sv = 0.0;
     for (int s = 0; s < div; ++s) {
         double g = gf[b * div + s];
@@ -748,6 +754,7 @@ struct ElboTable {
     const double* kl[ELBO_MAX_LAYERS];
     double lo[ELBO_MAX_LAYERS], hi[ELBO_MAX_LAYERS];
     int div[ELBO_MAX_LAYERS];
+    int64_t rows[ELBO_MAX_LAYERS];      // base rows layer l holds: the FIRST rows[l] of the batch (<= B)
 };
 __global__ void elbo_all_fwd_kernel(ElboTable t, const double* y, const double* fid, int64_t B, double* part) {
     __shared__ double sh[4];
@@ -757,7 +764,7 @@ __global__ void elbo_all_fwd_kernel(ElboTable t, const double* y, const double* 
         const double lo = t.lo[l], hi = t.hi[l], raw = t.raw[l][0];
         const double tau = hi > lo ? lo + (hi - lo) / (1.0 + exp(-raw)) : raw, ltau = log(tau);
         const int div = t.div[l];
-        const int64_t n = B * div;
+        const int64_t n = t.rows[l] * div;
         const double level = (double)l;
         const double* mean = t.mean[l];
         const double* var = t.var[l];
@@ -800,7 +807,7 @@ __global__ void elbo_all_bwd_kernel(ElboTable t, const double* y, const double* 
         const double lo = t.lo[l], hi = t.hi[l], raw = t.raw[l][0];
         const double tau = hi > lo ? lo + (hi - lo) / (1.0 + exp(-raw)) : raw;
         const int div = t.div[l];
-        const int64_t n = B * div;
+        const int64_t n = t.rows[l] * div;
         const double level = (double)l, g = ge / div;
         const double* mean = t.mean[l];
         const double* var = t.var[l];
@@ -1098,10 +1105,15 @@ int mobocmf_propagate_rng_forward(const double* mean, const double* var, int64_t
 
 int mobocmf_propagate_backward(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
                                int64_t n_out, int32_t div, mobocmf_stream_t stream) {
-    if (n_out < 0 || div < 1 || n_out % div) return MOBOCMF_BAD_ARG;
-    if (n_out == 0) return MOBOCMF_OK;
-    hipLaunchKernelGGL(propagate_bwd_kernel, GRID1(n_out / div), 0, (hipStream_t)stream, var, eps, g_f, g_mean, g_var,
-                       n_out / div, div);
+    return mobocmf_propagate_backward_prefix(var, eps, g_f, g_mean, g_var, n_out, div, div > 0 ? n_out / div : 0, stream);
+}
+
+int mobocmf_propagate_backward_prefix(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
+                                      int64_t n_out, int32_t div, int64_t n_prev, mobocmf_stream_t stream) {
+    if (n_out < 0 || div < 1 || n_out % div || n_prev < n_out / div) return MOBOCMF_BAD_ARG;
+    if (n_prev == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(propagate_bwd_kernel, GRID1(n_prev), 0, (hipStream_t)stream, var, eps, g_f, g_mean, g_var,
+                       n_out / div, div, n_prev);
     return CHECK_LAUNCH();
 }
 
@@ -1163,8 +1175,8 @@ static int elbo_blocks(int32_t L, const double* const* mean, const int32_t* div,
 
 int mobocmf_elbo_forward(int32_t L, const double* const* mean, const double* const* var, const int32_t* div,
                          const double* const* raw_noise, const double* lo, const double* hi, const double* y,
-                         const double* fid, int64_t B, int32_t n_kl, const double* const* kls, double scale, double* out3,
-                         void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
+                         const double* fid, int64_t B, const int64_t* rows, int32_t n_kl, const double* const* kls, double scale,
+                         double* out3, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
     if (L < 1 || L > ELBO_MAX_LAYERS || n_kl < 0 || n_kl > ELBO_MAX_LAYERS || !mean || !var || !div || !raw_noise || !lo ||
         !hi || !y || !fid || B < 0 || !out3 || !scratch || (n_kl && !kls))
         return MOBOCMF_BAD_ARG;
@@ -1172,7 +1184,9 @@ int mobocmf_elbo_forward(int32_t L, const double* const* mean, const double* con
     ElboTable t = {};
     for (int l = 0; l < L; ++l) {
         if (mean[l] && (!var[l] || !raw_noise[l] || div[l] < 1)) return MOBOCMF_BAD_ARG;
+        if (rows && (rows[l] < 0 || rows[l] > B)) return MOBOCMF_BAD_ARG;
         t.mean[l] = mean[l]; t.var[l] = var[l]; t.raw[l] = raw_noise[l]; t.lo[l] = lo[l]; t.hi[l] = hi[l]; t.div[l] = div[l];
+        t.rows[l] = rows ? rows[l] : B;
     }
     for (int j = 0; j < n_kl; ++j) { if (!kls[j]) return MOBOCMF_BAD_ARG; t.kl[j] = kls[j]; }
     const int nb = elbo_blocks(L, mean, div, B);
@@ -1184,9 +1198,9 @@ int mobocmf_elbo_forward(int32_t L, const double* const* mean, const double* con
 
 int mobocmf_elbo_backward(int32_t L, const double* const* mean, const double* const* var, const int32_t* div,
                           const double* const* raw_noise, const double* lo, const double* hi, const double* y,
-                          const double* fid, int64_t B, double scale, const double* g_elbo, const double* g_skl,
-                          double* const* g_mean, double* const* g_var, double* const* g_raw_noise, double* g_kl,
-                          void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
+                          const double* fid, int64_t B, const int64_t* rows, double scale, const double* g_elbo,
+                          const double* g_skl, double* const* g_mean, double* const* g_var, double* const* g_raw_noise,
+                          double* g_kl, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
     if (L < 1 || L > ELBO_MAX_LAYERS || !mean || !var || !div || !raw_noise || !lo || !hi || !y || !fid || B < 0 ||
         !g_mean || !g_var || !g_raw_noise || !g_kl || !scratch)
         return MOBOCMF_BAD_ARG;
@@ -1194,7 +1208,9 @@ int mobocmf_elbo_backward(int32_t L, const double* const* mean, const double* co
     ElboTable t = {};
     for (int l = 0; l < L; ++l) {
         if (mean[l] && (!var[l] || !raw_noise[l] || div[l] < 1 || !g_mean[l] || !g_var[l])) return MOBOCMF_BAD_ARG;
+        if (rows && (rows[l] < 0 || rows[l] > B)) return MOBOCMF_BAD_ARG;
         t.mean[l] = mean[l]; t.var[l] = var[l]; t.raw[l] = raw_noise[l]; t.lo[l] = lo[l]; t.hi[l] = hi[l]; t.div[l] = div[l];
+        t.rows[l] = rows ? rows[l] : B;
         t.gmean[l] = g_mean[l]; t.gvar[l] = g_var[l]; t.graw[l] = g_raw_noise[l];
     }
     const int nb = elbo_blocks(L, mean, div, B);

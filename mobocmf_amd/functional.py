@@ -606,14 +606,25 @@ def predictive_covariance(x, f, Zx, zf, hyp, m, L_S, kind, xdiv=1, jitter=JITTER
     return mean, cov
 
 
+def _propagate_backward(ctx, g):
+    """g_mean / g_var of the previous layer's moments: zeros beyond the propagated prefix (one launch either way)."""
+    lib = _lib.require_device()
+    var, eps = ctx.saved_tensors
+    g = _prep(g)
+    gm, gv = _empty_like(var), _empty_like(var)
+    _lib.check(lib.mobocmf_propagate_backward_prefix(_ptr(var), _ptr(eps), _ptr(g), _ptr(gm), _ptr(gv), eps.numel(),
+                                                     ctx.div, var.numel(), _stream()), "mobocmf_propagate_backward_prefix")
+    return gm, gv
+
+
 class _PropagateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mean, var, eps, div):
         lib = _lib.require_device()
         mean, var, eps = _prep(mean.reshape(-1)), _prep(var.reshape(-1)), _prep(eps.reshape(-1))
         n = eps.numel()
-        if mean.numel() * div != n:
-            raise _lib.MobocmfError("propagate: eps must have mean.numel()*div entries")
+        if mean.numel() * div < n or n % div or var.numel() != mean.numel():
+            raise _lib.MobocmfError("propagate: eps must have k*div entries, k <= mean.numel() (a prefix of the rows)")
         out = _empty(n, device=mean.device)
         _lib.check(lib.mobocmf_propagate_forward(_ptr(mean), _ptr(var), _ptr(eps), _ptr(out), n, div, _stream()),
                    "mobocmf_propagate_forward")
@@ -623,12 +634,7 @@ class _PropagateFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.require_device()
-        var, eps = ctx.saved_tensors
-        g = _prep(g)
-        gm, gv = _empty_like(var), _empty_like(var)
-        _lib.check(lib.mobocmf_propagate_backward(_ptr(var), _ptr(eps), _ptr(g), _ptr(gm), _ptr(gv), eps.numel(),
-                                                  ctx.div, _stream()), "mobocmf_propagate_backward")
+        gm, gv = _propagate_backward(ctx, g)
         return gm, gv, None, None
 
 
@@ -637,8 +643,9 @@ class _PropagateRngFn(torch.autograd.Function):
     def forward(ctx, mean, var, rng_state, n_out, div):
         lib = _lib.require_device()
         mean, var = _prep(mean.reshape(-1)), _prep(var.reshape(-1))
-        if mean.numel() * div != n_out or rng_state.dtype != torch.int64 or rng_state.numel() != 3 or not rng_state.is_cuda:
-            raise _lib.MobocmfError("propagate_rng: n_out must be mean.numel()*div and rng_state three int64 on the GPU")
+        if mean.numel() * div < n_out or n_out % div or var.numel() != mean.numel() or rng_state.dtype != torch.int64 or \
+                rng_state.numel() != 3 or not rng_state.is_cuda:
+            raise _lib.MobocmfError("propagate_rng: n_out must be k*div, k <= mean.numel(), and rng_state three int64 on the GPU")
         out, eps = _empty(n_out, device=mean.device), _empty(n_out, device=mean.device)
         _lib.check(lib.mobocmf_propagate_rng_forward(_ptr(mean), _ptr(var), _ptr(rng_state), _ptr(out), _ptr(eps), n_out, div,
                                                      _stream()), "mobocmf_propagate_rng_forward")
@@ -649,12 +656,7 @@ class _PropagateRngFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_eps):
-        lib = _lib.require_device()
-        var, eps = ctx.saved_tensors
-        g = _prep(g)
-        gm, gv = _empty_like(var), _empty_like(var)
-        _lib.check(lib.mobocmf_propagate_backward(_ptr(var), _ptr(eps), _ptr(g), _ptr(gm), _ptr(gv), eps.numel(),
-                                                  ctx.div, _stream()), "mobocmf_propagate_backward")
+        gm, gv = _propagate_backward(ctx, g)
         return gm, gv, None, None, None
 
 
@@ -665,7 +667,8 @@ def propagate_rng(mean, var, rng_state, n_out, div=1):
 
 
 def propagate(mean, var, eps, div=1):
-    """f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n]   (mfdgp_hidden_layer.py:263-274)."""
+    """f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n]   (mfdgp_hidden_layer.py:263-274).  ``eps`` may cover only a prefix of
+    the rows of (mean, var): the rest is not propagated and gets zero gradient."""
     return _PropagateFn.apply(mean, var, eps, div)
 
 
@@ -781,6 +784,7 @@ class _ElboFusedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scale, B, specs, y, fid, n_kl, *tensors):
+        # specs[l] = None | (div, lo, hi, rows): the layer holds the first ``rows`` base rows of the batch
         lib = _lib.require_device()
         L = len(specs)
         y, fid = _prep(y.reshape(-1)), _prep(fid.reshape(-1))
@@ -789,8 +793,8 @@ class _ElboFusedFn(torch.autograd.Function):
         for l, sp in enumerate(specs):
             if sp is not None:
                 means[l], vars_[l], raws[l] = _prep(next(it).reshape(-1)), _prep(next(it).reshape(-1)), _prep(next(it).reshape(-1))
-                if means[l].numel() != B * sp[0] or vars_[l].numel() != B * sp[0]:
-                    raise _lib.MobocmfError("elbo: layer %d holds %d rows, expected %d" % (l, means[l].numel(), B * sp[0]))
+                if means[l].numel() != sp[3] * sp[0] or vars_[l].numel() != sp[3] * sp[0] or not 0 <= sp[3] <= B:
+                    raise _lib.MobocmfError("elbo: layer %d holds %d rows, expected %d" % (l, means[l].numel(), sp[3] * sp[0]))
         kls = [_prep(next(it).reshape(())) for _ in range(n_kl)]
         if y.numel() != B or fid.numel() != B:
             raise _lib.MobocmfError("elbo: target / fidelities shape mismatch")
@@ -800,7 +804,8 @@ class _ElboFusedFn(torch.autograd.Function):
         div = (ctypes.c_int32 * L)(*[1 if sp is None else sp[0] for sp in specs])
         lo = (ctypes.c_double * L)(*[0.0 if sp is None else sp[1] for sp in specs])
         hi = (ctypes.c_double * L)(*[0.0 if sp is None else sp[2] for sp in specs])
-        _lib.check(lib.mobocmf_elbo_forward(L, T(means), T(vars_), div, T(raws), lo, hi, _ptr(y), _ptr(fid), B, n_kl,
+        rows = (ctypes.c_int64 * L)(*[B if sp is None else sp[3] for sp in specs])
+        _lib.check(lib.mobocmf_elbo_forward(L, T(means), T(vars_), div, T(raws), lo, hi, _ptr(y), _ptr(fid), B, rows, n_kl,
                                             T(kls) if n_kl else None, float(scale), _ptr(out), _ptr(scratch),
                                             scratch.numel(), _stream()), "mobocmf_elbo_forward")
         ctx.set_materialize_grads(False)
@@ -832,7 +837,8 @@ class _ElboFusedFn(torch.autograd.Function):
         div = (ctypes.c_int32 * L)(*[1 if sp is None else sp[0] for sp in specs])
         lo = (ctypes.c_double * L)(*[0.0 if sp is None else sp[1] for sp in specs])
         hi = (ctypes.c_double * L)(*[0.0 if sp is None else sp[2] for sp in specs])
-        _lib.check(lib.mobocmf_elbo_backward(L, T(means), T(vars_), div, T(raws), lo, hi, _ptr(y), _ptr(fid), B, scale,
+        rows = (ctypes.c_int64 * L)(*[B if sp is None else sp[3] for sp in specs])
+        _lib.check(lib.mobocmf_elbo_backward(L, T(means), T(vars_), div, T(raws), lo, hi, _ptr(y), _ptr(fid), B, rows, scale,
                                              _ptr(ge), _ptr(gs), T(gm), T(gv), T(gr), _ptr(gkl), _ptr(scratch),
                                              scratch.numel(), _stream()), "mobocmf_elbo_backward")
         grads, k = [], 0
@@ -848,9 +854,12 @@ ELBO_MAX_LAYERS = 8
 
 
 def elbo_fused(layers, y, fid, kls, scale):
-    """``layers``: per fidelity level None or (mean, var, raw_noise, div, lo, hi) -- hi <= lo: ``raw_noise`` is the noise
-    itself.  Returns (elbo, scaled_kl, -elbo); the last one carries no gradient (the loss value a training step reports)."""
-    specs = [None if lay is None else (int(lay[3]), float(lay[4]), float(lay[5])) for lay in layers]
+    """``layers``: per fidelity level None or (mean, var, raw_noise, div, lo, hi[, rows]) -- hi <= lo: ``raw_noise`` is the
+    noise itself; ``rows`` (default: all of y): the layer holds the first ``rows`` rows of the batch only (rows * div
+    entries).  Returns (elbo, scaled_kl, -elbo); the last one carries no gradient (the loss value a training step reports)."""
+    B = int(y.numel())
+    specs = [None if lay is None else (int(lay[3]), float(lay[4]), float(lay[5]), int(lay[6]) if len(lay) > 6 else B)
+             for lay in layers]
     tensors = [t for lay in layers if lay is not None for t in lay[:3]]
     return _ElboFusedFn.apply(float(scale), int(y.numel()), specs, y, fid, len(kls), *tensors, *kls)
 

@@ -194,6 +194,8 @@ def gram_cpu_init(covar_module, kind, X):
 class MultivariateNormal:
     """Mean + marginal variance (+ optional dense covariance): what the callers of the path read."""
 
+    batch_rows = None      # set by MFDGP.forward(rows=...): the distribution covers the first batch_rows rows of the batch
+
     def __init__(self, mean, variance=None, covariance_matrix=None):
         self.mean = mean
         self._variance = variance

@@ -375,7 +375,13 @@ class MFDGPHiddenLayer(nn.Module):
         n_rows = x.shape[0] * xdiv
         if isinstance(inp, gp.MultivariateNormal):
             mean_p, var_p = inp.mean.reshape(-1), inp.variance.reshape(-1)
-            fdiv = n_rows // mean_p.numel()
+            if inp.batch_rows is None:
+                fdiv = n_rows // mean_p.numel()
+            else:
+                # the previous layer holds batch_rows >= x.shape[0] rows of the batch (MFDGP.forward(rows=...)): this layer
+                # propagates the first x.shape[0] of them; the kernels read that prefix and zero the rest's gradient
+                fdiv = xdiv // (mean_p.numel() // inp.batch_rows)
+                assert fdiv >= 1 and n_rows % fdiv == 0 and n_rows // fdiv <= mean_p.numel()
             if self._eval_mode:
                 S = self.num_samples_for_acquisition
                 assert n_rows % S == 0, "eval_mode expects inputs tiled num_samples_for_acquisition-fold"

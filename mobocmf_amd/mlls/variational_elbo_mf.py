@@ -36,11 +36,16 @@ class VariationalELBOMF(nn.Module):
                 continue
             likelihood = getattr(self.model, self.model.name_hidden_layer_likelihood + str(i))
             mean, var = dist.mean.reshape(-1), dist.variance.reshape(-1)
+            # MFDGP.forward(..., rows=...) evaluates layer i on the first rows[i] rows of the batch only (those that can reach
+            # the loss) and says so on the distribution; otherwise every layer holds the whole batch
+            rows = getattr(dist, "batch_rows", None)
+            rows = num_batch if rows is None else int(rows)
+            div = mean.numel() // max(rows, 1)
             c = likelihood.raw_noise_constraint
             if type(c) is gp.Interval and math.isfinite(c.upper_bound) and c.upper_bound > c.lower_bound:
-                layers.append((mean, var, likelihood.raw_noise, mean.numel() // num_batch, c.lower_bound, c.upper_bound))
+                layers.append((mean, var, likelihood.raw_noise, div, c.lower_bound, c.upper_bound, rows))
             else:
-                layers.append((mean, var, likelihood.noise, mean.numel() // num_batch, 0.0, 0.0))
+                layers.append((mean, var, likelihood.noise, div, 0.0, 0.0, rows))
         if all(lay is None for lay in layers):
             if not include_kl_term:
                 return 0.0
@@ -52,6 +57,8 @@ class VariationalELBOMF(nn.Module):
             self.last_neg_elbo = neg
             return (elbo, skl) if include_kl_term else elbo
         self.last_neg_elbo = None
+        if any(lay is not None and lay[6] != num_batch for lay in layers):
+            raise ValueError("row-pruned layer outputs need the fused ELBO (at most %d fidelities)" % F.ELBO_MAX_LAYERS)
         data_terms = [F.elbo_data(lay[0], lay[1], y, fid, lay[2], float(i), div=lay[3],
                                   interval=(lay[4], lay[5]) if lay[5] > lay[4] else None)
                       for i, lay in enumerate(layers) if lay is not None]

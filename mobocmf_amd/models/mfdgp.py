@@ -157,14 +157,26 @@ class MFDGP(nn.Module):
             layer.check_pd = bool(value)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, inputs, max_fidelity=None, eps=None, want_dx=False, _xdiv=None):
+    def forward(self, inputs, max_fidelity=None, eps=None, want_dx=False, _xdiv=None, rows=None):
         """List of per-layer predictive distributions (mfdgp.py:174-196).
 
         train mode: layer 0 sees the N rows; layers >= 1 see N * num_samples_for_training rows (row n*S+s is
         sample s of input row n).  ``eps``: optional list, eps[l] (N*S values) for layer l >= 1.
         eval_mode: the caller tiled the inputs (mfdgp.py:248), eps = the layer's fixed ``samples``.
+
+        ``rows`` (training fast path, util/graphed_step.py): non-increasing counts, layer l is evaluated on the FIRST
+        rows[l] input rows only and its distribution says so (``batch_rows``).  The reference evaluates every layer at
+        every row and the ELBO then keeps, per layer, the rows of that layer's fidelity (variational_elbo_mf.py:33-38): a
+        row of fidelity f reaches the loss through layers 0..f only, so with the batch ordered by descending fidelity layer
+        l needs the rows of fidelity >= l -- a prefix -- and the rest of its work is dead.  ``eps[l]`` then holds
+        rows[l] * S values.  Same ELBO, same gradients.
         """
         num_layers = self.num_hidden_layers if max_fidelity is None else max_fidelity + 1
+        if rows is not None:
+            rows = [int(r) for r in rows[:num_layers]]
+            if len(rows) != num_layers or any(a < b for a, b in zip(rows, rows[1:])) or rows[0] > inputs.shape[0] or \
+                    rows[-1] < 1 or want_dx or self._eval_mode:
+                raise ValueError("rows: one non-increasing count per layer, 1 <= rows[l] <= N (training forward only)")
         if self.training:
             self.clear_kl_cache()      # drop the previous iteration's graph (and its AccumulateGrad nodes) up front
         S = 1 if self._eval_mode else self.num_samples_for_training
@@ -175,16 +187,21 @@ class MFDGP(nn.Module):
         if self._frozen is not None:
             chains = self._frozen_chains(num_layers)
         else:
-            chains = self._batched_chains(inputs, num_layers) or self._launch_chains(inputs, num_layers, S, want_dx)
+            chains = self._batched_chains(inputs, num_layers) or self._launch_chains(inputs, num_layers, S, want_dx, rows)
         for i in range(num_layers):
             hidden_layer = getattr(self, self.name_hidden_layer + str(i))
+            x_i = inputs if rows is None else inputs[:rows[i]]
             if i == 0:
-                output_layer = hidden_layer(inputs, want_dx=want_dx, chain=chains[i])
+                output_layer = hidden_layer(x_i, want_dx=want_dx, chain=chains[i])
             else:
                 if self.use_only_highest_fidelity:
                     output_layer = output_layer.mean * 0.0
-                output_layer = hidden_layer(inputs, output_layer, eps=None if eps is None else eps[i], xdiv=S,
+                    if rows is not None:      # the previous layer's entries of this layer's rows
+                        output_layer = output_layer.reshape(-1)[:rows[i] * (1 if i == 1 else S)]
+                output_layer = hidden_layer(x_i, output_layer, eps=None if eps is None else eps[i], xdiv=S,
                                             want_dx=want_dx, chain=chains[i])
+            if rows is not None:
+                output_layer.batch_rows = rows[i]
             l_outputs[i] = output_layer
         return l_outputs
 
@@ -244,14 +261,14 @@ class MFDGP(nn.Module):
     overlap_chains = False                # opt-in (HIP-graph replay of forked captures is slower on ROCm 7.2)
     OVERLAP_MAX_ROWS = 1 << 21            # above this the private backward scratch per layer is not worth its memory
 
-    def _launch_chains(self, inputs, num_layers, S, want_dx):
+    def _launch_chains(self, inputs, num_layers, S, want_dx, rows=None):
         """The parameter-only (CHAIN) half of every layer, issued up front on a side stream so the latency-bound M x M
         work of layer l runs under the grid-filling panel work of the other layers -- forward here, and backward through
         autograd, which replays each half on the stream its forward used.  Only without per-call host checks
         (``set_check_pd(False)``: graphed / bench / fitter fast path); otherwise the layers run serially."""
         layers = [getattr(self, self.name_hidden_layer + str(i)) for i in range(num_layers)]
         if not (self.overlap_chains and inputs.is_cuda and num_layers > 1 and not any(l.check_pd for l in layers)
-                and inputs.shape[0] * S <= self.OVERLAP_MAX_ROWS):
+                and inputs.shape[0] * S <= self.OVERLAP_MAX_ROWS):      # (rows: an upper bound)
             return [None] * num_layers
         main = torch.cuda.current_stream(inputs.device)
         side = F.side_stream_for(main)
@@ -262,8 +279,8 @@ class MFDGP(nn.Module):
         chains = []
         with torch.cuda.stream(side):
             for i, layer in enumerate(layers):
-                chains.append(layer.launch_chain(inputs.shape[0] * (1 if i == 0 else S), 1 if i == 0 else S, want_dx,
-                                                 main, side))
+                nb = inputs.shape[0] if rows is None else rows[i]
+                chains.append(layer.launch_chain(nb * (1 if i == 0 else S), 1 if i == 0 else S, want_dx, main, side))
         return chains
 
     def fix_variational_hypers(self, value):

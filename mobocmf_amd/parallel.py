@@ -396,10 +396,10 @@ class RowShardedELBOStep(_graphed_base()):
 
     def _fwd_bwd(self):
         self.bucket.zero_()
-        n = self.x.shape[0] * self.S
+        rows = self.layer_rows if self.layer_rows is not None else [self.x.shape[0]] * self.L
         eps = self.fixed_eps if self.fixed_eps is not None else \
-            [None] + [torch.randn(n, dtype=torch.float64, device=self.x.device) for _ in range(1, self.L)]
-        out = self.model(self.x, eps=eps)
+            [None] + [torch.randn(rows[l] * self.S, dtype=torch.float64, device=self.x.device) for l in range(1, self.L)]
+        out = self.model(self.x, eps=eps, rows=self.layer_rows)
         res = self.elbo(out, self.y.T, self.fid)
         (-res[0]).backward()
         self.bucket.extra[0].copy_(-res[0].detach())

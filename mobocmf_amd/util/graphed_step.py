@@ -18,13 +18,30 @@ class GraphedELBOStep:
     exchanges = False      # True in subclasses whose step has a collective between backward and update
 
     def __init__(self, model, elbo, x, y, fidelities, lr, betas=(0.9, 0.999), eps=1e-8, use_graph=True, stream=None,
-                 warmup=3, fixed_eps=None):
+                 warmup=3, fixed_eps=None, prune_rows=True):
         self.model, self.elbo = model, elbo
+        self.S = model.num_samples_for_training
+        self.L = model.num_hidden_layers
+        # Dead rows: the ELBO keeps, per layer, the rows of that layer's fidelity (variational_elbo_mf.py:33-38), so a row of
+        # fidelity f reaches the loss through layers 0..f only.  The batch is static: order it ONCE by descending fidelity
+        # (the full-batch ELBO is a sum over rows, their order is free -- the reference's loader shuffles it every epoch,
+        # blackbox_mfdgp_fitter.py:35) and evaluate layer l on the prefix of rows with fidelity >= l (MFDGP.forward(rows=)).
+        # Same ELBO and gradients as evaluating every layer at every row; the upper layers' panels shrink to their share.
+        self.layer_rows = None
+        if prune_rows and self.L > 1:
+            fidv = fidelities.reshape(-1)
+            counts = [int((fidv >= l).sum()) for l in range(self.L)]
+            if counts[-1] >= 1 and counts[0] == fidv.numel():
+                order = torch.argsort(fidv, descending=True, stable=True)
+                x, y, fidelities = x[order].contiguous(), y[order].contiguous(), fidelities[order].contiguous()
+                if fixed_eps is not None:      # given for the batch as passed in (N*S per layer): follow the rows
+                    N = fidv.numel()
+                    fixed_eps = [None if e is None else e.reshape(N, self.S)[order][:counts[l]].reshape(-1).contiguous()
+                                 for l, e in enumerate(fixed_eps)]
+                self.layer_rows = counts
         self.x, self.y, self.fid = x, y, fidelities
         self.use_graph = use_graph
         self.stream = stream if stream is not None else torch.cuda.Stream(device=x.device)
-        self.S = model.num_samples_for_training
-        self.L = model.num_hidden_layers
         params = [p for p in model.parameters()]
         from ..functional import FusedAdam
         if os.environ.get("MOBOCMF_TORCH_ADAM"):      # A/B knob: torch's capturable Adam (seven foreach launches)
@@ -49,7 +66,7 @@ class GraphedELBOStep:
         self.optimizer.zero_grad(set_to_none=True)
         # eps: explicit (deterministic tests) or drawn inside the layers' propagation launches (no torch generator in the
         # captured graph: its replay support costs two fill launches per replay, the draw a third)
-        out = self.model(self.x, eps=self.fixed_eps)
+        out = self.model(self.x, eps=self.fixed_eps, rows=self.layer_rows)
         res = self.elbo(out, self.y.T, self.fid)
         # d(-ELBO): the sign goes in as the upstream gradient (no negation node, no ones fill, no negation backward)
         res[0].backward(gradient=self._minus_one)

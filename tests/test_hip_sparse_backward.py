@@ -246,3 +246,97 @@ def test_model_step_sparse_equals_dense(L, N, S):
     for (n, a), (_, b) in zip(grads[True], grads[False]):
         scale = max(float(b.abs().max()), 1e-300)
         assert float((a - b).abs().max()) / scale < 1e-6, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Dead rows: layer l evaluated on the rows of fidelity >= l only (MFDGP.forward(rows=...), GraphedELBOStep(prune_rows=True))
+
+def _elbo_and_grads(prob, L, N, S, rows, sparse=True):
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd import functional as F
+    model = synthetic.model_from_problem(prob, device=DEV)
+    elbo = VariationalELBOMF(model, N, L)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=DEV)
+    eps = [None] + [t(e) for e in prob["eps"][1:]]
+    if rows is not None:
+        eps = [None] + [e.reshape(N, S)[:rows[l + 1]].reshape(-1).contiguous() for l, e in enumerate(eps[1:])]
+    F.set_sparse_backward(sparse)
+    try:
+        out = model(t(prob["x"]), eps=eps, rows=rows)
+        res = elbo(out, t(prob["y"])[None, :], t(prob["fid"])[:, None])
+        (-res[0]).backward()
+        torch.cuda.synchronize()
+    finally:
+        F.set_sparse_backward(True)
+    model.clear_kl_cache()
+    return float(res[0]), float(res[1]), [(n, p.grad.clone()) for n, p in model.named_parameters() if p.grad is not None], out
+
+
+@pytest.mark.parametrize("L,N,S", [(2, 2000, 4), (3, 1536, 8), (2, 64, 10)])
+def test_pruned_forward_gives_the_same_elbo_and_gradients(L, N, S):
+    """MFDGP.forward(rows=[#rows of fidelity >= l]) on a fidelity-ordered batch: the layers above 0 run on a prefix of the
+    rows, the ELBO and every parameter gradient equal those of the reference layout (every layer at every row, dense
+    backward), and the pruned layers' moments equal the full ones on the rows they cover."""
+    prob = synthetic.make_problem(d=3, L=L, M=min(96, N), N=N, S=S, seed=5)
+    fid = np.asarray(prob["fid"])
+    assert bool((np.diff(fid) <= 0).all())                 # synthetic batches are ordered by descending fidelity
+    rows = [int((fid >= l).sum()) for l in range(L)]
+    assert rows[0] == N and rows[-1] < N
+    e0, k0, g0, out0 = _elbo_and_grads(prob, L, N, S, None, sparse=False)
+    e1, k1, g1, out1 = _elbo_and_grads(prob, L, N, S, rows)
+    assert abs(e1 - e0) <= 1e-10 * abs(e0) and abs(k1 - k0) <= 1e-13 * abs(k0)
+    for l in range(L):
+        n = rows[l] * (1 if l == 0 else S)
+        assert out1[l].mean.numel() == n and out1[l].batch_rows == rows[l]
+        # another N' may take another kernel / tile height (another summation order) through L^-1: ~cond(K_mm) * eps
+        assert rel(out1[l].mean.reshape(-1), out0[l].mean.reshape(-1)[:n]) < 1e-9
+        assert rel(out1[l].variance.reshape(-1), out0[l].variance.reshape(-1)[:n]) < 1e-9
+    assert len(g0) == len(g1) > 0
+    for (n, a), (_, b) in zip(g1, g0):
+        scale = max(float(b.abs().max()), 1e-300)
+        assert float((a - b).abs().max()) / scale < 1e-6, n      # ~cond(K_mm) * eps, as above
+
+
+def test_pruned_forward_rejects_bad_row_counts():
+    prob = synthetic.make_problem(d=2, L=2, M=16, N=64, S=2, seed=1)
+    model = synthetic.model_from_problem(prob, device=DEV)
+    x = torch.as_tensor(prob["x"], dtype=torch.float64, device=DEV)
+    for bad in ([64], [32, 64], [65, 10], [64, 0]):
+        with pytest.raises(ValueError):
+            model(x, rows=bad)
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+@pytest.mark.parametrize("L,N,S", [(2, 600, 4), (3, 512, 4)])
+def test_graphed_step_orders_the_batch_and_prunes(L, N, S, use_graph):
+    """GraphedELBOStep on a SHUFFLED batch: with prune_rows it orders the rows by descending fidelity once (explicit eps follow
+    their rows) and prunes; parameters after three Adam steps and the reported loss equal those of the unpruned step."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.util.graphed_step import GraphedELBOStep
+    prob = synthetic.make_problem(d=3, L=L, M=48, N=N, S=S, seed=9)
+    perm = torch.as_tensor(np.random.default_rng(3).permutation(N), device=DEV)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=DEV)
+    x, y, fid = t(prob["x"])[perm].contiguous(), t(prob["y"])[perm, None].contiguous(), t(prob["fid"])[perm, None].contiguous()
+    eps = [None] + [t(e).reshape(N, S)[perm].reshape(-1).contiguous() for e in prob["eps"][1:]]
+    finals, losses = [], []
+    for prune in (False, True):
+        model = synthetic.model_from_problem(prob, device=DEV)
+        step = GraphedELBOStep(model, VariationalELBOMF(model, N, L), x, y, fid, lr=1e-2, use_graph=use_graph,
+                               fixed_eps=eps, prune_rows=prune)
+        assert (step.layer_rows is not None) == prune
+        if prune:
+            assert bool((step.fid.reshape(-1)[:-1] >= step.fid.reshape(-1)[1:]).all())
+            assert step.layer_rows == [int((fid >= l).sum()) for l in range(L)]
+        ls = []
+        for _ in range(3):
+            loss, _ = step.step()
+            step.stream.synchronize()
+            ls.append(float(loss))
+        step.check()
+        finals.append([p.detach().clone() for p in model.parameters()])
+        losses.append(ls)
+        step.retire()
+    for a, b in zip(losses[0], losses[1]):
+        assert abs(a - b) <= 1e-9 * abs(a)
+    for a, b in zip(finals[0], finals[1]):
+        assert float((a - b).abs().max()) <= 1e-7 * max(float(a.abs().max()), 1e-30)
