@@ -407,6 +407,7 @@ def main():
     ap.add_argument("--potrf-cols", type=int, default=0, help="A/B knob: columns per hand-over of the Cholesky panel kernel (4 | 1)")
     ap.add_argument("--dense-backward", action="store_true",
                     help="A/B knob: do not skip the column blocks of a layer backward whose upstream gradients are all zero")
+    ap.add_argument("--syrk-wgs", type=int, default=0, help="A/B knob: workgroups a k-sliced weighted syrk may occupy (default 512)")
     ap.add_argument("--no-prune-rows", action="store_true",
                     help="A/B knob: evaluate every layer at every row (the reference's layout) instead of the rows that reach the loss")
     ap.add_argument("--no-dense-leg", action="store_true",
@@ -447,6 +448,9 @@ def main():
     if args.dense_backward:
         from mobocmf_amd import functional as F_
         F_.set_sparse_backward(False)
+    if args.syrk_wgs:
+        from mobocmf_amd import functional as F_
+        F_.set_syrk_workgroups(args.syrk_wgs)
     if args.potrf_cols:
         from mobocmf_amd import functional as F_
         F_.set_potrf_cols(args.potrf_cols)

@@ -347,6 +347,11 @@ int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, i
  * like mobocmf_set_tuning: size sweeps, tests, A/B timing. */
 int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode);
 
+/* Workgroups a k-sliced weighted syrk may occupy (16..4096; 0 = default: by shape, 256 for N' <= 16384 and 512 = one round
+ * of two per CU above): fewer, longer k slices write and re-read fewer slabs.  Changes mobocmf_syrk_workspace_bytes and the layer workspaces' sizes: set it before
+ * sizing buffers.  Process-wide; sweeps and A/B timing. */
+int mobocmf_set_syrk_workgroups(int32_t n);
+
 /* Zero-gradient column blocks of the layer backward.  The backward of a layer is linear in its upstream gradients
  * (g_mean, g_var), column by column of the N' side: a 128-column block in which both are exactly zero contributes exactly
  * zero to every product of the backward (dA, the weighted syrk H, da, dK, the Gram backward).  The top layer of a

@@ -75,6 +75,7 @@ SYMBOLS = {
     "mobocmf_gemm_colstat_rows": [_I32, _I32, _I64, _I64, ctypes.POINTER(_I32)],
     "mobocmf_set_tile_rows": [_I32, _I32],
     "mobocmf_set_sparse_backward": [_I32],
+    "mobocmf_set_syrk_workgroups": [_I32],
     "mobocmf_set_block_activity": [_P],
     "mobocmf_set_potrf_cols": [_I32],
     "mobocmf_syrk_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ)],

@@ -90,10 +90,12 @@ static inline void probe_at(int i, int64_t N, hipStream_t s) {
 // CU and the triangular operand resolved in 64-row blocks).  0 = automatic: launch_gemm picks it from the shape
 // (gemm_f64.hip tile_rows); 64 / 128 force it for every panel product (mobocmf_set_tile_rows: sweeps, tests, A/B timing).
 static std::atomic<int> g_tile_rows{0}, g_pair_mode{0};
+static std::atomic<int> g_syrk_wgs{0};         // workgroups a k-sliced weighted syrk may use, 0 = by shape (mobocmf_set_syrk_workgroups)
 static std::atomic<int> g_sparse_bwd{1};      // skip column blocks whose upstream gradients are all zero (mobocmf_set_sparse_backward)
 // the standalone product entry points (mobocmf_gemm_f64 / mobocmf_syrk_weighted_f64) take this device array as their
 // column-block / K-block activity (mobocmf_set_block_activity; NULL = dense): how the tests drive the skipping directly
 static std::atomic<const int32_t*> g_block_activity{nullptr};
+static void set_pairing(GemmArgs& g) { g.pair_mode = g_pair_mode.load(std::memory_order_relaxed); }
 static int panel_tile_rows(int, int64_t) { return g_tile_rows.load(std::memory_order_relaxed); }
 
 #define TRY(x)              \
@@ -149,11 +151,15 @@ int syrk_splitk(int Mp, int64_t Np, int* sD) {
         if (sk >= 8) sk &= ~7;
         return sk;
     }
+    // one round of resident workgroups: two per CU -- one per CU for short contractions (N' <= 16384: the slices are a few
+    // dozen K steps, half as many slabs to write and add again costs less than the thinner grid; r3 sweep, profiles/)
+    int budget = g_syrk_wgs.load(std::memory_order_relaxed);
+    if (budget <= 0) budget = Np <= 16384 ? 256 : 512;
     double best = 1e30;
     int bF = 1, bD = 1;
     for (int f = 1; f <= cap; ++f)
         for (int d = 1; d <= f; ++d) {
-            if (nF * f + nD * d > 512) break;
+            if (nF * f + nD * d > budget) break;
             const double cf = (double)((ksteps + f - 1) / f), cd = 0.625 * (double)((ksteps + d - 1) / d);
             double c = cf > cd ? cf : cd;
             if ((f & 7) || (d & 7)) c *= 1.10;
@@ -427,7 +433,7 @@ int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& 
     ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = c.a;
     ga.Kreal = D.M;      // rows >= M of K_mn (and of A, C, dA below) are zero padding
     ga.rm = panel_tile_rows(Mp, Np);
-    ga.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
+    set_pairing(ga);
     TRY(launch_gemm(ga, false, 1, s));
     probe_at(1, D.N, s);
     GemmArgs gc = gemm_args(c.UT, Mp, P.A, Np, P.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
@@ -467,7 +473,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
         ga.rowdot_part = inputs_only ? nullptr : B.dapart;      // da = A gmu rides in the epilogue (it reads A anyway)
         ga.colact = act;
         ga.rm = panel_tile_rows(Mp, Np);
-        ga.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
+        set_pairing(ga);
         probe_at(3, D.N, s);
         TRY(launch_gemm(ga, false, 1, s));
         probe_at(4, D.N, s);
@@ -488,7 +494,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
         GemmArgs ga = gemm_args(c.LinvT, Mp, B.dA, Np, B.dK, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
         ga.Kreal = D.M;
         ga.rm = panel_tile_rows(Mp, Np);
-        ga.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
+        set_pairing(ga);
         ga.colact = act;      // inactive column blocks of dK stay unwritten: the Gram backward below does not read them
         probe_at(7, D.N, s);
         TRY(launch_gemm(ga, false, 1, s));
@@ -1045,7 +1051,7 @@ int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, 
     g.colsq_part = colsq_part; g.coldot_part = coldot_part; g.avec = avec;
     g.bscale = epi == EPI_DA ? bscale : nullptr; g.gmu = gmu; g.cgv = cgv; g.Aaux = Aaux; g.rowdot_part = rowdot_part;
     g.rm = panel_tile_rows(Mr, Nc);
-    g.pair_mode = g_pair_mode.load(std::memory_order_relaxed);
+    set_pairing(g);
     g.colact = g_block_activity.load(std::memory_order_relaxed);
     return launch_gemm(g, false, 1, (hipStream_t)stream);
 }
@@ -1078,6 +1084,12 @@ int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t l
     if (workspace_bytes < syrk_slab_elems(Mr, Kd) * (int64_t)sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
     return weighted_syrk(A, lda, w, Mr, Kd, (double*)workspace, H, nullptr, nullptr, g_block_activity.load(std::memory_order_relaxed),
                          (hipStream_t)stream);
+}
+
+int mobocmf_set_syrk_workgroups(int32_t n) {
+    if (n != 0 && (n < 16 || n > 4096)) return MOBOCMF_BAD_ARG;
+    g_syrk_wgs.store(n, std::memory_order_relaxed);
+    return MOBOCMF_OK;
 }
 
 int mobocmf_set_sparse_backward(int32_t on) {

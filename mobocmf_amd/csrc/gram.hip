@@ -484,12 +484,16 @@ int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* o
 
 static inline int d_bucket(int d) { return d <= 2 ? 2 : (d <= 8 ? 8 : 32); }
 
-// Inducing rows per workgroup: GM, or GM / 4 when that still leaves fewer workgroups than CUs (M x M Gram matrices, small
-// problems: a 64-workgroup launch looping over 32 rows each was a 70 us latency-bound kernel)
+// Inducing rows per workgroup
 static int gram_rows_per_block(const GramArgs& g) {
     int64_t nb_cols = (g.Np + g.xdiv - 1) / g.xdiv;
     int64_t gx = (nb_cols + GT - 1) / GT;
-    return gx * (g.Mp / GM) < 256 ? GM / 4 : GM;
+    // GM, halved down to GM / 4 while the grid stays under 1024 two-wavefront workgroups (one wavefront per SIMD): the
+    // threads walk their inducing rows serially, a thin grid is latency-bound (2048 base rows x 8 replicas, M = 512:
+    // 256 workgroups x 32 rows took 61 us in backward for 67 MB of G)
+    int gm = GM;
+    while (gm > GM / 4 && gx * (g.Mp / gm) < 1024) gm /= 2;
+    return gm;
 }
 void gram_grid(const GramArgs& g, dim3* grid) {
     int64_t nb_cols = (g.Np + g.xdiv - 1) / g.xdiv;   // base rows incl. the ones that only own padded columns

@@ -988,6 +988,11 @@ def gemm_colstat_rows(Mr, Nc, Kd, tri=0):
     return rows.value
 
 
+def set_syrk_workgroups(n=0):
+    """Workgroups a k-sliced weighted syrk may occupy (mobocmf_set_syrk_workgroups); set before any workspace is sized."""
+    _lib.check(_lib.load().mobocmf_set_syrk_workgroups(int(n)), "mobocmf_set_syrk_workgroups")
+
+
 def set_sparse_backward(on=True):
     """Skip the 128-column blocks of a layer backward whose upstream gradients are all exactly zero (default on;
     mobocmf_set_sparse_backward).  Off = the dense backward: A/B timing and the parity tests."""

@@ -13,7 +13,7 @@ from mobocmf_amd import functional as F  # noqa: E402
 dev = torch.device("cuda")
 F.set_tile_rows(int(os.environ.get("TILE_ROWS", "0")), int(os.environ.get("PAIR_MODE", "0")))      # rows: 0 automatic | 64 | 128; pairing: 0 auto | 1 never | 2 always
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 g = torch.Generator(device=dev)
 g.manual_seed(1)
 rnd = lambda *s: torch.randn(*s, dtype=torch.float64, device=dev, generator=g)

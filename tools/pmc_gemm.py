@@ -1,6 +1,7 @@
-"""Runs only the dominant kernel of the step -- A = L^-1 K_mn with the column-statistics epilogue, 512 x 65536 x 512
-lower-triangular, launched exactly as mobocmf_layer_forward launches it -- a few times: used under
-rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) to measure its HBM traffic per launch."""
+"""Runs only the dominant kernel of the step -- A = L^-1 K_mn with the column-statistics epilogue, lower-triangular, M x N' x M
+(argv: M N', default 512 16384 = the widest panel of the C3 step with dead rows pruned), launched exactly as
+mobocmf_layer_forward launches it -- a few times: used under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)
+to measure its HBM traffic per launch."""
 import os
 import sys
 
@@ -10,7 +11,8 @@ import torch
 from mobocmf_amd import functional as F
 
 dev = torch.device("cuda")
-M, N = 512, 65536
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 A = torch.tril(torch.randn(M, M, dtype=torch.float64, device=dev))
 B = torch.randn(M, N, dtype=torch.float64, device=dev)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)

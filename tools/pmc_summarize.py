@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py -> profiles/rNN_pmc_gemm.json.
-usage: python tools/pmc_summarize.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+usage: python tools/pmc_summarize.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [M N']"""
 import csv
 import hashlib
 import json
@@ -16,13 +16,14 @@ def per_launch(path, counter):
 
 f, nf = per_launch(sys.argv[1], "FETCH_SIZE")
 w, nw = per_launch(sys.argv[2], "WRITE_SIZE")
-M, N = 512, 65536
+M = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+N = int(sys.argv[5]) if len(sys.argv) > 5 else 16384
 read_b, write_b = f * 1024 * 2, w * 1024
 alg = (M * N * 2 + M * M // 2) * 8 + 2 * M * N // M * 8 * 0   # K_mn read + A written (+ the L2-resident L^-1 once)
 src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mobocmf_amd", "csrc", "gemm_f64.hip")
 out = {
-    "kernel": "gemm_f64_kernel<false, true, 1>  A = L^-1 K_mn with the column-statistics epilogue, 512 x 65536 x 512 "
-              "lower-triangular (as mobocmf_layer_forward launches it)",
+    "kernel": "gemm_f64_kernel<false, true, 1>  A = L^-1 K_mn with the column-statistics epilogue, %d x %d x %d "
+              "lower-triangular (as mobocmf_layer_forward launches it)" % (M, N, M),
     "shape": [M, N, M],
     "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/pmc_gemm.py  (two separate passes)",
@@ -34,7 +35,7 @@ out = {
     "algorithmic_bytes_per_launch": alg,
     "note": "reads are %.2fx the K_mn bytes: the two workgroup pairs of a 128-column block walk k together (long row "
             "block first, same direction) so the slab one pulls into the XCD's L2 serves the other; the second parts "
-            "re-read 256 of the 512 rows.  The counter sits on the L2's fabric side and also counts Infinity-Cache hits, "
+            "re-read part of the rows.  The counter sits on the L2's fabric side and also counts Infinity-Cache hits, "
             "so it bounds HBM traffic from above." % (read_b / (M * N * 8)),
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -30,9 +30,10 @@ if os.path.exists(F + "/gemm_stamps.txt"):
 if os.path.exists(F + "/gemm_instep_vs_isolated.txt"):
     open(os.path.join(P, R + "_gemm_instep_vs_isolated.txt"), "w").write(clean(F + "/gemm_instep_vs_isolated.txt"))
 with open(os.path.join(P, R + "_gemm_variants.txt"), "w") as o:
-    for name, title in (("gemm_variants.txt", "M = 512, N' = 65536 (C3 top layer)"),
-                        ("gemm_variants_M1024.txt", "M = 1024, N' = 65536 (C5 top layer)"),
-                        ("gemm_variants_layer0.txt", "M = 512, N' = 8192 (C3 layer 0)")):
+    for name, title in (("gemm_variants.txt", "M = 512, N' = 16384 (C3 top layer: the 2048 rows of the top fidelity x 8 samples)"),
+                        ("gemm_variants_M1024.txt", "M = 1024, N' = 16384 (C5 top layer)"),
+                        ("gemm_variants_layer0.txt", "M = 512, N' = 8192 (C3 layer 0)"),
+                        ("gemm_variants_reflayout.txt", "M = 512, N' = 65536 (C3 top layer in the reference's layout: every row)")):
         o.write("# tools/gemm_variants.py -- %s; HIP events, 20 launches per timing, three interleaved rounds after 0.3 s of load\n" % title)
         o.write(clean(F + "/" + name) + "\n")
 with open(os.path.join(P, R + "_other_measurements.txt"), "w") as o:
