@@ -347,6 +347,11 @@ int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, i
  * like mobocmf_set_tuning: size sweeps, tests, A/B timing. */
 int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode);
 
+/* Largest dimension of a plain product (the M x M chain; mobocmf_gemm_f64) that runs on the mid-size kernel -- 64 x 64
+ * tiles, the whole contraction in one workgroup, one launch, no k-slicing -- instead of the 128 x 128 pipeline; default
+ * 512 (up to 1024 accepted by the kernel's users; slower than k-slicing there), 0 = off.  Process-wide; sweeps, tests. */
+int mobocmf_set_mid_gemm_max(int32_t n);
+
 /* Workgroups a k-sliced weighted syrk may occupy (16..4096; 0 = default: by shape, 256 for N' <= 16384 and 512 = one round
  * of two per CU above): fewer, longer k slices write and re-read fewer slabs.  Changes mobocmf_syrk_workspace_bytes and the layer workspaces' sizes: set it before
  * sizing buffers.  Process-wide; sweeps and A/B timing. */

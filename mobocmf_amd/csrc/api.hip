@@ -1022,7 +1022,8 @@ int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64
     if (!A || !B || !C || Mr <= 0 || Nc <= 0 || Kd <= 0 || (lda & 1) || (ldb & 1)) return MOBOCMF_BAD_ARG;
     GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, Mr, Nc, Kd, tri, alpha);
     g.accumulate = accumulate;
-    return launch_gemm(g, trans_b != 0, 1, (hipStream_t)stream);
+    // small / mid-size operands take the kernels the M x M chain uses for them; no workspace: never k-sliced
+    return launch_gemm_auto(g, trans_b != 0, nullptr, 0, (hipStream_t)stream);
 }
 
 int mobocmf_gram_forward(int32_t kind, int32_t d, const double* x1, const double* f1, int64_t n1, const double* x2,

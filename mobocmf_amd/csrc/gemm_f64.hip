@@ -814,7 +814,20 @@ int launch_gemm(const GemmArgs& g0, bool B_T, int splitk, hipStream_t s) {
     // instantiation spills loop-invariant LDS addresses and reloads them -- a scratch round trip -- in every K step
     // (dense 512 x 65536 x 512: 0.62 ms against 0.53 ms through this instantiation)
     const bool tri = (g.tri & (TRI_LOWER_A | TRI_UPPER_A)) != 0 || g.epi == EPI_STORE;
+#ifdef GEMM_LDS_PAD64
+    // experiment (tools/build_variant.sh): dynamic LDS on the 64-row launches caps the workgroups a CU takes (48 KB static:
+    // three fit in 160 KB; + 32 KB -> two, + 64 KB -> one), to see how the dispatcher spreads a grid smaller than the slots
+    const size_t dyn64 = GEMM_LDS_PAD64;
+#define LAUNCH(BT, TR, EP, RM_)                                                                                         \
+    do {                                                                                                                \
+        const size_t dyn = (RM_) == 64 ? dyn64 : 0;                                                                     \
+        if (dyn) (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<BT, TR, EP, RM_>,                               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                       \
+        hipLaunchKernelGGL((gemm_f64_kernel<BT, TR, EP, RM_>), grid, dim3(256), dyn, s, g, nrb, ncb, splitk, pair);      \
+    } while (0)
+#else
 #define LAUNCH(BT, TR, EP, RM_) hipLaunchKernelGGL((gemm_f64_kernel<BT, TR, EP, RM_>), grid, dim3(256), 0, s, g, nrb, ncb, splitk, pair)
+#endif
     if (B_T) {
         if (g.epi != EPI_STORE) return MOBOCMF_BAD_ARG;
         LAUNCH(true, false, EPI_STORE, 128);
@@ -1155,6 +1168,164 @@ static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
 // slabs a k-sliced A B^T product will write: 1 when the small-operand kernel takes it whole
 int gemm_nt_slabs(const GemmArgs& g, int splitk) { return small_gemm_ok(g, true) ? 1 : splitk; }
 
+// ---------------------------------------------------------------------------------- mid-size operands (the M x M chain)
+// M x M x M products with 384 < M <= 512 (the chain of a C3 surrogate: U = L^-1 L_S, the panels of the triangular inverse,
+// ten products of the chain backward).  On the 128 x 128 pipeline they are 10-16 tiles: to occupy the chip they are k-sliced
+// 8-16 ways into slabs -- one or two K steps per workgroup between a prologue and a 128 KB slab store, then a reduction
+// launch: 19 + 7 us for 4 us of MFMA work, 64 MB of slab traffic, and 320-512 workgroups that the other streams' panel
+// kernels share the chip with.  Here: 64 x 64 tiles (four wavefronts of 32 x 32), the whole contraction in one workgroup,
+// ONE launch and no slabs -- 64 workgroups per layer at M = 512.  Operands are cache-resident, so plain global loads
+// (two stages ahead, in registers) replace the LDS-DMA pipeline; the four k-groups of a stage are software-pipelined
+// (fragments of group G + 1 read while the 32 MFMAs of group G issue).  Triangular operands bound the k range per 64-block;
+// inside a diagonal block the stored zeros of the unused triangle do the rest (all chain operands hold them).  Fragment /
+// accumulator lane maps as in gemm_f64_kernel.
+// Measured (r3, M = 512, two layers per launch): 26 us per product -- the same latency as slices + reduction (the longest
+// tile walks all 16 stages at ~1.2 us: 0.8 of MFMAs at one wavefront per SIMD + barriers and the first fragment reads), ten
+// launches less per step and a chip three streams no longer contend for: C3 930 -> 950 steps/s, a lone surrogate 600 -> 591.
+// At M = 1024 the k-sliced form is faster (C5 231 vs 222): mobocmf_set_mid_gemm_max defaults to 512.
+#define MD_BM 64
+#define MD_BN 64
+#define MD_BK 32
+#define MD_LDA (MD_BK + 2)      // k contiguous; 272-byte rows: 16-byte aligned, off the 256-byte bank period
+#define MD_LDB (MD_BN + 2)      // columns contiguous (A B form)
+template <bool B_T>
+__global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g, int nrb, int ncb) {
+    __shared__ __attribute__((aligned(16))) double As[MD_BM * MD_LDA];
+    __shared__ __attribute__((aligned(16))) double Bs[B_T ? MD_BN * MD_LDA : MD_BK * MD_LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
+    // row blocks from the bottom: with a lower-triangular A (or lower_out) the long tiles start first
+    const int rb = nrb - 1 - (int)(blockIdx.x / ncb), cb = (int)(blockIdx.x % ncb);
+    if (g.lower_out && cb > (rb | 1)) return;      // the 128 x 128 lower tiles, as the tiled kernel writes them
+    const int z = blockIdx.z;
+    const double* A = g.A + (g.zlayers > 1 ? z * g.zsA : 0);
+    const double* B = g.B + (g.zlayers > 1 ? z * g.zsB : 0);
+    double* C = g.C + (g.zlayers > 1 ? z * g.zsC : 0);
+    int64_t k0 = 0, k1 = g.Kd;
+    if (g.Kreal > 0) { const int64_t ke = (g.Kreal + MD_BK - 1) / MD_BK * MD_BK; if (k1 > ke) k1 = ke; }
+    if (g.tri & TRI_LOWER_A) { const int64_t e = (int64_t)(rb + 1) * MD_BM; if (k1 > e) k1 = e; }
+    if (g.tri & TRI_UPPER_A) { const int64_t b = (int64_t)rb * MD_BM; if (k0 < b) k0 = b; }
+    if (g.tri & TRI_LOWER_B) { const int64_t b = (int64_t)cb * MD_BN; if (k0 < b) k0 = b; }
+    if (g.tri & TRI_UPPER_B) { const int64_t e = (int64_t)(cb + 1) * MD_BN; if (k1 > e) k1 = e; }
+    const int nst = k1 > k0 ? (int)((k1 - k0) / MD_BK) : 0;
+
+    // staging maps: A (and B^T) image 64 rows x 32 k -- thread = (row t/4, 8 k); B image 32 k x 64 columns -- (k t/8, 8 columns)
+    const int ar = tid >> 2, ak = (tid & 3) * 8;
+    const int bk = tid >> 3, bc = (tid & 7) * 8;
+    const double* Ag = A + ((int64_t)rb * MD_BM + ar) * g.lda + ak;
+    const double* Bg = B_T ? B + ((int64_t)cb * MD_BN + ar) * g.ldb + ak : B + (int64_t)bk * g.ldb + (int64_t)cb * MD_BN + bc;
+    // two register sets: stages st + 1 and st + 2 are in flight while stage st multiplies (one workgroup per CU, one wavefront
+    // per SIMD: nothing else hides the L2 round trip, ~1.3 us against 0.85 us of MFMAs per stage)
+    v2f64 ra0[4], rb0[4], ra1[4], rb1[4];
+#define MD_FETCH(ST, RA, RB)                                                                                \
+    {                                                                                                       \
+        const int64_t k = k0 + (int64_t)(ST) * MD_BK;                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) RA[i] = *(const v2f64*)(Ag + k + 2 * i);             \
+        if (B_T) {                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) RB[i] = *(const v2f64*)(Bg + k + 2 * i);         \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) RB[i] = *(const v2f64*)(Bg + k * g.ldb + 2 * i); \
+        }                                                                                                   \
+    }
+    v4f64 acc[2][2];      // [mt][nt][r]: row = wr*16 + mt*32 + 4r + lk, column = wc*32 + 2 li + nt
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    if (nst > 0) MD_FETCH(0, ra0, rb0)
+    if (nst > 1) MD_FETCH(1, ra1, rb1)
+    const int a_off = (wr * 16 + (lane & 3)) * MD_LDA + 4 * lk;
+    const int bn_off = (4 * lk) * MD_LDB + wc * 32 + 2 * li;
+    const int bt_off = (wc * 32 + 2 * li) * MD_LDA + 4 * lk;
+#define MD_STAGE(ST, RA, RB)                                                                                \
+    {                                                                                                       \
+        __syncthreads();      /* the previous stage's fragment reads are done */                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) *(v2f64*)(As + ar * MD_LDA + ak + 2 * i) = RA[i];    \
+        if (B_T) {                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) *(v2f64*)(Bs + ar * MD_LDA + ak + 2 * i) = RB[i]; \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) *(v2f64*)(Bs + bk * MD_LDB + bc + 2 * i) = RB[i]; \
+        }                                                                                                   \
+        __syncthreads();                                                                                    \
+        if ((ST) + 2 < nst) MD_FETCH((ST) + 2, RA, RB)                                                      \
+        /* fragment sets of the 4 k-groups (kk, p) of the stage, software-pipelined: group G + 1 is read from LDS while  \
+           the 32 MFMAs of group G issue (one wavefront per SIMD: nothing else overlaps LDS with the matrix pipe) */      \
+        MD_LOADF(0, fa0, fb0)                                                                               \
+        MD_LOADF(1, fa1, fb1) MD_MMA(fa0, fb0) __builtin_amdgcn_sched_barrier(0);                           \
+        MD_LOADF(2, fa0, fb0) MD_MMA(fa1, fb1) __builtin_amdgcn_sched_barrier(0);                           \
+        MD_LOADF(3, fa1, fb1) MD_MMA(fa0, fb0) __builtin_amdgcn_sched_barrier(0);                           \
+        MD_MMA(fa1, fb1)                                                                                    \
+    }
+    v2f64 fa0[2][4], fa1[2][4];
+    double fb0[2][2], fb1[2][2];      // [e][nt]
+#define MD_LOADF(G, FA, FB)                                                                                 \
+    {                                                                                                       \
+        constexpr int kq = ((G) >> 1) * 16 + ((G) & 1) * 2;      /* k offset of the group inside the stage */ \
+        if (B_T) {                                                                                          \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                             \
+                const v2f64 v = *(const v2f64*)(Bs + bt_off + nt * MD_LDA + kq);                            \
+                FB[0][nt] = v[0];                                                                           \
+                FB[1][nt] = v[1];                                                                           \
+            }                                                                                               \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
+                const v2f64 v = *(const v2f64*)(Bs + bn_off + (kq + e) * MD_LDB);                           \
+                FB[e][0] = v[0];                                                                            \
+                FB[e][1] = v[1];                                                                            \
+            }                                                                                               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                   \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+                FA[mt][r] = *(const v2f64*)(As + a_off + (mt * 32 + 4 * r) * MD_LDA + kq);                  \
+    }
+/* 16 independent accumulators between two uses of one */
+#define MD_MMA(FA, FB)                                                                                      \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                          \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                   \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                           \
+                    acc[mt][nt][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(FA[mt][r][e], FB[e][nt], acc[mt][nt][r], 0, 0, 0);
+    for (int st = 0; st < nst; st += 2) {
+        MD_STAGE(st, ra0, rb0)
+        if (st + 1 < nst) MD_STAGE(st + 1, ra1, rb1)
+    }
+#undef MD_STAGE
+#undef MD_FETCH
+#undef MD_LOADF
+#undef MD_MMA
+    double* cp = C + ((int64_t)rb * MD_BM + wr * 16 + lk) * g.ldc + (int64_t)cb * MD_BN + wc * 32 + 2 * li;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* q = cp + (int64_t)(mt * 32 + 4 * r) * g.ldc;
+            v2f64 v = (v2f64){g.alpha * acc[mt][0][r], g.alpha * acc[mt][1][r]};
+            if (g.accumulate) v += *(const v2f64*)q;
+            *(v2f64*)q = v;
+        }
+}
+
+static std::atomic<int> g_mid_gemm_max{512};
+extern "C" int mobocmf_set_mid_gemm_max(int32_t n) {
+    if (n < 0 || n > 4096) return MOBOCMF_BAD_ARG;
+    g_mid_gemm_max.store(n, std::memory_order_relaxed);
+    return MOBOCMF_OK;
+}
+static bool mid_gemm_ok(const GemmArgs& g) {
+    const int L = g_mid_gemm_max.load(std::memory_order_relaxed);
+    return g.epi == EPI_STORE && g.batched <= 1 && !g.bscale && !g.skip_if_zero && !g.sym_out && !g.dual_flag && !g.colact &&
+           !g.kact && g.Mr <= L && g.Nc <= L && g.Kd <= L && g.Mr % MD_BM == 0 && g.Nc % MD_BN == 0 && g.Kd % MD_BK == 0 &&
+           !(g.lda & 1) && !(g.ldb & 1) && !(g.ldc & 1) && !((uintptr_t)g.A & 15) && !((uintptr_t)g.B & 15) &&
+           !((uintptr_t)g.C & 15) && (g.zlayers <= 1 || (!(g.zsA & 1) && !(g.zsB & 1) && !(g.zsC & 1)));
+}
+static int launch_mid_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
+    const int nrb = g.Mr / MD_BM, ncb = (int)(g.Nc / MD_BN);
+    const dim3 grid((unsigned)(nrb * ncb), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
+    if (B_T) hipLaunchKernelGGL(gemm_mid_kernel<true>, grid, dim3(256), 0, s, g, nrb, ncb);
+    else hipLaunchKernelGGL(gemm_mid_kernel<false>, grid, dim3(256), 0, s, g, nrb, ncb);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
 // Small-grid GEMMs (M x M operands: a handful of 128x128 tiles on 256 CUs) are bound by one CU's MFMA rate:
 // slice k over more workgroups into slabs, then add the slabs.  ws must hold splitk * Mr * Nc doubles.
 int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems, hipStream_t s) {
@@ -1167,6 +1338,7 @@ int launch_gemm_auto(const GemmArgs& g0, bool B_T, double* ws, int64_t ws_elems,
         g1.batched = 1;
         if (small_gemm_ok(g1, B_T)) return launch_small_gemm(g1, B_T, s);
     } else if (small_gemm_ok(g0, B_T)) return launch_small_gemm(g0, B_T, s);
+    if (mid_gemm_ok(g0)) return launch_mid_gemm(g0, B_T, s);      // one launch, no slabs (the M x M chain at 384 < M <= 1024)
     GemmArgs g = g0;
     const int nrb = g.Mr / BM;
     const int64_t ncb = g.Nc / BN;

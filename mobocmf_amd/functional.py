@@ -988,6 +988,12 @@ def gemm_colstat_rows(Mr, Nc, Kd, tri=0):
     return rows.value
 
 
+def set_mid_gemm_max(n=512):
+    """Largest dimension of a plain product that runs on the mid-size (64 x 64 tiles, one launch, no k-slicing) kernel;
+    0 = off (mobocmf_set_mid_gemm_max)."""
+    _lib.check(_lib.load().mobocmf_set_mid_gemm_max(int(n)), "mobocmf_set_mid_gemm_max")
+
+
 def set_syrk_workgroups(n=0):
     """Workgroups a k-sliced weighted syrk may occupy (mobocmf_set_syrk_workgroups); set before any workspace is sized."""
     _lib.check(_lib.load().mobocmf_set_syrk_workgroups(int(n)), "mobocmf_set_syrk_workgroups")

@@ -248,3 +248,47 @@ def test_propagate_rng_draws_standard_normals_and_advances():
     mean.grad = var.grad = None
     (F.propagate(mean, var, e1, div) * w).sum().backward()
     assert torch.equal(mean.grad, gm) and torch.equal(var.grad, gv)
+
+
+@pytest.mark.parametrize("Mr,Nc,Kd", [(512, 512, 512), (640, 640, 640), (1024, 1024, 1024), (128, 384, 384), (128, 896, 896),
+                                      (768, 512, 1024)])
+def test_mid_gemm_matches_torch_and_the_tiled_kernel(Mr, Nc, Kd):
+    """Plain products with every dimension in (384, 1024] -- the M x M chain of C3 / C5 -- run on the mid-size kernel (64 x 64
+    tiles, whole contraction per workgroup, one launch; mobocmf_set_mid_gemm_max): all triangular-operand flags the chain uses,
+    A B and A B^T, alpha / accumulate, vs float64 torch and vs the 128 x 128 pipeline (knob off)."""
+    from mobocmf_amd import functional as F
+    F.set_mid_gemm_max(1024)      # (default 512: the larger shapes exercise the kernel's own range)
+    try:
+        _mid_gemm_cases(F, Mr, Nc, Kd)
+    finally:
+        F.set_mid_gemm_max(512)
+
+
+def _mid_gemm_cases(F, Mr, Nc, Kd):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(Mr + 3 * Nc + 7 * Kd)
+    rnd = lambda *s: torch.randn(*s, dtype=torch.float64, device=DEV, generator=g)
+    A0, B0, Bt0 = rnd(Mr, Kd), rnd(Kd, Nc), rnd(Nc, Kd)
+    LOWER_A, UPPER_A, LOWER_B, UPPER_B = 1, 2, 4, 8
+    cases = [(0, False), (LOWER_A, False), (UPPER_A, False), (LOWER_B, False), (LOWER_A | LOWER_B, False),
+             (UPPER_A | LOWER_B, False), (0, True), (LOWER_A | UPPER_B, True)]
+    for tri, tb in cases:
+        # the unused triangle holds zeros (as every chain operand does); square blocks decide what "triangle" means
+        A = torch.tril(A0) if tri & LOWER_A else torch.triu(A0) if tri & UPPER_A else A0
+        Bl = Bt0.T if tb else B0                       # logical B [Kd x Nc]
+        Bl = torch.tril(Bl) if tri & LOWER_B else torch.triu(Bl) if tri & UPPER_B else Bl
+        Bop = Bl.T.contiguous() if tb else Bl.contiguous()
+        ref = A @ Bl
+        for alpha, acc in ((1.0, False), (-0.5, True)):
+            C0 = rnd(Mr, Nc)
+            want = alpha * ref + (C0 if acc else 0.0)
+            C = C0.clone() if acc else torch.full((Mr, Nc), float("nan"), dtype=torch.float64, device=DEV)
+            F.gemm_f64(A.contiguous(), Bop, C, tri=tri, trans_b=tb, alpha=alpha, accumulate=acc)
+            assert rel(C, want) < 1e-12, (tri, tb, alpha)
+            F.set_mid_gemm_max(0)
+            try:
+                C2 = C0.clone() if acc else torch.full((Mr, Nc), float("nan"), dtype=torch.float64, device=DEV)
+                F.gemm_f64(A.contiguous(), Bop, C2, tri=tri, trans_b=tb, alpha=alpha, accumulate=acc)
+            finally:
+                F.set_mid_gemm_max(1024)
+            assert rel(C2, want) < 1e-12 and rel(C, C2) < 1e-12, (tri, tb, alpha)
