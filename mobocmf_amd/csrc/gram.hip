@@ -413,7 +413,7 @@ __global__ void sum_partials_multi_kernel(SumTasksArg T) {
     int k = 0;
     while (k + 1 < T.n && (int)blockIdx.x >= T.blk0[k + 1]) ++k;
     const SumTask& t = T.t[k];
-    if (T.wide[k]) {
+    if (T.wide[k] == 1) {
         const int64_t j = (int64_t)(blockIdx.x - T.blk0[k]);
         double v = 0.0;
         for (int64_t p = threadIdx.x; p < t.P; p += 256) v += t.part[p * t.stride + j];
@@ -425,6 +425,26 @@ __global__ void sum_partials_multi_kernel(SumTasksArg T) {
         __syncthreads();
         if (threadIdx.x == 0) {
             v = sh[0] + sh[1] + sh[2] + sh[3];
+            t.out[j] = t.accumulate ? t.out[j] + v : v;
+        }
+        return;
+    }
+    if (T.wide[k] == 2) {
+        // many outputs AND a few dozen partials each: 64 outputs per block, four wavefronts share an output's partial rows
+        // (p = q, q + 4, ...) and combine through LDS in a fixed order -- a quarter of the dependent loads per thread
+        __shared__ double sq[4][64];
+        const int jj = threadIdx.x & 63, q = threadIdx.x >> 6;
+        const int64_t j = (int64_t)(blockIdx.x - T.blk0[k]) * 64 + jj;
+        double v = 0.0;
+        if (j < t.len) {
+            for (int64_t p = q; p < t.P; p += 4) v += t.part[p * t.stride + j];
+            if (t.part2)
+                for (int64_t p = q; p < t.P2; p += 4) v += t.part2[p * t.stride2 + j];
+        }
+        sq[q][jj] = v;
+        __syncthreads();
+        if (q == 0 && j < t.len) {
+            v = (sq[0][jj] + sq[1][jj]) + (sq[2][jj] + sq[3][jj]);
             t.out[j] = t.accumulate ? t.out[j] + v : v;
         }
         return;
@@ -457,8 +477,8 @@ int launch_sum_partials_multi(const SumTask* tasks, int n, hipStream_t s) {
         T.t[m] = tasks[i];
         T.blk0[m] = (int)nb;
         const int64_t pmax = tasks[i].P > (tasks[i].part2 ? tasks[i].P2 : 0) ? tasks[i].P : tasks[i].P2;
-        T.wide[m] = (pmax >= 64 && tasks[i].len <= 4096) ? 1 : 0;
-        nb += T.wide[m] ? tasks[i].len : (tasks[i].len + 255) / 256;
+        T.wide[m] = (pmax >= 64 && tasks[i].len <= 4096) ? 1 : (pmax >= 16 ? 2 : 0);
+        nb += T.wide[m] == 1 ? tasks[i].len : T.wide[m] == 2 ? (tasks[i].len + 63) / 64 : (tasks[i].len + 255) / 256;
         ++m;
     }
     T.blk0[m] = (int)nb;

@@ -652,10 +652,13 @@ class _PropagateRngFn(torch.autograd.Function):
         ctx.save_for_backward(var, eps)
         ctx.div = div
         ctx.mark_non_differentiable(eps)
+        ctx.set_materialize_grads(False)      # no zero-filled "gradient of eps" (a fill launch per backward)
         return out, eps
 
     @staticmethod
     def backward(ctx, g, _g_eps):
+        if g is None:
+            return None, None, None, None, None
         gm, gv = _propagate_backward(ctx, g)
         return gm, gv, None, None, None
 

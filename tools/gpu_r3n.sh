@@ -29,7 +29,7 @@ for M in (512, 640, 768, 1024):
     F.set_mid_gemm_max(1024)
     print("M=%d | %s" % (M, " | ".join(row)), flush=True)
 PY
-for mx in 1024; do
+for mx in 512; do
 for a in "--surrogates 1" "--config C5" ""; do
   timeout -k 10 300 python bench.py $a --mid-gemm-max $mx --no-cpu-baseline --no-roofline --no-dense-leg > $O/b.json 2> $O/b.err || { tail -5 $O/b.err; exit 1; }
   python -c "
