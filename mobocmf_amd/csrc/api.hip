@@ -29,10 +29,6 @@ int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab,
                             const double* fallback, hipStream_t s);
 int launch_reduce_slabs_sym2(const double* slabs, const double* slabs2, int64_t slab_stride, int nslab, int nslab_diag,
                              double* out, double* out2, int Mp, const int32_t* flag, hipStream_t s);
-int launch_dutot(const double* X, const double* U, const double* da, const double* a, const double* gkl, int Mp,
-                 double* dU, double* da_tot, hipStream_t s);
-int launch_y_combine(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
-                     double* Y, hipStream_t s);
 int launch_add_kl_terms(double* dU, const double* U, double* da, const double* a, const double* gkl, int Mp, hipStream_t s);
 int launch_rank1_add(double* X, const double* u, const double* v, int Mp, hipStream_t s);
 int launch_dl_from_t2(const double* T2, const double* L, const double* gkl, int M, int Mp, double* dL, hipStream_t s);
@@ -65,10 +61,8 @@ int launch_gemv_rows_z(const double* Mat, int64_t ld, const double* vec, double*
                        int accumulate, int nz, int64_t zs, hipStream_t s);
 int launch_kl_z(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* const* kl,
                 double* part, int nz, int64_t zs, hipStream_t s);
-int launch_dutot_z(const double* X, const double* U, const double* da, const double* a, const double* const* gkl, int Mp,
-                   double* dU, double* da_tot, int nz, int64_t zs, hipStream_t s);
-int launch_y_combine_z(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
-                       double* Y, int nz, int64_t zs, hipStream_t s);
+int launch_dutot_y_z(const double* G1, const double* G2, const double* Hc, const double* U, const double* da, const double* a,
+                     const double* const* gkl, int Mp, double* dU, double* da_tot, double* Y, int nz, int64_t zs, hipStream_t s);
 int launch_dl_from_t2_z(const double* T2, const double* L, const double* const* gkl, int M, int Mp, double* dL, int nz,
                         int64_t zs, hipStream_t s);
 int launch_phi_z(const double* T3, int Mp, double* P, int nz, int64_t zs, hipStream_t s);
@@ -550,12 +544,8 @@ int chain_backward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const
         GemmArgs g2 = gemm_args(c.U, Mp, G1, Mp, G2, Mp, Mp, Mp, Mp, TRI_LOWER_A, 1.0);            // G2 = U U^T H
         g2.Kreal = D.M;
         TRY(chain_gemm(g2, false, c, n, zs, s));
-        GemmArgs g3 = gemm_args(c.H, Mp, c.U, Mp, X, Mp, Mp, Mp, Mp, TRI_LOWER_B, 1.0);            // X = H U (lower tiles)
-        g3.lower_out = 1;
-        g3.Kreal = D.M;
-        TRY(chain_gemm(g3, false, c, n, zs, s));
-        TRY(launch_dutot_z(X, c.U, c.da, c.a, io.g_kl, Mp, dU, c.da_tot, n, zs, s));
-        TRY(launch_y_combine_z(G2, Hc, c.a, c.da, c.da_tot, Mp, Y, n, zs, s));
+        // X = H U is G1^T (H symmetric): dU_tot = 2 tril(X) + gkl U reads it out of G1, in the launch that also forms Y
+        TRY(launch_dutot_y_z(G1, G2, Hc, c.U, c.da, c.a, io.g_kl, Mp, dU, c.da_tot, Y, n, zs, s));
         GemmArgs g4 = gemm_args(dU, Mp, c.U, Mp, Y, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);   // Y += dU_tot U^T
         g4.accumulate = 1;
         g4.Kreal = D.M;

@@ -320,52 +320,43 @@ int launch_reduce_slabs_sym(const double* slabs, int64_t slab_stride, int nslab,
     return CHECK_LAUNCH();
 }
 
-// dU_tot = 2 tril(X) + gkl U  (X = H U, lower tiles valid);  da_tot = da + gkl a
-__global__ void dutot_kernel(const double* X, const double* U, const double* da, const double* a, ScalZ gklz,
-                             int Mp, double* dU, double* da_tot, int64_t zs) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dU_tot = 2 tril(X) + gkl U with X = H U = (U^T H)^T = G1^T (H is exactly symmetric: the slab reduction mirrors it) -- the
+// product X is never formed, its lower triangle is read out of G1 transposed (32 x 32 tiles through LDS);
+// da_tot = da + gkl a;  Y = 2 G2 - 2 Hc + a da^T + da_tot a^T.  One launch for all three, all layers (blockIdx.z).
+__global__ void dutot_y_kernel(const double* G1, const double* G2, const double* Hc, const double* U, const double* da,
+                               const double* a, ScalZ gklz, int Mp, double* dU, double* da_tot, double* Y, int64_t zs) {
+    __shared__ double tl[32][33];
     const double* gkl = gklz.p[blockIdx.z];
     const double g = gkl ? gkl[0] : 0.0;
-    X += blockIdx.z * zs; U += blockIdx.z * zs; da += blockIdx.z * zs; a += blockIdx.z * zs;
-    dU += blockIdx.z * zs; da_tot += blockIdx.z * zs;
-    if (idx < (int64_t)Mp * Mp) {
-        int i = (int)(idx / Mp), j = (int)(idx % Mp);
-        dU[idx] = j <= i ? 2.0 * X[idx] + g * U[idx] : 0.0;
+    const int64_t zo = blockIdx.z * zs;
+    G1 += zo; G2 += zo; Hc += zo; U += zo; da += zo; a += zo; dU += zo; da_tot += zo; Y += zo;
+    const int nt = Mp / 32, ti = blockIdx.x / nt, tj = blockIdx.x % nt;      // tile (ti, tj) of the outputs
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                   // 32 x 8 threads
+    if (tj <= ti) {      // the tile touches the lower triangle: stage G1's tile (tj, ti), coalesced along its rows
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) tl[r][tx] = G1[(int64_t)(tj * 32 + r) * Mp + ti * 32 + tx];
     }
-    if (idx < Mp) da_tot[idx] = da[idx] + g * a[idx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int i = ti * 32 + r, j = tj * 32 + tx;
+        const int64_t idx = (int64_t)i * Mp + j;
+        const double ai = a[i], aj = a[j], dai = da[i], daj = da[j];
+        dU[idx] = j <= i ? 2.0 * tl[tx][r] + g * U[idx] : 0.0;      // X[i][j] = G1[j][i]
+        Y[idx] = 2.0 * (G2[idx] - Hc[idx]) + ai * daj + (dai + g * ai) * aj;
+        if (tj == 0 && tx == 0) da_tot[i] = dai + g * ai;
+    }
 }
-int launch_dutot_z(const double* X, const double* U, const double* da, const double* a, const double* const* gkl, int Mp,
-                   double* dU, double* da_tot, int nz, int64_t zs, hipStream_t s) {
+int launch_dutot_y_z(const double* G1, const double* G2, const double* Hc, const double* U, const double* da, const double* a,
+                     const double* const* gkl, int Mp, double* dU, double* da_tot, double* Y, int nz, int64_t zs, hipStream_t s) {
     ScalZ t = {};
     for (int z = 0; z < nz; ++z) t.p[z] = gkl[z];
-    hipLaunchKernelGGL(dutot_kernel, GRIDZ((int64_t)Mp * Mp, nz), 0, s, X, U, da, a, t, Mp, dU, da_tot, zs);
+    const int nt = Mp / 32;
+    hipLaunchKernelGGL(dutot_y_kernel, dim3((unsigned)(nt * nt), 1, (unsigned)nz), dim3(256), 0, s, G1, G2, Hc, U, da, a, t, Mp,
+                       dU, da_tot, Y, zs);
     return CHECK_LAUNCH();
-}
-int launch_dutot(const double* X, const double* U, const double* da, const double* a, const double* gkl, int Mp,
-                 double* dU, double* da_tot, hipStream_t s) {
-    const double* one[1] = {gkl};
-    return launch_dutot_z(X, U, da, a, one, Mp, dU, da_tot, 1, 0, s);
 }
 
-// Y = 2 G2 - 2 Hc + a da^T + da_tot a^T
-__global__ void y_combine_kernel(const double* G2, const double* Hc, const double* a, const double* da,
-                                 const double* da_tot, int Mp, double* Y, int64_t zs) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)Mp * Mp) return;
-    G2 += blockIdx.z * zs; Hc += blockIdx.z * zs; a += blockIdx.z * zs; da += blockIdx.z * zs;
-    da_tot += blockIdx.z * zs; Y += blockIdx.z * zs;
-    int i = (int)(idx / Mp), j = (int)(idx % Mp);
-    Y[idx] = 2.0 * (G2[idx] - Hc[idx]) + a[i] * da[j] + da_tot[i] * a[j];
-}
-int launch_y_combine_z(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
-                       double* Y, int nz, int64_t zs, hipStream_t s) {
-    hipLaunchKernelGGL(y_combine_kernel, GRIDZ((int64_t)Mp * Mp, nz), 0, s, G2, Hc, a, da, da_tot, Mp, Y, zs);
-    return CHECK_LAUNCH();
-}
-int launch_y_combine(const double* G2, const double* Hc, const double* a, const double* da, const double* da_tot, int Mp,
-                     double* Y, hipStream_t s) {
-    return launch_y_combine_z(G2, Hc, a, da, da_tot, Mp, Y, 1, 0, s);
-}
 
 // ------------------------------------------------------------------ Cholesky-chain backward glue (Mp x Mp)
 // dU_tot = dU + gkl*U ;  da_tot = da + gkl*a        (in place on dU, da)
