@@ -546,17 +546,22 @@ int chain_backward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const
         TRY(chain_gemm(g2, false, c, n, zs, s));
         // X = H U is G1^T (H symmetric): dU_tot = 2 tril(X) + gkl U reads it out of G1, in the launch that also forms Y
         TRY(launch_dutot_y_z(G1, G2, Hc, c.U, c.da, c.a, io.g_kl, Mp, dU, c.da_tot, Y, n, zs, s));
-        GemmArgs g4 = gemm_args(dU, Mp, c.U, Mp, Y, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);   // Y += dU_tot U^T
+    }
+    // Y += dU_tot U^T (as dU_tot x UT: both products in the A B form) and T1 = L^-T dU_tot are independent: one launch for
+    // the pair where the mid-size kernel takes them.  g_LS = tril(T1) - gkl diag(1/LS_ii) and g_m = L^-T da_tot: the user
+    // tensors of all layers in one launch
+    {
+        GemmArgs g4 = gemm_args(dU, Mp, c.UT, Mp, Y, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_UPPER_B, 1.0);
         g4.accumulate = 1;
         g4.Kreal = D.M;
-        TRY(chain_gemm(g4, true, c, n, zs, s));
-    }
-    // g_LS = tril(L^-T dU_tot) - gkl diag(1/LS_ii) and g_m = L^-T da_tot: the user tensors of all layers in one launch
-    {
         GemmArgs ga = gemm_args(c.LinvT, Mp, dU, Mp, T1, Mp, Mp, Mp, Mp, TRI_UPPER_A | TRI_LOWER_B, 1.0);
         ga.lower_out = 1;
         ga.Kreal = D.M;
-        TRY(chain_gemm(ga, false, c, n, zs, s));
+        if (n > 1) {
+            g4.zlayers = ga.zlayers = n;
+            g4.zsA = g4.zsB = g4.zsC = ga.zsA = ga.zsB = ga.zsC = zs;
+        }
+        TRY(launch_gemm_auto_pair(g4, ga, c.slabs, c.slab_elems, s));
         TRY(launch_chain_outputs_z(T1, c.LSp, c.LinvT, c.da_tot, D.M, Mp, io.g_kl, io.g_LS, io.g_m, n, zs, s));
     }
     // dL

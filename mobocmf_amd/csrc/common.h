@@ -99,6 +99,7 @@ int gemm_nt_slabs(const GemmArgs& g, int splitk);   // k-slices (slabs) an A B^T
 int gemm_rowdot_parts(const GemmArgs& g);   // number of column slices EPI_DA writes to rowdot_part
 int gemm_colstat_rows(const GemmArgs& g);   // number of partial rows EPI_COLSTATS writes to colsq_part / coldot_part
 int launch_gemm_auto(const GemmArgs& g, bool B_T, double* ws, int64_t ws_elems, hipStream_t s);
+int launch_gemm_auto_pair(const GemmArgs& a, const GemmArgs& b, double* ws, int64_t ws_elems, hipStream_t s);
 // out[i][j] = scale * sum_z slabs[z][i][j]  (lower_only: zero above the diagonal), Mr x Mr
 int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, double* out, int64_t ld, int Mr,
                         double scale, int lower_only, int accumulate, hipStream_t s);

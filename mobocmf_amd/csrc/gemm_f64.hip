@@ -1189,7 +1189,7 @@ int gemm_nt_slabs(const GemmArgs& g, int splitk) { return small_gemm_ok(g, true)
 #define MD_LDA (MD_BK + 2)      // k contiguous; 272-byte rows: 16-byte aligned, off the 256-byte bank period
 #define MD_LDB (MD_BN + 2)      // columns contiguous (A B form)
 template <bool B_T>
-__global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g, int nrb, int ncb) {
+__device__ __forceinline__ void gemm_mid_body(const GemmArgs& g, int nrb, int ncb) {
     __shared__ __attribute__((aligned(16))) double As[MD_BM * MD_LDA];
     __shared__ __attribute__((aligned(16))) double Bs[B_T ? MD_BN * MD_LDA : MD_BK * MD_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1305,6 +1305,16 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g, int nrb, int 
         }
 }
 
+template <bool B_T>
+__global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g, int nrb, int ncb) {
+    gemm_mid_body<B_T>(g, nrb, ncb);
+}
+// two independent A B products of the same shape in one launch (blockIdx.y picks the problem): half-empty grids side by side
+__global__ __launch_bounds__(256) void gemm_mid2_kernel(GemmArgs g0, GemmArgs g1, int nrb, int ncb) {
+    if (blockIdx.y == 0) gemm_mid_body<false>(g0, nrb, ncb);
+    else gemm_mid_body<false>(g1, nrb, ncb);
+}
+
 static std::atomic<int> g_mid_gemm_max{512};
 extern "C" int mobocmf_set_mid_gemm_max(int32_t n) {
     if (n < 0 || n > 4096) return MOBOCMF_BAD_ARG;
@@ -1324,6 +1334,23 @@ static int launch_mid_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
     if (B_T) hipLaunchKernelGGL(gemm_mid_kernel<true>, grid, dim3(256), 0, s, g, nrb, ncb);
     else hipLaunchKernelGGL(gemm_mid_kernel<false>, grid, dim3(256), 0, s, g, nrb, ncb);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+// Two independent plain A B products (same shape, same layer batching) -- one launch on the mid-size kernel when both qualify,
+// otherwise one after the other through launch_gemm_auto.
+int launch_gemm_auto_pair(const GemmArgs& a, const GemmArgs& b, double* ws, int64_t ws_elems, hipStream_t s) {
+    const int nza = a.zlayers > 1 ? a.zlayers : 1, nzb = b.zlayers > 1 ? b.zlayers : 1;
+    GemmArgs a1 = a, b1 = b;
+    a1.batched = b1.batched = 1;
+    const bool small = small_gemm_ok(nza > 1 ? a1 : a, false) || small_gemm_ok(nzb > 1 ? b1 : b, false);
+    if (!small && nza == nzb && a.Mr == b.Mr && a.Nc == b.Nc && a.batched <= 1 && b.batched <= 1 && mid_gemm_ok(a) && mid_gemm_ok(b)) {
+        const int nrb = a.Mr / MD_BM, ncb = (int)(a.Nc / MD_BN);
+        hipLaunchKernelGGL(gemm_mid2_kernel, dim3((unsigned)(nrb * ncb), 2, (unsigned)nza), dim3(256), 0, s, a, b, nrb, ncb);
+        return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+    }
+    int rc = launch_gemm_auto(a, false, ws, ws_elems, s);
+    if (rc) return rc;
+    return launch_gemm_auto(b, false, ws, ws_elems, s);
 }
 
 // Small-grid GEMMs (M x M operands: a handful of 128x128 tiles on 256 CUs) are bound by one CU's MFMA rate:

@@ -271,7 +271,7 @@ def _mid_gemm_cases(F, Mr, Nc, Kd):
     A0, B0, Bt0 = rnd(Mr, Kd), rnd(Kd, Nc), rnd(Nc, Kd)
     LOWER_A, UPPER_A, LOWER_B, UPPER_B = 1, 2, 4, 8
     cases = [(0, False), (LOWER_A, False), (UPPER_A, False), (LOWER_B, False), (LOWER_A | LOWER_B, False),
-             (UPPER_A | LOWER_B, False), (0, True), (LOWER_A | UPPER_B, True)]
+             (UPPER_A | LOWER_B, False), (LOWER_A | UPPER_B, False), (0, True), (LOWER_A | UPPER_B, True)]
     for tri, tb in cases:
         # the unused triangle holds zeros (as every chain operand does); square blocks decide what "triangle" means
         A = torch.tril(A0) if tri & LOWER_A else torch.triu(A0) if tri & UPPER_A else A0
