@@ -409,6 +409,7 @@ def main():
                     help="A/B knob: do not skip the column blocks of a layer backward whose upstream gradients are all zero")
     ap.add_argument("--small-gemm-max", type=int, default=0, help="A/B knob: largest M x M product the small-operand kernel takes (mobocmf_set_tuning)")
     ap.add_argument("--mid-gemm-max", type=int, default=-1, help="A/B knob: largest M x M product on the mid-size kernel (0 = off)")
+    ap.add_argument("--mid-gemm-waves", type=int, default=0, help="A/B knob: wavefronts per workgroup of the mid-size kernel (8 | 4)")
     ap.add_argument("--syrk-wgs", type=int, default=0, help="A/B knob: workgroups a k-sliced weighted syrk may occupy (default 512)")
     ap.add_argument("--no-prune-rows", action="store_true",
                     help="A/B knob: evaluate every layer at every row (the reference's layout) instead of the rows that reach the loss")
@@ -456,6 +457,9 @@ def main():
     if args.mid_gemm_max >= 0:
         from mobocmf_amd import functional as F_
         F_.set_mid_gemm_max(args.mid_gemm_max)
+    if args.mid_gemm_waves:
+        from mobocmf_amd import functional as F_
+        F_.set_mid_gemm_waves(args.mid_gemm_waves)
     if args.syrk_wgs:
         from mobocmf_amd import functional as F_
         F_.set_syrk_workgroups(args.syrk_wgs)

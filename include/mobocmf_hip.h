@@ -351,6 +351,9 @@ int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode);
  * tiles, the whole contraction in one workgroup, one launch, no k-slicing -- instead of the 128 x 128 pipeline; default
  * 512 (up to 1024 accepted by the kernel's users; slower than k-slicing there), 0 = off.  Process-wide; sweeps, tests. */
 int mobocmf_set_mid_gemm_max(int32_t n);
+/* Wavefronts per workgroup of that kernel: 8 (default: two per SIMD, one's barriers and LDS traffic under the other's MFMAs)
+ * or 4.  Process-wide; A/B timing, tests. */
+int mobocmf_set_mid_gemm_waves(int32_t n);
 
 /* Workgroups a k-sliced weighted syrk may occupy (16..4096; 0 = default: by shape, 256 for N' <= 16384 and 512 = one round
  * of two per CU above): fewer, longer k slices write and re-read fewer slabs.  Changes mobocmf_syrk_workspace_bytes and the layer workspaces' sizes: set it before

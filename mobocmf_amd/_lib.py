@@ -77,6 +77,7 @@ SYMBOLS = {
     "mobocmf_set_sparse_backward": [_I32],
     "mobocmf_set_syrk_workgroups": [_I32],
     "mobocmf_set_mid_gemm_max": [_I32],
+    "mobocmf_set_mid_gemm_waves": [_I32],
     "mobocmf_set_block_activity": [_P],
     "mobocmf_set_potrf_cols": [_I32],
     "mobocmf_syrk_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ)],

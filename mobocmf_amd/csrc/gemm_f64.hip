@@ -1232,8 +1232,10 @@ __device__ __forceinline__ void gemm_mid_body(const GemmArgs& g, int nrb, int nc
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    if (nst > 0) MD_FETCH(0, ra0, rb0)
-    if (nst > 1) MD_FETCH(1, ra1, rb1)
+    if (nst > 0) {
+        MD_FETCH(0, ra0, rb0)
+        MD_FETCH((nst > 1 ? 1 : 0), ra1, rb1)
+    }
     const int a_off = (wr * 16 + (lane & 3)) * MD_LDA + 4 * lk;
     const int bn_off = (4 * lk) * MD_LDB + wc * 32 + 2 * li;
     const int bt_off = (wc * 32 + 2 * li) * MD_LDA + 4 * lk;
@@ -1247,7 +1249,10 @@ __device__ __forceinline__ void gemm_mid_body(const GemmArgs& g, int nrb, int nc
             _Pragma("unroll") for (int i = 0; i < 4; ++i) *(v2f64*)(Bs + bk * MD_LDB + bc + 2 * i) = RB[i]; \
         }                                                                                                   \
         __syncthreads();                                                                                    \
-        if ((ST) + 2 < nst) MD_FETCH((ST) + 2, RA, RB)                                                      \
+        /* unconditional (the last two stages re-fetch the final one): with a conditional fetch the number of loads in     \
+           flight depends on the path and hipcc waits for ALL of them (vmcnt(0)) before the next LDS store -- that  \
+           halved the prefetch distance; the operands come from the Infinity Cache / HBM at ~1.5 us a round trip */  \
+        MD_FETCH(((ST) + 2 < nst ? (ST) + 2 : nst - 1), RA, RB)                                             \
         /* fragment sets of the 4 k-groups (kk, p) of the stage, software-pipelined: group G + 1 is read from LDS while  \
            the 32 MFMAs of group G issue (one wavefront per SIMD: nothing else overlaps LDS with the matrix pipe) */      \
         MD_LOADF(0, fa0, fb0)                                                                               \
@@ -1285,10 +1290,13 @@ __device__ __forceinline__ void gemm_mid_body(const GemmArgs& g, int nrb, int nc
             _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                           \
                     acc[mt][nt][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(FA[mt][r][e], FB[e][nt], acc[mt][nt][r], 0, 0, 0);
-    for (int st = 0; st < nst; st += 2) {
+    // pairs of stages without a branch between them (see MD_FETCH above: the load count in flight must not depend on the path)
+    int st = 0;
+    for (; st + 1 < nst; st += 2) {
         MD_STAGE(st, ra0, rb0)
-        if (st + 1 < nst) MD_STAGE(st + 1, ra1, rb1)
+        MD_STAGE(st + 1, ra1, rb1)
     }
+    if (st < nst) MD_STAGE(st, ra0, rb0)
 #undef MD_STAGE
 #undef MD_FETCH
 #undef MD_LOADF
@@ -1305,9 +1313,110 @@ __device__ __forceinline__ void gemm_mid_body(const GemmArgs& g, int nrb, int nc
         }
 }
 
+// The same tile on EIGHT wavefronts (2 x 4 of 32 x 16): two wavefronts per SIMD, so one's barriers, LDS stores and fragment
+// reads run under the other's MFMAs -- the four-wavefront form executes them back to back (measured per 32-k stage:
+// 0.77 us of MFMAs + 0.46 us of everything else, additive).
+template <bool B_T>
+__device__ __forceinline__ void gemm_mid8_body(const GemmArgs& g, int nrb, int ncb) {
+    __shared__ __attribute__((aligned(16))) double As[MD_BM * MD_LDA];
+    __shared__ __attribute__((aligned(16))) double Bs[B_T ? MD_BN * MD_LDA : MD_BK * MD_LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3, li = lane & 15, lk = lane >> 4;
+    const int rb = nrb - 1 - (int)(blockIdx.x / ncb), cb = (int)(blockIdx.x % ncb);
+    if (g.lower_out && cb > (rb | 1)) return;
+    const int z = blockIdx.z;
+    const double* A = g.A + (g.zlayers > 1 ? z * g.zsA : 0);
+    const double* B = g.B + (g.zlayers > 1 ? z * g.zsB : 0);
+    double* C = g.C + (g.zlayers > 1 ? z * g.zsC : 0);
+    int64_t k0 = 0, k1 = g.Kd;
+    if (g.Kreal > 0) { const int64_t ke = (g.Kreal + MD_BK - 1) / MD_BK * MD_BK; if (k1 > ke) k1 = ke; }
+    if (g.tri & TRI_LOWER_A) { const int64_t e = (int64_t)(rb + 1) * MD_BM; if (k1 > e) k1 = e; }
+    if (g.tri & TRI_UPPER_A) { const int64_t b = (int64_t)rb * MD_BM; if (k0 < b) k0 = b; }
+    if (g.tri & TRI_LOWER_B) { const int64_t b = (int64_t)cb * MD_BN; if (k0 < b) k0 = b; }
+    if (g.tri & TRI_UPPER_B) { const int64_t e = (int64_t)(cb + 1) * MD_BN; if (k1 > e) k1 = e; }
+    const int nst = k1 > k0 ? (int)((k1 - k0) / MD_BK) : 0;
+    // staging maps (512 threads): A / B^T image 64 rows x 32 k -- (row t/8, 4 k); B image 32 k x 64 columns -- (k t/16, 4 columns)
+    const int ar = tid >> 3, ak = (tid & 7) * 4;
+    const int bk = tid >> 4, bc = (tid & 15) * 4;
+    const double* Ag = A + ((int64_t)rb * MD_BM + ar) * g.lda + ak;
+    const double* Bg = B_T ? B + ((int64_t)cb * MD_BN + ar) * g.ldb + ak : B + (int64_t)bk * g.ldb + (int64_t)cb * MD_BN + bc;
+    v2f64 ra[2], rbv[2];
+    auto fetch = [&](int st) {
+        const int64_t k = k0 + (int64_t)st * MD_BK;
+        ra[0] = *(const v2f64*)(Ag + k);
+        ra[1] = *(const v2f64*)(Ag + k + 2);
+        const double* bp = B_T ? Bg + k : Bg + k * g.ldb;
+        rbv[0] = *(const v2f64*)bp;
+        rbv[1] = *(const v2f64*)(bp + 2);
+    };
+    v4f64 acc[2];      // [mt][r]: row = wr*16 + mt*32 + 4r + lk, column = wc*16 + li
+    acc[0] = acc[1] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    if (nst > 0) fetch(0);
+    const int a_off = (wr * 16 + (lane & 3)) * MD_LDA + 4 * lk;
+    const int bn_off = (4 * lk) * MD_LDB + wc * 16 + li;
+    const int bt_off = (wc * 16 + li) * MD_LDA + 4 * lk;
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();      // the previous stage's fragment reads are done
+        *(v2f64*)(As + ar * MD_LDA + ak) = ra[0];
+        *(v2f64*)(As + ar * MD_LDA + ak + 2) = ra[1];
+        if (B_T) {
+            *(v2f64*)(Bs + ar * MD_LDA + ak) = rbv[0];
+            *(v2f64*)(Bs + ar * MD_LDA + ak + 2) = rbv[1];
+        } else {
+            *(v2f64*)(Bs + bk * MD_LDB + bc) = rbv[0];
+            *(v2f64*)(Bs + bk * MD_LDB + bc + 2) = rbv[1];
+        }
+        __syncthreads();
+        if (st + 1 < nst) fetch(st + 1);      // in flight while this stage multiplies
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const int kq = (G >> 1) * 16 + (G & 1) * 2;
+            double fb[2];
+            if (B_T) {
+                const v2f64 v = *(const v2f64*)(Bs + bt_off + kq);
+                fb[0] = v[0];
+                fb[1] = v[1];
+            } else {
+                fb[0] = Bs[bn_off + kq * MD_LDB];
+                fb[1] = Bs[bn_off + (kq + 1) * MD_LDB];
+            }
+            v2f64 fa[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fa[mt][r] = *(const v2f64*)(As + a_off + (mt * 32 + 4 * r) * MD_LDA + kq);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[mt][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[mt][r][e], fb[e], acc[mt][r], 0, 0, 0);
+        }
+    }
+    double* cp = C + ((int64_t)rb * MD_BM + wr * 16 + lk) * g.ldc + (int64_t)cb * MD_BN + wc * 16 + li;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* q = cp + (int64_t)(mt * 32 + 4 * r) * g.ldc;
+            double v = g.alpha * acc[mt][r];
+            if (g.accumulate) v += *q;
+            *q = v;
+        }
+}
+
 template <bool B_T>
 __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g, int nrb, int ncb) {
     gemm_mid_body<B_T>(g, nrb, ncb);
+}
+template <bool B_T>
+__global__ __launch_bounds__(512) void gemm_mid8_kernel(GemmArgs g, int nrb, int ncb) {
+    gemm_mid8_body<B_T>(g, nrb, ncb);
+}
+__global__ __launch_bounds__(512) void gemm_mid8x2_kernel(GemmArgs g0, GemmArgs g1, int nrb, int ncb) {
+    if (blockIdx.y == 0) gemm_mid8_body<false>(g0, nrb, ncb);
+    else gemm_mid8_body<false>(g1, nrb, ncb);
 }
 // two independent A B products of the same shape in one launch (blockIdx.y picks the problem): half-empty grids side by side
 __global__ __launch_bounds__(256) void gemm_mid2_kernel(GemmArgs g0, GemmArgs g1, int nrb, int ncb) {
@@ -1328,11 +1437,22 @@ static bool mid_gemm_ok(const GemmArgs& g) {
            !(g.lda & 1) && !(g.ldb & 1) && !(g.ldc & 1) && !((uintptr_t)g.A & 15) && !((uintptr_t)g.B & 15) &&
            !((uintptr_t)g.C & 15) && (g.zlayers <= 1 || (!(g.zsA & 1) && !(g.zsB & 1) && !(g.zsC & 1)));
 }
+static std::atomic<int> g_mid_waves{8};
+extern "C" int mobocmf_set_mid_gemm_waves(int32_t n) {
+    if (n != 4 && n != 8) return MOBOCMF_BAD_ARG;
+    g_mid_waves.store(n, std::memory_order_relaxed);
+    return MOBOCMF_OK;
+}
 static int launch_mid_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
     const int nrb = g.Mr / MD_BM, ncb = (int)(g.Nc / MD_BN);
     const dim3 grid((unsigned)(nrb * ncb), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
-    if (B_T) hipLaunchKernelGGL(gemm_mid_kernel<true>, grid, dim3(256), 0, s, g, nrb, ncb);
-    else hipLaunchKernelGGL(gemm_mid_kernel<false>, grid, dim3(256), 0, s, g, nrb, ncb);
+    if (g_mid_waves.load(std::memory_order_relaxed) == 8) {
+        if (B_T) hipLaunchKernelGGL(gemm_mid8_kernel<true>, grid, dim3(512), 0, s, g, nrb, ncb);
+        else hipLaunchKernelGGL(gemm_mid8_kernel<false>, grid, dim3(512), 0, s, g, nrb, ncb);
+    } else {
+        if (B_T) hipLaunchKernelGGL(gemm_mid_kernel<true>, grid, dim3(256), 0, s, g, nrb, ncb);
+        else hipLaunchKernelGGL(gemm_mid_kernel<false>, grid, dim3(256), 0, s, g, nrb, ncb);
+    }
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
@@ -1345,7 +1465,10 @@ int launch_gemm_auto_pair(const GemmArgs& a, const GemmArgs& b, double* ws, int6
     const bool small = small_gemm_ok(nza > 1 ? a1 : a, false) || small_gemm_ok(nzb > 1 ? b1 : b, false);
     if (!small && nza == nzb && a.Mr == b.Mr && a.Nc == b.Nc && a.batched <= 1 && b.batched <= 1 && mid_gemm_ok(a) && mid_gemm_ok(b)) {
         const int nrb = a.Mr / MD_BM, ncb = (int)(a.Nc / MD_BN);
-        hipLaunchKernelGGL(gemm_mid2_kernel, dim3((unsigned)(nrb * ncb), 2, (unsigned)nza), dim3(256), 0, s, a, b, nrb, ncb);
+        if (g_mid_waves.load(std::memory_order_relaxed) == 8)
+            hipLaunchKernelGGL(gemm_mid8x2_kernel, dim3((unsigned)(nrb * ncb), 2, (unsigned)nza), dim3(512), 0, s, a, b, nrb, ncb);
+        else
+            hipLaunchKernelGGL(gemm_mid2_kernel, dim3((unsigned)(nrb * ncb), 2, (unsigned)nza), dim3(256), 0, s, a, b, nrb, ncb);
         return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
     }
     int rc = launch_gemm_auto(a, false, ws, ws_elems, s);

@@ -997,6 +997,11 @@ def set_mid_gemm_max(n=512):
     _lib.check(_lib.load().mobocmf_set_mid_gemm_max(int(n)), "mobocmf_set_mid_gemm_max")
 
 
+def set_mid_gemm_waves(n=8):
+    """Wavefronts per workgroup of the mid-size product kernel, 8 or 4 (mobocmf_set_mid_gemm_waves)."""
+    _lib.check(_lib.load().mobocmf_set_mid_gemm_waves(int(n)), "mobocmf_set_mid_gemm_waves")
+
+
 def set_syrk_workgroups(n=0):
     """Workgroups a k-sliced weighted syrk may occupy (mobocmf_set_syrk_workgroups); set before any workspace is sized."""
     _lib.check(_lib.load().mobocmf_set_syrk_workgroups(int(n)), "mobocmf_set_syrk_workgroups")

@@ -250,18 +250,21 @@ def test_propagate_rng_draws_standard_normals_and_advances():
     assert torch.equal(mean.grad, gm) and torch.equal(var.grad, gv)
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("Mr,Nc,Kd", [(512, 512, 512), (640, 640, 640), (1024, 1024, 1024), (128, 384, 384), (128, 896, 896),
                                       (768, 512, 1024)])
-def test_mid_gemm_matches_torch_and_the_tiled_kernel(Mr, Nc, Kd):
+def test_mid_gemm_matches_torch_and_the_tiled_kernel(Mr, Nc, Kd, waves):
     """Plain products with every dimension in (384, 1024] -- the M x M chain of C3 / C5 -- run on the mid-size kernel (64 x 64
     tiles, whole contraction per workgroup, one launch; mobocmf_set_mid_gemm_max): all triangular-operand flags the chain uses,
     A B and A B^T, alpha / accumulate, vs float64 torch and vs the 128 x 128 pipeline (knob off)."""
     from mobocmf_amd import functional as F
     F.set_mid_gemm_max(1024)      # (default 512: the larger shapes exercise the kernel's own range)
+    F.set_mid_gemm_waves(waves)   # 8 wavefronts per workgroup (default) and the 4-wavefront form
     try:
         _mid_gemm_cases(F, Mr, Nc, Kd)
     finally:
         F.set_mid_gemm_max(512)
+        F.set_mid_gemm_waves(8)
 
 
 def _mid_gemm_cases(F, Mr, Nc, Kd):
