@@ -251,10 +251,10 @@ def test_model_step_sparse_equals_dense(L, N, S):
 # ---------------------------------------------------------------------------------------------------------------------
 # Dead rows: layer l evaluated on the rows of fidelity >= l only (MFDGP.forward(rows=...), GraphedELBOStep(prune_rows=True))
 
-def _elbo_and_grads(prob, L, N, S, rows, sparse=True):
+def _elbo_and_grads(prob, L, N, S, rows, sparse=True, **model_kwargs):
     from mobocmf_amd.mlls import VariationalELBOMF
     from mobocmf_amd import functional as F
-    model = synthetic.model_from_problem(prob, device=DEV)
+    model = synthetic.model_from_problem(prob, device=DEV, **model_kwargs)
     elbo = VariationalELBOMF(model, N, L)
     t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=DEV)
     eps = [None] + [t(e) for e in prob["eps"][1:]]
@@ -295,6 +295,21 @@ def test_pruned_forward_gives_the_same_elbo_and_gradients(L, N, S):
     for (n, a), (_, b) in zip(g1, g0):
         scale = max(float(b.abs().max()), 1e-300)
         assert float((a - b).abs().max()) / scale < 1e-6, n      # ~cond(K_mm) * eps, as above
+
+
+def test_pruned_forward_with_the_only_highest_fidelity_ablation():
+    """use_only_highest_fidelity (mfdgp.py:189-190: the previous layer's output enters as zeros): the zeros are cut to the
+    layer's rows as well; same ELBO and gradients as the reference layout."""
+    L, N, S = 2, 1200, 4
+    prob = synthetic.make_problem(d=3, L=L, M=64, N=N, S=S, seed=8)
+    fid = np.asarray(prob["fid"])
+    rows = [int((fid >= l).sum()) for l in range(L)]
+    e0, k0, g0, _ = _elbo_and_grads(prob, L, N, S, None, sparse=False, use_only_highest_fidelity=True)
+    e1, k1, g1, out1 = _elbo_and_grads(prob, L, N, S, rows, use_only_highest_fidelity=True)
+    assert out1[1].mean.numel() == rows[1] * S
+    assert abs(e1 - e0) <= 1e-10 * abs(e0) and abs(k1 - k0) <= 1e-13 * abs(k0)
+    for (n, a), (_, b) in zip(g1, g0):
+        assert float((a - b).abs().max()) / max(float(b.abs().max()), 1e-300) < 1e-6, n
 
 
 def test_pruned_forward_rejects_bad_row_counts():
