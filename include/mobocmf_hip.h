@@ -348,11 +348,11 @@ int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, i
 int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode);
 
 /* Largest dimension of a plain product (the M x M chain; mobocmf_gemm_f64) that runs on the mid-size kernel -- 64 x 64
- * tiles, the whole contraction in one workgroup, one launch, no k-slicing -- instead of the 128 x 128 pipeline; default
- * 512 (up to 1024 accepted by the kernel's users; slower than k-slicing there), 0 = off.  Process-wide; sweeps, tests. */
+ * or 32 x 64 tiles, the whole contraction in one workgroup, one launch, no k-slicing -- instead of the 128 x 128 pipeline;
+ * default 1024, 0 = off.  Process-wide; sweeps, tests. */
 int mobocmf_set_mid_gemm_max(int32_t n);
-/* Wavefronts per workgroup of that kernel: 8 (default: two per SIMD, one's barriers and LDS traffic under the other's MFMAs)
- * or 4.  Process-wide; A/B timing, tests. */
+/* Form of that kernel: 32 (default) = 32 x 64 tiles on four wavefronts with 64-k stages; 8 / 4 = 64 x 64 tiles on eight /
+ * four wavefronts with 32-k stages.  Process-wide; A/B timing, tests. */
 int mobocmf_set_mid_gemm_waves(int32_t n);
 
 /* Workgroups a k-sliced weighted syrk may occupy (16..4096; 0 = default: by shape, 256 for N' <= 16384 and 512 = one round

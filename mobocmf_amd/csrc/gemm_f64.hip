@@ -1169,8 +1169,8 @@ static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
 int gemm_nt_slabs(const GemmArgs& g, int splitk) { return small_gemm_ok(g, true) ? 1 : splitk; }
 
 // ---------------------------------------------------------------------------------- mid-size operands (the M x M chain)
-// M x M x M products with 384 < M <= 512 (the chain of a C3 surrogate: U = L^-1 L_S, the panels of the triangular inverse,
-// ten products of the chain backward).  On the 128 x 128 pipeline they are 10-16 tiles: to occupy the chip they are k-sliced
+// M x M x M products with 384 < M <= 1024 (the chain of a C3 / C5 surrogate: U = L^-1 L_S, the panels of the triangular inverse,
+// eight products of the chain backward).  On the 128 x 128 pipeline they are 10-16 tiles: to occupy the chip they are k-sliced
 // 8-16 ways into slabs -- one or two K steps per workgroup between a prologue and a 128 KB slab store, then a reduction
 // launch: 19 + 7 us for 4 us of MFMA work, 64 MB of slab traffic, and 320-512 workgroups that the other streams' panel
 // kernels share the chip with.  Here: 64 x 64 tiles (four wavefronts of 32 x 32), the whole contraction in one workgroup,
@@ -1179,10 +1179,15 @@ int gemm_nt_slabs(const GemmArgs& g, int splitk) { return small_gemm_ok(g, true)
 // (fragments of group G + 1 read while the 32 MFMAs of group G issue).  Triangular operands bound the k range per 64-block;
 // inside a diagonal block the stored zeros of the unused triangle do the rest (all chain operands hold them).  Fragment /
 // accumulator lane maps as in gemm_f64_kernel.
-// Measured (r3, M = 512, two layers per launch): 26 us per product -- the same latency as slices + reduction (the longest
-// tile walks all 16 stages at ~1.2 us: 0.8 of MFMAs at one wavefront per SIMD + barriers and the first fragment reads), ten
-// launches less per step and a chip three streams no longer contend for: C3 930 -> 950 steps/s, a lone surrogate 600 -> 591.
-// At M = 1024 the k-sliced form is faster (C5 231 vs 222): mobocmf_set_mid_gemm_max defaults to 512.
+// Three forms, same lane maps (mobocmf_set_mid_gemm_waves):
+//   32 (default)  32 x 64 tiles, four wavefronts of 16 x 32, 64-k stages: 19.5 us per product at M = 512, 38 at 1024
+//    8            64 x 64 tiles, eight wavefronts of 32 x 16, 32-k stages: 27 / 51 us
+//    4            64 x 64 tiles, four wavefronts of 32 x 32, 32-k stages, fragments software-pipelined: 29 / 55 us
+// (k-sliced 128 x 128 pipeline + slab reduction: 19 + 7 us at M = 512, 45-80 + 16 at 1024.)  What a stage costs beside
+// its MFMAs at one workgroup per CU -- two barriers, the LDS hand-over, the first fragment reads: ~0.5-0.7 us, measured
+// with the MFMAs / the fragment reads compiled out -- does not overlap with them (one wavefront per SIMD executes in
+// order; eight wavefronts or a deeper prefetch changed little), so the form with the fewest stages per k and the most
+// workgroups wins.  tools/mid_k_sweep.py.
 #define MD_BM 64
 #define MD_BN 64
 #define MD_BK 32
@@ -1406,6 +1411,121 @@ __device__ __forceinline__ void gemm_mid8_body(const GemmArgs& g, int nrb, int n
         }
 }
 
+// 32 x 64 tiles, 64-k stages (four wavefronts of 16 x 32): twice the workgroups of the 64 x 64 form, and half the barriers,
+// LDS hand-overs and exposed fragment reads per k -- what a stage costs beside its MFMAs at one workgroup per CU.
+#define MS_BM 32
+#define MS_BK 64
+#define MS_LDA (MS_BK + 2)
+template <bool B_T>
+__device__ __forceinline__ void gemm_mid32_body(const GemmArgs& g, int nrb, int ncb) {
+    __shared__ __attribute__((aligned(16))) double As[MS_BM * MS_LDA];
+    __shared__ __attribute__((aligned(16))) double Bs[B_T ? MD_BN * MS_LDA : MS_BK * MD_LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
+    const int rb = nrb - 1 - (int)(blockIdx.x / ncb), cb = (int)(blockIdx.x % ncb);      // 32-row blocks, 64-column blocks
+    if (g.lower_out && cb > (rb >> 1 | 1)) return;      // the 128 x 128 lower tiles, as the tiled kernel writes them
+    const int z = blockIdx.z;
+    const double* A = g.A + (g.zlayers > 1 ? z * g.zsA : 0);
+    const double* B = g.B + (g.zlayers > 1 ? z * g.zsB : 0);
+    double* C = g.C + (g.zlayers > 1 ? z * g.zsC : 0);
+    int64_t k0 = 0, k1 = g.Kd;
+    if (g.Kreal > 0) { const int64_t ke = (g.Kreal + MS_BK - 1) / MS_BK * MS_BK; if (k1 > ke) k1 = ke; }
+    // triangular operands: k range per 64-block (the rows of this tile lie in 64-block rb / 2)
+    if (g.tri & TRI_LOWER_A) { const int64_t e = (int64_t)(rb / 2 + 1) * 64; if (k1 > e) k1 = e; }
+    if (g.tri & TRI_UPPER_A) { const int64_t b = (int64_t)(rb / 2) * 64; if (k0 < b) k0 = b; }
+    if (g.tri & TRI_LOWER_B) { const int64_t b = (int64_t)cb * MD_BN; if (k0 < b) k0 = b; }
+    if (g.tri & TRI_UPPER_B) { const int64_t e = (int64_t)(cb + 1) * MD_BN; if (k1 > e) k1 = e; }
+    const int nst = k1 > k0 ? (int)((k1 - k0) / MS_BK) : 0;
+    // staging maps: A image 32 rows x 64 k -- thread = (row t/8, 8 k); B image 64 k x 64 columns -- (k t/8 and t/8 + 32, 8 columns);
+    // B^T image 64 columns x 64 k -- (column t/8 and t/8 + 32, 8 k)
+    const int ar = tid >> 3, ak = (tid & 7) * 8;
+    const double* Ag = A + ((int64_t)rb * MS_BM + ar) * g.lda + ak;
+    const double* Bg = B_T ? B + ((int64_t)cb * MD_BN + ar) * g.ldb + ak : B + (int64_t)ar * g.ldb + (int64_t)cb * MD_BN + ak;
+    const int64_t bstep = B_T ? 32 * g.ldb : 32 * g.ldb;      // second half: 32 columns (B^T) / 32 k rows (B) further
+    v2f64 ra[4], rb0[4], rb1[4];
+    auto fetch = [&](int st) {
+        const int64_t k = k0 + (int64_t)st * MS_BK;
+        const double* bp = B_T ? Bg + k : Bg + k * g.ldb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *(const v2f64*)(Ag + k + 2 * i);
+            rb0[i] = *(const v2f64*)(bp + 2 * i);
+            rb1[i] = *(const v2f64*)(bp + bstep + 2 * i);
+        }
+    };
+    v4f64 acc[2];      // [nt][r]: row = wr*16 + 4r + lk, column = wc*32 + 2 li + nt
+    acc[0] = acc[1] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    if (nst > 0) fetch(0);
+    const int a_off = (wr * 16 + (lane & 3)) * MS_LDA + 4 * lk;
+    const int bn_off = (4 * lk) * MD_LDB + wc * 32 + 2 * li;
+    const int bt_off = (wc * 32 + 2 * li) * MS_LDA + 4 * lk;
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();      // the previous stage's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(v2f64*)(As + ar * MS_LDA + ak + 2 * i) = ra[i];
+            if (B_T) {
+                *(v2f64*)(Bs + ar * MS_LDA + ak + 2 * i) = rb0[i];
+                *(v2f64*)(Bs + (ar + 32) * MS_LDA + ak + 2 * i) = rb1[i];
+            } else {
+                *(v2f64*)(Bs + ar * MD_LDB + ak + 2 * i) = rb0[i];
+                *(v2f64*)(Bs + (ar + 32) * MD_LDB + ak + 2 * i) = rb1[i];
+            }
+        }
+        __syncthreads();
+        fetch(st + 1 < nst ? st + 1 : st);      // unconditional: a path-dependent load count costs a full drain (see above)
+#pragma unroll
+        for (int kq = 0; kq < MS_BK; kq += 16) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int kk = kq + 2 * p;
+                double b[2][2];      // [e][nt]
+                if (B_T) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const v2f64 v = *(const v2f64*)(Bs + bt_off + nt * MS_LDA + kk);
+                        b[0][nt] = v[0];
+                        b[1][nt] = v[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const v2f64 v = *(const v2f64*)(Bs + bn_off + (kk + e) * MD_LDB);
+                        b[e][0] = v[0];
+                        b[e][1] = v[1];
+                    }
+                }
+                v2f64 a[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = *(const v2f64*)(As + a_off + (4 * r) * MS_LDA + kk);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[nt][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[r][e], b[e][nt], acc[nt][r], 0, 0, 0);
+            }
+        }
+    }
+    double* cp = C + ((int64_t)rb * MS_BM + wr * 16 + lk) * g.ldc + (int64_t)cb * MD_BN + wc * 32 + 2 * li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double* q = cp + (int64_t)(4 * r) * g.ldc;
+        v2f64 v = (v2f64){g.alpha * acc[0][r], g.alpha * acc[1][r]};
+        if (g.accumulate) v += *(const v2f64*)q;
+        *(v2f64*)q = v;
+    }
+}
+template <bool B_T>
+__global__ __launch_bounds__(256) void gemm_mid32_kernel(GemmArgs g, int nrb, int ncb) {
+    gemm_mid32_body<B_T>(g, nrb, ncb);
+}
+__global__ __launch_bounds__(256) void gemm_mid32x2_kernel(GemmArgs g0, GemmArgs g1, int nrb, int ncb) {
+    if (blockIdx.y == 0) gemm_mid32_body<false>(g0, nrb, ncb);
+    else gemm_mid32_body<false>(g1, nrb, ncb);
+}
+
 template <bool B_T>
 __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g, int nrb, int ncb) {
     gemm_mid_body<B_T>(g, nrb, ncb);
@@ -1424,7 +1544,7 @@ __global__ __launch_bounds__(256) void gemm_mid2_kernel(GemmArgs g0, GemmArgs g1
     else gemm_mid_body<false>(g1, nrb, ncb);
 }
 
-static std::atomic<int> g_mid_gemm_max{512};
+static std::atomic<int> g_mid_gemm_max{1024};
 extern "C" int mobocmf_set_mid_gemm_max(int32_t n) {
     if (n < 0 || n > 4096) return MOBOCMF_BAD_ARG;
     g_mid_gemm_max.store(n, std::memory_order_relaxed);
@@ -1437,16 +1557,21 @@ static bool mid_gemm_ok(const GemmArgs& g) {
            !(g.lda & 1) && !(g.ldb & 1) && !(g.ldc & 1) && !((uintptr_t)g.A & 15) && !((uintptr_t)g.B & 15) &&
            !((uintptr_t)g.C & 15) && (g.zlayers <= 1 || (!(g.zsA & 1) && !(g.zsB & 1) && !(g.zsC & 1)));
 }
-static std::atomic<int> g_mid_waves{8};
+static std::atomic<int> g_mid_waves{32};
 extern "C" int mobocmf_set_mid_gemm_waves(int32_t n) {
-    if (n != 4 && n != 8) return MOBOCMF_BAD_ARG;
+    if (n != 4 && n != 8 && n != 32) return MOBOCMF_BAD_ARG;      // 32: the 32 x 64-tile form (four wavefronts, 64-k stages)
     g_mid_waves.store(n, std::memory_order_relaxed);
     return MOBOCMF_OK;
 }
 static int launch_mid_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
     const int nrb = g.Mr / MD_BM, ncb = (int)(g.Nc / MD_BN);
     const dim3 grid((unsigned)(nrb * ncb), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
-    if (g_mid_waves.load(std::memory_order_relaxed) == 8) {
+    if (g_mid_waves.load(std::memory_order_relaxed) == 32 && g.Kd % MS_BK == 0) {
+        const int nrb32 = g.Mr / MS_BM;
+        const dim3 grid32((unsigned)(nrb32 * ncb), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
+        if (B_T) hipLaunchKernelGGL(gemm_mid32_kernel<true>, grid32, dim3(256), 0, s, g, nrb32, ncb);
+        else hipLaunchKernelGGL(gemm_mid32_kernel<false>, grid32, dim3(256), 0, s, g, nrb32, ncb);
+    } else if (g_mid_waves.load(std::memory_order_relaxed) == 8) {
         if (B_T) hipLaunchKernelGGL(gemm_mid8_kernel<true>, grid, dim3(512), 0, s, g, nrb, ncb);
         else hipLaunchKernelGGL(gemm_mid8_kernel<false>, grid, dim3(512), 0, s, g, nrb, ncb);
     } else {
@@ -1465,7 +1590,10 @@ int launch_gemm_auto_pair(const GemmArgs& a, const GemmArgs& b, double* ws, int6
     const bool small = small_gemm_ok(nza > 1 ? a1 : a, false) || small_gemm_ok(nzb > 1 ? b1 : b, false);
     if (!small && nza == nzb && a.Mr == b.Mr && a.Nc == b.Nc && a.batched <= 1 && b.batched <= 1 && mid_gemm_ok(a) && mid_gemm_ok(b)) {
         const int nrb = a.Mr / MD_BM, ncb = (int)(a.Nc / MD_BN);
-        if (g_mid_waves.load(std::memory_order_relaxed) == 8)
+        if (g_mid_waves.load(std::memory_order_relaxed) == 32 && a.Kd % MS_BK == 0 && b.Kd % MS_BK == 0)
+            hipLaunchKernelGGL(gemm_mid32x2_kernel, dim3((unsigned)((a.Mr / MS_BM) * ncb), 2, (unsigned)nza), dim3(256), 0, s, a, b,
+                               a.Mr / MS_BM, ncb);
+        else if (g_mid_waves.load(std::memory_order_relaxed) == 8)
             hipLaunchKernelGGL(gemm_mid8x2_kernel, dim3((unsigned)(nrb * ncb), 2, (unsigned)nza), dim3(512), 0, s, a, b, nrb, ncb);
         else
             hipLaunchKernelGGL(gemm_mid2_kernel, dim3((unsigned)(nrb * ncb), 2, (unsigned)nza), dim3(256), 0, s, a, b, nrb, ncb);

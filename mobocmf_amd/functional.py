@@ -991,14 +991,15 @@ def gemm_colstat_rows(Mr, Nc, Kd, tri=0):
     return rows.value
 
 
-def set_mid_gemm_max(n=512):
+def set_mid_gemm_max(n=1024):
     """Largest dimension of a plain product that runs on the mid-size (64 x 64 tiles, one launch, no k-slicing) kernel;
     0 = off (mobocmf_set_mid_gemm_max)."""
     _lib.check(_lib.load().mobocmf_set_mid_gemm_max(int(n)), "mobocmf_set_mid_gemm_max")
 
 
-def set_mid_gemm_waves(n=8):
-    """Wavefronts per workgroup of the mid-size product kernel, 8 or 4 (mobocmf_set_mid_gemm_waves)."""
+def set_mid_gemm_waves(n=32):
+    """Form of the mid-size product kernel: 32 (32 x 64 tiles, 64-k stages; default), 8 or 4 (64 x 64 tiles on that many
+    wavefronts) (mobocmf_set_mid_gemm_waves)."""
     _lib.check(_lib.load().mobocmf_set_mid_gemm_waves(int(n)), "mobocmf_set_mid_gemm_waves")
 
 

@@ -250,7 +250,7 @@ def test_propagate_rng_draws_standard_normals_and_advances():
     assert torch.equal(mean.grad, gm) and torch.equal(var.grad, gv)
 
 
-@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("waves", [4, 8, 32])
 @pytest.mark.parametrize("Mr,Nc,Kd", [(512, 512, 512), (640, 640, 640), (1024, 1024, 1024), (128, 384, 384), (128, 896, 896),
                                       (768, 512, 1024)])
 def test_mid_gemm_matches_torch_and_the_tiled_kernel(Mr, Nc, Kd, waves):
@@ -258,13 +258,13 @@ def test_mid_gemm_matches_torch_and_the_tiled_kernel(Mr, Nc, Kd, waves):
     tiles, whole contraction per workgroup, one launch; mobocmf_set_mid_gemm_max): all triangular-operand flags the chain uses,
     A B and A B^T, alpha / accumulate, vs float64 torch and vs the 128 x 128 pipeline (knob off)."""
     from mobocmf_amd import functional as F
-    F.set_mid_gemm_max(1024)      # (default 512: the larger shapes exercise the kernel's own range)
-    F.set_mid_gemm_waves(waves)   # 8 wavefronts per workgroup (default) and the 4-wavefront form
+    F.set_mid_gemm_max(1024)
+    F.set_mid_gemm_waves(waves)   # the three forms of the kernel
     try:
         _mid_gemm_cases(F, Mr, Nc, Kd)
     finally:
-        F.set_mid_gemm_max(512)
-        F.set_mid_gemm_waves(8)
+        F.set_mid_gemm_max(1024)
+        F.set_mid_gemm_waves(32)
 
 
 def _mid_gemm_cases(F, Mr, Nc, Kd):

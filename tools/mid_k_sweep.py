@@ -10,7 +10,7 @@ def timeit(fn, iters=100):
     en.record(); torch.cuda.synchronize()
     return st.elapsed_time(en) / iters * 1e3
 F.set_mid_gemm_max(1024)
-for waves in (4, 8):
+for waves in (4, 8, 32):
     F.set_mid_gemm_waves(waves)
     for M in (128, 512):
         row = []
