@@ -505,7 +505,7 @@ int launch_sum_partials(const double* part, int64_t P, int64_t stride, double* o
 static inline int d_bucket(int d) { return d <= 2 ? 2 : (d <= 8 ? 8 : 32); }
 
 // Inducing rows per workgroup
-static int gram_rows_per_block(const GramArgs& g) {
+static int gram_rows_per_block(const GramArgs& g, bool fwd = false) {
     int64_t nb_cols = (g.Np + g.xdiv - 1) / g.xdiv;
     int64_t gx = (nb_cols + GT - 1) / GT;
     // GM, halved down to GM / 4 while the grid stays under 1024 two-wavefront workgroups (one wavefront per SIMD): the
@@ -513,6 +513,11 @@ static int gram_rows_per_block(const GramArgs& g) {
     // 256 workgroups x 32 rows took 61 us in backward for 67 MB of G)
     int gm = GM;
     while (gm > GM / 4 && gx * (g.Mp / gm) < 1024) gm /= 2;
+    // the forward writes no partials, so shorter workgroups cost nothing.  For K_mm (a few hundred columns: 256 workgroups at
+    // M = 512) two rows per workgroup take the launch from 7.4 to 5.2 us; on the panels (exp-bound: ~13 us of FP64 VALU work
+    // beside 13 us of row stores at 512 x 16384) a finer grid changed nothing and is not used
+    if (fwd && g.is_kmm)
+        while (gm > 2 && gx * (g.Mp / gm) < 4096) gm /= 2;
     return gm;
 }
 void gram_grid(const GramArgs& g, dim3* grid) {
@@ -522,10 +527,11 @@ void gram_grid(const GramArgs& g, dim3* grid) {
 
 int launch_gram_fwd(const GramArgs& g0, hipStream_t s) {
     GramArgs g = g0;
-    g.gm = gram_rows_per_block(g0);
+    g.gm = gram_rows_per_block(g0, true);
     if (g.d < 1 || g.d > 32) return MOBOCMF_BAD_ARG;
     dim3 grid;
     gram_grid(g, &grid);
+    grid.y = (unsigned)(g.Mp / g.gm);
     const int db = d_bucket(g.d);
 #define GF(K, D, X) hipLaunchKernelGGL((gram_fwd_kernel<K, D, X>), grid, dim3(GT), 0, s, g)
     // fast replica paths (f in registers, 16-byte stores) for the usual S = 8 / 16 of layers >= 1
