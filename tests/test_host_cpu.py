@@ -175,3 +175,37 @@ def test_rff_posterior_function_samples():
         assert np.abs(gr - fd).max() < 1e-5 * max(1.0, np.abs(fd).max())
     pr = model.sample_function_from_prior_each_layer(nFeatures=100, generator=g)
     assert len(pr) == 2 and np.isfinite(pr[1](np.random.default_rng(0).random((5, 2)))).all()
+
+
+def test_bench_accounting_of_dead_rows_and_active_blocks():
+    """bench.py's bookkeeping of the work the step does not do: columns per layer with the dead rows pruned,
+    executed GEMM flops, and the share of 128-column blocks a layer backward keeps -- on the synthetic fidelity layout and on
+    an interleaved one."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = dict(d=8, L=2, M=512, N=8192, S=8)
+    fid = np.zeros(8192)
+    fid[:2048] = 1.0                                   # synthetic layout: the first quarter is the top fidelity
+    assert bench.panel_columns(cfg) == [8192, 65536]
+    assert bench.panel_columns(cfg, [8192, 2048]) == [8192, 16384]
+    assert bench.executed_gemm_flops(cfg) == 5.0 * 512 ** 2 * (8192 + 65536)
+    assert bench.executed_gemm_flops(cfg, [8192, 2048]) == 5.0 * 512 ** 2 * (8192 + 16384)
+    # reference layout, sorted rows: the top layer's backward keeps a quarter of its blocks, layer 0 all of them
+    assert bench.backward_active_fractions(cfg, fid, None, True) == [1.0, 0.25]
+    assert bench.backward_active_fractions(cfg, fid, None, False) == [1.0, 1.0]
+    assert bench.executed_gemm_flops(cfg, None, [1.0, 0.25]) == 512 ** 2 * (5.0 * 8192 + (2.0 + 0.75) * 65536)
+    # pruned: every remaining block is active
+    assert bench.backward_active_fractions(cfg, fid, [8192, 2048], True) == [1.0, 1.0]
+    # interleaved fidelities: every block of 16 base rows x 8 samples holds a top-fidelity row -- nothing to skip
+    fid2 = np.zeros(8192)
+    fid2[::4] = 1.0
+    assert bench.backward_active_fractions(cfg, fid2, None, True) == [1.0, 1.0]
+    # three fidelities: the middle layer is reached by its own rows and by the rows the top layer sends gradient back to
+    cfg3 = dict(d=4, L=3, M=128, N=1024, S=4)
+    fid3 = np.zeros(1024)
+    fid3[:256], fid3[256:512] = 2.0, 1.0
+    assert bench.backward_active_fractions(cfg3, fid3, None, True) == [1.0, 0.5, 0.25]
+    assert bench.panel_columns(cfg3, [1024, 512, 256]) == [1024, 2048, 1024]
