@@ -637,6 +637,14 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = measure_dominant_kernel(cfg, device, n_cols=cols[dom], layer=dom)
+            if layer_rows is not None and cols[dom] != cfg["N"] * cfg["S"]:
+                # the same four launches on the panel the reference's layout gives the top layer (every row): the fraction the
+                # kernel reaches when the panel is wide enough for a launch's fixed costs not to show
+                var_ref, fl_ref, (Mp_r, Np_r) = measure_gemm_variants(cfg, device, 20, cfg["N"] * cfg["S"])
+                tot_ref = sum(v["kernel_ms"] for v in var_ref)
+                line["roofline"]["same_kernel_on_reference_layout_panel"] = {
+                    "shape": [Mp_r, Np_r, Mp_r], "kernel_ms": var_ref[0]["kernel_ms"], "frac": var_ref[0]["frac"],
+                    "weighted_frac": len(var_ref) * fl_ref / (tot_ref * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "variants": var_ref}
             if not args.eager and not rows:
                 ins = measure_instep_kernels(gsteps[0], cfg, n_cols=cols[dom])
                 iso = {v["kernel"]: v["kernel_ms"] for v in line["roofline"]["variants"]}
