@@ -45,7 +45,7 @@ def algorithmic_flops(cfg):
     return 3.0 * tot
 
 
-def build_graphed(cfg, outputs, device, use_graph, shard_rows=False, prune_rows=True):
+def build_graphed(cfg, outputs, device, use_graph, shard_rows=False, prune_rows=True, top_fraction=0.25):
     """One GraphedELBOStep (HIP-graph replay of the whole step) per surrogate, each on its own stream.
     shard_rows: every rank holds the SAME surrogates and 1/W of their batch rows (SURVEY 8(e) level 2)."""
     from mobocmf_amd.mlls import VariationalELBOMF
@@ -54,7 +54,8 @@ def build_graphed(cfg, outputs, device, use_graph, shard_rows=False, prune_rows=
         from mobocmf_amd.parallel import RowShardedELBOStep as GraphedELBOStep
     steps = []
     for o in outputs:
-        prob = synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=cfg["M"], N=cfg["N"], S=cfg["S"], output=o % 3, seed=o)
+        prob = synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=cfg["M"], N=cfg["N"], S=cfg["S"], output=o % 3, seed=o,
+                                      top_fraction=top_fraction)
         model = synthetic.model_from_problem(prob, device=device)
         elbo = VariationalELBOMF(model, cfg["N"], cfg["L"])
         t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=device)
@@ -423,6 +424,8 @@ def main():
     ap.add_argument("--small-gemm-max", type=int, default=0, help="A/B knob: largest M x M product the small-operand kernel takes (mobocmf_set_tuning)")
     ap.add_argument("--mid-gemm-max", type=int, default=-1, help="A/B knob: largest M x M product on the mid-size kernel (0 = off)")
     ap.add_argument("--mid-gemm-waves", type=int, default=0, help="A/B knob: wavefronts per workgroup of the mid-size kernel (8 | 4)")
+    ap.add_argument("--top-fraction", type=float, default=0.25,
+                    help="sensitivity sweep only: share of the rows at the top fidelity (SURVEY 8(d) / BASELINE.md fix it at 1/4)")
     ap.add_argument("--syrk-wgs", type=int, default=0, help="A/B knob: workgroups a k-sliced weighted syrk may occupy (default 512)")
     ap.add_argument("--no-prune-rows", action="store_true",
                     help="A/B knob: evaluate every layer at every row (the reference's layout) instead of the rows that reach the loss")
@@ -498,7 +501,8 @@ def main():
     if rows and args.eager:
         raise SystemExit("--shard rows runs through RowShardedELBOStep (graph | all-reduce | graph)")
     if not args.eager:
-        gsteps = build_graphed(cfg, outputs, device, use_graph=True, shard_rows=rows, prune_rows=not args.no_prune_rows)
+        gsteps = build_graphed(cfg, outputs, device, use_graph=True, shard_rows=rows, prune_rows=not args.no_prune_rows,
+                               top_fraction=args.top_fraction)
         sur = [(g.model, g.elbo, g.optimizer, (g.x, g.y, g.fid)) for g in gsteps]
 
         def one_step(*_a):
@@ -561,7 +565,7 @@ def main():
 
     layer_rows = gsteps[0].layer_rows if (not args.eager and not rows) else None
     sparse = not args.dense_backward
-    fid0 = synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=8, N=cfg["N"], S=1, seed=0)["fid"]
+    fid0 = synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=8, N=cfg["N"], S=1, seed=0, top_fraction=args.top_fraction)["fid"]
     if layer_rows is not None:
         import numpy as np
         fid0 = np.sort(np.asarray(fid0).reshape(-1))[::-1]
@@ -575,7 +579,7 @@ def main():
         from mobocmf_amd import functional as F_
         F_.set_sparse_backward(False)
         try:
-            dsteps = build_graphed(cfg, outputs, device, use_graph=True, prune_rows=False)
+            dsteps = build_graphed(cfg, outputs, device, use_graph=True, prune_rows=False, top_fraction=args.top_fraction)
         finally:
             F_.set_sparse_backward(sparse)
         for _ in range(args.warmup):

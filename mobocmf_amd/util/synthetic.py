@@ -26,14 +26,15 @@ def target(x, o):
     return y_low, y_high
 
 
-def make_problem(d, L, M, N, S, output=0, seed=0, num_fidelities=None):
-    """Returns a dict of numpy float64 arrays (see SURVEY 8(d) 'Synthetic inputs')."""
+def make_problem(d, L, M, N, S, output=0, seed=0, num_fidelities=None, top_fraction=0.25):
+    """Returns a dict of numpy float64 arrays (see SURVEY 8(d) 'Synthetic inputs').  ``top_fraction``: share of the rows at
+    every fidelity above the lowest (SURVEY / BASELINE.md: a quarter; other values only for sensitivity sweeps)."""
     L = L if num_fidelities is None else num_fidelities
     rng = np.random.default_rng(seed)
     x = rng.random((N, d))
     fid = np.zeros(N)
     # first N/4 rows highest fidelity; for L=3 the next N/4 rows are the middle fidelity
-    q = N // 4
+    q = N // 4 if top_fraction == 0.25 else min(int(N * top_fraction), N // max(L - 1, 1))
     for l in range(L - 1, 0, -1):
         lo = (L - 1 - l) * q
         fid[lo:lo + q] = float(l)
