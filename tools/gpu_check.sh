@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r3p
+O=gpurun_out/check
 rm -rf $O && mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1
 rc=$?
