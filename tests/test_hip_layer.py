@@ -59,6 +59,8 @@ CASES = [
     (1, 8, 300, 257, 2, 1),
     (0, 32, 64, 200, 1, 0),
     (1, 32, 64, 90, 2, 0),
+    (1, 6, 700, 450, 2, 0),      # Mp = 768: the chain's M x M products on the mid-size kernel between its 512 and 1024 cases
+    (0, 6, 600, 900, 1, 1),      # Mp = 640
 ]
 
 
