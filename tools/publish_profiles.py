@@ -54,16 +54,19 @@ dur = sum(d) / len(d)
 mf = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(acc["SQ_VALU_MFMA_BUSY_CYCLES"])
 clk = sum(acc["GRBM_GUI_ACTIVE"]) / len(acc["GRBM_GUI_ACTIVE"]) / 8 / dur / 1e3
 ms = json.load(open(F + "/bench_C3.json"))["roofline"]["kernel_ms"]
-open(os.path.join(P, R + "_pmc_sq_counters.md"), "w").write("""# SQ counters of the dominant kernel (A = L^-1 K_mn with the column-statistics epilogue, 512 x 65536 x 512)
+shape = json.load(open(F + "/pmc_gemm.json"))["shape"]
+alg = shape[0] * shape[0] * shape[1] / 1e9
+open(os.path.join(P, R + "_pmc_sq_counters.md"), "w").write(("# SQ counters of the dominant kernel (A = L^-1 K_mn with the "
+    "column-statistics epilogue, %d x %d x %d)\n" % tuple(shape)) + """
 
 command: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 tools/pmc_gemm.py` (5 cold launches in a fresh process)
 
 | quantity | value |
 |---|---|
 | duration under the profiler (cold clock) | %.1f us |
-| SQ_VALU_MFMA_BUSY_CYCLES, summed over the 1024 SIMDs | %.3e  (= %.2e per SIMD; x 32 flops = %.2f GFLOP executed: M^2 N' = 17.18 algorithmic + the dense part of the diagonal blocks) |
+| SQ_VALU_MFMA_BUSY_CYCLES, summed over the 1024 SIMDs | %.3e  (= %.2e per SIMD; x 32 flops = %.2f GFLOP executed: M^2 N' = %.2f algorithmic + the dense part of the diagonal blocks) |
 | effective clock (GRBM_GUI_ACTIVE / 8 / duration) | %.2f GHz |
 | MFMA pipe busy / launch duration at that clock | %.2f |
 | the same busy cycles over the settled-clock duration (%.3f ms, bench) at 2.4 GHz | %.2f |
-""" % (dur, mf, mf / 1024, mf * 32 / 1e9, clk, mf / 1024 / (dur * 1e-6 * clk * 1e9), ms, mf / 1024 / (ms * 1e-3 * 2.4e9)))
+""" % (dur, mf, mf / 1024, mf * 32 / 1e9, alg, clk, mf / 1024 / (dur * 1e-6 * clk * 1e9), ms, mf / 1024 / (ms * 1e-3 * 2.4e9)))
 print("published to", P, "as", R + "_*")
