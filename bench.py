@@ -632,6 +632,7 @@ def main():
                           "what": "layer l runs on the rows of fidelity >= l (batch ordered once by descending fidelity); a "
                                   "layer backward skips 128-column blocks whose upstream gradients are all zero"},
             "reference_layout": dense_leg,
+            "value_over_reference_layout": (value / dense_leg["value"]) if dense_leg else None,
             # SURVEY 8(d)'s F_step prices the reference's solve-based op sequence (~1.9x the flops executed here): a
             # speed-up-adjusted figure, NOT a roofline fraction
             "step_algorithmic_fp64_frac": algorithmic_flops(cfg) * value / world / (FP64_PEAK_TFLOPS * 1e12),
