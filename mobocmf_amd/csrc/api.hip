@@ -1150,6 +1150,7 @@ int mobocmf_debug_touch_workspaces(const mobocmf_layer_desc* desc, void* saved, 
     };
     auto panel_bwd = [&](PanelBwd& B) {
         touch(B.gmu, D.Np, &n); touch(B.gv, D.Np, &n); touch(B.gv2, D.Np, &n); touch(B.cgv, D.Np, &n);
+        touch((double*)B.blkact, (D.Np / TILE + 1) / 2, &n);
         touch(B.dA, mn, &n); touch(B.dK, mn, &n); touch(B.slabs, B.slab_elems, &n); touch(B.slabs2, B.slab_elems, &n);
         touch(B.dapart, (D.Np <= 8192 ? D.Np / 16 : D.Np / 64) * (int64_t)D.Mp, &n);
         touch(B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y * D.H, &n);
