@@ -58,6 +58,35 @@ def test_mfgp_kernel_conditioning_and_fit():
     assert f(x[0], gradient=True).shape == (600, 2) or f(x[0], gradient=True).shape == (2,)
 
 
+def test_torch_statement_matches_exact_gp_oracle():
+    """The package's differentiable torch statement of both baselines vs oracle/exact_gp_oracle.py (numpy, dense inverses):
+    kernel matrix, marginal likelihood, predictive moments at every fidelity, off-default hyper-parameters."""
+    from oracle import exact_gp_oracle as EO
+    for cls, nf, n, d in ((MFGP, 2, 14, 2), (MFGP, 3, 60, 4), (MFGP_lin, 3, 15, 2), (MFGP_lin, 5, 80, 3)):
+        X, Y, x, fid, y = _data(n=n, d=d, nf=nf, seed=n)
+        m = cls(X, Y, nf)
+        with torch.no_grad():
+            m.covar_module.cov_funct_signal.outputscale = 0.8
+            m.covar_module.cov_funct_noise.outputscale = 0.35
+            m.covar_module.cov_funct_noise.base_kernel.lengthscale = 0.7 * m.covar_module.cov_funct_signal.base_kernel.lengthscale.reshape(-1)
+            m.likelihood.noise = 0.02
+            if cls is MFGP_lin:
+                m.covar_module.rho.copy_(torch.linspace(0.6, 1.4, nf - 1))
+        hyp, Xn, noise = EO.hyp_of(m), X.numpy(), float(m.likelihood.noise)
+        kind = "MFGP" if cls is MFGP else "MFGP_lin"
+        K_or = EO.mf_kernel(Xn, Xn, hyp) if cls is MFGP else EO.mf_kernel_lin(Xn, Xn, hyp, nf)
+        assert np.abs(m.covar_module(X, X).detach().numpy() - K_or).max() < 1e-12
+        mll_or = EO.marginal_log_likelihood(kind, Xn, y, hyp, noise, nf)
+        assert abs(float(m.marginal_log_likelihood()) - mll_or) < 1e-9 * max(1.0, abs(mll_or))
+        Xt = np.random.default_rng(1).random((9, d))
+        for f in range(nf):
+            mu, var = EO.predict(kind, Xn, y, hyp, noise, nf, Xt, f)
+            with torch.no_grad():
+                p = m.predict(torch.as_tensor(Xt), f)
+            assert np.abs(p.mean.numpy() - mu).max() < 1e-9 * max(1.0, np.abs(mu).max())
+            assert np.abs(p.variance.numpy() - var).max() < 1e-9 * max(1.0, np.abs(var).max())
+
+
 def test_mfgp_lin_kernel_and_mean_function():
     X, Y, x, fid, y = _data(n=15, nf=3, seed=3)
     m = MFGP_lin(X, Y, 3)

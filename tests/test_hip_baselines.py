@@ -1,8 +1,9 @@
 """SURVEY 8(f) N4 on the GPU path: the exact-GP comparison baselines (mobocmf/models/mfgp.py:24-141,145-184;
 mfgp_lin.py:101-189) evaluated on this package's kernels -- Gram (mobocmf_gram_forward), multi-fidelity combination, the
-layer's blocked Cholesky + triangular inverse, the triangular MFMA product with column statistics -- against the plain
-float64 torch statement of the same model (CPU), which tests/test_baselines_cpu.py pins to numpy restatements of the
-reference's formulas."""
+layer's blocked Cholesky + triangular inverse, the triangular MFMA product with column statistics -- against
+oracle/exact_gp_oracle.py (a numpy restatement of the reference's formulas with dense inverses: kernel matrix, marginal
+likelihood, predictive moments at every fidelity), and beside it against the package's own differentiable torch statement
+(which tests/test_baselines_cpu.py pins to the same oracle on the CPU)."""
 import copy
 import math
 
@@ -43,11 +44,24 @@ def test_exact_gp_baselines_on_the_hip_kernels_match_torch(cls_name, n, d, nf):
         if cls is MFGP_lin:
             ref.covar_module.rho.copy_(torch.linspace(0.6, 1.4, nf - 1))
     gpu = copy.deepcopy(ref).to(DEV)
+    from oracle import exact_gp_oracle as EO
+    hyp, Xn, yn, noise = EO.hyp_of(ref), X.numpy(), Y.numpy()[:, 0], float(ref.likelihood.noise)
     # kernel matrix
     with torch.no_grad():
         K_ref = ref.covar_module(ref.x_train, ref.x_train)
         K_hip = gpu._hip_cov(gpu.x_train, gpu.x_train)
         assert _rel(K_hip, K_ref) < 1e-12
+        K_or = EO.mf_kernel(Xn, Xn, hyp) if cls is MFGP else EO.mf_kernel_lin(Xn, Xn, hyp, nf)
+        assert _rel(K_hip, torch.as_tensor(K_or)) < 1e-12
+        # oracle: marginal likelihood and predictive moments from dense numpy inverses (cond(K + noise I) <= ~1e5 here)
+        mll_or = EO.marginal_log_likelihood(cls_name, Xn, yn, hyp, noise, nf)
+        assert abs(float(gpu.marginal_log_likelihood()) - mll_or) < 1e-8 * max(1.0, abs(mll_or))
+        Xo = np.random.default_rng(1).random((37, d))
+        for f in range(nf):
+            mu_or, var_or = EO.predict(cls_name, Xn, yn, hyp, noise, nf, Xo, f)
+            p_hip = gpu.predict(torch.as_tensor(Xo).to(DEV), f)
+            assert _rel(p_hip.mean, torch.as_tensor(mu_or)) < 1e-7, f
+            assert float((p_hip.variance.cpu() - torch.as_tensor(var_or)).abs().max()) < 1e-7 * float(np.abs(var_or).max() + 1.0), f
         # marginal likelihood: dispatches to the kernels on the GPU under no_grad
         mll_ref = ref.marginal_log_likelihood(hip=False)
         mll_hip = gpu.marginal_log_likelihood()

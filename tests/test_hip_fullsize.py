@@ -33,12 +33,36 @@ def _to_dev(raw):
 FULL_CASES = [("C2", s, 0) for s in range(3)] + [("C3", s, o) for s in range(3) for o in (0, 2)] + [("C5", 0, 0)]
 
 
+def _pruned_elbo(model, prob, S):
+    """The step's own evaluation (graphed_step.py:32-43, the configuration bench.py times): rows ordered by descending
+    fidelity, layer l on the prefix of rows with fidelity >= l, explicit eps following their rows.  Synthetic batches are
+    generated in that order already (asserted); the oracle evaluates every layer at every row, as the reference does
+    (variational_elbo_mf.py:33-38 masks afterwards)."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    L, N = prob["L"], prob["x"].shape[0]
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device=DEV)
+    fid = np.asarray(prob["fid"])
+    assert bool((np.diff(fid) <= 0).all())
+    rows = [int((fid >= l).sum()) for l in range(L)]
+    assert rows[0] == N and rows[-1] < N
+    eps = [None] + [t(e).reshape(N, S)[:rows[l + 1]].reshape(-1).contiguous() for l, e in enumerate(prob["eps"][1:])]
+    out = model(t(prob["x"]), eps=eps, rows=rows)
+    for l in range(L):
+        assert out[l].batch_rows == rows[l] and out[l].mean.numel() == rows[l] * (1 if l == 0 else S)
+    return VariationalELBOMF(model, N, L)(out, t(prob["y"])[None, :], t(prob["fid"])[:, None]), out
+
+
+@pytest.mark.parametrize("layout", ["reference_layout", "pruned"])
 @pytest.mark.parametrize("name,seed,output", FULL_CASES, ids=["%s_seed%d_out%d" % c for c in FULL_CASES])
-def test_full_size_elbo_and_gradients(name, seed, output):
+def test_full_size_elbo_and_gradients(name, seed, output, layout):
     """ELBO, per-layer moments and every raw-parameter gradient at the configured sizes, seeds 0-2, objective and
     constraint outputs (tolerance: north-star 1e-4; observed ~1e-9 for values, ~1e-6 for gradients at C3).  C2: 128
     inducing points in 2-D, cond(K_mm + 1e-6 I) ~ 1e9 -- either implementation carries ~cond * eps, the gates there are
-    the north star's 1e-4 (1e-5 for the ELBO)."""
+    the north star's 1e-4 (1e-5 for the ELBO).
+
+    layout = reference_layout: model(x), every layer at every row.  layout = pruned: the launches the headline number
+    runs (at C3 the top-layer panel is 512 x 16384 on 64-row tiles, prefix propagation, per-layer row counts in the
+    fused ELBO), against the SAME dense oracle evaluation -- moments compared on the prefix each layer covers."""
     cfg = {k: v for k, v in synthetic.CONFIGS[name].items() if k != "outputs"}
     prob = synthetic.make_problem(**cfg, output=output, seed=seed)
     S, L = cfg["S"], cfg["L"]
@@ -52,13 +76,18 @@ def test_full_size_elbo_and_gradients(name, seed, output):
     (-e_o).backward()
     with torch.no_grad():
         outs_o = O.model_forward(st, x, eps=eps, S=S, ref_equiv=True)
-    (e, skl), out = hip_elbo(model, prob, S)
+    if layout == "pruned":
+        model.set_check_pd(False)             # as the captured step runs it: no host check between chain and panels
+        (e, skl), out = _pruned_elbo(model, prob, S)
+    else:
+        (e, skl), out = hip_elbo(model, prob, S)
     (-e).backward()
     ill = name == "C2"
     assert rel(e, e_o) < (1e-5 if ill else 1e-7) and rel(skl, skl_o) < (1e-5 if ill else 1e-7)
     for l in range(L):
-        assert rel(out[l].mean.reshape(-1), outs_o[l][0]) < (1e-4 if ill else 1e-6)
-        assert rel(out[l].variance.reshape(-1), outs_o[l][1]) < (1e-4 if ill else 1e-5)
+        n = out[l].mean.numel()               # the prefix the layer covers (all rows in the reference layout)
+        assert rel(out[l].mean.reshape(-1), outs_o[l][0].reshape(-1)[:n]) < (1e-4 if ill else 1e-6)
+        assert rel(out[l].variance.reshape(-1), outs_o[l][1].reshape(-1)[:n]) < (1e-4 if ill else 1e-5)
     for l in range(L):
         for key, tt in raw["layers"][l].items():
             p = _model_param_for(model, l, key)

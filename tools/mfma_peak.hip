@@ -29,9 +29,14 @@ __global__ __launch_bounds__(256) void loop_kernel(double* out, int iters, doubl
         v4f64 acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = (v4f64){0, 0, 0, 0};
+        // Round 4: through the builtin hipcc keeps these accumulators in AGPRs across the back edge and copies all of them to
+        // VGPRs and back in every iteration (128 v_accvgpr_write + 128 v_accvgpr_read per 16 MFMAs): the round-2/3 figure of
+        // 36 TFLOP/s measured those copies.  The instruction is written out with the accumulator tied to one VGPR tuple, so
+        // the loop body is 16 MFMAs and the loop counter (checked with hipcc -S: no v_accvgpr_* in the loop).
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < 16; ++i)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
