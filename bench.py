@@ -15,7 +15,7 @@ the timed region and is reported as `exchange_ms`.
 The line's `value` is the median of --repeats (default 5) timed regions of exactly K steps each (all listed in
 `repeat_values`); `roofline` times the GEMM instantiations the layer really launches (column-statistics and dA
 epilogues included), each on its own, and `per_kernel_instep_ms` the same launches INSIDE a training step (HIP events
-recorded by the library around them, mobocmf_set_probe_events); `cpu_baseline` is 3 warm-up + 10 timed oracle steps on
+recorded by the library around them, mobocmf_layer_desc.probe_events); `cpu_baseline` is 3 warm-up + 10 timed oracle steps on
 the box's host cores.
 """
 import argparse
@@ -246,33 +246,29 @@ PROBE_SPANS = (("Gram forward K_mn", 9, 0), ("A = L^-1 K (lower, colstats q+mean
                ("Gram backward of K_mn", 8, 10))
 
 
-def measure_instep_kernels(gstep, cfg, steps=6, skip=2, n_cols=None):
-    """Durations of the top layer's grid-filling launches INSIDE a training step of one surrogate (the other surrogates
-    idle): the library records caller-created HIP events around them (mobocmf_set_probe_events) while the step is issued
-    eagerly on the surrogate's own stream -- the same launch sequence the captured graph replays.  Mean over the last
-    steps - skip steps."""
+def measure_instep_kernels(gstep, cfg, steps=6, skip=2, layer=None):
+    """Durations of one layer's grid-filling launches INSIDE a training step of one surrogate (the other surrogates idle): the
+    library records caller-created HIP events around them (mobocmf_layer_desc.probe_events, attached to the PANEL calls of
+    layer index `layer` only -- two layers with the same N' cannot be mixed up) while the step is issued eagerly on the
+    surrogate's own stream -- the same launch sequence the captured graph replays.  Mean over the last steps - skip steps."""
     import ctypes
 
     from mobocmf_amd import _lib
-    lib = _lib.load()
-    n_ev = 11
-    Np_top = cfg["N"] * cfg["S"] if n_cols is None else n_cols      # the library fires the probes in the layer of this N'
+    from mobocmf_amd import functional as F_
+    n_ev = _lib.PROBE_EVENTS
     acc = {name: [] for name, _, _ in PROBE_SPANS}
-    try:
-        for k in range(steps):
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
-            with torch.cuda.stream(gstep.stream):
-                for e in evs:
-                    e.record(gstep.stream)      # creates the underlying hipEvent_t (lazy in torch) before it is handed over
-                table = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in evs])
-                _lib.check(lib.mobocmf_set_probe_events(table, n_ev, Np_top), "mobocmf_set_probe_events")
+    for k in range(steps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+        with torch.cuda.stream(gstep.stream):
+            for e in evs:
+                e.record(gstep.stream)      # creates the underlying hipEvent_t (lazy in torch) before it is handed over
+            table = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in evs])
+            with F_.probe_events(table, layer):
                 gstep._eager()
-            gstep.stream.synchronize()
-            if k >= skip:
-                for name, a, b in PROBE_SPANS:
-                    acc[name].append(evs[a].elapsed_time(evs[b]))
-    finally:
-        lib.mobocmf_set_probe_events(None, 0, 0)
+        gstep.stream.synchronize()
+        if k >= skip:
+            for name, a, b in PROBE_SPANS:
+                acc[name].append(evs[a].elapsed_time(evs[b]))
     return {name: sum(v) / len(v) for name, v in acc.items() if v}
 
 
@@ -661,12 +657,12 @@ def main():
                     "shape": [Mp_r, Np_r, Mp_r], "kernel_ms": var_ref[0]["kernel_ms"], "frac": var_ref[0]["frac"],
                     "weighted_frac": len(var_ref) * fl_ref / (tot_ref * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "variants": var_ref}
             if not args.eager and not rows:
-                ins = measure_instep_kernels(gsteps[0], cfg, n_cols=cols[dom])
+                ins = measure_instep_kernels(gsteps[0], cfg, layer=dom)
                 iso = {v["kernel"]: v["kernel_ms"] for v in line["roofline"]["variants"]}
                 line["per_kernel_instep_ms"] = {
                     "kernels": ins, "instep_over_isolated": {k: ins[k] / iso[k] for k in ins if k in iso},
                     "how": "widest layer of ONE surrogate, step issued eagerly on its own stream (the launch sequence the graph "
-                           "replays), HIP events recorded by the library around each launch (mobocmf_set_probe_events), mean "
+                           "replays), HIP events recorded by the library around each launch (mobocmf_layer_desc.probe_events), mean "
                            "of 4 steps; `instep_over_isolated` divides by the same launch timed alone (roofline.variants)"}
         if world == 1 and not args.no_cpu_baseline:
             cb, parity = cpu_baseline(cfg, device=device)

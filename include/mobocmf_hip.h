@@ -18,8 +18,12 @@
  *
  * Conventions: all pointers are DEVICE pointers to row-major float64 unless stated; sizes are explicit;
  * every function enqueues work on `stream` and returns immediately (no allocation, no free, no host sync;
- * re-entrant, one process per GPU).  The only process-wide state is the pair of kernel-selection thresholds of
- * mobocmf_set_tuning (atomic words with compiled-in defaults) and a per-device "attribute set" bit mask.  Return value: MOBOCMF_OK or an error
+ * re-entrant, one process per GPU).  The library holds NO mutable state between calls: every kernel-selection knob
+ * travels with the call in a `mobocmf_tuning` (a pointer in the layer descriptor, or an argument of the standalone
+ * product entry points; NULL = the compiled-in defaults), block-activity arrays and probe events are explicit arguments,
+ * and the workspace-size queries take the same descriptor / tuning as the launch they size for.  Two host threads with
+ * different tunings on different streams do not interact.  (One write-once per-device bit mask remembers that a kernel's
+ * dynamic-LDS attribute was set.)  Return value: MOBOCMF_OK or an error
  * code; a non-positive-definite K_mm is reported through the device word `info` (0 = OK, k>0 = pivot k
  * failed), mirroring LAPACK potrf / torch.linalg.cholesky_ex, so the caller may retry with more jitter
  * (gpytorch psd_safe_cholesky semantics) without a sync on the fast path.
@@ -48,6 +52,27 @@ enum {
     MOBOCMF_BAD_ARCH = 5
 };
 
+/* Kernel-selection knobs of one call.  Fill with mobocmf_tuning_init() (compiled-in defaults, struct_size), change what is
+ * needed, and pass the pointer with the call; NULL everywhere means the defaults.  Knobs never change results beyond
+ * summation order; they exist for size sweeps, A/B timing and the parity tests.  A workspace-size query and the launch it
+ * sizes for must be given the same values (syrk_workgroups changes the slab count, tile_rows the partial-row count): the
+ * launches re-derive their layout from the tuning they receive and return MOBOCMF_WORKSPACE_TOO_SMALL on a mismatch. */
+typedef struct mobocmf_tuning {
+    uint32_t struct_size;    /* sizeof(mobocmf_tuning) of the caller (versioning; set by mobocmf_tuning_init) */
+    int32_t small_gemm_max;  /* largest dimension of an M x M product on the small-operand kernel (default 384, <= 512) */
+    int32_t small_panel_max; /* largest K of an M x N' panel product on the whole-block panel kernel (default 512, <= 512) */
+    int32_t tile_rows;       /* tile height of the M x N' panel products: 0 = by shape (default) | 64 | 128 */
+    int32_t pair_mode;       /* one workgroup does the row blocks (p, n-1-p) of a triangular product: 0 auto | 1 never | 2 always */
+    int32_t mid_gemm_max;    /* largest dimension of a plain M x M product on the mid-size kernel (default 1024; 0 = off) */
+    int32_t mid_gemm_waves;  /* its form: 32 (default) = 32 x 64 tiles, 64-k stages | 8 | 4 = 64 x 64 tiles on 8 / 4 wavefronts */
+    int32_t syrk_workgroups; /* workgroups a k-sliced weighted syrk may occupy: 0 = by shape (default) | 16..4096 */
+    int32_t sparse_backward; /* 1 (default): a layer backward skips 128-column blocks whose upstream gradients are all
+                              * exactly zero (the rows of other fidelities, variational_elbo_mf.py:33-38) -- found on the
+                              * device, same numbers; 0: the dense backward (A/B timing, parity tests) */
+    int32_t potrf_cols;      /* columns per hand-over of the 64-wide Cholesky panel kernel: 4 (default) | 1 */
+} mobocmf_tuning;
+int mobocmf_tuning_init(mobocmf_tuning* t);
+
 /* One variational GP layer.
  * kind 0 (first layer):  k = alpha * RBF_ard(x, x')                              hyp = [alpha, ls[0..d)]
  * kind 1 (layer >= 1):   k = a1*RBF(x,x';ls1) * (nu*f*f' + af*RBF(f,f';lsf)) + a2*RBF(x,x';ls2)
@@ -67,7 +92,17 @@ typedef struct {
     double min_var;  /* MultivariateNormal.variance clamp; gpytorch min_variance = 1e-10 */
     int32_t phase;   /* MOBOCMF_PHASE_*: which half of the layer call to run (0 = both) */
     int32_t reserved;
+    const mobocmf_tuning* tuning; /* kernel-selection knobs of THIS call and of the size queries made with this descriptor;
+                                   * NULL = defaults */
+    void* const* probe_events;    /* diagnostic, NULL = off: MOBOCMF_PROBE_EVENTS hipEvent_t (created by the caller with timing
+                                   * enabled; NULL entries are skipped) recorded on the call's stream around the
+                                   * grid-filling launches of this layer's PANEL half:
+                                   *   [9] Gram forward [0] A = L^-1 K [1] C = U^T A [2]  ...  [3] dA [4] ... [5] weighted
+                                   *   syrk + slab reduction [6] ... [7] dK = L^-T dA [8] Gram backward [10]
+                                   * -- per-kernel durations inside a training step without a profiler (bench.py:
+                                   * per_kernel_instep_ms).  Not under stream capture. */
 } mobocmf_layer_desc;
+#define MOBOCMF_PROBE_EVENTS 11
 
 /* A layer call has two halves that only meet in `saved` (forward) / `scratch` (backward):
  *   CHAIN  the M x M work that depends on the parameters alone: K_mm, its Cholesky and inverse, U = L^-1 L_S,
@@ -194,9 +229,12 @@ int mobocmf_propagate_backward(const double* var, const double* eps, const doubl
                                int64_t n_out, int32_t div, mobocmf_stream_t stream);
 /* Prefix propagation: the previous layer holds n_prev >= n_out/div rows of which only the FIRST n_out/div were propagated
  * (the next layer is evaluated on a prefix of the batch -- the rows that can reach the loss, see mobocmf_elbo_forward);
- * g_mean / g_var [n_prev] get zeros beyond the prefix. */
+ * g_mean / g_var [n_prev] get zeros beyond the prefix.  add_mean / add_var [n_prev] (each may be NULL): gradients the same
+ * moments receive from their other consumer -- the ELBO data term of the previous layer's own fidelity
+ * (variational_elbo_mf.py:33-35) -- added in this launch (autograd would spend one element-wise launch per sum). */
 int mobocmf_propagate_backward_prefix(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
-                                      int64_t n_out, int32_t div, int64_t n_prev, mobocmf_stream_t stream);
+                                      int64_t n_out, int32_t div, int64_t n_prev, const double* add_mean,
+                                      const double* add_var, mobocmf_stream_t stream);
 
 /* out[0] = (1/div) * sum_{n : fid[n/div] == level} -0.5 * (((y[n/div]-mean[n])^2 + var[n]) / tau + log tau + log 2pi)
  * tau is a device scalar.  n < n_rows. */
@@ -310,18 +348,20 @@ int mobocmf_mf_kernel_combine(int64_t n1, int64_t n2, const double* Ks, const do
                               double* out, int64_t ldo, int64_t rows_p, int64_t cols_p, mobocmf_stream_t stream);
 int mobocmf_exact_gp_workspace_bytes(int32_t n, int64_t nt, size_t* state_bytes, size_t* scratch_bytes);
 int mobocmf_exact_gp_factor(int32_t n, const double* K, int64_t ldk, const double* y, double* mll, int32_t* info, void* state,
-                            size_t state_bytes, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream);
+                            size_t state_bytes, void* scratch, size_t scratch_bytes, const mobocmf_tuning* tuning,
+                            mobocmf_stream_t stream);
 int mobocmf_exact_gp_predict(int32_t n, int64_t nt, const double* Kts, int64_t ld, const double* kss, double* mean,
                              double* var, const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
-                             mobocmf_stream_t stream);
+                             const mobocmf_tuning* tuning, mobocmf_stream_t stream);
 
 /* The f64 MFMA GEMM used by the layer (exposed for tests and for the roofline measurement of bench.py):
  * C[Mr x Nc] (+)= alpha * A[Mr x Kd] * B, B is [Kd x Nc] (trans_b = 0) or [Nc x Kd] (trans_b = 1).
  * Mr, Nc multiples of 128, Kd multiple of 16, leading dimensions even, pointers 16-byte aligned.
- * tri: bit 0 A lower-triangular, bit 1 A upper-triangular, bit 2 B lower, bit 3 B upper (square operands). */
+ * tri: bit 0 A lower-triangular, bit 1 A upper-triangular, bit 2 B lower, bit 3 B upper (square operands).
+ * tuning: NULL = defaults (the small / mid-size operand thresholds decide which kernel a product runs on). */
 int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
                      const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t accumulate,
-                     mobocmf_stream_t stream);
+                     const mobocmf_tuning* tuning, mobocmf_stream_t stream);
 
 /* The same kernel with the epilogues the layer launches it with (tests, and bench.py's per-variant roofline):
  *   epi 0  plain store (dK = L^-T dA);
@@ -331,77 +371,29 @@ int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64
  *          mean; C = U^T A -> r);
  *   epi 2  C[i][n] = alpha bscale[n] (A B)[i][n] + avec[i] gmu[n] - 2 Aaux[i][n] cgv[n]   (dA), and (rowdot_part
  *          non-NULL) rowdot_part[slice][i] = partial sums over 64-column slices of Aaux[i][n] gmu[n]   (da).
- * B is [Kd x Nc] (no transposed form).  stream_out: non-temporal stores of C.  Pointers an epilogue does not use: NULL. */
+ * B is [Kd x Nc] (no transposed form).  stream_out: non-temporal stores of C.  Pointers an epilogue does not use: NULL.
+ * col_activity (NULL = dense): DEVICE array of one int32 per 128 columns of C; the column blocks marked 0 are left unwritten
+ * (their row-dot partials zeroed) -- how the tests drive the block skipping of the layer backward directly.  The tile
+ * height / pairing come from `tuning`. */
 int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
                               const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t stream_out,
                               double* colsq_part, double* coldot_part, const double* avec, const double* bscale,
                               const double* gmu, const double* cgv, const double* Aaux, double* rowdot_part,
-                              mobocmf_stream_t stream);
+                              const int32_t* col_activity, const mobocmf_tuning* tuning, mobocmf_stream_t stream);
 
-/* Partial rows an epi-1 launch of that shape writes to colsq_part / coldot_part (depends on the tile height in force). */
-int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, int32_t* rows);
-
-/* Tile height of the M x N' panel products: 0 = automatic (default), 64 = 64 x 128 tiles (three workgroups per CU, a
- * triangular operand resolved in 64-row blocks), 128 = 128 x 128 tiles.  pair_mode: 0 = automatic, 1 = never, 2 = always
- * let one workgroup do the two row blocks (p, n-1-p) of a triangular product (equal work per workgroup).  Process-wide,
- * like mobocmf_set_tuning: size sweeps, tests, A/B timing. */
-int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode);
-
-/* Largest dimension of a plain product (the M x M chain; mobocmf_gemm_f64) that runs on the mid-size kernel -- 64 x 64
- * or 32 x 64 tiles, the whole contraction in one workgroup, one launch, no k-slicing -- instead of the 128 x 128 pipeline;
- * default 1024, 0 = off.  Process-wide; sweeps, tests. */
-int mobocmf_set_mid_gemm_max(int32_t n);
-/* Form of that kernel: 32 (default) = 32 x 64 tiles on four wavefronts with 64-k stages; 8 / 4 = 64 x 64 tiles on eight /
- * four wavefronts with 32-k stages.  Process-wide; A/B timing, tests. */
-int mobocmf_set_mid_gemm_waves(int32_t n);
-
-/* Workgroups a k-sliced weighted syrk may occupy (16..4096; 0 = default: by shape, 256 for N' <= 16384 and 512 = one round
- * of two per CU above): fewer, longer k slices write and re-read fewer slabs.  Changes mobocmf_syrk_workspace_bytes and the layer workspaces' sizes: set it before
- * sizing buffers.  Process-wide; sweeps and A/B timing. */
-int mobocmf_set_syrk_workgroups(int32_t n);
-
-/* Zero-gradient column blocks of the layer backward.  The backward of a layer is linear in its upstream gradients
- * (g_mean, g_var), column by column of the N' side: a 128-column block in which both are exactly zero contributes exactly
- * zero to every product of the backward (dA, the weighted syrk H, da, dK, the Gram backward).  The top layer of a
- * multi-fidelity model is such a case by construction: the reference's ELBO scores each row at ITS fidelity only
- * (variational_elbo_mf.py:33-38), so autograd hands the top layer zeros for every row of another fidelity -- and then
- * multiplies them through (GPyTorch has no notion of it).  With on != 0 (the default) mobocmf_layer_backward /
- * mobocmf_panels_backward find those blocks on the device (no host read) and leave them out; results are the same numbers
- * (sums over fewer exact zeros).  on = 0: the dense backward, for A/B timing and the parity tests.  Process-wide. */
-int mobocmf_set_sparse_backward(int32_t on);
-
-/* Tests / tools: a DEVICE array of one int32 per 128 columns that mobocmf_gemm_f64 (column blocks of C: inactive blocks
- * are left unwritten, their row-dot partials zeroed) and mobocmf_syrk_weighted_f64 (128-wide blocks of the contraction:
- * inactive ones are left out) apply to their next launches; NULL (default) = dense.  The array must outlive those
- * launches.  Process-wide. */
-int mobocmf_set_block_activity(const int32_t* act);
+/* Partial rows an epi-1 launch of that shape writes to colsq_part / coldot_part under the same `tuning` (tile height). */
+int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, const mobocmf_tuning* tuning, int32_t* rows);
 
 /* The weighted symmetric rank-k update of the layer backward, H[Mr x Mr] = A diag(w) A^T with A [Mr x Kd] (k contiguous,
  * lda even) and w [Kd]: k-sliced over one round of resident workgroups into slabs (workspace), the slabs added and the
  * result written as the FULL symmetric matrix.  Both M x M contractions over N' of the reference's autograd backward
- * (A diag(gv) C^T for dU and dA K^T for dL^-1) reduce to it.  Mr, Kd multiples of 128. */
-int mobocmf_syrk_workspace_bytes(int32_t Mr, int64_t Kd, size_t* bytes);
+ * (A diag(gv) C^T for dU and dA K^T for dL^-1) reduce to it.  Mr, Kd multiples of 128.
+ * k_activity (NULL = dense): DEVICE array of one int32 per 128 entries of the contraction; the blocks marked 0 (w is zero
+ * throughout them) are left out.  The size query and the launch take the same `tuning` (syrk_workgroups sets the slab count). */
+int mobocmf_syrk_workspace_bytes(int32_t Mr, int64_t Kd, const mobocmf_tuning* tuning, size_t* bytes);
 int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t lda, const double* w, double* H,
-                              void* workspace, int64_t workspace_bytes, mobocmf_stream_t stream);
-
-/* Kernel-selection thresholds (largest operand dimension up to which the small-operand kernels are used instead of the
- * tiled MFMA pipeline): small_gemm_max for M x M products (default 384), small_panel_max for M x N' panel products
- * (default 512).  A value <= 0 leaves that threshold unchanged.  Process-wide; meant for size sweeps, set it before
- * the work it should affect is enqueued. */
-int mobocmf_set_tuning(int32_t small_gemm_max, int32_t small_panel_max);
-
-/* Diagnostic, process-wide, off by default: HIP events (hipEvent_t, created by the caller with timing enabled) recorded on the
- * call's stream around the grid-filling launches of the PANEL halves of every layer call whose desc->Np equals `Np`:
- *   [9] Gram forward [0] A = L^-1 K [1] C = U^T A [2]   ...   [3] dA [4] ... [5] weighted syrk + slab reduction [6] ...
- *   [7] dK = L^-T dA [8] Gram backward [10]
- * -- per-kernel durations INSIDE a training step without a profiler (bench.py: per_kernel_instep_ms).  n = 0 disarms.  Not
- * for use under stream capture or from several threads at once. */
-#define MOBOCMF_PROBE_EVENTS 11
-int mobocmf_set_probe_events(void* const* events, int32_t n, int64_t Np);
-
-/* Columns the 64-wide Cholesky panel kernel eliminates per hand-over between its two wavefronts: 4 (default) or 1 (the
- * round-2 kernel).  Process-wide A/B and test knob, like mobocmf_set_tuning. */
-int mobocmf_set_potrf_cols(int32_t cols);
+                              void* workspace, int64_t workspace_bytes, const int32_t* k_activity,
+                              const mobocmf_tuning* tuning, mobocmf_stream_t stream);
 
 /* Host-side, synchronising: copies the device word and returns MOBOCMF_OK or MOBOCMF_NOT_PD (pivot in *pivot). */
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream);

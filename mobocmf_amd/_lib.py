@@ -14,11 +14,28 @@ _ERR = {1: "MOBOCMF_BAD_ARG", 2: "MOBOCMF_WORKSPACE_TOO_SMALL", 3: "MOBOCMF_HIP_
         5: "MOBOCMF_BAD_ARCH"}
 
 
+class Tuning(ctypes.Structure):
+    """mobocmf_tuning of include/mobocmf_hip.h: the kernel-selection knobs that travel with a call (NULL = defaults)."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("small_gemm_max", ctypes.c_int32), ("small_panel_max", ctypes.c_int32),
+                ("tile_rows", ctypes.c_int32), ("pair_mode", ctypes.c_int32), ("mid_gemm_max", ctypes.c_int32),
+                ("mid_gemm_waves", ctypes.c_int32), ("syrk_workgroups", ctypes.c_int32), ("sparse_backward", ctypes.c_int32),
+                ("potrf_cols", ctypes.c_int32)]
+    KNOBS = tuple(n for n, _ in _fields_[1:])
+
+    def copy(self):
+        t = Tuning()
+        ctypes.memmove(ctypes.byref(t), ctypes.byref(self), ctypes.sizeof(Tuning))
+        return t
+
+
+PROBE_EVENTS = 11      # MOBOCMF_PROBE_EVENTS
+
+
 class LayerDesc(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("d", ctypes.c_int32), ("M", ctypes.c_int32), ("xdiv", ctypes.c_int32),
                 ("Np", ctypes.c_int64), ("branch", ctypes.c_int32), ("want_dx", ctypes.c_int32),
                 ("jitter", ctypes.c_double), ("min_var", ctypes.c_double), ("phase", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("tuning", ctypes.POINTER(Tuning)), ("probe_events", ctypes.c_void_p)]
 
 
 class MobocmfError(RuntimeError):
@@ -50,7 +67,7 @@ SYMBOLS = {
     "mobocmf_propagate_forward": [_P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_propagate_rng_forward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
     "mobocmf_propagate_backward": [_P, _P, _P, _P, _P, _I64, _I32, _P],
-    "mobocmf_propagate_backward_prefix": [_P, _P, _P, _P, _P, _I64, _I32, _I64, _P],
+    "mobocmf_propagate_backward_prefix": [_P, _P, _P, _P, _P, _I64, _I32, _I64, _P, _P, _P],
     "mobocmf_elbo_data_forward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _SZ, _P],
     "mobocmf_elbo_data_backward": [_P, _P, _P, _P, _P, _D, _I64, _I32, _P, _P, _P, _P, _P, _SZ, _P],
     "mobocmf_elbo_data_interval_forward": [_P, _P, _P, _P, _P, _D, _D, _D, _I64, _I32, _P, _P, _SZ, _P],
@@ -66,28 +83,21 @@ SYMBOLS = {
     "mobocmf_elbo_combine_backward": [_P, _P, _D, _P, _P],
     "mobocmf_adam_multi": [_I32, _P, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P],
     "mobocmf_adam_step": [_P, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P],
-    "mobocmf_gemm_f64": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32, _P],
-    "mobocmf_gemm_f64_epilogue": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32] + [_P] * 8 + [_P],
+    "mobocmf_tuning_init": [ctypes.POINTER(Tuning)],
+    "mobocmf_gemm_f64": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32, ctypes.POINTER(Tuning), _P],
+    "mobocmf_gemm_f64_epilogue": [_I32, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I32] + [_P] * 8 +
+                                 [_P, ctypes.POINTER(Tuning), _P],
     "mobocmf_mf_kernel_combine": [_I64, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _D, _P, _I64, _I64, _I64, _P],
     "mobocmf_exact_gp_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
-    "mobocmf_exact_gp_factor": [_I32, _P, _I64, _P, _P, _P, _P, _SZ, _P, _SZ, _P],
-    "mobocmf_exact_gp_predict": [_I32, _I64, _P, _I64, _P, _P, _P, _P, _SZ, _P, _SZ, _P],
-    "mobocmf_gemm_colstat_rows": [_I32, _I32, _I64, _I64, ctypes.POINTER(_I32)],
-    "mobocmf_set_tile_rows": [_I32, _I32],
-    "mobocmf_set_sparse_backward": [_I32],
-    "mobocmf_set_syrk_workgroups": [_I32],
-    "mobocmf_set_mid_gemm_max": [_I32],
-    "mobocmf_set_mid_gemm_waves": [_I32],
-    "mobocmf_set_block_activity": [_P],
-    "mobocmf_set_potrf_cols": [_I32],
-    "mobocmf_syrk_workspace_bytes": [_I32, _I64, ctypes.POINTER(_SZ)],
-    "mobocmf_syrk_weighted_f64": [_I32, _I64, _P, _I64, _P, _P, _P, _I64, _P],
+    "mobocmf_exact_gp_factor": [_I32, _P, _I64, _P, _P, _P, _P, _SZ, _P, _SZ, ctypes.POINTER(Tuning), _P],
+    "mobocmf_exact_gp_predict": [_I32, _I64, _P, _I64, _P, _P, _P, _P, _SZ, _P, _SZ, ctypes.POINTER(Tuning), _P],
+    "mobocmf_gemm_colstat_rows": [_I32, _I32, _I64, _I64, ctypes.POINTER(Tuning), ctypes.POINTER(_I32)],
+    "mobocmf_syrk_workspace_bytes": [_I32, _I64, ctypes.POINTER(Tuning), ctypes.POINTER(_SZ)],
+    "mobocmf_syrk_weighted_f64": [_I32, _I64, _P, _I64, _P, _P, _P, _I64, _P, ctypes.POINTER(Tuning), _P],
     "mobocmf_softplus_pack": [_I32, _P, _P, _P, _P],
     "mobocmf_softplus_pack_backward": [_I32, _P, _P, _P, _P, _P],
-    "mobocmf_set_tuning": [_I32, _I32],
     "mobocmf_rff_eval": [_I32, _I32, _I32, _I64] + [_P] * 8 + [_D, _D, _D, _P, _P],
     "mobocmf_gram_forward": [_I32, _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P],
-    "mobocmf_set_probe_events": [_P, _I32, _I64],
     "mobocmf_check_info": [_P, ctypes.POINTER(_I32), _P],
 }
 MAX_D, MAX_XDIV = 32, 48        # MOBOCMF_MAX_D / MOBOCMF_MAX_XDIV of include/mobocmf_hip.h

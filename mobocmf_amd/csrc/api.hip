@@ -68,29 +68,40 @@ int launch_dl_from_t2_z(const double* T2, const double* L, const double* const* 
 int launch_phi_z(const double* T3, int Mp, double* P, int nz, int64_t zs, hipStream_t s);
 int launch_symmetrize_z(const double* S, int Mp, double* G, int nz, int64_t zs, hipStream_t s);
 
-// Diagnostic probe (bench.py's per_kernel_instep_ms; include/mobocmf_hip.h, mobocmf_set_probe_events): caller-created HIP
-// events recorded around the grid-filling launches of the PANEL halves of the layer whose N' matches -- per-kernel
-// durations INSIDE a step, in the driver's own run, without a profiler.  Off (n = 0) unless armed.
-#include <atomic>
-static hipEvent_t g_probe_ev[MOBOCMF_PROBE_EVENTS];
-static std::atomic<int> g_probe_n{0};
-static std::atomic<int64_t> g_probe_Np{0};
-static inline void probe_at(int i, int64_t N, hipStream_t s) {
-    if (i < g_probe_n.load(std::memory_order_acquire) && N == g_probe_Np.load(std::memory_order_relaxed))
-        (void)hipEventRecord(g_probe_ev[i], s);
+// ---- the tuning / probe events of the C-ABI call this thread is inside (common.h: TuneScope).  Call-scoped, thread-local:
+// the library keeps no state between calls (include/mobocmf_hip.h preamble).
+static const mobocmf_tuning kDefaultTuning = {(uint32_t)sizeof(mobocmf_tuning), 384, 512, 0, 0, 1024, 32, 0, 1, 4};
+static thread_local const mobocmf_tuning* t_tuning = nullptr;
+static thread_local void* const* t_probe = nullptr;
+const mobocmf_tuning& tune() { return t_tuning ? *t_tuning : kDefaultTuning; }
+bool tuning_ok(const mobocmf_tuning* t) {
+    if (!t) return true;
+    return t->struct_size == sizeof(mobocmf_tuning) && t->small_gemm_max >= 1 && t->small_gemm_max <= 512 &&
+           t->small_panel_max >= 1 && t->small_panel_max <= 512 && (t->tile_rows == 0 || t->tile_rows == 64 || t->tile_rows == 128) &&
+           t->pair_mode >= 0 && t->pair_mode <= 2 && t->mid_gemm_max >= 0 && t->mid_gemm_max <= 4096 &&
+           (t->mid_gemm_waves == 4 || t->mid_gemm_waves == 8 || t->mid_gemm_waves == 32) &&
+           (t->syrk_workgroups == 0 || (t->syrk_workgroups >= 16 && t->syrk_workgroups <= 4096)) &&
+           (t->sparse_backward == 0 || t->sparse_backward == 1) && (t->potrf_cols == 1 || t->potrf_cols == 4);
 }
-
+TuneScope::TuneScope(const mobocmf_tuning* t, void* const* probe) : prev_t(t_tuning), prev_p(t_probe) {
+    t_tuning = t;
+    t_probe = probe;
+}
+TuneScope::~TuneScope() {
+    t_tuning = prev_t;
+    t_probe = prev_p;
+}
+// Diagnostic probe (bench.py's per_kernel_instep_ms; mobocmf_layer_desc.probe_events): caller-created HIP events recorded
+// around the grid-filling launches of the PANEL halves of the layer call in progress -- per-kernel durations INSIDE a step,
+// in the driver's own run, without a profiler.  Off unless the descriptor carries events.
+void probe_at(int i, hipStream_t s) {
+    if (t_probe && i < MOBOCMF_PROBE_EVENTS && t_probe[i]) (void)hipEventRecord((hipEvent_t)t_probe[i], s);
+}
 // Tile height of the M x N' panel products (gemm_f64.hip: 128 x 128 tiles, or 64 x 128 tiles with three workgroups per
 // CU and the triangular operand resolved in 64-row blocks).  0 = automatic: launch_gemm picks it from the shape
-// (gemm_f64.hip tile_rows); 64 / 128 force it for every panel product (mobocmf_set_tile_rows: sweeps, tests, A/B timing).
-static std::atomic<int> g_tile_rows{0}, g_pair_mode{0};
-static std::atomic<int> g_syrk_wgs{0};         // workgroups a k-sliced weighted syrk may use, 0 = by shape (mobocmf_set_syrk_workgroups)
-static std::atomic<int> g_sparse_bwd{1};      // skip column blocks whose upstream gradients are all zero (mobocmf_set_sparse_backward)
-// the standalone product entry points (mobocmf_gemm_f64 / mobocmf_syrk_weighted_f64) take this device array as their
-// column-block / K-block activity (mobocmf_set_block_activity; NULL = dense): how the tests drive the skipping directly
-static std::atomic<const int32_t*> g_block_activity{nullptr};
-static void set_pairing(GemmArgs& g) { g.pair_mode = g_pair_mode.load(std::memory_order_relaxed); }
-static int panel_tile_rows(int, int64_t) { return g_tile_rows.load(std::memory_order_relaxed); }
+// (gemm_f64.hip tile_rows); 64 / 128 force it for every panel product of the call (mobocmf_tuning.tile_rows).
+static void set_pairing(GemmArgs& g) { g.pair_mode = tune().pair_mode; }
+static int panel_tile_rows(int, int64_t) { return tune().tile_rows; }
 
 #define TRY(x)              \
     do {                    \
@@ -147,7 +158,7 @@ int syrk_splitk(int Mp, int64_t Np, int* sD) {
     }
     // one round of resident workgroups: two per CU -- one per CU for short contractions (N' <= 16384: the slices are a few
     // dozen K steps, half as many slabs to write and add again costs less than the thinner grid; r3 sweep, profiles/)
-    int budget = g_syrk_wgs.load(std::memory_order_relaxed);
+    int budget = tune().syrk_workgroups;
     if (budget <= 0) budget = Np <= 16384 ? 256 : 512;
     double best = 1e30;
     int bF = 1, bD = 1;
@@ -204,7 +215,7 @@ int weighted_syrk_pair(const double* A, int64_t lda, const double* w, const doub
 }
 
 bool valid_desc(const mobocmf_layer_desc* d) {
-    return d && (d->kind == 0 || d->kind == 1) && d->d >= 1 && d->d <= MOBOCMF_MAX_D && d->M >= 1 && d->xdiv >= 1 &&
+    return d && tuning_ok(d->tuning) && (d->kind == 0 || d->kind == 1) && d->d >= 1 && d->d <= MOBOCMF_MAX_D && d->M >= 1 && d->xdiv >= 1 &&
            d->xdiv <= MOBOCMF_MAX_XDIV && d->Np >= 1 && d->Np % d->xdiv == 0 && (d->branch == 0 || d->branch == 1) && d->phase >= 0 &&
            d->phase <= MOBOCMF_PHASE_PANEL_INPUTS;
 }
@@ -420,23 +431,23 @@ int panel_forward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs& 
     g.kind = desc->kind; g.d = desc->d; g.zdiv = 1; g.Zx = Zx; g.zf = zf; g.M = D.M; g.hyp = hyp; g.Mp = Mp;
     g.xdiv = desc->xdiv; g.x = x; g.f = f; g.nbase = D.nbase; g.jitter = desc->jitter;
     g.K = F.K; g.ldk = Np; g.Np = Np; g.knn = P.knn; g.is_kmm = 0;
-    probe_at(9, D.N, s);
+    probe_at(9, s);
     TRY(launch_gram_fwd(g, s));
-    probe_at(0, D.N, s);
+    probe_at(0, s);
     GemmArgs ga = gemm_args(c.Linv, Mp, F.K, Np, P.A, Np, Mp, Np, Mp, TRI_LOWER_A, 1.0);
     ga.epi = EPI_COLSTATS; ga.colsq_part = F.qpart; ga.coldot_part = F.mupart; ga.avec = c.a;
     ga.Kreal = D.M;      // rows >= M of K_mn (and of A, C, dA below) are zero padding
     ga.rm = panel_tile_rows(Mp, Np);
     set_pairing(ga);
     TRY(launch_gemm(ga, false, 1, s));
-    probe_at(1, D.N, s);
+    probe_at(1, s);
     GemmArgs gc = gemm_args(c.UT, Mp, P.A, Np, P.C, Np, Mp, Np, Mp, TRI_UPPER_A, 1.0);
     gc.epi = EPI_COLSTATS; gc.colsq_part = F.rpart; gc.coldot_part = nullptr; gc.avec = c.a;
     gc.Kreal = D.M;
     gc.stream_out = (desc->branch == 0 && Np * Mp * 8 >= ((int64_t)64 << 20)) ? 1 : 0;   // C is next read in backward
     gc.rm = ga.rm; gc.pair_mode = ga.pair_mode;
     TRY(launch_gemm(gc, false, 1, s));
-    probe_at(2, D.N, s);
+    probe_at(2, s);
     // chain-block layout: the clamped-column counter of the backward lives in the block and is cleared here
     TRY(launch_moments_finish(F.qpart, F.mupart, F.rpart, gemm_colstat_rows(ga), Np, D.N, P.knn, desc->branch, desc->min_var, P.q, P.r,
                               P.varraw, mean, var, block_layout ? (int32_t*)c.flag : nullptr, s));
@@ -456,7 +467,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     // act: one word per 128 columns, zero where every upstream gradient of the block is exactly zero (the top layer of a
     // multi-fidelity model only gets gradient from the rows scored at ITS fidelity): those blocks' shares of dA, H, da,
     // dK and the Gram backward are exactly zero and are not computed
-    const int32_t* act = g_sparse_bwd.load(std::memory_order_relaxed) ? B.blkact : nullptr;
+    const int32_t* act = tune().sparse_backward ? B.blkact : nullptr;
     TRY(launch_moments_bwd_prep(g_mean, g_var, P.knn, P.q, P.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
                                 B.gv2, B.cgv, nclamped, block_layout ? 1 : 0, (int32_t*)act, s));
     // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
@@ -468,9 +479,9 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
         ga.colact = act;
         ga.rm = panel_tile_rows(Mp, Np);
         set_pairing(ga);
-        probe_at(3, D.N, s);
+        probe_at(3, s);
         TRY(launch_gemm(ga, false, 1, s));
-        probe_at(4, D.N, s);
+        probe_at(4, s);
         if (!inputs_only) TRY(launch_sum_partials(B.dapart, gemm_rowdot_parts(ga), Mp, c.da, Mp, 1.0, 0, s));
     }
     // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
@@ -478,10 +489,10 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
     // (skip_if_zero) when no column is clamped.
     if (!inputs_only) {
-        probe_at(5, D.N, s);
+        probe_at(5, s);
         if (desc->branch == 0) TRY(weighted_syrk_pair(P.A, Np, B.gv, B.cgv, Mp, Np, B.slabs, B.slabs2, c.H, Hc, nclamped, act, s));
         else TRY(weighted_syrk(P.A, Np, B.gv, Mp, Np, B.slabs, c.H, nullptr, nullptr, act, s));
-        probe_at(6, D.N, s);
+        probe_at(6, s);
     }
     // dK = L^-T dA
     {
@@ -490,9 +501,9 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
         ga.rm = panel_tile_rows(Mp, Np);
         set_pairing(ga);
         ga.colact = act;      // inactive column blocks of dK stay unwritten: the Gram backward below does not read them
-        probe_at(7, D.N, s);
+        probe_at(7, s);
         TRY(launch_gemm(ga, false, 1, s));
-        probe_at(8, D.N, s);
+        probe_at(8, s);
     }
     // Gram backward of K_mn and k_nn
     GramArgs g = {};
@@ -501,7 +512,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     g.ldk = Np; g.Np = Np; g.G = B.dK; g.gknn = B.cgv; g.colact = act;
     g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
     TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
-    probe_at(10, D.N, s);
+    probe_at(10, s);
     SumTask tk[4];
     int nt = 0;
     tk[nt++] = {B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, nullptr, 0, 0, g_hyp, D.H, 0};
@@ -655,6 +666,7 @@ int mobocmf_device_arch_ok(void) {
 
 int mobocmf_layer_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes) {
     if (!valid_desc(desc) || !saved_bytes || !scratch_bytes) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     Dims D = dims_of(desc);
     const size_t big = ~(size_t)0 >> 1;
     ChainWs c;
@@ -672,6 +684,7 @@ int mobocmf_layer_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_
 
 int mobocmf_layer_chain_state_bytes(const mobocmf_layer_desc* desc, size_t* bytes) {
     if (!valid_desc(desc) || !bytes) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     Dims D = dims_of(desc);
     Bump b(nullptr, ~(size_t)0 >> 1);
     ChainWs c;
@@ -686,6 +699,7 @@ int mobocmf_layer_forward(const mobocmf_layer_desc* desc, const double* x, const
                           size_t scratch_bytes, mobocmf_stream_t stream) {
     if (!valid_desc(desc) || desc->phase == MOBOCMF_PHASE_CHAIN_ONLY || !Zx || !hyp || !saved || !scratch)
         return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     const bool do_chain = desc->phase == MOBOCMF_PHASE_ALL || desc->phase == MOBOCMF_PHASE_CHAIN;
     const bool do_panel = desc->phase != MOBOCMF_PHASE_CHAIN;
     if (do_chain && (!m || !L_S || !kl || !info)) return MOBOCMF_BAD_ARG;
@@ -713,6 +727,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
                            double* g_hyp, double* g_m, double* g_LS, double* g_x, void* saved, size_t saved_bytes,
                            void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
     if (!valid_desc(desc) || !Zx || !hyp || !g_hyp || !saved || !scratch) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     const bool inputs_only = desc->phase == MOBOCMF_PHASE_PANEL_INPUTS;   // parameters are constants: no H / Hc / da
     const bool do_panel = desc->phase == MOBOCMF_PHASE_ALL || desc->phase == MOBOCMF_PHASE_PANEL || inputs_only;
     const bool do_chain = desc->phase == MOBOCMF_PHASE_ALL || desc->phase == MOBOCMF_PHASE_CHAIN ||
@@ -741,6 +756,7 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
 // ------------------------------------------------------------------------------------------------- multi-layer forms
 int mobocmf_chain_block_bytes(const mobocmf_layer_desc* desc, size_t* block_bytes, size_t* state_bytes) {
     if (!valid_desc(desc) || !block_bytes) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     Dims D = dims_of(desc);
     ChainWs c;
     size_t st = 0, used = 0;
@@ -752,6 +768,7 @@ int mobocmf_chain_block_bytes(const mobocmf_layer_desc* desc, size_t* block_byte
 
 int mobocmf_panel_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes) {
     if (!valid_desc(desc) || !saved_bytes || !scratch_bytes) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     Dims D = dims_of(desc);
     const size_t big = ~(size_t)0 >> 1;
     Bump bs(nullptr, big), bf(nullptr, big), bb(nullptr, big);
@@ -773,6 +790,7 @@ int mobocmf_layers_chain_forward(int32_t n, const mobocmf_layer_desc* const* des
     if (n < 1 || n > MAX_ZL || !desc || !Zx || !zf || !hyp || !m || !L_S || !kl || !info || !blocks || (block_stride & 255))
         return MOBOCMF_BAD_ARG;
     if (!same_chain_shape(n, desc)) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc[0]->tuning);      // one z-batched sequence of launches: the first layer's tuning serves all
     if (blocks_bytes / (size_t)n < block_stride) return MOBOCMF_WORKSPACE_TOO_SMALL;      // layer z works at blocks + z * stride
     for (int z = 0; z < n; ++z)
         if (!Zx[z] || !hyp[z] || !m[z] || !L_S[z] || !kl[z] || !info[z] || (desc[z]->kind == 1 && !zf[z])) return MOBOCMF_BAD_ARG;
@@ -793,6 +811,7 @@ int mobocmf_layers_chain_backward(int32_t n, const mobocmf_layer_desc* const* de
         !blocks || (block_stride & 255))
         return MOBOCMF_BAD_ARG;
     if (!same_chain_shape(n, desc)) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc[0]->tuning);      // one z-batched sequence of launches: the first layer's tuning serves all
     if (blocks_bytes / (size_t)n < block_stride) return MOBOCMF_WORKSPACE_TOO_SMALL;
     bool zero[MAX_ZL];
     int acc[MAX_ZL];
@@ -816,6 +835,7 @@ int mobocmf_layer_panel_forward(const mobocmf_layer_desc* desc, const double* x,
                                 size_t block_bytes, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                                 mobocmf_stream_t stream) {
     if (!valid_desc(desc) || !x || !Zx || !hyp || !mean || !var || !chain_block || !saved || !scratch) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     if (desc->kind == 1 && (!zf || !f)) return MOBOCMF_BAD_ARG;
     Dims D = dims_of(desc);
     ChainWs c = {};
@@ -837,6 +857,7 @@ int mobocmf_layer_panel_backward(const mobocmf_layer_desc* desc, const double* x
     if (!valid_desc(desc) || !x || !Zx || !hyp || !g_mean || !g_var || !g_hyp || !chain_block || !saved || !scratch ||
         (desc->want_dx && !g_x))
         return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     if (desc->kind == 1 && (!zf || !f || !g_f || !g_zf)) return MOBOCMF_BAD_ARG;
     Dims D = dims_of(desc);
     ChainWs c = {};
@@ -853,6 +874,7 @@ int mobocmf_layer_panel_backward(const mobocmf_layer_desc* desc, const double* x
 
 int mobocmf_predictive_covariance_workspace_bytes(const mobocmf_layer_desc* desc, size_t* scratch_bytes) {
     if (!valid_desc(desc) || !scratch_bytes) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     Dims D = dims_of(desc);
     CovWs w;
     carve_cov(nullptr, ~(size_t)0 >> 1, desc, D, w, scratch_bytes);
@@ -863,6 +885,7 @@ int mobocmf_predictive_covariance(const mobocmf_layer_desc* desc, const double* 
                                   const double* zf, const double* hyp, double* cov, int64_t ldcov, const void* chain_state,
                                   size_t chain_state_bytes, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
     if (!valid_desc(desc) || !x || !Zx || !hyp || !cov || !chain_state || !scratch || ldcov < desc->Np) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     if (desc->kind == 1 && (!f || !zf)) return MOBOCMF_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     Dims D = dims_of(desc);
@@ -965,8 +988,10 @@ int mobocmf_exact_gp_workspace_bytes(int32_t n, int64_t nt, size_t* state_bytes,
 /* K: the n x n training covariance INCLUDING the noise on its diagonal (ld ldk); y[n].  state <- L, L^-1, a = L^-1 y;
  * mll[0] = log N(y | 0, K); info as in the layer calls (0 or the failed pivot). */
 int mobocmf_exact_gp_factor(int32_t n, const double* K, int64_t ldk, const double* y, double* mll, int32_t* info, void* state,
-                            size_t state_bytes, void* scratch, size_t scratch_bytes, mobocmf_stream_t stream) {
-    if (n < 1 || !K || ldk < n || !y || !mll || !info || !state || !scratch) return MOBOCMF_BAD_ARG;
+                            size_t state_bytes, void* scratch, size_t scratch_bytes, const mobocmf_tuning* tuning,
+                            mobocmf_stream_t stream) {
+    if (n < 1 || !K || ldk < n || !y || !mll || !info || !state || !scratch || !tuning_ok(tuning)) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(tuning);
     hipStream_t s = (hipStream_t)stream;
     const int np = (int)round_up(n, TILE);
     Bump bs(state, state_bytes), bf(scratch, scratch_bytes);
@@ -988,8 +1013,9 @@ int mobocmf_exact_gp_factor(int32_t n, const double* K, int64_t ldk, const doubl
  * column-statistics epilogue. */
 int mobocmf_exact_gp_predict(int32_t n, int64_t nt, const double* Kts, int64_t ld, const double* kss, double* mean,
                              double* var, const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
-                             mobocmf_stream_t stream) {
-    if (n < 1 || nt < 1 || !Kts || ld < nt || !kss || !mean || !var || !state || !scratch) return MOBOCMF_BAD_ARG;
+                             const mobocmf_tuning* tuning, mobocmf_stream_t stream) {
+    if (n < 1 || nt < 1 || !Kts || ld < nt || !kss || !mean || !var || !state || !scratch || !tuning_ok(tuning)) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(tuning);
     hipStream_t s = (hipStream_t)stream;
     const int np = (int)round_up(n, TILE);
     const int64_t ntp = round_up(nt, TILE);
@@ -1013,8 +1039,9 @@ extern "C" {
 
 int mobocmf_gemm_f64(int32_t tri, int32_t trans_b, int32_t Mr, int64_t Nc, int64_t Kd, const double* A, int64_t lda,
                      const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t accumulate,
-                     mobocmf_stream_t stream) {
-    if (!A || !B || !C || Mr <= 0 || Nc <= 0 || Kd <= 0 || (lda & 1) || (ldb & 1)) return MOBOCMF_BAD_ARG;
+                     const mobocmf_tuning* tuning, mobocmf_stream_t stream) {
+    if (!A || !B || !C || Mr <= 0 || Nc <= 0 || Kd <= 0 || (lda & 1) || (ldb & 1) || !tuning_ok(tuning)) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(tuning);
     GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, Mr, Nc, Kd, tri, alpha);
     g.accumulate = accumulate;
     // small / mid-size operands take the kernels the M x M chain uses for them; no workspace: never k-sliced
@@ -1037,23 +1064,25 @@ int mobocmf_gemm_f64_epilogue(int32_t tri, int32_t epi, int32_t Mr, int64_t Nc, 
                               const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t stream_out,
                               double* colsq_part, double* coldot_part, const double* avec, const double* bscale,
                               const double* gmu, const double* cgv, const double* Aaux, double* rowdot_part,
-                              mobocmf_stream_t stream) {
-    if (!A || !B || !C || Mr <= 0 || Nc <= 0 || Kd <= 0 || (lda & 1) || (ldb & 1)) return MOBOCMF_BAD_ARG;
+                              const int32_t* col_activity, const mobocmf_tuning* tuning, mobocmf_stream_t stream) {
+    if (!A || !B || !C || Mr <= 0 || Nc <= 0 || Kd <= 0 || (lda & 1) || (ldb & 1) || !tuning_ok(tuning)) return MOBOCMF_BAD_ARG;
     if (epi < EPI_STORE || epi > EPI_DA) return MOBOCMF_BAD_ARG;
     if (epi == EPI_COLSTATS && (!colsq_part || !avec)) return MOBOCMF_BAD_ARG;
     if (epi == EPI_DA && (!avec || !gmu || !cgv || !Aaux)) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(tuning);
     GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, Mr, Nc, Kd, tri, alpha);
     g.epi = epi; g.stream_out = stream_out;
     g.colsq_part = colsq_part; g.coldot_part = coldot_part; g.avec = avec;
     g.bscale = epi == EPI_DA ? bscale : nullptr; g.gmu = gmu; g.cgv = cgv; g.Aaux = Aaux; g.rowdot_part = rowdot_part;
     g.rm = panel_tile_rows(Mr, Nc);
     set_pairing(g);
-    g.colact = g_block_activity.load(std::memory_order_relaxed);
+    g.colact = col_activity;
     return launch_gemm(g, false, 1, (hipStream_t)stream);
 }
 
-int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, int32_t* rows) {
-    if (!rows || Mr <= 0 || Nc <= 0 || Kd <= 0) return MOBOCMF_BAD_ARG;
+int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, const mobocmf_tuning* tuning, int32_t* rows) {
+    if (!rows || Mr <= 0 || Nc <= 0 || Kd <= 0 || !tuning_ok(tuning)) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(tuning);
     GemmArgs g = gemm_args(nullptr, Kd, nullptr, Nc, nullptr, Nc, Mr, Nc, Kd, tri, 1.0);
     g.epi = EPI_COLSTATS;
     g.rm = panel_tile_rows(Mr, Nc);
@@ -1061,49 +1090,26 @@ int mobocmf_gemm_colstat_rows(int32_t tri, int32_t Mr, int64_t Nc, int64_t Kd, i
     return MOBOCMF_OK;
 }
 
-int mobocmf_set_tile_rows(int32_t rows, int32_t pair_mode) {
-    if ((rows != 0 && rows != 64 && rows != 128) || pair_mode < 0 || pair_mode > 2) return MOBOCMF_BAD_ARG;
-    g_tile_rows.store(rows, std::memory_order_relaxed);
-    g_pair_mode.store(pair_mode, std::memory_order_relaxed);
-    return MOBOCMF_OK;
-}
-
-int mobocmf_syrk_workspace_bytes(int32_t Mr, int64_t Kd, size_t* bytes) {
-    if (!bytes || Mr <= 0 || Kd <= 0 || Mr % TILE || Kd % TILE) return MOBOCMF_BAD_ARG;
+int mobocmf_syrk_workspace_bytes(int32_t Mr, int64_t Kd, const mobocmf_tuning* tuning, size_t* bytes) {
+    if (!bytes || Mr <= 0 || Kd <= 0 || Mr % TILE || Kd % TILE || !tuning_ok(tuning)) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(tuning);
     *bytes = (size_t)syrk_slab_elems(Mr, Kd) * sizeof(double);
     return MOBOCMF_OK;
 }
 
 int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t lda, const double* w, double* H,
-                              void* workspace, int64_t workspace_bytes, mobocmf_stream_t stream) {
-    if (!A || !w || !H || !workspace || Mr <= 0 || Kd <= 0 || Mr % TILE || Kd % TILE || (lda & 1)) return MOBOCMF_BAD_ARG;
+                              void* workspace, int64_t workspace_bytes, const int32_t* k_activity,
+                              const mobocmf_tuning* tuning, mobocmf_stream_t stream) {
+    if (!A || !w || !H || !workspace || Mr <= 0 || Kd <= 0 || Mr % TILE || Kd % TILE || (lda & 1) || !tuning_ok(tuning))
+        return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(tuning);
     if (workspace_bytes < syrk_slab_elems(Mr, Kd) * (int64_t)sizeof(double)) return MOBOCMF_WORKSPACE_TOO_SMALL;
-    return weighted_syrk(A, lda, w, Mr, Kd, (double*)workspace, H, nullptr, nullptr, g_block_activity.load(std::memory_order_relaxed),
-                         (hipStream_t)stream);
+    return weighted_syrk(A, lda, w, Mr, Kd, (double*)workspace, H, nullptr, nullptr, k_activity, (hipStream_t)stream);
 }
 
-int mobocmf_set_syrk_workgroups(int32_t n) {
-    if (n != 0 && (n < 16 || n > 4096)) return MOBOCMF_BAD_ARG;
-    g_syrk_wgs.store(n, std::memory_order_relaxed);
-    return MOBOCMF_OK;
-}
-
-int mobocmf_set_sparse_backward(int32_t on) {
-    g_sparse_bwd.store(on ? 1 : 0, std::memory_order_relaxed);
-    return MOBOCMF_OK;
-}
-
-int mobocmf_set_block_activity(const int32_t* act) {
-    g_block_activity.store(act, std::memory_order_relaxed);
-    return MOBOCMF_OK;
-}
-
-int mobocmf_set_probe_events(void* const* events, int32_t n, int64_t Np) {
-    if (n < 0 || n > MOBOCMF_PROBE_EVENTS || (n > 0 && !events)) return MOBOCMF_BAD_ARG;
-    g_probe_n.store(0, std::memory_order_release);
-    for (int i = 0; i < n; ++i) g_probe_ev[i] = (hipEvent_t)events[i];
-    g_probe_Np.store(Np, std::memory_order_relaxed);
-    g_probe_n.store(n, std::memory_order_release);
+int mobocmf_tuning_init(mobocmf_tuning* t) {
+    if (!t) return MOBOCMF_BAD_ARG;
+    *t = kDefaultTuning;
     return MOBOCMF_OK;
 }
 
@@ -1121,6 +1127,7 @@ int mobocmf_debug_touch_workspaces(const mobocmf_layer_desc* desc, void* saved, 
                                    size_t scratch_bytes, void* block, size_t block_bytes, void* psaved, size_t psaved_bytes,
                                    void* pscratch, size_t pscratch_bytes, void* cov, size_t cov_bytes, int32_t* regions) {
     if (!valid_desc(desc) || !regions) return MOBOCMF_BAD_ARG;
+    TuneScope tune_scope(desc->tuning, desc->probe_events);
     Dims D = dims_of(desc);
     const int64_t mm = (int64_t)D.Mp * D.Mp, mn = (int64_t)D.Mp * D.Np;
     int n = 0;

@@ -477,14 +477,7 @@ __global__ void identity_blocks_kernel(double* Dinv, double* Ld, int b0, int b1,
     Ld[(int64_t)b0 * NB * NB + idx] = v;
 }
 
-// columns per hand-over of the 64-wide panel kernel: 4 (potrf_panel4_kernel, default) or 1 (potrf_panel2_kernel); A/B knob
-static std::atomic<int> g_potrf_cols{4};
-extern "C" int mobocmf_set_potrf_cols(int32_t c) {
-    if (c != 1 && c != 4) return MOBOCMF_BAD_ARG;
-    g_potrf_cols.store(c, std::memory_order_relaxed);
-    return MOBOCMF_OK;
-}
-
+// columns per hand-over of the 64-wide panel kernel: tune().potrf_cols = 4 (potrf_panel4_kernel, default) or 1 (potrf_panel2_kernel)
 // Dinv and Ld: (Mp/64) x 64 x 64 doubles each.  M = real order: rows/columns >= M of A are identity padding, which the
 // factorisation leaves alone -- a 16-point problem padded to 128 costs 16 elimination steps, not 128.
 int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
@@ -499,7 +492,7 @@ int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* L
         nact = nact >= NB ? NB : (nact + 15) & ~15;
         const dim3 grid(nreal - jb, nz);          // blocks below the real rows are zero in these columns and stay zero
         if (nact == 16) hipLaunchKernelGGL(potrf_panel_pad_kernel<16>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
-        else if (g_potrf_cols.load(std::memory_order_relaxed) == 1)
+        else if (tune().potrf_cols == 1)
             hipLaunchKernelGGL(potrf_panel2_kernel, grid, dim3(128), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
         else hipLaunchKernelGGL(potrf_panel4_kernel, grid, dim3(128), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
         int nt = nreal - jb - 1;

@@ -16,6 +16,23 @@ static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * 
         if (_e != hipSuccess) return MOBOCMF_HIP_ERROR; \
     } while (0)
 
+// ------------------------------------------------------------------ tuning of the call in progress (api.hip)
+// The kernel-selection knobs (include/mobocmf_hip.h: mobocmf_tuning) travel with every C-ABI call.  An entry point opens a
+// TuneScope on the pointer it was given (NULL = defaults); the launch helpers below it read tune().  The scope is a
+// thread-local pointer that lives for the duration of the call only: nothing survives the call, two threads never see each
+// other's values.
+const mobocmf_tuning& tune();
+bool tuning_ok(const mobocmf_tuning* t);      // NULL, or a struct of the right size with every field in range
+void probe_at(int i, hipStream_t s);          // records the i-th probe event of the call in progress, if it has any
+struct TuneScope {
+    const mobocmf_tuning* prev_t;
+    void* const* prev_p;
+    explicit TuneScope(const mobocmf_tuning* t, void* const* probe = nullptr);
+    ~TuneScope();
+    TuneScope(const TuneScope&) = delete;
+    TuneScope& operator=(const TuneScope&) = delete;
+};
+
 // ------------------------------------------------------------------ GEMM (gemm_f64.hip)
 // bit mask: which k range of a tile is structurally non-zero (A is Mr x Kd, logical B is Kd x Nc)
 enum { TRI_NONE = 0, TRI_LOWER_A = 1, TRI_UPPER_A = 2, TRI_LOWER_B = 4, TRI_UPPER_B = 8 };

@@ -651,13 +651,16 @@ __global__ void propagate_rng_fwd_kernel(const double* mean, const double* var, 
     }
 }
 // rows b >= nbase of the previous layer (up to nprev) fed nothing forward (prefix propagation): zero gradient
+// add_mean / add_var (may be null): gradients the SAME moments receive from their other consumer (the ELBO's data term of the
+// previous layer's own fidelity) -- added here, in the launch that writes the result anyway, instead of by two autograd adds
 __global__ void propagate_bwd_kernel(const double* var, const double* eps, const double* gf, double* gmean, double* gvar,
-                                     int64_t nbase, int div, int64_t nprev) {
+                                     int64_t nbase, int div, int64_t nprev, const double* add_mean, const double* add_var) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nprev) return;
+    const double am = add_mean ? add_mean[b] : 0.0, av = add_var ? add_var[b] : 0.0;
     if (b >= nbase) {
-        gmean[b] = 0.0;
-        gvar[b] = 0.0;
+        gmean[b] = am;
+        gvar[b] = av;
         return;
     }
     double sm = 0.0, sv = 0.0;
@@ -666,8 +669,8 @@ __global__ void propagate_bwd_kernel(const double* var, const double* eps, const
         sm += g;
         sv += g * eps[b * div + s];
     }
-    gmean[b] = sm;
-    gvar[b] = sv * 0.5 / sqrt(var[b]);
+    gmean[b] = sm + am;
+    gvar[b] = sv * 0.5 / sqrt(var[b]) + av;
 }
 
 __device__ __forceinline__ double elp_term(double y, double mu, double v, double tau, double ltau) {
@@ -1096,15 +1099,17 @@ int mobocmf_propagate_rng_forward(const double* mean, const double* var, int64_t
 
 int mobocmf_propagate_backward(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
                                int64_t n_out, int32_t div, mobocmf_stream_t stream) {
-    return mobocmf_propagate_backward_prefix(var, eps, g_f, g_mean, g_var, n_out, div, div > 0 ? n_out / div : 0, stream);
+    return mobocmf_propagate_backward_prefix(var, eps, g_f, g_mean, g_var, n_out, div, div > 0 ? n_out / div : 0, nullptr, nullptr,
+                                             stream);
 }
 
 int mobocmf_propagate_backward_prefix(const double* var, const double* eps, const double* g_f, double* g_mean, double* g_var,
-                                      int64_t n_out, int32_t div, int64_t n_prev, mobocmf_stream_t stream) {
+                                      int64_t n_out, int32_t div, int64_t n_prev, const double* add_mean, const double* add_var,
+                                      mobocmf_stream_t stream) {
     if (n_out < 0 || div < 1 || n_out % div || n_prev < n_out / div) return MOBOCMF_BAD_ARG;
     if (n_prev == 0) return MOBOCMF_OK;
     hipLaunchKernelGGL(propagate_bwd_kernel, GRID1(n_prev), 0, (hipStream_t)stream, var, eps, g_f, g_mean, g_var,
-                       n_out / div, div, n_prev);
+                       n_out / div, div, n_prev, add_mean, add_var);
     return CHECK_LAUNCH();
 }
 

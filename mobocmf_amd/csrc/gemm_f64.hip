@@ -36,6 +36,28 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 #define KL_MAX 1024   // active K blocks one k-slice of an A B^T product can hold (GemmArgs.kact; launch_gemm checks)
 #define TILE_ELEMS (BM * BK)   // 2048 doubles = 16 KiB per operand tile
 
+// Matrix instruction of gemm_f64_kernel's main loop.  16: v_mfma_f64_16x16x4_f64 (round 4; 77 TFLOP/s sustained, one fragment
+// value feeds 2048 flops).  4: v_mfma_f64_4x4x4_4b_f64 (rounds 1-3; 73 TFLOP/s, 512 flops per fragment value) -- kept for
+// A/B builds (EXTRA_HIPCC_FLAGS=-DGEMM_MI=4).  Accumulator lane map is the SAME for both: acc[mt][nt][r] of lane (li, lk) is
+// row mt*32 + wr*16 + 4r + lk, so every epilogue serves either.  What differs is the operand side:
+//   4x4x4:   lane (kk = l>>4, i = l&3) feeds A[4r + i][k = kk] to MFMA r (four MFMAs cover 16 rows), 16 ds_read_b128 of A per kpair
+//   16x16x4: lane (li, lk) feeds A[li][k = lk] -- one MFMA covers the 16 rows x 16 columns x 4 k; with MFMA kq of a K step
+//            taking k = 4*lk + kq a lane's four A values are 32 contiguous bytes of its image row: two ds_read_b128 per
+//            16-row group and K step (16 b128 per K step and wavefront where the 4x4x4 form issues 40, 64 MFMAs instead of 256).
+// Image swizzle (XOR on the 16-byte chunk index of a [rows][16 k] image row, applied on the DMA source and on the read):
+// the four 16-lane groups a ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...) must hit 16 different 16-byte slots of the
+// 256-byte bank row.  16x16x4: a group holds 8 rows x chunk c and 8 other rows x chunk c^2; slot = (row&1)*8 + chunk, so the
+// four rows of one parity need four different XOR values that keep bit 1 clear: s = bit1(row) | bit3(row) << 2.
+#ifndef GEMM_MI
+#define GEMM_MI 16
+#endif
+#if GEMM_MI == 16
+#define IMG_SWZ(row) ((((row) >> 1) & 1) | ((((row) >> 3) & 1) << 2))
+#else
+#define IMG_SWZ(row) ((((row) >> 1) & 1) << 2)
+#endif
+
+
 // Cross-lane sums without the LDS crossbar (ds_bpermute round trips): DPP moves inside a 16-lane row, permlane swaps across
 // rows.  row16_sum: every lane ends with the sum over its row of 16 lanes (quad butterflies, then the mirrored half, then
 // the mirrored row).  rows4_sum: every lane ends with the sum over the 4 lanes {l mod 16 + 16 r} (v_permlane16_swap pairs
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
     // ---- LDS-DMA staging maps (one instruction = 64 lanes x 16 B = 1 KiB of the image)
     // A / B_T image: lane -> (row = 8*wave + l/8 (+32 per round), physical chunk l%8); source chunk swizzled
     const int a_row = tid >> 3;
-    const int a_lchk = (tid & 7) ^ (((a_row >> 1) & 1) << 2);
+    const int a_lchk = (tid & 7) ^ IMG_SWZ(a_row);
     const double* Ag0 = A + (int64_t)a_row * g.lda + a_lchk * 2;
     // B image: lane -> (k = wave (+4 per round), chunk l)
     const double* Bg = B_T ? B + (cb * BN + a_row) * g.ldb + a_lchk * 2
@@ -279,11 +301,21 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
 
     // ---- fragment read offsets (doubles).  k pairs (2*kp', 2*kp'+1) are adjacent: one ds_read_b128 per pair.
     // kpair p (0,1) covers ks = 2p, 2p+1, i.e. k = 4*lk + 2p + {0,1}: logical 16-B chunk 2*lk + p.
+#if GEMM_MI == 16
+    // 16x16x4: lane (li, lk) feeds row li of a 16-row group with k = 4*lk + kq (kq = 0..3: MFMA number kq of the K step takes
+    // lane group lk's k = 4*lk + kq on both operands), i.e. logical 16-byte chunks 2*lk and 2*lk + 1 of its row.
+    const int swA = IMG_SWZ(li);
+#else
     const int swA = ((lane >> 1) & 1) << 2;
+#endif
     const int colP0 = ((2 * lk + 0) ^ swA) << 1, colP1 = ((2 * lk + 1) ^ swA) << 1;
     // the two row-wavefronts own INTERLEAVED 16-row groups (group 2*mt + wr): inside a triangular diagonal block both
     // then skip a similar share of structurally-zero groups (critical path 20/32 of a dense block instead of 26/32)
+#if GEMM_MI == 16
+    const int a_base = (wr * 16 + li) * BK;                         // + mt*32*BK + colP
+#else
     const int a_base = (wr * 16 + (lane & 3)) * BK;                 // + (mt*32 + 4r)*BK + colP
+#endif
     // A B^T: the two column-wavefronts own INTERLEAVED 16-column groups (group 2*nt + wc), like the row-wavefronts their row
     // groups: in a diagonal tile of a symmetric product the 16 x 16 blocks strictly above the diagonal (column group > row
     // group) then spread evenly over the four wavefronts
@@ -400,6 +432,48 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
     // (4 x ds_read_b128) and, at a kpair boundary, the B fragments of the next kpair are read while the 32 MFMAs of
     // group g issue.  sched_barrier(0) pins the group boundaries so the register allocator sees two fragment sets, not
     // eight.  (Literal indices through macros: lambdas / late-unrolled loops left the fragment arrays in scratch.)
+#if GEMM_MI == 16
+    // ---- 16x16x4 main loop.  All fragments of a K step are read up front (B: 8 ds_read_b128, A: 2 per 16-row group), the
+    // next stage's DMA is issued behind the first of them, then the MFMAs go row group by row group -- a wavefront issues one
+    // 64-cycle MFMA after the other, so the reads of the later groups return under the first group's MFMAs and the
+    // co-resident wavefronts' bursts; no software pipeline of fragment sets is needed (the 4x4x4 form's eight groups).
+    v2f64 fa[MT][2];             // A: [row group][chunk]: k = 4*lk + 2*chunk + {0, 1}
+    double fb[4][4];             // B: [kq][nt]: k = 4*lk + kq
+#define LOAD_A16(MT_)                                                                                       \
+    fa[MT_][0] = *(const v2f64*)(As + a_base + (MT_) * 32 * BK + colP0);                                    \
+    fa[MT_][1] = *(const v2f64*)(As + a_base + (MT_) * 32 * BK + colP1);
+#define LOAD_B16                                                                                            \
+    if (B_T) {                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+            const v2f64 v0 = *(const v2f64*)(Bs + bt_base + t * 32 * BK + colP0);                           \
+            const v2f64 v1 = *(const v2f64*)(Bs + bt_base + t * 32 * BK + colP1);                           \
+            fb[0][t] = v0[0];                                                                               \
+            fb[1][t] = v0[1];                                                                               \
+            fb[2][t] = v1[0];                                                                               \
+            fb[3][t] = v1[1];                                                                               \
+        }                                                                                                   \
+        if (g.bscale) {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) fb[q][t] *= w4[q];                           \
+        }                                                                                                   \
+    } else {                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                      \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                \
+                const v2f64 v = *(const v2f64*)(Bs + bn_base + q * BN + h * 32);                            \
+                fb[q][2 * h] = v[0];                                                                        \
+                fb[q][2 * h + 1] = v[1];                                                                    \
+            }                                                                                               \
+    }
+// the first JN column groups of row group MT_ over the four k quads of the step
+#define MMA16(MT_, JN)                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
+        _Pragma("unroll") for (int j = 0; j < (JN); ++j)                                                   \
+            acc[MT_][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[MT_][q >> 1][q & 1], fb[q][j], acc[MT_][j], 0, 0, 0);
+#define MMA_ALL(MT_) MMA16(MT_, 4)
+#define MMA_IF(MT_)                                                                                         \
+    if (act & (1 << (MT_))) { MMA16(MT_, 4) }
+#endif
+#if GEMM_MI != 16
     v2f64 a0[4], a1[4];          // A fragment sets (even / odd group)
     double b0[2][4], b1[2][4];   // B fragment sets (kpair 0 / 1): [ks&1][nt]
 #define LOAD_A(dst, P, MT)                                                                                  \
@@ -435,6 +509,7 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
 #define MMA_IF(asrc, bsrc, MT)                                                                              \
     if (act & (1 << (MT))) { MMA_DO(asrc, bsrc, MT) }                                                       \
     __builtin_amdgcn_sched_barrier(0);
+#endif
 // The LDS-DMA of the NEXT stage is issued behind the step's first fragment reads (it writes the other buffer): in front
 // of them its address arithmetic and eight issues sat on the critical path between the barrier and the first MFMA.
 #define STAGE_NEXT                                                                                          \
@@ -445,6 +520,48 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
             stage(Ag, knext, buf ^ 1);                                                                      \
         }                                                                                                   \
         STEP_STAMP(1);
+#if GEMM_MI == 16
+#define KSTEP_STD(MMA)                                                                                      \
+        LOAD_B16                                                                                            \
+        LOAD_A16(0)                                                                                         \
+        STAGE_NEXT                                                                                          \
+        LOAD_A16(MT - 1)                                                                                    \
+        if constexpr (MT == 4) {                                                                            \
+            LOAD_A16(1)                                                                                     \
+            LOAD_A16(2)                                                                                     \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        MMA(0)                                                                                              \
+        if constexpr (MT == 4) {                                                                            \
+            MMA(1)                                                                                          \
+            MMA(2)                                                                                          \
+        }                                                                                                   \
+        MMA(MT - 1)                                                                                         \
+        /* the MFMAs stay IN FRONT of the step's closing wait + barrier: they only touch registers, so without this fence   \
+           hipcc hoists "s_waitcnt vmcnt(0); s_barrier" to right behind the first MFMA -- the wavefront then waits for the   \
+           next stage's DMA (a full L2 / HBM round trip) before it has issued anything that could hide it (first build of   \
+           this loop: 5-10 % slower than the 4x4x4 form at every shape) */                                                 \
+        __builtin_amdgcn_sched_barrier(0);
+// Diagonal tile of a symmetric A B^T product (sym_out): with row group 2*mt + wr and column group 2*nt + wc a 16 x 16
+// block lies on or below the diagonal iff 2*nt + wc <= 2*mt + wr, i.e. nt <= mt for three of the wavefronts (KSTEP_LE:
+// 10 of 16 blocks) and nt < mt for (wr, wc) = (0, 1) (KSTEP_LT: 6 of 16); the slab reduction mirrors the rest.
+#define KSTEP_LE                                                                                            \
+        LOAD_B16                                                                                            \
+        LOAD_A16(0)                                                                                         \
+        STAGE_NEXT                                                                                          \
+        LOAD_A16(1) LOAD_A16(2) LOAD_A16(3)                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        MMA16(0, 1) MMA16(1, 2) MMA16(2, 3) MMA16(3, 4)                                                     \
+        __builtin_amdgcn_sched_barrier(0);
+#define KSTEP_LT                                                                                            \
+        LOAD_B16                                                                                            \
+        LOAD_A16(1)                                                                                         \
+        STAGE_NEXT                                                                                          \
+        LOAD_A16(2) LOAD_A16(3)                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        MMA16(1, 1) MMA16(2, 2) MMA16(3, 3)                                                                 \
+        __builtin_amdgcn_sched_barrier(0);
+#else
 // The standard K step: all four row groups, MMA = MMA_ALL or the skipping MMA_IF.
 #define KSTEP_STD(MMA)                                                                                      \
         LOAD_B(b0, 0)                                                                                       \
@@ -497,6 +614,7 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
         LOAD_A(a0, 1, 2) GRPJ(a1, b1, 1, 1)                                                                 \
         LOAD_A(a1, 1, 3) GRPJ(a0, b1, 2, 2)                                                                 \
         GRPJ(a1, b1, 3, 3)
+#endif
 // K steps [KT0, KT1) of the pipeline with the K-step body BODY.  COND = 1: inside a triangular diagonal block, 16-row
 // groups that are structurally zero for the step are skipped (bit mt of `act`, used by MMA_IF).
 #define STAGE_LOOP(KT0, KT1, COND, BODY)                                                                    \
@@ -569,6 +687,9 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
 #undef MMA_DO
 #undef LOAD_A
 #undef LOAD_B
+#undef LOAD_A16
+#undef LOAD_B16
+#undef MMA16
 
     // ------------------------------------------------------------------ epilogue
     // Every operand of an epilogue is fetched up front in batches (the row vector `avec` through LDS, staged at the top
@@ -890,15 +1011,8 @@ int launch_reduce_slabs(const double* slabs, int64_t slab_stride, int nslab, dou
 // Hand-over to the tiled MFMA kernels (largest dimension), from tools/size_sweep.py + the C3 bench: the 16x16-block
 // product wins up to 384 (a 512^3 product is LDS-bound at ~27 us and costs C3 3 %), the whole-block panel kernel up to
 // K = 512 when the launch stays within 512 workgroups (M = N = 300: 1.98 -> 1.54 ms per step, 450: 2.47 -> 2.2).
-static std::atomic<int> g_small_gemm_max{384}, g_small_panel_max{512};
-static int small_gemm_limit() { return g_small_gemm_max.load(std::memory_order_relaxed); }
-static int small_panel_limit() { return g_small_panel_max.load(std::memory_order_relaxed); }
-extern "C" int mobocmf_set_tuning(int32_t small_gemm_max, int32_t small_panel_max) {
-    if (small_gemm_max > 512 || small_panel_max > 512) return MOBOCMF_BAD_ARG;   // the small kernels' own size limits
-    if (small_gemm_max > 0) g_small_gemm_max.store(small_gemm_max, std::memory_order_relaxed);
-    if (small_panel_max > 0) g_small_panel_max.store(small_panel_max, std::memory_order_relaxed);
-    return MOBOCMF_OK;
-}
+static int small_gemm_limit() { return tune().small_gemm_max; }
+static int small_panel_limit() { return tune().small_panel_max; }
 // ---------------------------------------------------------------------------------- small operands
 // All dimensions <= 256 (the M x M chain of a surrogate with M <= 256 -- the sizes the reference's own BO runs live at):
 // the 128x128x16 MFMA pipeline is pure latency there (one to four workgroups walking 8-16 dependent K steps, ~20 us a
@@ -1544,34 +1658,22 @@ __global__ __launch_bounds__(256) void gemm_mid2_kernel(GemmArgs g0, GemmArgs g1
     else gemm_mid_body<false>(g1, nrb, ncb);
 }
 
-static std::atomic<int> g_mid_gemm_max{1024};
-extern "C" int mobocmf_set_mid_gemm_max(int32_t n) {
-    if (n < 0 || n > 4096) return MOBOCMF_BAD_ARG;
-    g_mid_gemm_max.store(n, std::memory_order_relaxed);
-    return MOBOCMF_OK;
-}
 static bool mid_gemm_ok(const GemmArgs& g) {
-    const int L = g_mid_gemm_max.load(std::memory_order_relaxed);
+    const int L = tune().mid_gemm_max;
     return g.epi == EPI_STORE && g.batched <= 1 && !g.bscale && !g.skip_if_zero && !g.sym_out && !g.dual_flag && !g.colact &&
            !g.kact && g.Mr <= L && g.Nc <= L && g.Kd <= L && g.Mr % MD_BM == 0 && g.Nc % MD_BN == 0 && g.Kd % MD_BK == 0 &&
            !(g.lda & 1) && !(g.ldb & 1) && !(g.ldc & 1) && !((uintptr_t)g.A & 15) && !((uintptr_t)g.B & 15) &&
            !((uintptr_t)g.C & 15) && (g.zlayers <= 1 || (!(g.zsA & 1) && !(g.zsB & 1) && !(g.zsC & 1)));
 }
-static std::atomic<int> g_mid_waves{32};
-extern "C" int mobocmf_set_mid_gemm_waves(int32_t n) {
-    if (n != 4 && n != 8 && n != 32) return MOBOCMF_BAD_ARG;      // 32: the 32 x 64-tile form (four wavefronts, 64-k stages)
-    g_mid_waves.store(n, std::memory_order_relaxed);
-    return MOBOCMF_OK;
-}
 static int launch_mid_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
     const int nrb = g.Mr / MD_BM, ncb = (int)(g.Nc / MD_BN);
     const dim3 grid((unsigned)(nrb * ncb), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
-    if (g_mid_waves.load(std::memory_order_relaxed) == 32 && g.Kd % MS_BK == 0) {
+    if (tune().mid_gemm_waves == 32 && g.Kd % MS_BK == 0) {
         const int nrb32 = g.Mr / MS_BM;
         const dim3 grid32((unsigned)(nrb32 * ncb), 1, (unsigned)(g.zlayers > 1 ? g.zlayers : 1));
         if (B_T) hipLaunchKernelGGL(gemm_mid32_kernel<true>, grid32, dim3(256), 0, s, g, nrb32, ncb);
         else hipLaunchKernelGGL(gemm_mid32_kernel<false>, grid32, dim3(256), 0, s, g, nrb32, ncb);
-    } else if (g_mid_waves.load(std::memory_order_relaxed) == 8) {
+    } else if (tune().mid_gemm_waves == 8) {
         if (B_T) hipLaunchKernelGGL(gemm_mid8_kernel<true>, grid, dim3(512), 0, s, g, nrb, ncb);
         else hipLaunchKernelGGL(gemm_mid8_kernel<false>, grid, dim3(512), 0, s, g, nrb, ncb);
     } else {
@@ -1590,10 +1692,10 @@ int launch_gemm_auto_pair(const GemmArgs& a, const GemmArgs& b, double* ws, int6
     const bool small = small_gemm_ok(nza > 1 ? a1 : a, false) || small_gemm_ok(nzb > 1 ? b1 : b, false);
     if (!small && nza == nzb && a.Mr == b.Mr && a.Nc == b.Nc && a.batched <= 1 && b.batched <= 1 && mid_gemm_ok(a) && mid_gemm_ok(b)) {
         const int nrb = a.Mr / MD_BM, ncb = (int)(a.Nc / MD_BN);
-        if (g_mid_waves.load(std::memory_order_relaxed) == 32 && a.Kd % MS_BK == 0 && b.Kd % MS_BK == 0)
+        if (tune().mid_gemm_waves == 32 && a.Kd % MS_BK == 0 && b.Kd % MS_BK == 0)
             hipLaunchKernelGGL(gemm_mid32x2_kernel, dim3((unsigned)((a.Mr / MS_BM) * ncb), 2, (unsigned)nza), dim3(256), 0, s, a, b,
                                a.Mr / MS_BM, ncb);
-        else if (g_mid_waves.load(std::memory_order_relaxed) == 8)
+        else if (tune().mid_gemm_waves == 8)
             hipLaunchKernelGGL(gemm_mid8x2_kernel, dim3((unsigned)(nrb * ncb), 2, (unsigned)nza), dim3(512), 0, s, a, b, nrb, ncb);
         else
             hipLaunchKernelGGL(gemm_mid2_kernel, dim3((unsigned)(nrb * ncb), 2, (unsigned)nza), dim3(256), 0, s, a, b, nrb, ncb);

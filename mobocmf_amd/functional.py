@@ -3,8 +3,10 @@
 PyTorch is plumbing here: it owns device memory, streams and the autograd tape; all arithmetic of
 the layer runs in libmobocmf_hip.so.  Tensors must be CUDA(HIP) float64; there is no CPU fallback.
 """
+import contextlib
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -106,15 +108,98 @@ def hyp_len(kind, d):
 PHASE_ALL, PHASE_CHAIN, PHASE_PANEL, PHASE_CHAIN_ONLY, PHASE_PANEL_INPUTS = 0, 1, 2, 3, 4
 
 
-def make_desc(kind, d, M, Np, xdiv=1, branch=0, want_dx=False, jitter=JITTER, min_var=MIN_VARIANCE, phase=PHASE_ALL):
+# ---------------------------------------------------------------------------------------------------------------------
+# Kernel-selection knobs (include/mobocmf_hip.h: mobocmf_tuning).  The LIBRARY keeps no state: the values travel with every
+# call.  This module keeps the host-side default record (`set_*` below change it: size sweeps, A/B timing, parity tests) and a
+# per-thread override (`tuning(...)` context manager).  A descriptor takes a SNAPSHOT when it is built in the forward; the
+# backward -- which autograd runs on its own thread -- reuses the forward's snapshot, so a call is sized and launched under one
+# set of values whatever happens to the defaults in between.
+# ---------------------------------------------------------------------------------------------------------------------
+_TUNING_DEFAULT = None
+_tuning_tls = threading.local()
+
+
+def _default_tuning():
+    global _TUNING_DEFAULT
+    if _TUNING_DEFAULT is None:
+        t = _lib.Tuning()
+        _lib.check(_lib.load().mobocmf_tuning_init(ctypes.byref(t)), "mobocmf_tuning_init")
+        _TUNING_DEFAULT = t
+    return _TUNING_DEFAULT
+
+
+def current_tuning():
+    """A snapshot (copy) of the tuning calls issued by this thread use now."""
+    t = getattr(_tuning_tls, "override", None)
+    return (t if t is not None else _default_tuning()).copy()
+
+
+def _set_default(**kw):
+    t = _default_tuning()
+    for k, v in kw.items():
+        assert k in _lib.Tuning.KNOBS, k
+        setattr(t, k, int(v))
+
+
+@contextlib.contextmanager
+def tuning(**kw):
+    """Per-THREAD override of the knobs for the calls issued inside the block (forward calls; a backward uses the snapshot
+    its forward took): ``with F.tuning(tile_rows=64, sparse_backward=0): ...``."""
+    prev = getattr(_tuning_tls, "override", None)
+    t = current_tuning()
+    for k, v in kw.items():
+        if k not in _lib.Tuning.KNOBS:
+            raise TypeError("unknown tuning knob %r" % k)
+        setattr(t, k, int(v))
+    _tuning_tls.override = t
+    try:
+        yield t
+    finally:
+        _tuning_tls.override = prev
+
+
+_probe_tls = threading.local()
+
+
+@contextlib.contextmanager
+def probe_events(table, layer=None):
+    """Diagnostic (bench.py per_kernel_instep_ms): the PANEL calls issued by this thread inside the block -- those of layer
+    index ``layer`` of a batched-chain forward, or every one if None -- carry ``table`` (a ctypes array of PROBE_EVENTS
+    hipEvent_t handles) in their descriptor; the backward of such a call records into the same table."""
+    prev = getattr(_probe_tls, "cur", None)
+    _probe_tls.cur = (table, layer)
+    try:
+        yield
+    finally:
+        _probe_tls.cur = prev
+
+
+def _probe_for(layer):
+    cur = getattr(_probe_tls, "cur", None)
+    if cur is None or (cur[1] is not None and layer is not None and cur[1] != layer):
+        return None
+    return cur[0]
+
+
+def make_desc(kind, d, M, Np, xdiv=1, branch=0, want_dx=False, jitter=JITTER, min_var=MIN_VARIANCE, phase=PHASE_ALL,
+              tune=None, probe=None):
+    """``tune``: a Tuning snapshot to carry (default: the calling thread's current one); ``probe``: a ctypes array of
+    PROBE_EVENTS hipEvent_t handles (mobocmf_layer_desc.probe_events) or None."""
     if not 1 <= d <= _lib.MAX_D:
         raise _lib.MobocmfError("mobocmf_amd: a layer takes 1..%d input dimensions (got %d): the Gram kernels keep one "
                                 "input row in registers" % (_lib.MAX_D, d))
     if not 1 <= xdiv <= _lib.MAX_XDIV:
         raise _lib.MobocmfError("mobocmf_amd: at most %d samples per input row (num_samples_for_acquisition / "
                                 "num_samples_for_training), got %d" % (_lib.MAX_XDIV, xdiv))
-    return LayerDesc(kind=kind, d=d, M=M, xdiv=xdiv, Np=Np, branch=branch, want_dx=int(want_dx), jitter=jitter,
+    desc = LayerDesc(kind=kind, d=d, M=M, xdiv=xdiv, Np=Np, branch=branch, want_dx=int(want_dx), jitter=jitter,
                      min_var=min_var, phase=phase, reserved=0)
+    snap = tune if tune is not None else current_tuning()
+    desc.tuning = ctypes.pointer(snap)
+    desc._tune = snap              # keeps the snapshot alive as long as the descriptor
+    if probe is not None:
+        desc.probe_events = ctypes.cast(probe, ctypes.c_void_p)
+        desc._probe = probe
+    return desc
 
 
 def workspace_bytes(desc):
@@ -208,11 +293,12 @@ def side_stream_for(main):
 class LayerPass:
     """State shared by the two halves of one split layer call."""
     __slots__ = ("kind", "d", "M", "Np", "xdiv", "branch", "jitter", "min_var", "want_dx", "info", "saved", "sb", "cb",
-                 "bscratch", "main", "side", "ready", "kl", "frozen")
+                 "bscratch", "main", "side", "ready", "kl", "frozen", "tune", "probe")
 
     def desc(self, phase):
+        # one tuning snapshot (taken when the pass was created, in the forward) serves both halves, forward and backward
         return make_desc(self.kind, self.d, self.M, self.Np, self.xdiv, self.branch, self.want_dx, self.jitter,
-                         self.min_var, phase)
+                         self.min_var, phase, tune=self.tune, probe=self.probe)
 
 
 class _ChainFn(torch.autograd.Function):
@@ -342,6 +428,7 @@ def layer_chain(Zx, zf, hyp, m, L_S, kind, Np, xdiv=1, branch=0, jitter=JITTER, 
     P.jitter, P.min_var, P.want_dx = jitter, min_var, want_dx
     P.info = info_out if info_out is not None else torch.zeros((), dtype=torch.int32, device=Zx.device)
     P.bscratch, P.main, P.side, P.frozen = None, main, side, False
+    P.tune, P.probe = current_tuning(), _probe_for(None)
     token, P.kl = _ChainFn.apply(Zx, zf, hyp, m, L_S, P)
     P.ready = None
     if side is not None:
@@ -366,11 +453,11 @@ def layer_panel(P, token, x, f, Zx, zf, hyp):
 class ChainBatch:
     """Workspace + bookkeeping shared by ``layers_chain`` and the per-layer ``layer_panel_batched`` calls of one forward."""
     __slots__ = ("n", "kinds", "ds", "M", "branch", "jitters", "min_var", "blocks", "stride", "block_bytes", "infos",
-                 "kls", "had_panel", "token", "panel_g")
+                 "kls", "had_panel", "token", "panel_g", "tune")
 
     def chain_desc(self, z):
         return make_desc(self.kinds[z], self.ds[z], self.M, 1, 1, self.branch, False, self.jitters[z], self.min_var,
-                         PHASE_CHAIN)
+                         PHASE_CHAIN, tune=self.tune)
 
     def block(self, z):
         return self.blocks[z * self.stride:z * self.stride + self.block_bytes]
@@ -464,6 +551,7 @@ def layers_chain(layers_params, kinds, branch, jitters, infos, min_var=MIN_VARIA
     if any(p[0].shape[0] != CB.M for p in layers_params):
         raise _lib.MobocmfError("layers_chain: the layers must share the number of inducing points")
     CB.branch, CB.jitters, CB.min_var, CB.infos = branch, list(jitters), min_var, list(infos)
+    CB.tune = current_tuning()      # one snapshot for the chains and every PANEL call that hangs off them
     out = _ChainsFn.apply(CB, *[t for p in layers_params for t in p])
     CB.token, CB.kls = out[0], list(out[1:])
     return CB
@@ -479,7 +567,8 @@ class _PanelBatchedFn(torch.autograd.Function):
         if x.shape[1] != CB.ds[z] or (kind == 1 and (f is None or f.numel() != Np)):
             raise _lib.MobocmfError("shape mismatch between the chain batch and a panel call")
         dev = x.device
-        desc = make_desc(kind, CB.ds[z], CB.M, Np, xdiv, CB.branch, want_dx, CB.jitters[z], CB.min_var, PHASE_PANEL)
+        desc = make_desc(kind, CB.ds[z], CB.M, Np, xdiv, CB.branch, want_dx, CB.jitters[z], CB.min_var, PHASE_PANEL,
+                         tune=CB.tune, probe=_probe_for(z))
         sb, cb = ctypes.c_size_t(), ctypes.c_size_t()
         _lib.check(lib.mobocmf_panel_workspace_bytes(ctypes.byref(desc), ctypes.byref(sb), ctypes.byref(cb)),
                    "mobocmf_panel_workspace_bytes")
@@ -569,6 +658,7 @@ def layer_panel_frozen(fc, x, f, xdiv=1, want_dx=False):
     P.jitter, P.min_var, P.want_dx, P.info = fc.jitter, fc.min_var, want_dx, fc.info
     P.bscratch = P.main = P.side = P.ready = None
     P.kl, P.frozen = fc.kl, True
+    P.tune, P.probe = current_tuning(), _probe_for(None)
     P.sb, P.cb = workspace_bytes(P.desc(PHASE_PANEL))
     P.saved = _poison(torch.empty(P.sb, dtype=torch.uint8, device=x.device))
     P.saved[:fc.state.numel()].copy_(fc.state)
@@ -606,21 +696,36 @@ def predictive_covariance(x, f, Zx, zf, hyp, m, L_S, kind, xdiv=1, jitter=JITTER
     return mean, cov
 
 
-def _propagate_backward(ctx, g):
-    """g_mean / g_var of the previous layer's moments: zeros beyond the propagated prefix (one launch either way)."""
+def _propagate_backward(ctx, g, add_mean=None, add_var=None):
+    """g_mean / g_var of the previous layer's moments: zeros beyond the propagated prefix (one launch either way).
+    add_mean / add_var: the gradients the pass-through copies of the moments received (``through=True``), added in the same
+    launch."""
     lib = _lib.require_device()
     var, eps = ctx.saved_tensors
+    if g is None:        # nothing came back through the propagated samples
+        if add_mean is None and add_var is None:
+            return None, None
+        z = lambda t: _prep(t) if t is not None else torch.zeros_like(var)
+        return z(add_mean), z(add_var)
     g = _prep(g)
+    add_mean = None if add_mean is None else _prep(add_mean.reshape(-1))
+    add_var = None if add_var is None else _prep(add_var.reshape(-1))
     gm, gv = _empty_like(var), _empty_like(var)
     _lib.check(lib.mobocmf_propagate_backward_prefix(_ptr(var), _ptr(eps), _ptr(g), _ptr(gm), _ptr(gv), eps.numel(),
-                                                     ctx.div, var.numel(), _stream()), "mobocmf_propagate_backward_prefix")
+                                                     ctx.div, var.numel(), _ptr(add_mean), _ptr(add_var), _stream()),
+               "mobocmf_propagate_backward_prefix")
     return gm, gv
 
 
 class _PropagateFn(torch.autograd.Function):
+    """f~ = mean + sqrt(var) eps.  through=True additionally returns pass-through aliases of (mean, var): a caller that
+    also scores the SAME moments (the ELBO's data term of the previous layer's own fidelity) uses those, so the moments have
+    one consumer node and their two gradient contributions are summed inside the propagate-backward launch."""
+
     @staticmethod
-    def forward(ctx, mean, var, eps, div):
+    def forward(ctx, mean, var, eps, div, through):
         lib = _lib.require_device()
+        shape = mean.shape
         mean, var, eps = _prep(mean.reshape(-1)), _prep(var.reshape(-1)), _prep(eps.reshape(-1))
         n = eps.numel()
         if mean.numel() * div < n or n % div or var.numel() != mean.numel():
@@ -629,19 +734,24 @@ class _PropagateFn(torch.autograd.Function):
         _lib.check(lib.mobocmf_propagate_forward(_ptr(mean), _ptr(var), _ptr(eps), _ptr(out), n, div, _stream()),
                    "mobocmf_propagate_forward")
         ctx.save_for_backward(var, eps)
-        ctx.div = div
+        ctx.div, ctx.shape = div, shape
+        ctx.set_materialize_grads(False)
+        if through:
+            return out, mean.view(shape), var.view(shape)
         return out
 
     @staticmethod
-    def backward(ctx, g):
-        gm, gv = _propagate_backward(ctx, g)
-        return gm, gv, None, None
+    def backward(ctx, g, g_mean_t=None, g_var_t=None):
+        gm, gv = _propagate_backward(ctx, g, g_mean_t, g_var_t)
+        r = lambda t: None if t is None else t.view(ctx.shape)
+        return r(gm), r(gv), None, None, None
 
 
 class _PropagateRngFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mean, var, rng_state, n_out, div):
+    def forward(ctx, mean, var, rng_state, n_out, div, through):
         lib = _lib.require_device()
+        shape = mean.shape
         mean, var = _prep(mean.reshape(-1)), _prep(var.reshape(-1))
         if mean.numel() * div < n_out or n_out % div or var.numel() != mean.numel() or rng_state.dtype != torch.int64 or \
                 rng_state.numel() != 3 or not rng_state.is_cuda:
@@ -650,29 +760,40 @@ class _PropagateRngFn(torch.autograd.Function):
         _lib.check(lib.mobocmf_propagate_rng_forward(_ptr(mean), _ptr(var), _ptr(rng_state), _ptr(out), _ptr(eps), n_out, div,
                                                      _stream()), "mobocmf_propagate_rng_forward")
         ctx.save_for_backward(var, eps)
-        ctx.div = div
+        ctx.div, ctx.shape = div, shape
         ctx.mark_non_differentiable(eps)
         ctx.set_materialize_grads(False)      # no zero-filled "gradient of eps" (a fill launch per backward)
+        if through:
+            return out, eps, mean.view(shape), var.view(shape)
         return out, eps
 
     @staticmethod
-    def backward(ctx, g, _g_eps):
-        if g is None:
-            return None, None, None, None, None
-        gm, gv = _propagate_backward(ctx, g)
-        return gm, gv, None, None, None
+    def backward(ctx, g, _g_eps, g_mean_t=None, g_var_t=None):
+        gm, gv = _propagate_backward(ctx, g, g_mean_t, g_var_t)
+        r = lambda t: None if t is None else t.view(ctx.shape)
+        return r(gm), r(gv), None, None, None, None
 
 
 def propagate_rng(mean, var, rng_state, n_out, div=1):
     """f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n] with eps ~ N(0, 1) drawn inside the launch (Philox4x32-10 keyed by
     rng_state = int64 [seed, calls, ticket] on the device; every call advances ``calls``).  Returns (f~, eps)."""
-    return _PropagateRngFn.apply(mean, var, rng_state, int(n_out), int(div))
+    return _PropagateRngFn.apply(mean, var, rng_state, int(n_out), int(div), False)
+
+
+def propagate_rng_through(mean, var, rng_state, n_out, div=1):
+    """``propagate_rng`` + pass-through aliases: returns (f~, eps, mean', var'); score mean' / var' instead of mean / var."""
+    return _PropagateRngFn.apply(mean, var, rng_state, int(n_out), int(div), True)
 
 
 def propagate(mean, var, eps, div=1):
     """f~[n] = mean[n/div] + sqrt(var[n/div]) * eps[n]   (mfdgp_hidden_layer.py:263-274).  ``eps`` may cover only a prefix of
     the rows of (mean, var): the rest is not propagated and gets zero gradient."""
-    return _PropagateFn.apply(mean, var, eps, div)
+    return _PropagateFn.apply(mean, var, eps, div, False)
+
+
+def propagate_through(mean, var, eps, div=1):
+    """``propagate`` + pass-through aliases: returns (f~, mean', var'); score mean' / var' instead of mean / var."""
+    return _PropagateFn.apply(mean, var, eps, div, True)
 
 
 class _ElboDataFn(torch.autograd.Function):
@@ -983,56 +1104,78 @@ def check_info(info):
     return 0
 
 
-def gemm_colstat_rows(Mr, Nc, Kd, tri=0):
+def gemm_colstat_rows(Mr, Nc, Kd, tri=0, tune=None):
     """Partial rows the column-statistics epilogue writes for a product of that shape (two per row block of the tile
-    height in force: mobocmf_gemm_colstat_rows)."""
+    height the tuning gives: mobocmf_gemm_colstat_rows)."""
     rows = ctypes.c_int32()
-    _lib.check(_lib.load().mobocmf_gemm_colstat_rows(tri, Mr, Nc, Kd, ctypes.byref(rows)), "mobocmf_gemm_colstat_rows")
+    snap = tune if tune is not None else current_tuning()
+    _lib.check(_lib.load().mobocmf_gemm_colstat_rows(tri, Mr, Nc, Kd, ctypes.byref(snap), ctypes.byref(rows)),
+               "mobocmf_gemm_colstat_rows")
     return rows.value
 
 
+# ---- host-side defaults of the knobs (process-wide in THIS module; the library itself holds nothing -- see `tuning` above).
 def set_mid_gemm_max(n=1024):
-    """Largest dimension of a plain product that runs on the mid-size (64 x 64 tiles, one launch, no k-slicing) kernel;
-    0 = off (mobocmf_set_mid_gemm_max)."""
-    _lib.check(_lib.load().mobocmf_set_mid_gemm_max(int(n)), "mobocmf_set_mid_gemm_max")
+    """Largest dimension of a plain product that runs on the mid-size (one launch, no k-slicing) kernel; 0 = off."""
+    if not 0 <= int(n) <= 4096:
+        raise _lib.MobocmfError("set_mid_gemm_max: 0..4096")
+    _set_default(mid_gemm_max=n)
 
 
 def set_mid_gemm_waves(n=32):
     """Form of the mid-size product kernel: 32 (32 x 64 tiles, 64-k stages; default), 8 or 4 (64 x 64 tiles on that many
-    wavefronts) (mobocmf_set_mid_gemm_waves)."""
-    _lib.check(_lib.load().mobocmf_set_mid_gemm_waves(int(n)), "mobocmf_set_mid_gemm_waves")
+    wavefronts)."""
+    if int(n) not in (4, 8, 32):
+        raise _lib.MobocmfError("set_mid_gemm_waves: 4 | 8 | 32")
+    _set_default(mid_gemm_waves=n)
 
 
 def set_syrk_workgroups(n=0):
-    """Workgroups a k-sliced weighted syrk may occupy (mobocmf_set_syrk_workgroups); set before any workspace is sized."""
-    _lib.check(_lib.load().mobocmf_set_syrk_workgroups(int(n)), "mobocmf_set_syrk_workgroups")
+    """Workgroups a k-sliced weighted syrk may occupy (0 = by shape).  Sizes follow the tuning a call carries."""
+    if int(n) != 0 and not 16 <= int(n) <= 4096:
+        raise _lib.MobocmfError("set_syrk_workgroups: 0 | 16..4096")
+    _set_default(syrk_workgroups=n)
 
 
 def set_sparse_backward(on=True):
-    """Skip the 128-column blocks of a layer backward whose upstream gradients are all exactly zero (default on;
-    mobocmf_set_sparse_backward).  Off = the dense backward: A/B timing and the parity tests."""
-    _lib.check(_lib.load().mobocmf_set_sparse_backward(1 if on else 0), "mobocmf_set_sparse_backward")
+    """Skip the 128-column blocks of a layer backward whose upstream gradients are all exactly zero (default on).  Off = the
+    dense backward: A/B timing and the parity tests.  Read when the FORWARD of a layer call is issued."""
+    _set_default(sparse_backward=1 if on else 0)
+
+
+_block_act_tls = threading.local()
 
 
 def set_block_activity(act=None):
-    """Tests / tools: int32 CUDA tensor (one word per 128 columns) that the standalone gemm_f64 / syrk_weighted calls apply
-    until it is cleared with None (mobocmf_set_block_activity).  The caller keeps the tensor alive."""
-    ptr = 0
+    """Tests / tools: int32 CUDA tensor (one word per 128 columns) that the standalone gemm_f64_epilogue / syrk_weighted calls
+    of THIS thread pass as their col_activity / k_activity argument until it is cleared with None."""
     if act is not None:
         assert act.dtype == torch.int32 and act.is_cuda and act.is_contiguous()
-        ptr = act.data_ptr()
-    _lib.check(_lib.load().mobocmf_set_block_activity(ctypes.c_void_p(ptr)), "mobocmf_set_block_activity")
+    _block_act_tls.act = act
 
 
 def set_tile_rows(rows=0, pair_mode=0):
-    """Tile height of the M x N' panel products: 0 automatic, 64 or 128; row-block pairing 0 automatic, 1 never, 2 always
-    (mobocmf_set_tile_rows)."""
-    _lib.check(_lib.load().mobocmf_set_tile_rows(int(rows), int(pair_mode)), "mobocmf_set_tile_rows")
+    """Tile height of the M x N' panel products: 0 automatic, 64 or 128; row-block pairing 0 automatic, 1 never, 2 always."""
+    if int(rows) not in (0, 64, 128) or not 0 <= int(pair_mode) <= 2:
+        raise _lib.MobocmfError("set_tile_rows: rows 0 | 64 | 128, pair_mode 0..2")
+    _set_default(tile_rows=rows, pair_mode=pair_mode)
 
 
 def set_potrf_cols(cols=4):
-    """Columns per hand-over of the Cholesky panel kernel: 4 (default) or 1 (mobocmf_set_potrf_cols)."""
-    _lib.check(_lib.load().mobocmf_set_potrf_cols(int(cols)), "mobocmf_set_potrf_cols")
+    """Columns per hand-over of the Cholesky panel kernel: 4 (default) or 1."""
+    if int(cols) not in (1, 4):
+        raise _lib.MobocmfError("set_potrf_cols: 1 | 4")
+    _set_default(potrf_cols=cols)
+
+
+def set_tuning(small_gemm_max=0, small_panel_max=0):
+    """Kernel-selection thresholds (size sweeps); 0 leaves a threshold unchanged."""
+    if int(small_gemm_max) > 512 or int(small_panel_max) > 512:
+        raise _lib.MobocmfError("set_tuning: the small kernels serve dimensions <= 512")
+    if small_gemm_max > 0:
+        _set_default(small_gemm_max=small_gemm_max)
+    if small_panel_max > 0:
+        _set_default(small_panel_max=small_panel_max)
 
 
 def gemm_f64_epilogue(A, B, C, tri, epi, alpha=1.0, stream_out=False, colsq_part=None, coldot_part=None, avec=None,
@@ -1042,8 +1185,9 @@ def gemm_f64_epilogue(A, B, C, tri, epi, alpha=1.0, stream_out=False, colsq_part
     A, B = _prep(A), _prep(B)
     Mr, Kd = A.shape
     Nc = B.shape[1]
+    snap = current_tuning()
     if epi == 1:
-        need = gemm_colstat_rows(Mr, Nc, Kd, tri) * Nc
+        need = gemm_colstat_rows(Mr, Nc, Kd, tri, tune=snap) * Nc
         for part in (colsq_part, coldot_part):
             if part is not None and part.numel() < need:
                 raise _lib.MobocmfError("gemm_f64_epilogue: the partial-statistics buffers need gemm_colstat_rows() = %d rows"
@@ -1051,7 +1195,8 @@ def gemm_f64_epilogue(A, B, C, tri, epi, alpha=1.0, stream_out=False, colsq_part
     _lib.check(lib.mobocmf_gemm_f64_epilogue(tri, epi, Mr, Nc, Kd, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C),
                                              C.stride(0), alpha, int(stream_out), _ptr(colsq_part), _ptr(coldot_part),
                                              _ptr(avec), _ptr(bscale), _ptr(gmu), _ptr(cgv), _ptr(Aaux), _ptr(rowdot_part),
-                                             _stream()), "mobocmf_gemm_f64_epilogue")
+                                             _ptr(getattr(_block_act_tls, "act", None)), ctypes.byref(snap), _stream()),
+               "mobocmf_gemm_f64_epilogue")
     return C
 
 
@@ -1136,7 +1281,8 @@ def exact_gp_factor(K, y):
         st.info = torch.zeros((), dtype=torch.int32, device=K.device)
         scratch = scratch_buffer(cb.value, K.device)
         _lib.check(lib.mobocmf_exact_gp_factor(n, _ptr(K), K.stride(0), _ptr(y), _ptr(st.mll), _ptr(st.info), _ptr(st.state),
-                                               sb.value, _ptr(scratch), scratch.numel(), _stream()), "mobocmf_exact_gp_factor")
+                                               sb.value, _ptr(scratch), scratch.numel(), ctypes.byref(current_tuning()), _stream()),
+                   "mobocmf_exact_gp_factor")
     return st
 
 
@@ -1153,8 +1299,8 @@ def exact_gp_predict(st, Kts, kss):
         scratch = scratch_buffer(cb.value, Kts.device)
         mean, var = _empty(nt, device=Kts.device), _empty(nt, device=Kts.device)
         _lib.check(lib.mobocmf_exact_gp_predict(n, nt, _ptr(Kts), Kts.stride(0), _ptr(kss), _ptr(mean), _ptr(var), _ptr(st.state),
-                                                st.state.numel(), _ptr(scratch), scratch.numel(), _stream()),
-                   "mobocmf_exact_gp_predict")
+                                                st.state.numel(), _ptr(scratch), scratch.numel(), ctypes.byref(current_tuning()),
+                                                _stream()), "mobocmf_exact_gp_predict")
     return mean, var
 
 
@@ -1200,18 +1346,15 @@ def syrk_weighted(A, w, H=None):
     A, w = _prep(A), _prep(w)
     Mr, Kd = A.shape
     nb = _lib._SZ()
-    _lib.check(lib.mobocmf_syrk_workspace_bytes(Mr, Kd, ctypes.byref(nb)), "mobocmf_syrk_workspace_bytes")
+    snap = current_tuning()      # the size query and the launch: the same values
+    _lib.check(lib.mobocmf_syrk_workspace_bytes(Mr, Kd, ctypes.byref(snap), ctypes.byref(nb)), "mobocmf_syrk_workspace_bytes")
     ws = scratch_buffer(nb.value, A.device)
     if H is None:
         H = _empty(Mr, Mr, device=A.device)
-    _lib.check(lib.mobocmf_syrk_weighted_f64(Mr, Kd, _ptr(A), A.stride(0), _ptr(w), _ptr(H), _ptr(ws), nb.value, _stream()),
+    _lib.check(lib.mobocmf_syrk_weighted_f64(Mr, Kd, _ptr(A), A.stride(0), _ptr(w), _ptr(H), _ptr(ws), nb.value,
+                                             _ptr(getattr(_block_act_tls, "act", None)), ctypes.byref(snap), _stream()),
                "mobocmf_syrk_weighted_f64")
     return H
-
-
-def set_tuning(small_gemm_max=0, small_panel_max=0):
-    """Kernel-selection thresholds of the library (size sweeps); 0 leaves a threshold unchanged."""
-    _lib.check(_lib.load().mobocmf_set_tuning(int(small_gemm_max), int(small_panel_max)), "mobocmf_set_tuning")
 
 
 def gemm_f64(A, B, C=None, tri=0, trans_b=False, alpha=1.0, accumulate=False):
@@ -1223,5 +1366,6 @@ def gemm_f64(A, B, C=None, tri=0, trans_b=False, alpha=1.0, accumulate=False):
     if C is None:
         C = _empty(Mr, Nc, device=A.device)
     _lib.check(lib.mobocmf_gemm_f64(tri, int(trans_b), Mr, Nc, Kd, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C),
-                                    C.stride(0), alpha, int(accumulate), _stream()), "mobocmf_gemm_f64")
+                                    C.stride(0), alpha, int(accumulate), ctypes.byref(current_tuning()), _stream()),
+               "mobocmf_gemm_f64")
     return C

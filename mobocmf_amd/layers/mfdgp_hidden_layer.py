@@ -390,12 +390,25 @@ class MFDGPHiddenLayer(nn.Module):
                 e = eps.reshape(-1)
             else:
                 e = None
+            # The previous layer's moments have two consumers: this propagation and the ELBO's data term of that layer's own
+            # fidelity.  With gradients recorded the propagation hands back pass-through aliases of (mean, var) and the
+            # distribution object is re-pointed at them, so whoever scores it afterwards goes THROUGH this node: the two
+            # gradient contributions are then summed inside the propagate-backward launch (autograd would spend two
+            # element-wise launches per layer and step on the sums).
+            through = torch.is_grad_enabled() and (mean_p.requires_grad or var_p.requires_grad) and inp._cov is None
             if e is None:
                 # the reference draws float32 N(0,1) on the CPU RNG; here float64, inside the propagation launch
                 # (counter-based Philox keyed by this layer's seed + call counter: capturable, fresh at every replay)
-                f, _ = F.propagate_rng(mean_p, var_p, self._rng(mean_p.device), n_rows, fdiv)
+                if through:
+                    f, _, mean_t, var_t = F.propagate_rng_through(mean_p, var_p, self._rng(mean_p.device), n_rows, fdiv)
+                else:
+                    f, _ = F.propagate_rng(mean_p, var_p, self._rng(mean_p.device), n_rows, fdiv)
+            elif through:
+                f, mean_t, var_t = F.propagate_through(mean_p, var_p, e, fdiv)
             else:
                 f = F.propagate(mean_p, var_p, e, fdiv)
+            if through:
+                inp.mean, inp._variance = mean_t.view(inp.mean.shape), var_t.view(inp._variance.shape)
         else:
             f = inp.reshape(-1)
             if f.numel() != n_rows:

@@ -46,6 +46,64 @@ def _forrester_model(**kw):
     return MFDGP(to_t(x), to_t(y)[:, None], to_t(fid)[:, None], 2, **kw), (x, y, fid)
 
 
+def test_tuning_travels_with_the_call_and_the_library_keeps_no_knobs():
+    """no global mutable state.  Every knob is a field of mobocmf_tuning, passed per call (descriptor pointer /
+    argument); the size queries follow the record they are given; a malformed record is refused; no mobocmf_set_* entry
+    point exists any more."""
+    import ctypes
+    import subprocess
+    from mobocmf_amd import _lib
+    from mobocmf_amd import functional as F
+    lib = _lib.load()
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "mobocmf_set_" not in exported
+    t = _lib.Tuning()
+    assert lib.mobocmf_tuning_init(ctypes.byref(t)) == _lib.OK and lib.mobocmf_tuning_init(None) == _lib.BAD_ARG
+    assert t.struct_size == ctypes.sizeof(_lib.Tuning)
+    assert [getattr(t, k) for k in _lib.Tuning.KNOBS] == [384, 512, 0, 0, 1024, 32, 0, 1, 4]
+    nb_def, nb_64, nb_4096 = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.mobocmf_syrk_workspace_bytes(512, 65536, None, ctypes.byref(nb_def)) == _lib.OK
+    t64, t4096 = t.copy(), t.copy()
+    t64.syrk_workgroups, t4096.syrk_workgroups = 64, 4096
+    assert lib.mobocmf_syrk_workspace_bytes(512, 65536, ctypes.byref(t64), ctypes.byref(nb_64)) == _lib.OK
+    assert lib.mobocmf_syrk_workspace_bytes(512, 65536, ctypes.byref(t4096), ctypes.byref(nb_4096)) == _lib.OK
+    assert nb_64.value < nb_def.value < nb_4096.value          # fewer workgroups = fewer slabs
+    # the layer workspaces follow the descriptor's record, and two descriptors do not influence each other
+    with F.tuning(syrk_workgroups=64):
+        d_small = F.make_desc(1, 8, 512, 65536, xdiv=8)
+    d_def = F.make_desc(1, 8, 512, 65536, xdiv=8)
+    assert F.workspace_bytes(d_small)[1] < F.workspace_bytes(d_def)[1]
+    assert F.workspace_bytes(d_def) == F.workspace_bytes(F.make_desc(1, 8, 512, 65536, xdiv=8))
+    rows = ctypes.c_int32()
+    for tr, want in ((64, 16), (128, 8)):
+        tt = t.copy()
+        tt.tile_rows = tr
+        assert lib.mobocmf_gemm_colstat_rows(1, 512, 65536, 512, ctypes.byref(tt), ctypes.byref(rows)) == _lib.OK
+        assert rows.value == want
+    # malformed records
+    for field, bad in (("struct_size", 8), ("tile_rows", 96), ("pair_mode", 3), ("mid_gemm_waves", 16), ("syrk_workgroups", 5),
+                       ("potrf_cols", 3), ("small_gemm_max", 513), ("sparse_backward", 2)):
+        tb = t.copy()
+        setattr(tb, field, bad)
+        assert lib.mobocmf_syrk_workspace_bytes(512, 65536, ctypes.byref(tb), ctypes.byref(nb_def)) == _lib.BAD_ARG, field
+        d_bad = F.make_desc(0, 2, 8, 12, tune=tb)
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        assert lib.mobocmf_layer_workspace_bytes(ctypes.byref(d_bad), ctypes.byref(a), ctypes.byref(b)) == _lib.BAD_ARG, field
+    # the host-side default record is this module's, per-thread overrides do not leak
+    import threading
+    seen = {}
+
+    def worker():
+        with F.tuning(tile_rows=64):
+            seen["inner"] = F.current_tuning().tile_rows
+    with F.tuning(tile_rows=128):
+        th = threading.Thread(target=worker)
+        th.start()
+        th.join()
+        seen["outer"] = F.current_tuning().tile_rows
+    assert seen == {"inner": 64, "outer": 128} and F.current_tuning().tile_rows == 0
+
+
 def test_model_surface_and_init_heuristics_match_reference_rules():
     model, (x, y, fid) = _forrester_model()
     model.double()

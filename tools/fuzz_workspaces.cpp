@@ -42,6 +42,30 @@ int main(int argc, char** argv) {
         d.min_var = 1e-10;
         d.phase = (int32_t)U(0, 4);
         bool ok = d.d <= MOBOCMF_MAX_D && d.xdiv <= MOBOCMF_MAX_XDIV;
+        // the tuning travels in the descriptor: NULL (defaults) or a record with random valid knobs -- the sizes reported and the
+        // regions carved below are both derived from it; now and then a record that must be refused
+        mobocmf_tuning tn;
+        mobocmf_tuning_init(&tn);
+        if (U(0, 2) != 0) {
+            const int32_t wg[] = {0, 16, 64, 256, 512, 4096}, tr[] = {0, 64, 128}, mw[] = {4, 8, 32};
+            tn.syrk_workgroups = wg[U(0, 5)];
+            tn.tile_rows = tr[U(0, 2)];
+            tn.pair_mode = (int32_t)U(0, 2);
+            tn.mid_gemm_waves = mw[U(0, 2)];
+            tn.mid_gemm_max = (int32_t)U(0, 4096);
+            tn.small_gemm_max = (int32_t)U(1, 512);
+            tn.small_panel_max = (int32_t)U(1, 512);
+            tn.sparse_backward = (int32_t)U(0, 1);
+            tn.potrf_cols = U(0, 1) ? 4 : 1;
+            d.tuning = &tn;
+            switch (U(0, 15)) {
+                case 0: tn.struct_size = 12; ok = false; break;
+                case 1: tn.tile_rows = 96; ok = false; break;
+                case 2: tn.syrk_workgroups = 8; ok = false; break;
+                case 3: tn.potrf_cols = 2; ok = false; break;
+                default: break;
+            }
+        }
         switch (U(0, 11)) {      // corrupt one field now and then
             case 0: d.kind = 2; ok = false; break;
             case 1: d.Np += 1; if (d.Np % d.xdiv) ok = false; break;
@@ -66,9 +90,9 @@ int main(int argc, char** argv) {
             const int32_t Mr = (int32_t)((d.M + 127) / 128 * 128);
             const int64_t Kd = (d.Np + 127) / 128 * 128;
             size_t sy = 0;
-            REQUIRE(mobocmf_syrk_workspace_bytes(Mr, Kd, &sy) == MOBOCMF_OK && sy >= (size_t)Mr * Mr * 8);
-            REQUIRE(mobocmf_syrk_workspace_bytes(Mr + 1, Kd, &sy) == MOBOCMF_BAD_ARG);
-            REQUIRE(mobocmf_syrk_workspace_bytes(Mr, Kd, nullptr) == MOBOCMF_BAD_ARG);
+            REQUIRE(mobocmf_syrk_workspace_bytes(Mr, Kd, d.tuning, &sy) == MOBOCMF_OK && sy >= (size_t)Mr * Mr * 8);
+            REQUIRE(mobocmf_syrk_workspace_bytes(Mr + 1, Kd, d.tuning, &sy) == MOBOCMF_BAD_ARG);
+            REQUIRE(mobocmf_syrk_workspace_bytes(Mr, Kd, d.tuning, nullptr) == MOBOCMF_BAD_ARG);
         }
         if (sv + sc + bb + ps + pc + cv > budget) { ++skipped_big; continue; }
         // uninitialised heap blocks of exactly the reported sizes (ASan red zones on both sides)
