@@ -162,7 +162,11 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
  * entries (device pointers inside).  The PANEL backward OVERWRITES g_hyp / g_zf with the K_mn share, the chain backward
  * OVERWRITES its own g_hyp / g_zf arguments with the K_mm share (the caller adds the two).  had_panel[l] = 0: layer l got no
  * upstream mean / var gradient (only its KL was differentiated); 1: its PANEL backward ran; 2: it ran AND the g_hyp[l] / g_zf[l]
- * passed to the chain backward already hold its share -- the chain backward adds to them instead of overwriting. */
+ * passed to the chain backward already hold its share -- the chain backward adds to them instead of overwriting.
+ * had_panel[l] |= 4 (l >= 1, kind 1): zf[l] IS the variational mean m[l-1] of the previous layer of this call (the reference's
+ * Z~_l = [Z_x, m_{l-1}], mfdgp_hidden_layer.py:555-556): the complete gradient of zf[l] -- this call's K_mm share plus, under
+ * 2, the PANEL share found in g_zf[l] -- is ADDED to g_m[l-1] and g_zf[l] is not written; the caller hands g_m[l-1] to m[l-1]
+ * and nothing to zf[l]. */
 int mobocmf_chain_block_bytes(const mobocmf_layer_desc* desc, size_t* block_bytes, size_t* state_bytes);
 int mobocmf_panel_workspace_bytes(const mobocmf_layer_desc* desc, size_t* saved_bytes, size_t* scratch_bytes);
 int mobocmf_layers_chain_forward(int32_t n, const mobocmf_layer_desc* const* desc, const double* const* Zx,

@@ -528,8 +528,11 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
 // CHAIN half, backward, of n layers:  dL = -tril(L^-T [dA A^T + dU_tot U^T + da_tot a^T]) + gkl diag(1/L_ii), g_m, g_LS,
 // Cholesky backward, Gram backward of K_mm.  H, Hc, da come from the PANEL halves (zero[z]: layer z had none -- no
 // upstream mean / var gradient).  acc[z]: add to g_hyp / g_zf (the PANEL half wrote its share there) instead of overwriting.
+// fold[z]: zf of layer z IS the variational mean of layer z - 1 of this batch (Z~_z = [Z_x, m_{z-1}], mfdgp_hidden_layer.py:
+// 555-556): its whole gradient -- the K_mm share formed here plus the PANEL half's share waiting in g_zf[z] if acc[z] -- is
+// added to g_m[z - 1] in the last launch, and g_zf[z] is not written (autograd would add the two tensors in a launch of its own).
 int chain_backward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const Dims& D, const bool* zero, const int* acc,
-                   hipStream_t s) {
+                   const bool* fold, hipStream_t s) {
     const int Mp = D.Mp;
     const int64_t mm = (int64_t)Mp * Mp;
     double *G1 = c.W[0], *G2 = c.W[1], *X = c.W[2], *dU = c.W[3], *Y = c.W[4], *T1 = c.W[5], *T2 = c.W[6], *LT = c.W[7];
@@ -611,8 +614,13 @@ int chain_backward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const
         TRY(launch_gram_bwd(g, false, s));
         const int H = hyp_len(d->kind, d->d);
         tk[nt++] = {g.hyp_part, (int64_t)D.ggrid_mm.x * D.ggrid_mm.y, H, nullptr, 0, 0, io.g_hyp[z], H, acc[z]};
-        if (d->kind == 1)      // both arguments of K_mm are Z~: the row-side and the column-side partials land in g_zf
-            tk[nt++] = {g.df_part, D.ggrid_mm.y, Mp, g.dzf_part, D.ggrid_mm.x, Mp, io.g_zf[z], D.M, acc[z]};
+        if (d->kind == 1) {    // both arguments of K_mm are Z~: the row-side and the column-side partials land in g_zf
+            if (fold[z])       // ... or, with the PANEL half's share, on top of g_m[z - 1] (written by chain_outputs above)
+                tk[nt++] = {g.df_part, D.ggrid_mm.y, Mp, g.dzf_part, D.ggrid_mm.x, Mp, io.g_m[z - 1], D.M, 1,
+                            acc[z] ? io.g_zf[z] : nullptr};
+            else
+                tk[nt++] = {g.df_part, D.ggrid_mm.y, Mp, g.dzf_part, D.ggrid_mm.x, Mp, io.g_zf[z], D.M, acc[z], nullptr};
+        }
     }
     return launch_sum_partials_multi(tk, nt, s);
 }
@@ -750,7 +758,8 @@ int mobocmf_layer_backward(const mobocmf_layer_desc* desc, const double* x, cons
     io.g_kl = &g_kl; io.g_zf = &g_zf; io.g_hyp = &g_hyp; io.g_m = &g_m; io.g_LS = &g_LS;
     const bool zero = desc->phase == MOBOCMF_PHASE_CHAIN_ONLY;     // no upstream mean/var gradient: H = Hc = 0, da = 0
     const int acc = desc->phase == MOBOCMF_PHASE_ALL ? 1 : 0;       // split: the chain half reports its own g_hyp / g_zf
-    return chain_backward(1, c, 0, io, D, &zero, &acc, s);
+    const bool fold = false;
+    return chain_backward(1, c, 0, io, D, &zero, &acc, &fold, s);
 }
 
 // ------------------------------------------------------------------------------------------------- multi-layer forms
@@ -813,13 +822,17 @@ int mobocmf_layers_chain_backward(int32_t n, const mobocmf_layer_desc* const* de
     if (!same_chain_shape(n, desc)) return MOBOCMF_BAD_ARG;
     TuneScope tune_scope(desc[0]->tuning);      // one z-batched sequence of launches: the first layer's tuning serves all
     if (blocks_bytes / (size_t)n < block_stride) return MOBOCMF_WORKSPACE_TOO_SMALL;
-    bool zero[MAX_ZL];
+    bool zero[MAX_ZL], fold[MAX_ZL];
     int acc[MAX_ZL];
     for (int z = 0; z < n; ++z) {
         if (!Zx[z] || !hyp[z] || !g_kl[z] || !g_hyp[z] || !g_m[z] || !g_LS[z] || (desc[z]->kind == 1 && (!zf[z] || !g_zf[z])))
             return MOBOCMF_BAD_ARG;
-        zero[z] = had_panel[z] == 0;
-        acc[z] = had_panel[z] == 2 ? 1 : 0;      // 2: g_hyp / g_zf hold the PANEL half's share already -- add to it
+        const int hp = had_panel[z] & 3;
+        if (hp == 3 || (had_panel[z] & ~7)) return MOBOCMF_BAD_ARG;
+        zero[z] = hp == 0;
+        acc[z] = hp == 2 ? 1 : 0;      // 2: g_hyp / g_zf hold the PANEL half's share already -- add to it
+        fold[z] = (had_panel[z] & 4) != 0;
+        if (fold[z] && (z == 0 || desc[z]->kind != 1)) return MOBOCMF_BAD_ARG;
     }
     Dims D = dims_of(desc[0]);
     ChainWs c = {};
@@ -827,7 +840,7 @@ int mobocmf_layers_chain_backward(int32_t n, const mobocmf_layer_desc* const* de
     ChainIO io = {};
     io.desc = desc; io.Zx = Zx; io.zf = zf; io.hyp = hyp;
     io.g_kl = g_kl; io.g_zf = g_zf; io.g_hyp = g_hyp; io.g_m = g_m; io.g_LS = g_LS;
-    return chain_backward(n, c, (int64_t)(block_stride / sizeof(double)), io, D, zero, acc, (hipStream_t)stream);
+    return chain_backward(n, c, (int64_t)(block_stride / sizeof(double)), io, D, zero, acc, fold, (hipStream_t)stream);
 }
 
 int mobocmf_layer_panel_forward(const mobocmf_layer_desc* desc, const double* x, const double* f, const double* Zx,

@@ -110,6 +110,7 @@ struct SumTask {
     const double* part; int64_t P, stride;
     const double* part2; int64_t P2, stride2;      // optional second source (part2 == nullptr: none)
     double* out; int64_t len; int accumulate;
+    const double* extra;                           // optional single row added to the result (nullptr: none)
 };
 int launch_sum_partials_multi(const SumTask* tasks, int n, hipStream_t s);
 int gemm_nt_slabs(const GemmArgs& g, int splitk);   // k-slices (slabs) an A B^T launch will really write

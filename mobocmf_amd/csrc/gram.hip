@@ -446,6 +446,7 @@ __global__ void sum_partials_multi_kernel(SumTasksArg T) {
         __syncthreads();
         if (threadIdx.x == 0) {
             v = sh[0] + sh[1] + sh[2] + sh[3];
+            if (t.extra) v += t.extra[j];
             t.out[j] = t.accumulate ? t.out[j] + v : v;
         }
         return;
@@ -466,6 +467,7 @@ __global__ void sum_partials_multi_kernel(SumTasksArg T) {
         __syncthreads();
         if (q == 0 && j < t.len) {
             v = (sq[0][jj] + sq[1][jj]) + (sq[2][jj] + sq[3][jj]);
+            if (t.extra) v += t.extra[j];
             t.out[j] = t.accumulate ? t.out[j] + v : v;
         }
         return;
@@ -476,6 +478,7 @@ __global__ void sum_partials_multi_kernel(SumTasksArg T) {
     for (int64_t p = 0; p < t.P; ++p) v += t.part[p * t.stride + j];
     if (t.part2)
         for (int64_t p = 0; p < t.P2; ++p) v += t.part2[p * t.stride2 + j];
+    if (t.extra) v += t.extra[j];
     t.out[j] = t.accumulate ? t.out[j] + v : v;
 }
 

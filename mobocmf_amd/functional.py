@@ -498,6 +498,13 @@ class _ChainsFn(torch.autograd.Function):
         _lib.check(rc, "mobocmf_layers_chain_forward")
         ctx.CB = CB
         ctx.descs = descs
+        # zf of layer z is the variational mean of layer z - 1 (the model's Z~_z = [Z_x, m_{z-1}]): its gradient is folded into
+        # g_m[z - 1] inside the chain backward (had_panel |= 4) instead of by an autograd add of two M-vectors
+        same = lambda a, b: a is not None and b is not None and (a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape
+                                                                            and a.stride() == b.stride()))
+        ctx.fold = [z > 0 and CB.kinds[z] == 1 and same(flat[5 * z + 1], flat[5 * (z - 1) + 3]) and
+                    bool(ctx.needs_input_grad[1 + 5 * z + 1]) and bool(ctx.needs_input_grad[1 + 5 * (z - 1) + 3])
+                    for z in range(n)]
         ctx.has = [[t is not None for t in per[z]] for z in range(n)]
         ctx.save_for_backward(*[t for z in range(n) for t in per[z] if t is not None])
         return (token,) + tuple(CB.kls)
@@ -527,6 +534,9 @@ class _ChainsFn(torch.autograd.Function):
                 g_zf.append(new(CB.M) if per[z][1] is not None else None)
         g_m = [new(CB.M) for _ in range(n)]
         g_LS = [new(CB.M, CB.M) for _ in range(n)]
+        for z in range(n):
+            if ctx.fold[z]:
+                had[z] |= 4
         T = lambda ts: _table([0 if t is None else t.data_ptr() for t in ts])
         rc = lib.mobocmf_layers_chain_backward(n, _desc_table(ctx.descs), T([p[0] for p in per]), T([p[1] for p in per]),
                                                T([p[2] for p in per]), T(gk), (ctypes.c_int32 * n)(*had),
@@ -535,7 +545,7 @@ class _ChainsFn(torch.autograd.Function):
         _lib.check(rc, "mobocmf_layers_chain_backward")
         out = [None]
         for z in range(n):
-            out += [None, g_zf[z], g_hyp[z], g_m[z], g_LS[z]]
+            out += [None, None if ctx.fold[z] else g_zf[z], g_hyp[z], g_m[z], g_LS[z]]
         return tuple(out)
 
 

@@ -88,6 +88,11 @@ class MFDGUnwhitenedVariationalStrategy(UnwhitenedVariationalStrategy):
         if self.previous_layer is None:
             return self._inducing_points
         Z = self._inducing_points
+        if Z.requires_grad:
+            # a TRAINABLE inducing matrix may be written through its raw pointer (the fused Adam kernel, any other C-ABI
+            # caller): such writes do not bump the version counter, so a cached copy could go stale unnoticed -- and a step
+            # captured on a cache hit would replay on it for ever.  No cache then: one copy launch per access.
+            return Z.detach()[:, :-1].contiguous()
         tag = (Z.data_ptr(), Z._version, Z.device)
         c = self.__dict__.get("_Zx_contig")
         if c is None or c[0] != tag:

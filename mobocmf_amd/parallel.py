@@ -223,29 +223,53 @@ def coupled_acquisition(local_acq):
 _gather_plans = {}
 
 
+def reset_gather_plans():
+    """Forget the negotiated row layouts (call on every rank when the sharding of the black-boxes changes inside one process
+    group; a new process group gets a new plan by itself)."""
+    _gather_plans.clear()
+
+
+def _group_key():
+    """Identity of the default process group: a plan never outlives the group it was negotiated in (tests destroy and
+    re-create groups inside one process; ``group_count`` grows with every init_process_group)."""
+    import torch.distributed as dist
+    c10d = dist.distributed_c10d
+    return (id(c10d._get_default_group()), getattr(c10d._world, "group_count", 0), dist.get_backend())
+
+
+def _layout_hash(k_obj, k_con, oi, ci):
+    h = 1469598103934665603
+    for v in (k_obj, k_con, -1 if oi is None else len(oi)) + (oi or ()) + (-2 if ci is None else len(ci),) + (ci or ()):
+        h = ((h ^ (int(v) & 0xFFFFFFFF)) * 1099511628211) & 0x7FFFFFFFFFFFFFF
+    return h
+
+
 def _gather_plan(k_obj, k_con, obj_index, con_index, device):
-    """Row bookkeeping of ``gather_with_local_grad``, negotiated ONCE per (world, local shard layout) and cached: per-rank
-    row counts, the padded row count of the per-step all-gather, and the permutations into global black-box order.  The
-    global indices are static for a whole training run, so their exchange and validation (a host sync) happen here, not at
-    every step.  Every rank enters the same two collectives whatever it holds; disagreements (some ranks pass indices,
-    others do not; indices that are no permutation) raise the same error on every rank instead of dead-locking.
-    Contract: the negotiation is collective, so all ranks must meet a NEW layout in the same call (they do: the layout is
-    fixed by the sharding of the black-boxes for a whole run)."""
+    """Row bookkeeping of ``gather_with_local_grad``, negotiated ONCE per process group and cached: per-rank row counts, the
+    padded row count of the per-step all-gather, the permutations into global black-box order, and every rank's layout hash.
+    The global indices are static for a whole training run, so their exchange and validation (a host sync) happen here, not
+    at every step.  Every rank enters the same two collectives whatever it holds -- a rank whose own arguments are malformed
+    says so INSIDE the first collective -- so disagreements (one index per row violated somewhere; some ranks pass indices,
+    others do not; indices that are no permutation) raise the same error on every rank instead of dead-locking the others.
+    The cache is keyed on the process group, not on the local layout: a layout that changes later inside the same group is
+    caught by the per-step check of ``gather_with_local_grad`` (on every rank, after the collective)."""
     import torch.distributed as dist
     r, w = world()
     oi = None if obj_index is None else tuple(int(i) for i in obj_index)
     ci = None if con_index is None else tuple(int(i) for i in con_index)
-    key = (r, w, k_obj, k_con, oi, ci, dist.get_backend())
+    key = _group_key()
     plan = _gather_plans.get(key)
     if plan is not None:
         return plan
-    if (oi is not None and len(oi) != k_obj) or (ci is not None and len(ci) != k_con):
-        raise ValueError("gather_with_local_grad: one global index per local row")
+    bad_local = int((oi is not None and len(oi) != k_obj) or (ci is not None and len(ci) != k_con))
     cdev = torch.device("cpu") if (device.type == "cuda" and dist.get_backend() == "gloo") else device
-    meta = torch.empty(w, 4, dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(meta, torch.tensor([[k_obj, k_con, int(oi is not None), int(ci is not None)]], dtype=torch.int64,
-                                                   device=cdev))
+    meta = torch.empty(w, 6, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(meta, torch.tensor([[k_obj, k_con, int(oi is not None), int(ci is not None), bad_local,
+                                                     _layout_hash(k_obj, k_con, oi, ci)]], dtype=torch.int64, device=cdev))
     meta = meta.cpu()
+    if int(meta[:, 4].sum()) > 0:
+        raise ValueError("gather_with_local_grad: one global index per local row (violated on rank(s) %s)" %
+                         [q for q in range(w) if int(meta[q, 4])])
     ko, kc = meta[:, 0].tolist(), meta[:, 1].tolist()
     has_o = {int(meta[q, 2]) for q in range(w) if ko[q] > 0}
     has_c = {int(meta[q, 3]) for q in range(w) if kc[q] > 0}
@@ -273,7 +297,8 @@ def _gather_plan(k_obj, k_con, obj_index, con_index, device):
             order_o = torch.argsort(torch.tensor(go, dtype=torch.int64)).to(device)
         if use_c:
             order_c = torch.argsort(torch.tensor(gc, dtype=torch.int64)).to(device)
-    plan = {"ko": ko, "kc": kc, "kmax": kmax, "order_o": order_o, "order_c": order_c, "cdev": cdev}
+    plan = {"ko": ko, "kc": kc, "kmax": kmax, "order_o": order_o, "order_c": order_c, "cdev": cdev,
+            "hashes": [int(h) for h in meta[:, 5].tolist()]}
     _gather_plans[key] = plan
     return plan
 
@@ -282,7 +307,9 @@ def gather_with_local_grad(fm, fv, cm, cv, obj_index=None, con_index=None):
     """omega-factor coupling of the conditioned training (blackbox_mfdgp_fitter.py:317-341) when the surrogates are
     sharded over ranks: every rank needs ALL models' (mean, var) at the 10 x~ points; its own rows keep their autograd
     history, the other ranks' rows arrive as constants.  ONE padded all-gather per call carries objectives and constraints
-    together (the row layout is negotiated once and cached, ``_gather_plan``).  Ranks may hold different numbers of
+    together (the row layout is negotiated once per process group and cached, ``_gather_plan``) plus one header row per rank
+    with that rank's CURRENT layout hash: a layout that differs from the negotiated one -- on this rank or on a peer -- raises
+    on every rank after the collective, instead of slicing stale rows or hanging.  Ranks may hold different numbers of
     objectives / constraints, none included.  ``obj_index`` / ``con_index``: the GLOBAL position of each local row (the
     column of the Pareto front / the entry of the threshold vector it belongs to); the result is ordered by it.  Without
     them the rows come back in rank order.  World size 1: identity."""
@@ -294,17 +321,29 @@ def gather_with_local_grad(fm, fv, cm, cv, obj_index=None, con_index=None):
     plan = _gather_plan(k_obj, k_con, obj_index, con_index, fm.device)
     T = fm.shape[1] if k_obj else cm.shape[1]
     dev, cdev, kmax = fm.device, plan["cdev"], plan["kmax"]
+    oi = None if obj_index is None else tuple(int(i) for i in obj_index)
+    ci = None if con_index is None else tuple(int(i) for i in con_index)
+    local = torch.cat([torch.stack([fm, fv], 1), torch.stack([cm, cv], 1)], 0)        # (k_obj + k_con, 2, T), with gradient
+    # row 0 = header (the layout hash, split into two exactly representable halves), rows 1.. = the moments, zero padded
+    pad = torch.zeros(kmax + 1, 2, T, dtype=local.dtype, device=cdev)
+    h = _layout_hash(k_obj, k_con, oi, ci)
+    pad[0, 0, 0], pad[0, 1, 0] = float(h >> 30), float(h & ((1 << 30) - 1))
+    nfit = min(local.shape[0], kmax)
+    if nfit:
+        pad[1:1 + nfit] = local.detach()[:nfit].to(cdev)
+    out = torch.empty(w * (kmax + 1), 2, T, dtype=local.dtype, device=cdev)
+    dist.all_gather_into_tensor(out, pad)
+    out = out.to(dev).reshape(w, kmax + 1, 2, T)
+    got = [(int(out[q, 0, 0, 0]) << 30) | int(out[q, 0, 1, 0]) for q in range(w)]
+    if got != plan["hashes"]:
+        raise ValueError("gather_with_local_grad: the row layout of rank(s) %s differs from the one negotiated for this "
+                         "process group; call parallel.reset_gather_plans() on every rank before changing the sharding" %
+                         [q for q in range(w) if got[q] != plan["hashes"][q]])
     if kmax == 0:
         return fm, fv, cm, cv
-    local = torch.cat([torch.stack([fm, fv], 1), torch.stack([cm, cv], 1)], 0)        # (k_obj + k_con, 2, T), with gradient
-    pad = torch.zeros(kmax, 2, T, dtype=local.dtype, device=cdev)
-    pad[:local.shape[0]] = local.detach().to(cdev)
-    out = torch.empty(w * kmax, 2, T, dtype=local.dtype, device=cdev)
-    dist.all_gather_into_tensor(out, pad)
-    out = out.to(dev)
     objs, cons = [], []
     for q in range(w):
-        rows = local if q == r else out[q * kmax:(q + 1) * kmax]                       # own rows: with gradient
+        rows = local if q == r else out[q, 1:]                                         # own rows: with gradient
         objs.append(rows[:plan["ko"][q]])
         cons.append(rows[plan["ko"][q]:plan["ko"][q] + plan["kc"][q]])
     allo, allc = torch.cat(objs, 0), torch.cat(cons, 0)
@@ -393,6 +432,8 @@ class RowShardedELBOStep(_graphed_base()):
         self.bucket = GradBucket(model.parameters(), extra=2)
         super().__init__(model, elbo, x[idx].contiguous(), y[idx].contiguous(), fidelities[idx].contiguous(), lr,
                          fixed_eps=fixed_eps, **kw)
+        if self.row_order is not None:      # the base class re-ordered the shard by fidelity: self.x == x[self.rows] again
+            self.rows = idx[self.row_order]
 
     def _fwd_bwd(self):
         self.bucket.zero_()

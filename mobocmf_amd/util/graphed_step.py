@@ -13,7 +13,9 @@ import torch
 
 
 class GraphedELBOStep:
-    """step() == one full-batch ELBO step on static (x, y, fidelities).  Falls back to eager with ``use_graph=False``."""
+    """step() == one full-batch ELBO step on static (x, y, fidelities).  Falls back to eager with ``use_graph=False``.
+    With ``prune_rows`` the rows are reordered once by descending fidelity: ``self.x`` etc. are ``x[self.row_order]``
+    (``row_order`` is None when the caller's order was kept); per-row quantities map back through it."""
 
     exchanges = False      # True in subclasses whose step has a collective between backward and update
 
@@ -28,6 +30,10 @@ class GraphedELBOStep:
         # blackbox_mfdgp_fitter.py:35) and evaluate layer l on the prefix of rows with fidelity >= l (MFDGP.forward(rows=)).
         # Same ELBO and gradients as evaluating every layer at every row; the upper layers' panels shrink to their share.
         self.layer_rows = None
+        self.row_order = None      # permutation applied to the caller's rows (None: kept): step.x == x[row_order]
+        from ..functional import ELBO_MAX_LAYERS
+        if prune_rows and self.L > ELBO_MAX_LAYERS:
+            prune_rows = False     # pruned layer outputs need the fused ELBO (<= ELBO_MAX_LAYERS fidelities): reference layout
         if prune_rows and self.L > 1:
             fidv = fidelities.reshape(-1)
             counts = [int((fidv >= l).sum()) for l in range(self.L)]
@@ -39,6 +45,7 @@ class GraphedELBOStep:
                     fixed_eps = [None if e is None else e.reshape(N, self.S)[order][:counts[l]].reshape(-1).contiguous()
                                  for l, e in enumerate(fixed_eps)]
                 self.layer_rows = counts
+                self.row_order = order
         self.x, self.y, self.fid = x, y, fidelities
         self.use_graph = use_graph
         self.stream = stream if stream is not None else torch.cuda.Stream(device=x.device)

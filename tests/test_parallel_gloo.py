@@ -81,22 +81,43 @@ def _ragged_worker(rank, world, port, q):
     acq = parallel.coupled_acquisition(torch.full((len(obj_idx) + len(con_idx), T), 1.0, dtype=torch.float64))
     x = torch.full((2,), float(rank + 5))
     parallel.broadcast_(x)
+    # a layout that changes INSIDE the process group without a reset (here: on rank 0 only): every rank still enters the one
+    # per-step collective, and every rank gets the same error afterwards -- no stale slicing, nobody left waiting
+    stale = None
+    try:
+        parallel.gather_with_local_grad(fm[:1] if rank == 0 else fm, fm[:1] if rank == 0 else fm, cm, cm,
+                                        obj_idx[:1] if rank == 0 else obj_idx, con_idx)
+    except ValueError as err:
+        stale = "differs from the one negotiated" in str(err) and "[0]" in str(err)
+    # errors of the negotiation itself (after reset_gather_plans() on every rank, the documented way to change a layout):
     bad = None
+    parallel.reset_gather_plans()
     try:
         parallel.gather_with_local_grad(fm, fm, cm, cm, [0] * len(obj_idx), con_idx)   # not a permutation
     except ValueError as err:
         bad = str(err)
     # one rank passes indices, the other does not: the SAME error on both ranks, no rank left waiting in a collective
     mismatch = None
+    parallel.reset_gather_plans()
     try:
-        # (a layout neither rank has negotiated before: the row layout is negotiated collectively on first use and cached)
         parallel.gather_with_local_grad(fm[:1], fm[:1], cm[:0], cm[:0], [0] if rank == 0 else None, [])
     except ValueError as err:
         mismatch = "either every rank" in str(err)
+    # ONE rank passes a malformed index list (two indices for one row): it says so inside the first collective, and BOTH ranks
+    # raise (round 3: the bad rank raised before the collective and the other one waited in it for ever)
+    badlen = None
+    parallel.reset_gather_plans()
+    try:
+        parallel.gather_with_local_grad(fm[:1], fm[:1], cm[:0], cm[:0], [0, 1] if rank == 1 else [0], [])
+    except ValueError as err:
+        badlen = "one global index per local row" in str(err) and "[1]" in str(err)
     # the negotiated layout is cached: a second step costs one collective and gives the same rows
+    parallel.reset_gather_plans()
+    cfm, _, _, _ = parallel.gather_with_local_grad(fm, fm * 2, cm, cm * 3, obj_idx, con_idx)
     n_plans = len(parallel._gather_plans)
     bfm, _, _, _ = parallel.gather_with_local_grad(fm, fm * 2, cm, cm * 3, obj_idx, con_idx)
-    cached = len(parallel._gather_plans) == n_plans and torch.equal(bfm.detach(), afm.detach())
+    cached = len(parallel._gather_plans) == n_plans == 1 and torch.equal(bfm.detach(), afm.detach()) and \
+        torch.equal(cfm.detach(), afm.detach()) and bool(stale) and bool(badlen)
     q.put((rank, afm[:, 0].tolist(), afv[:, 0].tolist(), acm[:, 0].tolist(), acv[:, 0].tolist(), fm.grad[:, 0].tolist(),
            None if cm.grad is None else cm.grad.reshape(-1).tolist(), [tuple(p.shape) for p in parts], acq.tolist(),
            x.tolist(), bad is not None and bool(mismatch) and cached))
