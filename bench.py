@@ -417,7 +417,7 @@ def main():
     ap.add_argument("--potrf-cols", type=int, default=0, help="A/B knob: columns per hand-over of the Cholesky panel kernel (4 | 1)")
     ap.add_argument("--dense-backward", action="store_true",
                     help="A/B knob: do not skip the column blocks of a layer backward whose upstream gradients are all zero")
-    ap.add_argument("--small-gemm-max", type=int, default=0, help="A/B knob: largest M x M product the small-operand kernel takes (mobocmf_set_tuning)")
+    ap.add_argument("--small-gemm-max", type=int, default=0, help="A/B knob: largest M x M product the small-operand kernel takes (mobocmf_tuning.small_gemm_max)")
     ap.add_argument("--mid-gemm-max", type=int, default=-1, help="A/B knob: largest M x M product on the mid-size kernel (0 = off)")
     ap.add_argument("--mid-gemm-waves", type=int, default=0, help="A/B knob: wavefronts per workgroup of the mid-size kernel (8 | 4)")
     ap.add_argument("--top-fraction", type=float, default=0.25,

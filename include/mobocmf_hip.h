@@ -333,6 +333,10 @@ int mobocmf_softplus_pack(int32_t n_tensors, const double* const* raw, const int
                           mobocmf_stream_t stream);
 int mobocmf_softplus_pack_backward(int32_t n_tensors, const double* const* raw, const int32_t* sizes, const double* g_out,
                                    double* const* g_raw, mobocmf_stream_t stream);
+/* The same with one upstream-gradient pointer PER TENSOR (g_out[i]: sizes[i] doubles, NULL = zero): for a caller that packs
+ * the hyper-parameters of several layers in one launch and hands the segments out as separate tensors. */
+int mobocmf_softplus_pack_backward_v(int32_t n_tensors, const double* const* raw, const int32_t* sizes,
+                                     const double* const* g_out, double* const* g_raw, mobocmf_stream_t stream);
 
 /* ---- Exact-GP comparison baselines (mobocmf/models/mfgp.py:24-141,145-184; mfgp_lin.py:101-189) on the layer's kernels.
  * The reference inherits exact inference from GPyTorch's ExactGP; here the Gram matrices come from mobocmf_gram_forward,

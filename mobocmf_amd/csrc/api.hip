@@ -59,6 +59,10 @@ int launch_transpose_z(const double* in, int64_t ldi, double* out, int64_t ldo, 
                        int64_t zs, hipStream_t s);
 int launch_gemv_rows_z(const double* Mat, int64_t ld, const double* vec, double* out, int rows, int64_t cols, double scale,
                        int accumulate, int nz, int64_t zs, hipStream_t s);
+int launch_transpose_pad_z(const double* in, double* out, int Mp, const double* const* LS, const double* const* m, int M,
+                           double* LSp, double* mp, int nz, int64_t zs, hipStream_t s);
+int launch_transpose_gemv_z(const double* in, double* out, int Mp, const double* Mat, const double* vec, double* vout, int nz,
+                            int64_t zs, hipStream_t s);
 int launch_kl_z(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* const* kl,
                 double* part, int nz, int64_t zs, hipStream_t s);
 int launch_dutot_y_z(const double* G1, const double* G2, const double* Hc, const double* U, const double* da, const double* a,
@@ -189,6 +193,10 @@ int weighted_syrk(const double* A, int64_t lda, const double* w, int Mp, int64_t
     int sD = 0;
     const int sF = syrk_splitk(Mp, Np, &sD);
     const int nsl = gemm_nt_slabs(ga, sF);      // 1: a small problem goes through whole, no k-slicing
+    if (gemm_nt_is_small(ga) && !skip) {      // ... and writes the full symmetric H itself: one launch, no slab, no reduction
+        ga.C = H; ga.ldc = Mp; ga.sym_full = 1;
+        return launch_gemm(ga, true, 1, s);
+    }
     if (nsl > 1) ga.splitk_diag = sD;
     TRY(launch_gemm(ga, true, nsl, s));
     return launch_reduce_slabs_sym(slabs, mm, nsl, (nsl > 1 && sD > 0) ? sD : nsl, H, Mp, skip, fallback, s);
@@ -204,7 +212,14 @@ int weighted_syrk_pair(const double* A, int64_t lda, const double* w, const doub
     int sD = 0;
     const int sF = syrk_splitk(Mp, Np, &sD);
     const int nsl = gemm_nt_slabs(ga, sF);
-    if (nsl <= 1) {      // small problem (no k-slicing): the plain pair of launches
+    if (gemm_nt_is_small(ga)) {      // small problem: ONE launch of the small-operand kernel forms both products (blockIdx.z)
+        // and writes them as full symmetric matrices -- where round 3 spent four launches (two products into slabs, two
+        // mirror / copy passes).  The twin is always computed here: at these sizes it costs less than the launch it saves.
+        ga.C = H; ga.ldc = Mp; ga.sym_full = 1;
+        ga.bscale2 = w2; ga.C2 = Hc;
+        return launch_gemm(ga, true, 1, s);
+    }
+    if (nsl <= 1) {      // a short contraction on the tiled kernel (one slab): the plain pair of launches
         TRY(weighted_syrk(A, lda, w, Mp, Np, slabs, H, nullptr, nullptr, kact, s));
         return weighted_syrk(A, lda, w2, Mp, Np, slabs, Hc, flag, H, kact, s);
     }
@@ -404,8 +419,8 @@ int chain_forward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const 
     // (the last launch of the factorisation also clears L^-1 and U, which are filled on and below the block diagonal only)
     TRY(launch_potrf_z(c.L, Mp, Mp, D.M, c.Dinv, c.Ld, io.info, n, zs, c.Linv, c.U, s));
     TRY(launch_trtri_z(c.L, Mp, Mp, c.Dinv, c.Linv, c.T, c.ws, c.ws_elems, n, zs, s));
-    TRY(launch_transpose_z(c.Linv, Mp, c.LinvT, Mp, Mp, Mp, n, zs, s));
-    TRY(launch_pad_params_z(io.L_S, io.m, D.M, c.LSp, c.mp, Mp, n, zs, s));      // user tensors -> padded copies, all layers
+    // L^-T, and the user tensors L_S, m -> padded copies (all layers): two independent jobs, one launch
+    TRY(launch_transpose_pad_z(c.Linv, c.LinvT, Mp, io.L_S, io.m, D.M, c.LSp, c.mp, n, zs, s));
     // U = L^-1 L_S (lower x lower), a = L^-1 m
     {
         GemmArgs ga = gemm_args(c.Linv, Mp, c.LSp, Mp, c.U, Mp, Mp, Mp, Mp, TRI_LOWER_A | TRI_LOWER_B, 1.0);
@@ -415,8 +430,7 @@ int chain_forward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const 
         if (n > 1) { gz.zlayers = n; gz.zsA = gz.zsB = gz.zsC = zs; }
         TRY(launch_gemm_auto(gz, false, c.ws, c.ws_elems, s));
     }
-    TRY(launch_transpose_z(c.U, Mp, c.UT, Mp, Mp, Mp, n, zs, s));
-    TRY(launch_gemv_rows_z(c.Linv, Mp, c.mp, c.a, Mp, Mp, 1.0, 0, n, zs, s));
+    TRY(launch_transpose_gemv_z(c.U, c.UT, Mp, c.Linv, c.mp, c.a, n, zs, s));      // U^T and a = L^-1 m: one launch
     TRY(launch_kl_z(c.L, c.LSp, c.U, c.a, D.M, Mp, io.kl, c.klpart, n, zs, s));
     return MOBOCMF_OK;
 }
@@ -471,6 +485,7 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     TRY(launch_moments_bwd_prep(g_mean, g_var, P.knn, P.q, P.varraw, desc->branch, desc->min_var, D.N, Np, B.gmu, B.gv,
                                 B.gv2, B.cgv, nclamped, block_layout ? 1 : 0, (int32_t*)act, s));
     // dA = 2 U (C diag(gv)) + a gmu^T - 2 A diag(cgv)
+    int da_parts = 0;
     {
         GemmArgs ga = gemm_args(c.U, Mp, P.C, Np, B.dA, Np, Mp, Np, Mp, TRI_LOWER_A, 2.0);
         ga.bscale = B.gv; ga.epi = EPI_DA; ga.avec = c.a; ga.gmu = B.gmu; ga.cgv = B.cgv; ga.Aaux = P.A;
@@ -482,8 +497,8 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
         probe_at(3, s);
         TRY(launch_gemm(ga, false, 1, s));
         probe_at(4, s);
-        if (!inputs_only) TRY(launch_sum_partials(B.dapart, gemm_rowdot_parts(ga), Mp, c.da, Mp, 1.0, 0, s));
-    }
+        da_parts = inputs_only ? 0 : gemm_rowdot_parts(ga);      // summed in the call's last launch (below): da is read by the
+    }                                                           // CHAIN half only
     // H = A diag(gv) A^T  (weighted syrk, split-K over N').  Both M x M contractions of the backward reduce to it:
     //   dU = 2 tril(A diag(gv) C^T) = 2 tril(H U),   dA A^T = 2 U U^T H + a da^T - 2 Hc,  Hc = A diag(cgv) A^T.
     // Hc differs from H only when clamp(k_nn - q, 0) is active in some column: its syrk is skipped on the device
@@ -513,8 +528,9 @@ int panel_backward(const mobocmf_layer_desc* desc, const Dims& D, const ChainWs&
     g.hyp_part = B.hyp_part; g.df_part = B.df_part; g.dzf_part = B.dzf_part; g.dx_part = B.dx_part;
     TRY(launch_gram_bwd(g, desc->want_dx != 0, s));
     probe_at(10, s);
-    SumTask tk[4];
+    SumTask tk[5];
     int nt = 0;
+    if (da_parts > 0) tk[nt++] = {B.dapart, da_parts, Mp, nullptr, 0, 0, c.da, Mp, 0};      // da = A g_mean (row-dot partials of dA)
     tk[nt++] = {B.hyp_part, (int64_t)D.ggrid_mn.x * D.ggrid_mn.y, D.H, nullptr, 0, 0, g_hyp, D.H, 0};
     if (desc->kind == 1) {
         tk[nt++] = {B.df_part, D.ggrid_mn.y, Np, nullptr, 0, 0, g_f, D.N, 0};

@@ -455,26 +455,30 @@ int launch_tril_inplace(double* A, int64_t ld, int n, hipStream_t s) {
 
 // strict upper triangle <- 0, diagonal 64x64 blocks <- the factors kept in Ld; z0 / z1 (n x n each, may be null) <- 0: the
 // buffers the triangular inverse and U = L^-1 L_S fill only on and below the block diagonal (no separate zero launches)
-__global__ void finish_l_kernel(double* A, int64_t ld, int n, const double* Ld, int64_t zs, double* z0, double* z1) {
+// Diagonal blocks >= nreal lie entirely in the identity padding of K_mm (no panel touched them): their Ld / Dinv blocks are
+// set to the identity HERE (round 3: a launch of their own) and the diagonal of A with them.
+__global__ void finish_l_kernel(double* A, int64_t ld, int n, double* Ld, double* Dinv, int nreal, int64_t zs, double* z0,
+                                double* z1) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)n * n) return;
-    A += blockIdx.z * zs; Ld += blockIdx.z * zs;
+    A += blockIdx.z * zs; Ld += blockIdx.z * zs; Dinv += blockIdx.z * zs;
     if (z0) z0[blockIdx.z * zs + idx] = 0.0;
     if (z1) z1[blockIdx.z * zs + idx] = 0.0;
     int i = (int)(idx / n), j = (int)(idx % n);
+    if (i / NB == j / NB) {
+        const int b = i / NB;
+        const int64_t e = (int64_t)b * NB * NB + (i % NB) * NB + (j % NB);
+        if (b >= nreal) {
+            const double v = i == j ? 1.0 : 0.0;
+            Ld[e] = v;
+            Dinv[e] = v;
+            A[(int64_t)i * ld + j] = v;
+            return;
+        }
+        A[(int64_t)i * ld + j] = j > i ? 0.0 : Ld[e];
+        return;
+    }
     if (j > i) A[(int64_t)i * ld + j] = 0.0;
-    else if (i / NB == j / NB) A[(int64_t)i * ld + j] = Ld[(int64_t)(i / NB) * NB * NB + (i % NB) * NB + (j % NB)];
-}
-
-// Ld / Dinv blocks [b0, b1) <- identity (panels that lie entirely in the identity padding of K_mm)
-__global__ void identity_blocks_kernel(double* Dinv, double* Ld, int b0, int b1, int64_t zs) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)(b1 - b0) * NB * NB) return;
-    Dinv += blockIdx.z * zs; Ld += blockIdx.z * zs;
-    const int e = (int)(idx % (NB * NB));
-    const double v = (e / NB == e % NB) ? 1.0 : 0.0;
-    Dinv[(int64_t)b0 * NB * NB + idx] = v;
-    Ld[(int64_t)b0 * NB * NB + idx] = v;
 }
 
 // columns per hand-over of the 64-wide panel kernel: tune().potrf_cols = 4 (potrf_panel4_kernel, default) or 1 (potrf_panel2_kernel)
@@ -498,14 +502,10 @@ int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* L
         int nt = nreal - jb - 1;
         if (nt > 0) hipLaunchKernelGGL(syrk64_update_kernel, dim3(nt, nt, nz), dim3(256), 0, s, A, ld, jb, zs);
     }
-    if (nreal < nblk) {
-        int64_t n = (int64_t)(nblk - nreal) * NB * NB;
-        hipLaunchKernelGGL(identity_blocks_kernel, dim3((unsigned)((n + 255) / 256), 1, nz), dim3(256), 0, s, Dinv, Ld, nreal,
-                           nblk, zs);
-    }
+    (void)nblk;
     int64_t n2 = (int64_t)Mp * Mp;
-    hipLaunchKernelGGL(finish_l_kernel, dim3((unsigned)((n2 + 255) / 256), 1, nz), dim3(256), 0, s, A, ld, Mp,
-                       (const double*)Ld, zs, zero0, zero1);
+    hipLaunchKernelGGL(finish_l_kernel, dim3((unsigned)((n2 + 255) / 256), 1, nz), dim3(256), 0, s, A, ld, Mp, Ld, Dinv, nreal,
+                       zs, zero0, zero1);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 

@@ -51,6 +51,9 @@ struct GemmArgs {
     int sym_out;       // 1 (with lower_out, A B^T with B = A: a syrk): the result is symmetric, so the 16 x 16 blocks
                        // strictly above the diagonal of every DIAGONAL tile are not computed either (left as zeros; the
                        // slab reduction mirrors them from below the diagonal)
+    int sym_full;      // 1 (small A B^T products only, with sym_out): the small-operand kernel writes the FULL symmetric result
+                       // straight into C (every block on or below the block diagonal stores its mirror image too) -- no slab,
+                       // no reduction launch; with C2 / bscale2 set the same launch also forms the twin product (blockIdx.z = 1)
     int splitk_diag;   // > 0 (k-sliced sym_out launches): the diagonal tiles -- 10/16 of a full tile's MFMA work on their
                        // critical wavefronts -- take this many k slices instead of `splitk`, so that all workgroups run
                        // equally long; slab z of a tile is only written for z < its own slice count
@@ -114,6 +117,7 @@ struct SumTask {
 };
 int launch_sum_partials_multi(const SumTask* tasks, int n, hipStream_t s);
 int gemm_nt_slabs(const GemmArgs& g, int splitk);   // k-slices (slabs) an A B^T launch will really write
+bool gemm_nt_is_small(const GemmArgs& g);           // the product runs on the small-operand kernel (GemmArgs.sym_full applies)
 int gemm_rowdot_parts(const GemmArgs& g);   // number of column slices EPI_DA writes to rowdot_part
 int gemm_colstat_rows(const GemmArgs& g);   // number of partial rows EPI_COLSTATS writes to colsq_part / coldot_part
 int launch_gemm_auto(const GemmArgs& g, bool B_T, double* ws, int64_t ws_elems, hipStream_t s);

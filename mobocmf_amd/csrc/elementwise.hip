@@ -115,6 +115,62 @@ int launch_transpose_z(const double* in, int64_t ldi, double* out, int64_t ldo, 
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, ldi, out, ldo, rows, cols, zs);
     return CHECK_LAUNCH();
 }
+// Two pairs of independent launches of the chain forward as ONE launch each (the chain is a string of latency-bound launches:
+// at the reference's own sizes every one of them is ~4.5 us of a ~300 us step):
+//   transpose_pad_z:   out = in^T (Mp x Mp, L^-1 -> L^-T)    +  the padded copies of the user tensors L_S, m of every layer
+//   transpose_gemv_z:  out = in^T (Mp x Mp, U -> U^T)        +  vout = Mat vec (a = L^-1 m), one wavefront per row
+__global__ void transpose_pad_z_kernel(const double* in, double* out, int Mp, int64_t zs, PadZ t, int M, double* LSp, double* mp) {
+    __shared__ double tl[32][33];
+    const int z = blockIdx.z;
+    in += z * zs; out += z * zs;
+    const int64_t c = (int64_t)blockIdx.x * 32 + threadIdx.x, r0 = (int64_t)blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int64_t i = r0 + k;
+        tl[k][threadIdx.x] = in[i * Mp + c];
+        LSp[z * zs + i * Mp + c] = (i < M && c <= i) ? t.LS[z][i * M + c] : 0.0;
+        if (i == 0) mp[z * zs + c] = c < M ? t.m[z][c] : 0.0;
+    }
+    __syncthreads();
+    const int64_t r = r0 + threadIdx.x, c0 = (int64_t)blockIdx.x * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) out[(c0 + k) * Mp + r] = tl[threadIdx.x][k];
+}
+int launch_transpose_pad_z(const double* in, double* out, int Mp, const double* const* LS, const double* const* m, int M,
+                           double* LSp, double* mp, int nz, int64_t zs, hipStream_t s) {
+    PadZ t = {};
+    for (int z = 0; z < nz; ++z) { t.LS[z] = LS[z]; t.m[z] = m[z]; }
+    hipLaunchKernelGGL(transpose_pad_z_kernel, dim3((unsigned)(Mp / 32), (unsigned)(Mp / 32), (unsigned)nz), dim3(32, 8), 0, s, in,
+                       out, Mp, zs, t, M, LSp, mp);
+    return CHECK_LAUNCH();
+}
+__global__ void transpose_gemv_z_kernel(const double* in, double* out, int Mp, int64_t zs, const double* Mat, const double* vec,
+                                        double* vout) {
+    __shared__ double tl[32][33];
+    const int z = blockIdx.z;
+    in += z * zs; out += z * zs; Mat += z * zs; vec += z * zs; vout += z * zs;
+    const int64_t c = (int64_t)blockIdx.x * 32 + threadIdx.x, r0 = (int64_t)blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) tl[k][threadIdx.x] = in[(r0 + k) * Mp + c];
+    // the matrix-vector product: this block's share of the rows, a wavefront per row
+    {
+        const int tid = threadIdx.y * 32 + threadIdx.x, wave = tid >> 6, lane = tid & 63;
+        const int nblk = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        for (int row = 4 * b + wave; row < Mp; row += 4 * nblk) {
+            const double* p = Mat + (int64_t)row * Mp;
+            double sacc = 0.0;
+            for (int j = lane; j < Mp; j += 64) sacc += p[j] * vec[j];
+            sacc = wave_sum(sacc);
+            if (lane == 0) vout[row] = sacc;
+        }
+    }
+    __syncthreads();
+    const int64_t r = r0 + threadIdx.x, c0 = (int64_t)blockIdx.x * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) out[(c0 + k) * Mp + r] = tl[threadIdx.x][k];
+}
+int launch_transpose_gemv_z(const double* in, double* out, int Mp, const double* Mat, const double* vec, double* vout, int nz,
+                            int64_t zs, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_gemv_z_kernel, dim3((unsigned)(Mp / 32), (unsigned)(Mp / 32), (unsigned)nz), dim3(32, 8), 0, s, in,
+                       out, Mp, zs, Mat, vec, vout);
+    return CHECK_LAUNCH();
+}
 int launch_transpose(const double* in, int64_t ldi, double* out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t s) {
     return launch_transpose_z(in, ldi, out, ldo, rows, cols, 1, 0, s);
 }
@@ -173,8 +229,33 @@ __global__ void kl_final_kernel(const double* part, int np, int M, KlZ kl, int64
     s = block_sum(s, sh);
     if (threadIdx.x == 0) kl.p[blockIdx.x][0] = 0.5 * (s - (double)M);
 }
+// small M (<= 128: the reference's own sizes): one block per layer does both stages -- one launch instead of two
+__global__ void kl_one_kernel(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, KlZ kl,
+                              int64_t zs) {
+    __shared__ double sh[4];
+    const int z = blockIdx.x;
+    L += z * zs; LSp += z * zs; U += z * zs; a += z * zs;
+    double s = 0.0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = wave; i < M; i += 4) {      // a wavefront per row of the lower triangle
+        const double* u = U + (int64_t)i * Mp;
+        for (int j = lane; j <= i; j += 64) s += u[j] * u[j];
+        if (lane == 0) {
+            const double l = L[(int64_t)i * Mp + i], ls = LSp[(int64_t)i * Mp + i];
+            s += 2.0 * log(l) - log(ls * ls) + a[i] * a[i];
+        }
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) kl.p[z][0] = 0.5 * (s - (double)M);
+}
 int launch_kl_z(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* const* kl,
                 double* part, int nz, int64_t zs, hipStream_t s) {
+    if (M <= 128) {
+        KlZ kz1 = {};
+        for (int z = 0; z < nz; ++z) kz1.p[z] = kl[z];
+        hipLaunchKernelGGL(kl_one_kernel, dim3(nz), dim3(256), 0, s, L, LSp, U, a, M, Mp, kz1, zs);
+        return CHECK_LAUNCH();
+    }
     const int nb = (M + 3) / 4;
     hipLaunchKernelGGL(kl_part_kernel, dim3(nb, 1, nz), dim3(256), 0, s, L, LSp, U, a, M, Mp, part, zs);
     KlZ kz = {};
@@ -789,6 +870,79 @@ __global__ void elbo_all_fwd_tail_kernel(ElboTable t, int L, int nb, int nkl, do
         out[2] = -(data - scale * kl);
     }
 }
+// Small problems (every layer <= 4096 rows: the reference's own sizes): the whole ELBO in ONE block and one launch -- the
+// layers one after the other, then the KL tail (two launches of ~4.5 us each are more than the work itself there).
+__global__ void elbo_all_fwd_one_kernel(ElboTable t, int L, int nkl, double scale, const double* y, const double* fid,
+                                        double* out) {
+    __shared__ double sh[4];
+    double data = 0.0;      // thread 0's
+    for (int l = 0; l < L; ++l) {
+        double s = 0.0;
+        if (t.mean[l]) {
+            const double lo = t.lo[l], hi = t.hi[l], raw = t.raw[l][0];
+            const double tau = hi > lo ? lo + (hi - lo) / (1.0 + exp(-raw)) : raw, ltau = log(tau);
+            const int div = t.div[l];
+            const int64_t n = t.rows[l] * div;
+            const double level = (double)l;
+            const double* mean = t.mean[l];
+            const double* var = t.var[l];
+            for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const int64_t b = i / div;
+                if (fid[b] == level) s += elp_term(y[b], mean[i], var[i], tau, ltau);
+            }
+        }
+        s = block_sum(s, sh);
+        if (t.mean[l]) data += s / t.div[l];
+    }
+    if (threadIdx.x == 0) {
+        double kl = 0.0;
+        for (int j = 0; j < nkl; ++j) kl += t.kl[j][0];
+        out[0] = data - scale * kl;
+        out[1] = scale * kl;
+        out[2] = -(data - scale * kl);
+    }
+}
+__global__ void elbo_all_bwd_one_kernel(ElboTable t, int L, double scale, const double* y, const double* fid,
+                                        const double* g_elbo, const double* g_skl, double* gkl) {
+    __shared__ double sh[4];
+    const double ge = g_elbo ? g_elbo[0] : 0.0;
+    for (int l = 0; l < L; ++l) {
+        double st = 0.0;
+        if (t.mean[l]) {
+            const double lo = t.lo[l], hi = t.hi[l], raw = t.raw[l][0];
+            const double tau = hi > lo ? lo + (hi - lo) / (1.0 + exp(-raw)) : raw;
+            const int div = t.div[l];
+            const int64_t n = t.rows[l] * div;
+            const double level = (double)l, g = ge / div;
+            const double* mean = t.mean[l];
+            const double* var = t.var[l];
+            double* gmean = t.gmean[l];
+            double* gvar = t.gvar[l];
+            for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const int64_t b = i / div;
+                double gm = 0.0, gvv = 0.0;
+                if (fid[b] == level) {
+                    const double dlt = y[b] - mean[i];
+                    gm = g * dlt / tau;
+                    gvv = -0.5 * g / tau;
+                    st += 0.5 * ((dlt * dlt + var[i]) / (tau * tau) - 1.0 / tau);
+                }
+                gmean[i] = gm;
+                gvar[i] = gvv;
+            }
+        }
+        st = block_sum(st, sh);
+        if (threadIdx.x == 0 && t.mean[l] && t.graw[l]) {
+            double chain = 1.0;
+            if (t.hi[l] > t.lo[l]) {
+                const double sg = 1.0 / (1.0 + exp(-t.raw[l][0]));
+                chain = (t.hi[l] - t.lo[l]) * sg * (1.0 - sg);
+            }
+            t.graw[l][0] = st / t.div[l] * ge * chain;
+        }
+    }
+    if (threadIdx.x == 0) gkl[0] = scale * ((g_skl ? g_skl[0] : 0.0) - ge);
+}
 // gradients: g_mean / g_var per layer row, g_raw (the noise parameter of each layer, chain rule of the Interval transform
 // included), gkl[0] = d / d(every KL) = scale * (g_skl - g_elbo)
 __global__ void elbo_all_bwd_kernel(ElboTable t, const double* y, const double* fid, int64_t B, const double* g_elbo,
@@ -1033,6 +1187,7 @@ int mobocmf_adam_multi(int32_t n_tensors, double* const* params, const double* c
 struct PackTable {
     const double* raw[PACK_MAX_TENSORS];
     double* g_raw[PACK_MAX_TENSORS];
+    const double* g_src[PACK_MAX_TENSORS];      // _backward_v: upstream gradient of each tensor's packed slice (null: zero)
     int32_t off[PACK_MAX_TENSORS + 1];
 };
 __global__ void softplus_pack_kernel(PackTable t, int nt, double* out) {
@@ -1049,6 +1204,17 @@ __global__ void softplus_pack_bwd_kernel(PackTable t, int nt, const double* g_ou
         while (e >= t.off[ti + 1]) ++ti;
         const double x = t.raw[ti][e - t.off[ti]];
         t.g_raw[ti][e - t.off[ti]] = x > 20.0 ? g_out[e] : g_out[e] / (1.0 + exp(-x));
+    }
+}
+// the same with one upstream-gradient pointer PER TENSOR (segments of the packed vector handed out as separate tensors)
+__global__ void softplus_pack_bwd_v_kernel(PackTable t, int nt) {
+    for (int e = threadIdx.x; e < t.off[nt]; e += blockDim.x) {
+        int ti = 0;
+        while (e >= t.off[ti + 1]) ++ti;
+        const int k = e - t.off[ti];
+        const double x = t.raw[ti][k];
+        const double g = t.g_src[ti] ? t.g_src[ti][k] : 0.0;
+        t.g_raw[ti][k] = x > 20.0 ? g : g / (1.0 + exp(-x));
     }
 }
 static int fill_pack_table(PackTable& t, int32_t n, const double* const* raw, double* const* g_raw, const int32_t* sizes) {
@@ -1078,6 +1244,17 @@ int mobocmf_softplus_pack_backward(int32_t n_tensors, const double* const* raw, 
     const int rc = fill_pack_table(t, n_tensors, raw, g_raw, sizes);
     if (rc) return rc;
     hipLaunchKernelGGL(softplus_pack_bwd_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, t, n_tensors, g_out);
+    return CHECK_LAUNCH();
+}
+
+int mobocmf_softplus_pack_backward_v(int32_t n_tensors, const double* const* raw, const int32_t* sizes,
+                                     const double* const* g_out, double* const* g_raw, mobocmf_stream_t stream) {
+    PackTable t;
+    if (!g_out || !g_raw) return MOBOCMF_BAD_ARG;
+    const int rc = fill_pack_table(t, n_tensors, raw, g_raw, sizes);
+    if (rc) return rc;
+    for (int i = 0; i < n_tensors; ++i) t.g_src[i] = g_out[i];
+    hipLaunchKernelGGL(softplus_pack_bwd_v_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, t, n_tensors);
     return CHECK_LAUNCH();
 }
 
@@ -1186,6 +1363,10 @@ int mobocmf_elbo_forward(int32_t L, const double* const* mean, const double* con
     }
     for (int j = 0; j < n_kl; ++j) { if (!kls[j]) return MOBOCMF_BAD_ARG; t.kl[j] = kls[j]; }
     const int nb = elbo_blocks(L, mean, div, B);
+    if (nb <= 4) {      // small: one block, one launch
+        hipLaunchKernelGGL(elbo_all_fwd_one_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, L, n_kl, scale, y, fid, out3);
+        return CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(elbo_all_fwd_kernel, dim3(nb, L), dim3(256), 0, (hipStream_t)stream, t, y, fid, B, (double*)scratch);
     hipLaunchKernelGGL(elbo_all_fwd_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, L, nb, n_kl, scale,
                        (const double*)scratch, out3);
@@ -1210,6 +1391,11 @@ int mobocmf_elbo_backward(int32_t L, const double* const* mean, const double* co
         t.gmean[l] = g_mean[l]; t.gvar[l] = g_var[l]; t.graw[l] = g_raw_noise[l];
     }
     const int nb = elbo_blocks(L, mean, div, B);
+    if (nb <= 4) {
+        hipLaunchKernelGGL(elbo_all_bwd_one_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, L, scale, y, fid, g_elbo, g_skl,
+                           g_kl);
+        return CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(elbo_all_bwd_kernel, dim3(nb, L), dim3(256), 0, (hipStream_t)stream, t, y, fid, B, g_elbo,
                        (double*)scratch);
     hipLaunchKernelGGL(elbo_all_bwd_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, L, nb, scale, g_elbo, g_skl,

@@ -1020,7 +1020,7 @@ static int small_panel_limit() { return tune().small_panel_max; }
 // streams 16 x 16 operand blocks through LDS and applies the structural zeros of triangular operands on load, so the
 // result never depends on what lies in the unused triangle.  ~4 us a product.
 template <bool B_T>
-__global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void small_gemm_body(GemmArgs g, const int bz) {
     // K is walked in chunks of 128: all 16 loads of a thread for a chunk (8 of A, 8 of B) are issued together, i.e. one
     // global-load latency per chunk instead of one per 16-wide K step (8 dependent steps made a 128^3 product ~7 us)
     constexpr int KC = 128;
@@ -1028,11 +1028,19 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
     if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int64_t r0 = (int64_t)blockIdx.y * 16, c0 = (int64_t)blockIdx.x * 16;
+    const bool sym_full = B_T && g.sym_full;
+    if (sym_full) {
+        // the weighted syrk of a small layer backward, H = A diag(w) A^T (and its twin with the clamped-column weights,
+        // bz = 1), written as the full symmetric matrix by this launch: blocks on or below the block diagonal only
+        if (c0 > r0) return;
+        if (bz == 1) { g.bscale = g.bscale2; g.C = g.C2; }
+    } else {
     if (g.lower_out && c0 / BM > r0 / BM) return;        // same contract as the tiled kernel: lower 128-tiles only
-    {   // blockIdx.z = batch * layers + layer, as in the tiled kernel (batched merges of the triangular inverse, layer
+    }
+    if (!sym_full) {   // bz = batch * layers + layer, as in the tiled kernel (batched merges of the triangular inverse, layer
         // batching of the chains, or both)
         const int nzl = g.zlayers > 1 ? g.zlayers : 1;
-        const int zl = (int)blockIdx.z % nzl, zb = (int)blockIdx.z / nzl;
+        const int zl = bz % nzl, zb = bz / nzl;
         g.A += zb * g.strideA + zl * g.zsA;
         g.B += zb * g.strideB + zl * g.zsB;
         g.C += zb * g.strideC + zl * g.zsC;
@@ -1089,8 +1097,27 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
     }
     double* c = g.C + (r0 + ty) * g.ldc + c0 + tx;
     double v = g.alpha * acc;
+    if (sym_full) {
+        // element (i, j) and its mirror image get the SAME number (the one computed for the lower triangle): the result is
+        // exactly symmetric, as the slab reduction of the tiled path makes it (the chain backward reads X = H U as (U^T H)^T)
+        if (c0 < r0 || tx <= ty) {
+            *c = v;
+            g.C[(c0 + tx) * g.ldc + r0 + ty] = v;
+        }
+        return;
+    }
     if (g.accumulate) v += *c;
     *c = v;
+}
+
+template <bool B_T>
+__global__ __launch_bounds__(256) void small_gemm_kernel(GemmArgs g) {
+    small_gemm_body<B_T>(g, (int)blockIdx.z);
+}
+// two independent A B products of the same shape and layer batching in one launch: even blockIdx.z -> g0, odd -> g1
+__global__ __launch_bounds__(256) void small_gemm2_kernel(GemmArgs g0, GemmArgs g1) {
+    if (blockIdx.z & 1) small_gemm_body<false>(g1, (int)(blockIdx.z >> 1));
+    else small_gemm_body<false>(g0, (int)(blockIdx.z >> 1));
 }
 
 // M x N' panel products of a small problem (K = Mp <= 256, at most two workgroups per CU in all): one workgroup per
@@ -1272,8 +1299,10 @@ static bool small_gemm_ok(const GemmArgs& g, bool B_T) {
 }
 
 static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
+    if (B_T && g.sym_full && (g.batched > 1 || g.zlayers > 1 || g.Mr != g.Nc || g.accumulate)) return MOBOCMF_BAD_ARG;
     const dim3 grid((unsigned)(g.Nc / 16), (unsigned)(g.Mr / 16),
-                    (unsigned)((g.batched > 1 ? g.batched : 1) * (g.zlayers > 1 ? g.zlayers : 1)));
+                    (B_T && g.sym_full) ? (g.C2 ? 2u : 1u)
+                                        : (unsigned)((g.batched > 1 ? g.batched : 1) * (g.zlayers > 1 ? g.zlayers : 1)));
     if (B_T) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, s, g);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
@@ -1281,6 +1310,8 @@ static int launch_small_gemm(const GemmArgs& g, bool B_T, hipStream_t s) {
 
 // slabs a k-sliced A B^T product will write: 1 when the small-operand kernel takes it whole
 int gemm_nt_slabs(const GemmArgs& g, int splitk) { return small_gemm_ok(g, true) ? 1 : splitk; }
+// true: an A B^T product of this shape runs on the small-operand kernel (which can write a symmetric result in full, sym_full)
+bool gemm_nt_is_small(const GemmArgs& g) { return small_gemm_ok(g, true); }
 
 // ---------------------------------------------------------------------------------- mid-size operands (the M x M chain)
 // M x M x M products with 384 < M <= 1024 (the chain of a C3 / C5 surrogate: U = L^-1 L_S, the panels of the triangular inverse,
@@ -1690,6 +1721,14 @@ int launch_gemm_auto_pair(const GemmArgs& a, const GemmArgs& b, double* ws, int6
     GemmArgs a1 = a, b1 = b;
     a1.batched = b1.batched = 1;
     const bool small = small_gemm_ok(nza > 1 ? a1 : a, false) || small_gemm_ok(nzb > 1 ? b1 : b, false);
+    if (small && nza == nzb && a.Mr == b.Mr && a.Nc == b.Nc && a.batched <= 1 && b.batched <= 1 &&
+        small_gemm_ok(nza > 1 ? a1 : a, false) && small_gemm_ok(nzb > 1 ? b1 : b, false) && !a.skip_if_zero && !b.skip_if_zero) {
+        // both on the small-operand kernel: one launch, the problems interleaved in blockIdx.z
+        GemmArgs x = nza > 1 ? a1 : a, y = nzb > 1 ? b1 : b;
+        const dim3 grid((unsigned)(x.Nc / 16), (unsigned)(x.Mr / 16), (unsigned)(2 * nza));
+        hipLaunchKernelGGL(small_gemm2_kernel, grid, dim3(256), 0, s, x, y);
+        return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+    }
     if (!small && nza == nzb && a.Mr == b.Mr && a.Nc == b.Nc && a.batched <= 1 && b.batched <= 1 && mid_gemm_ok(a) && mid_gemm_ok(b)) {
         const int nrb = a.Mr / MD_BM, ncb = (int)(a.Nc / MD_BN);
         if (tune().mid_gemm_waves == 32 && a.Kd % MS_BK == 0 && b.Kd % MS_BK == 0)

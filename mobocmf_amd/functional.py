@@ -1344,6 +1344,60 @@ class _SoftplusPackFn(torch.autograd.Function):
         return tuple(grads)
 
 
+class _SoftplusPackSegFn(torch.autograd.Function):
+    """``softplus_pack`` of the raw tensors of SEVERAL consumers (the layers of a model) in one launch: the packed vector is
+    handed out as one tensor per consumer (``seg`` = raw tensors per consumer); the backward collects the consumers' gradients
+    through a per-tensor pointer table -- one launch, no concatenation of gradients, no slice-backward launches."""
+
+    @staticmethod
+    def forward(ctx, seg, *raws):
+        lib = _lib.require_device()
+        flat = [_prep(r.detach().reshape(-1)) for r in raws]
+        n = len(flat)
+        sizes = (ctypes.c_int32 * n)(*[f.numel() for f in flat])
+        ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in flat])
+        out = _empty(sum(f.numel() for f in flat), device=flat[0].device)
+        _lib.check(lib.mobocmf_softplus_pack(n, ptrs, sizes, _ptr(out), _stream()), "mobocmf_softplus_pack")
+        ctx.save_for_backward(*raws)
+        ctx.seg = tuple(seg)
+        ctx.set_materialize_grads(False)
+        outs, off, k = [], 0, 0
+        for cnt in seg:
+            ln = sum(f.numel() for f in flat[k:k + cnt])
+            outs.append(out[off:off + ln])
+            off, k = off + ln, k + cnt
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        lib = _lib.require_device()
+        raws = ctx.saved_tensors
+        flat = [_prep(r.detach().reshape(-1)) for r in raws]
+        n = len(flat)
+        grads = [_empty_like(r) for r in raws]
+        sizes = (ctypes.c_int32 * n)(*[f.numel() for f in flat])
+        ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in flat])
+        gptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
+        src, k, keep = [], 0, []
+        for cnt, g in zip(ctx.seg, gs):
+            g = None if g is None else _prep(g)
+            keep.append(g)
+            off = 0
+            for f in flat[k:k + cnt]:
+                src.append(0 if g is None else g.data_ptr() + 8 * off)
+                off += f.numel()
+            k += cnt
+        _lib.check(lib.mobocmf_softplus_pack_backward_v(n, ptrs, sizes, (ctypes.c_void_p * n)(*src), gptrs, _stream()),
+                   "mobocmf_softplus_pack_backward_v")
+        return (None,) + tuple(grads)
+
+
+def softplus_pack_segments(raw_groups):
+    """One launch for several groups of raw tensors (<= 16 tensors in all): returns one packed, differentiable vector per group."""
+    seg = [len(g) for g in raw_groups]
+    return list(_SoftplusPackSegFn.apply(seg, *[r for g in raw_groups for r in g]))
+
+
 def softplus_pack(raws):
     """``softplus(cat(raws))`` for float64 device tensors (<= 16 of them) in one launch, differentiable."""
     return _SoftplusPackFn.apply(*raws)

@@ -173,6 +173,21 @@ def pack_hypers(covar_module, kind):
     return torch.cat([getattr(m, n + "_constraint").transform(r) for (m, n), r in zip(src, raws)])
 
 
+def pack_hypers_many(modules_kinds):
+    """``pack_hypers`` for several layers in ONE launch forward and one backward (the layers of a model at the top of a
+    training step): returns the list of packed vectors (views of one buffer), or None when the single-launch form does not
+    apply (a non-softplus constraint, host tensors, more raw tensors than one launch takes) -- the caller then packs layer
+    by layer."""
+    srcs = [_hyper_sources(cm, kind) for cm, kind in modules_kinds]
+    flat = [(m, n) for src in srcs for m, n in src]
+    params = [getattr(m, n) for m, n in flat]
+    if len(params) > 16 or not all(type(getattr(m, n + "_constraint")) is Positive for m, n in flat) or \
+            not all(p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() for p in params):
+        return None
+    from . import functional as F
+    return F.softplus_pack_segments([[getattr(m, n) for m, n in src] for src in srcs])
+
+
 def gram_cpu_init(covar_module, kind, X):
     """k(X, X) on the host, ONLY for the one-time initial S of the top layer (mfdgp_hidden_layer.py:131-132)."""
     h = pack_hypers(covar_module, kind).detach().double()

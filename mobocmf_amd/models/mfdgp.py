@@ -242,14 +242,16 @@ class MFDGP(nn.Module):
                 and not any(l.check_pd for l in layers)):
             return None
         params, kinds, jit, infos, hyps = [], [], [], [], []
-        for layer in layers:
+        # the constrained hyper-parameters of ALL layers from one launch (and one backward launch for every raw gradient)
+        packed = gp.pack_hypers_many([(layer.covar_module, layer.kind) for layer in layers])
+        for li, layer in enumerate(layers):
             vs = layer.variational_strategy
             vd = vs._variational_distribution
             if vs.Zx.shape[0] != layers[0].variational_strategy.Zx.shape[0] or (layer.kind == 1 and vs.zf is None):
                 return None
             if layer._info is None or layer._info.device != inputs.device:
                 layer._info = torch.zeros((), dtype=torch.int32, device=inputs.device)
-            hyp = gp.pack_hypers(layer.covar_module, layer.kind)
+            hyp = packed[li] if packed is not None else gp.pack_hypers(layer.covar_module, layer.kind)
             hyps.append(hyp)
             params.append((vs.Zx, vs.zf if layer.kind == 1 else None, hyp, vd.variational_mean, vd.chol_variational_covar))
             kinds.append(layer.kind)

@@ -44,10 +44,10 @@ for M in (512, 1024):
         H = torch.empty(M, M, dtype=torch.float64, device=dev)
         L = torch.tril(torch.randn(M, M, dtype=torch.float64, device=dev))
         nb = _lib._SZ()
-        _lib.check(lib.mobocmf_syrk_workspace_bytes(M, N, ctypes.byref(nb)), "ws")
+        _lib.check(lib.mobocmf_syrk_workspace_bytes(M, N, None, ctypes.byref(nb)), "ws")
         ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
-        t_syrk = timeit(lambda: lib.mobocmf_syrk_weighted_f64(M, N, P(A), ld, P(w), P(H), P(ws), nb.value, st))
-        t_gemm = timeit(lambda: lib.mobocmf_gemm_f64_epilogue(1, 0, M, N, M, P(L), M, P(A), ld, P(C), ld, 1.0, 0, None, None, None, None, None, None, None, None, st))
+        t_syrk = timeit(lambda: lib.mobocmf_syrk_weighted_f64(M, N, P(A), ld, P(w), P(H), P(ws), nb.value, None, None, st))
+        t_gemm = timeit(lambda: lib.mobocmf_gemm_f64_epilogue(1, 0, M, N, M, P(L), M, P(A), ld, P(C), ld, 1.0, 0, None, None, None, None, None, None, None, None, None, None, st))
         if pad == 0:
             ref = (A[:, :N] * w[None, :]) @ A[:, :N].T
         print("M=%d ld=N'+%-5d syrk %.4f ms   lower-tri NN product (plain store) %.4f ms" % (M, pad, t_syrk, t_gemm), flush=True)
