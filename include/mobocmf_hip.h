@@ -338,6 +338,31 @@ int mobocmf_softplus_pack_backward(int32_t n_tensors, const double* const* raw, 
 int mobocmf_softplus_pack_backward_v(int32_t n_tensors, const double* const* raw, const int32_t* sizes,
                                      const double* const* g_out, double* const* g_raw, mobocmf_stream_t stream);
 
+/* ---- Conditioned training: the theta / omega factor losses of blackbox_mfdgp_fitter.py:227-243 and the glue
+ * around them -- a few hundred flops that cost ~100 framework launches per iteration of a launch-bound loop.
+ *
+ * mobocmf_cond_factors_forward:  loss[0] = sum_{p < P, t < T} [ coef_c c(p,t) + coef_1mc (1 - c(p,t)) ] with
+ *   c(p,t) = prod_k Phi((cs_mean[k][t] - thresholds[k]) / sqrt(cs_var[k][t]))
+ *          * prod_j Phi((pareto_front[p][j] - fs_mean[j][t]) / sqrt(fs_var[j][t]))
+ *   (n_obj, n_con <= 8; one row pointer per objective / constraint, T entries each; pareto_front [P x n_obj] row-major).
+ *   omega factors (:235-243): coef_c = log eps, coef_1mc = log(1 - eps), P = Pareto points, T = the x~ points.
+ *   theta factors (:227-233): n_obj = 0, n_con = 1, P = 1, T = Pareto points, coef_c = log(1 - eps), coef_1mc = log eps.
+ *   g_*: d loss / d (every input entry) for an upstream gradient of 1, formed in the same launch.
+ * mobocmf_scale_segments:   out_i[e] = g[0] * coef_i * in_i[e]   (g: device scalar, NULL = 1; coef NULL = 1): the backward of
+ *   anything whose forward formed its own gradient.
+ * mobocmf_gather_segments:  out = segments back to back, zeros where in[i] is NULL: the backward of a split into row ranges.
+ * mobocmf_scalar_combine:   out[0] = sum_i coef[i] * x[i][0]: a loss assembled from scalar terms (coef: HOST array).
+ * n <= 32 segments; sizes / coef are HOST arrays. */
+int mobocmf_cond_factors_forward(int32_t n_obj, int32_t n_con, int32_t P, int32_t T, const double* const* fs_mean,
+                                 const double* const* fs_var, const double* const* cs_mean, const double* const* cs_var,
+                                 const double* pareto_front, const double* thresholds, double coef_c, double coef_1mc,
+                                 double* loss, double* const* g_fs_mean, double* const* g_fs_var, double* const* g_cs_mean,
+                                 double* const* g_cs_var, mobocmf_stream_t stream);
+int mobocmf_scale_segments(int32_t n, const double* const* in, double* const* out, const int64_t* sizes, const double* coef,
+                           const double* g, mobocmf_stream_t stream);
+int mobocmf_gather_segments(int32_t n, const double* const* in, const int64_t* sizes, double* out, mobocmf_stream_t stream);
+int mobocmf_scalar_combine(int32_t n, const double* const* x, const double* coef, double* out, mobocmf_stream_t stream);
+
 /* ---- Exact-GP comparison baselines (mobocmf/models/mfgp.py:24-141,145-184; mfgp_lin.py:101-189) on the layer's kernels.
  * The reference inherits exact inference from GPyTorch's ExactGP; here the Gram matrices come from mobocmf_gram_forward,
  * the multi-fidelity combination is one element-wise launch, the factorisation / triangular inverse are the variational

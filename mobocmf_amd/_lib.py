@@ -97,6 +97,10 @@ SYMBOLS = {
     "mobocmf_softplus_pack": [_I32, _P, _P, _P, _P],
     "mobocmf_softplus_pack_backward": [_I32, _P, _P, _P, _P, _P],
     "mobocmf_softplus_pack_backward_v": [_I32, _P, _P, _P, _P, _P],
+    "mobocmf_cond_factors_forward": [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _D, _D, _P, _P, _P, _P, _P, _P],
+    "mobocmf_scale_segments": [_I32, _P, _P, _P, _P, _P, _P],
+    "mobocmf_gather_segments": [_I32, _P, _P, _P, _P],
+    "mobocmf_scalar_combine": [_I32, _P, _P, _P, _P],
     "mobocmf_rff_eval": [_I32, _I32, _I32, _I64] + [_P] * 8 + [_D, _D, _D, _P, _P],
     "mobocmf_gram_forward": [_I32, _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P],
     "mobocmf_check_info": [_P, ctypes.POINTER(_I32), _P],

@@ -28,6 +28,19 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return t;
 }
 
+// the same for any block size up to 1024 threads (sh: 16 doubles)
+__device__ __forceinline__ double block_sum_wide(double v, double* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) t += sh[w];
+    return t;
+}
+
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR)
 
@@ -229,31 +242,40 @@ __global__ void kl_final_kernel(const double* part, int np, int M, KlZ kl, int64
     s = block_sum(s, sh);
     if (threadIdx.x == 0) kl.p[blockIdx.x][0] = 0.5 * (s - (double)M);
 }
-// small M (<= 128: the reference's own sizes): one block per layer does both stages -- one launch instead of two
-__global__ void kl_one_kernel(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, KlZ kl,
-                              int64_t zs) {
-    __shared__ double sh[4];
+// small M (<= 128: the reference's own sizes): one block of 1024 threads per layer does both stages -- one launch instead of
+// two.  Element-parallel with the loads unrolled (a first version walked a row per wavefront: 32 dependent row reads, 41 us).
+__global__ __launch_bounds__(1024) void kl_one_kernel(const double* L, const double* LSp, const double* U, const double* a, int M,
+                                                      int Mp, KlZ kl, int64_t zs) {
+    __shared__ double sh[16];
     const int z = blockIdx.x;
     L += z * zs; LSp += z * zs; U += z * zs; a += z * zs;
     double s = 0.0;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = wave; i < M; i += 4) {      // a wavefront per row of the lower triangle
-        const double* u = U + (int64_t)i * Mp;
-        for (int j = lane; j <= i; j += 64) s += u[j] * u[j];
-        if (lane == 0) {
-            const double l = L[(int64_t)i * Mp + i], ls = LSp[(int64_t)i * Mp + i];
-            s += 2.0 * log(l) - log(ls * ls) + a[i] * a[i];
-        }
+    const int total = M * Mp;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < total; e += 1024) {
+        const int i = e / Mp, j = e - i * Mp;
+        const double u = U[e];
+        s += j <= i ? u * u : 0.0;
     }
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) kl.p[z][0] = 0.5 * (s - (double)M);
+    for (int i = threadIdx.x; i < M; i += 1024) {
+        const double l = L[(int64_t)i * Mp + i], ls = LSp[(int64_t)i * Mp + i];
+        s += 2.0 * log(l) - log(ls * ls) + a[i] * a[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        kl.p[z][0] = 0.5 * (t - (double)M);
+    }
 }
 int launch_kl_z(const double* L, const double* LSp, const double* U, const double* a, int M, int Mp, double* const* kl,
                 double* part, int nz, int64_t zs, hipStream_t s) {
     if (M <= 128) {
         KlZ kz1 = {};
         for (int z = 0; z < nz; ++z) kz1.p[z] = kl[z];
-        hipLaunchKernelGGL(kl_one_kernel, dim3(nz), dim3(256), 0, s, L, LSp, U, a, M, Mp, kz1, zs);
+        hipLaunchKernelGGL(kl_one_kernel, dim3(nz), dim3(1024), 0, s, L, LSp, U, a, M, Mp, kz1, zs);
         return CHECK_LAUNCH();
     }
     const int nb = (M + 3) / 4;
@@ -872,9 +894,9 @@ __global__ void elbo_all_fwd_tail_kernel(ElboTable t, int L, int nb, int nkl, do
 }
 // Small problems (every layer <= 4096 rows: the reference's own sizes): the whole ELBO in ONE block and one launch -- the
 // layers one after the other, then the KL tail (two launches of ~4.5 us each are more than the work itself there).
-__global__ void elbo_all_fwd_one_kernel(ElboTable t, int L, int nkl, double scale, const double* y, const double* fid,
+__global__ __launch_bounds__(1024) void elbo_all_fwd_one_kernel(ElboTable t, int L, int nkl, double scale, const double* y, const double* fid,
                                         double* out) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     double data = 0.0;      // thread 0's
     for (int l = 0; l < L; ++l) {
         double s = 0.0;
@@ -891,7 +913,7 @@ __global__ void elbo_all_fwd_one_kernel(ElboTable t, int L, int nkl, double scal
                 if (fid[b] == level) s += elp_term(y[b], mean[i], var[i], tau, ltau);
             }
         }
-        s = block_sum(s, sh);
+        s = block_sum_wide(s, sh);
         if (t.mean[l]) data += s / t.div[l];
     }
     if (threadIdx.x == 0) {
@@ -902,9 +924,9 @@ __global__ void elbo_all_fwd_one_kernel(ElboTable t, int L, int nkl, double scal
         out[2] = -(data - scale * kl);
     }
 }
-__global__ void elbo_all_bwd_one_kernel(ElboTable t, int L, double scale, const double* y, const double* fid,
+__global__ __launch_bounds__(1024) void elbo_all_bwd_one_kernel(ElboTable t, int L, double scale, const double* y, const double* fid,
                                         const double* g_elbo, const double* g_skl, double* gkl) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     const double ge = g_elbo ? g_elbo[0] : 0.0;
     for (int l = 0; l < L; ++l) {
         double st = 0.0;
@@ -931,7 +953,7 @@ __global__ void elbo_all_bwd_one_kernel(ElboTable t, int L, double scale, const 
                 gvar[i] = gvv;
             }
         }
-        st = block_sum(st, sh);
+        st = block_sum_wide(st, sh);
         if (threadIdx.x == 0 && t.mean[l] && t.graw[l]) {
             double chain = 1.0;
             if (t.hi[l] > t.lo[l]) {
@@ -1258,6 +1280,165 @@ int mobocmf_softplus_pack_backward_v(int32_t n_tensors, const double* const* raw
     return CHECK_LAUNCH();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Conditioned training (blackbox_mfdgp_fitter.py:227-243): the theta / omega factor losses and the glue
+// around them.  The arithmetic is a few hundred flops; as framework ops it was ~100 element-wise launches per iteration
+// (cdf, products, sums, the backward of every slice / stack / scalar subtraction), i.e. a third of an iteration that is
+// bound by its launch count.  One block each.
+// ---------------------------------------------------------------------------------------------------------------------
+#define FACT_MAX 8
+struct FactTable {
+    const double* fm[FACT_MAX]; const double* fv[FACT_MAX]; const double* cm[FACT_MAX]; const double* cv[FACT_MAX];
+    double* gfm[FACT_MAX]; double* gfv[FACT_MAX]; double* gcm[FACT_MAX]; double* gcv[FACT_MAX];
+};
+__device__ __forceinline__ double ncdf(double z) { return 0.5 * (1.0 + erf(z * 0.7071067811865476)); }
+__device__ __forceinline__ double npdf(double z) { return 0.3989422804014327 * exp(-0.5 * z * z); }
+// loss = sum_{p < P, t < T} [ coef_c c(p,t) + coef_1mc (1 - c(p,t)) ],
+//   c(p,t) = prod_k Phi((cm_k[t] - thr[k]) / sqrt(cv_k[t])) * prod_j Phi((front[p][j] - fm_j[t]) / sqrt(fv_j[t]));
+// the gradients w.r.t. every fm_j[t], fv_j[t], cm_k[t], cv_k[t] (for an upstream gradient of 1) come out of the same pass.
+__global__ void cond_factors_kernel(FactTable tb, int n_obj, int n_con, int P, int T, const double* front, const double* thr,
+                                    double coef_c, double coef_1mc, double* loss) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    const double dldc = coef_c - coef_1mc;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        double phic[FACT_MAX], dzm[FACT_MAX], dzv[FACT_MAX];      // Phi(z_k), dPhi/dcm_k, dPhi/dcv_k
+        double C = 1.0;
+        for (int k = 0; k < n_con; ++k) {
+            const double sd = sqrt(tb.cv[k][t]), z = (tb.cm[k][t] - thr[k]) / sd, pd = npdf(z);
+            phic[k] = ncdf(z);
+            dzm[k] = pd / sd;
+            dzv[k] = -0.5 * pd * z / tb.cv[k][t];
+            C *= phic[k];
+        }
+        double isd[FACT_MAX], gm[FACT_MAX], gv[FACT_MAX];
+        for (int j = 0; j < n_obj; ++j) { isd[j] = 1.0 / sqrt(tb.fv[j][t]); gm[j] = 0.0; gv[j] = 0.0; }
+        double osum = 0.0;      // sum_p O(p,t)
+        for (int p = 0; p < P; ++p) {
+            double ph[FACT_MAX], u[FACT_MAX], O = 1.0;
+            for (int j = 0; j < n_obj; ++j) {
+                u[j] = (front[(int64_t)p * n_obj + j] - tb.fm[j][t]) * isd[j];
+                ph[j] = ncdf(u[j]);
+                O *= ph[j];
+            }
+            osum += O;
+            for (int j = 0; j < n_obj; ++j) {
+                double rest = C;      // c / Phi(u_j), formed without the division
+                for (int q = 0; q < n_obj; ++q) rest *= q == j ? 1.0 : ph[q];
+                const double pd = npdf(u[j]);
+                gm[j] += rest * pd * (-isd[j]);
+                gv[j] += rest * pd * (-0.5 * u[j] / tb.fv[j][t]);
+            }
+        }
+        acc += dldc * C * osum + coef_1mc * (double)P;
+        for (int j = 0; j < n_obj; ++j) { tb.gfm[j][t] = dldc * gm[j]; tb.gfv[j][t] = dldc * gv[j]; }
+        for (int k = 0; k < n_con; ++k) {
+            double rest = osum;
+            for (int q = 0; q < n_con; ++q) rest *= q == k ? 1.0 : phic[q];
+            tb.gcm[k][t] = dldc * rest * dzm[k];
+            tb.gcv[k][t] = dldc * rest * dzv[k];
+        }
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) loss[0] = acc;
+}
+int mobocmf_cond_factors_forward(int32_t n_obj, int32_t n_con, int32_t P, int32_t T, const double* const* fs_mean,
+                                 const double* const* fs_var, const double* const* cs_mean, const double* const* cs_var,
+                                 const double* pareto_front, const double* thresholds, double coef_c, double coef_1mc,
+                                 double* loss, double* const* g_fs_mean, double* const* g_fs_var, double* const* g_cs_mean,
+                                 double* const* g_cs_var, mobocmf_stream_t stream) {
+    if (n_obj < 0 || n_obj > FACT_MAX || n_con < 0 || n_con > FACT_MAX || n_obj + n_con < 1 || P < 1 || T < 1 || !loss ||
+        (n_obj && (!fs_mean || !fs_var || !g_fs_mean || !g_fs_var || !pareto_front)) ||
+        (n_con && (!cs_mean || !cs_var || !g_cs_mean || !g_cs_var || !thresholds)))
+        return MOBOCMF_BAD_ARG;
+    FactTable tb = {};
+    for (int j = 0; j < n_obj; ++j) {
+        if (!fs_mean[j] || !fs_var[j] || !g_fs_mean[j] || !g_fs_var[j]) return MOBOCMF_BAD_ARG;
+        tb.fm[j] = fs_mean[j]; tb.fv[j] = fs_var[j]; tb.gfm[j] = g_fs_mean[j]; tb.gfv[j] = g_fs_var[j];
+    }
+    for (int k = 0; k < n_con; ++k) {
+        if (!cs_mean[k] || !cs_var[k] || !g_cs_mean[k] || !g_cs_var[k]) return MOBOCMF_BAD_ARG;
+        tb.cm[k] = cs_mean[k]; tb.cv[k] = cs_var[k]; tb.gcm[k] = g_cs_mean[k]; tb.gcv[k] = g_cs_var[k];
+    }
+    hipLaunchKernelGGL(cond_factors_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tb, n_obj, n_con, P, T, pareto_front,
+                       thresholds, coef_c, coef_1mc, loss);
+    return CHECK_LAUNCH();
+}
+
+// Segment glue, one launch each:  scale: out_i = g[0] * in_i (the backward of anything whose forward already formed its own
+// gradient for an upstream 1);  gather: out = the segments back to back, zeros where a segment is absent (the backward of a
+// split into row ranges);  combine: out[0] = sum_i coef_i * x_i[0] (a loss assembled from scalar terms).
+#define SEG_MAX 32
+struct SegTable { const double* in[SEG_MAX]; double* out[SEG_MAX]; int64_t off[SEG_MAX + 1]; double coef[SEG_MAX]; };
+__global__ void seg_scale_kernel(SegTable t, int n, const double* g) {
+    const double gg = g ? g[0] : 1.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < t.off[n]; e += (int64_t)gridDim.x * blockDim.x) {
+        int i = 0;
+        while (e >= t.off[i + 1]) ++i;
+        t.out[i][e - t.off[i]] = gg * t.coef[i] * t.in[i][e - t.off[i]];
+    }
+}
+__global__ void seg_gather_kernel(SegTable t, int n, double* out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < t.off[n]; e += (int64_t)gridDim.x * blockDim.x) {
+        int i = 0;
+        while (e >= t.off[i + 1]) ++i;
+        out[e] = t.in[i] ? t.in[i][e - t.off[i]] : 0.0;
+    }
+}
+__global__ void scalar_combine_kernel(SegTable t, int n, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double v = 0.0;
+        for (int i = 0; i < n; ++i) v += t.coef[i] * t.in[i][0];
+        out[0] = v;
+    }
+}
+static int fill_seg(SegTable& t, int32_t n, const double* const* in, double* const* out, const int64_t* sizes, const double* coef,
+                    bool in_may_be_null) {
+    if (n < 1 || n > SEG_MAX || !in || !sizes) return MOBOCMF_BAD_ARG;
+    t.off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (sizes[i] < 0 || (!in[i] && !in_may_be_null && sizes[i] > 0) || (out && !out[i] && sizes[i] > 0)) return MOBOCMF_BAD_ARG;
+        t.in[i] = in[i];
+        t.out[i] = out ? out[i] : nullptr;
+        t.off[i + 1] = t.off[i] + sizes[i];
+        t.coef[i] = coef ? coef[i] : 1.0;
+    }
+    return MOBOCMF_OK;
+}
+static unsigned seg_blocks(int64_t total) {
+    const int64_t nb = (total + 255) / 256;
+    return (unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+int mobocmf_scale_segments(int32_t n, const double* const* in, double* const* out, const int64_t* sizes, const double* coef,
+                           const double* g, mobocmf_stream_t stream) {
+    SegTable t;
+    if (!out) return MOBOCMF_BAD_ARG;
+    const int rc = fill_seg(t, n, in, out, sizes, coef, false);
+    if (rc) return rc;
+    if (t.off[n] == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(seg_scale_kernel, dim3(seg_blocks(t.off[n])), dim3(256), 0, (hipStream_t)stream, t, n, g);
+    return CHECK_LAUNCH();
+}
+int mobocmf_gather_segments(int32_t n, const double* const* in, const int64_t* sizes, double* out, mobocmf_stream_t stream) {
+    SegTable t;
+    if (!out) return MOBOCMF_BAD_ARG;
+    const int rc = fill_seg(t, n, in, nullptr, sizes, nullptr, true);
+    if (rc) return rc;
+    if (t.off[n] == 0) return MOBOCMF_OK;
+    hipLaunchKernelGGL(seg_gather_kernel, dim3(seg_blocks(t.off[n])), dim3(256), 0, (hipStream_t)stream, t, n, out);
+    return CHECK_LAUNCH();
+}
+int mobocmf_scalar_combine(int32_t n, const double* const* x, const double* coef, double* out, mobocmf_stream_t stream) {
+    SegTable t;
+    if (!out || !coef) return MOBOCMF_BAD_ARG;
+    int64_t ones[SEG_MAX];
+    for (int i = 0; i < SEG_MAX; ++i) ones[i] = 1;
+    const int rc = fill_seg(t, n, x, nullptr, ones, coef, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scalar_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, n, out);
+    return CHECK_LAUNCH();
+}
+
 int mobocmf_propagate_forward(const double* mean, const double* var, const double* eps, double* f_out, int64_t n_out,
                               int32_t div, mobocmf_stream_t stream) {
     if (n_out < 0 || div < 1) return MOBOCMF_BAD_ARG;
@@ -1364,7 +1545,7 @@ int mobocmf_elbo_forward(int32_t L, const double* const* mean, const double* con
     for (int j = 0; j < n_kl; ++j) { if (!kls[j]) return MOBOCMF_BAD_ARG; t.kl[j] = kls[j]; }
     const int nb = elbo_blocks(L, mean, div, B);
     if (nb <= 4) {      // small: one block, one launch
-        hipLaunchKernelGGL(elbo_all_fwd_one_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, L, n_kl, scale, y, fid, out3);
+        hipLaunchKernelGGL(elbo_all_fwd_one_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, t, L, n_kl, scale, y, fid, out3);
         return CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(elbo_all_fwd_kernel, dim3(nb, L), dim3(256), 0, (hipStream_t)stream, t, y, fid, B, (double*)scratch);
@@ -1392,7 +1573,7 @@ int mobocmf_elbo_backward(int32_t L, const double* const* mean, const double* co
     }
     const int nb = elbo_blocks(L, mean, div, B);
     if (nb <= 4) {
-        hipLaunchKernelGGL(elbo_all_bwd_one_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, L, scale, y, fid, g_elbo, g_skl,
+        hipLaunchKernelGGL(elbo_all_bwd_one_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, t, L, scale, y, fid, g_elbo, g_skl,
                            g_kl);
         return CHECK_LAUNCH();
     }

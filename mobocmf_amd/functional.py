@@ -998,6 +998,147 @@ def elbo_fused(layers, y, fid, kls, scale):
     return _ElboFusedFn.apply(float(scale), int(y.numel()), specs, y, fid, len(kls), *tensors, *kls)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Conditioned training: the theta / omega factor losses and the glue around them, one launch each way
+# (include/mobocmf_hip.h: mobocmf_cond_factors_forward, _scale_segments, _gather_segments, _scalar_combine).
+# ---------------------------------------------------------------------------------------------------------------------
+def _ptr_table(ts):
+    return (ctypes.c_void_p * max(len(ts), 1))(*[0 if t is None else t.data_ptr() for t in ts])
+
+
+class _SplitRowsFn(torch.autograd.Function):
+    """(mean, var) -> their consecutive row ranges [0, c0), [c0, c0 + c1), ... as views (no launch); the backward writes the
+    ranges' gradients -- zeros where a range got none -- into one buffer in ONE launch (autograd's slice backward: a zero fill,
+    a copy and an add per range and tensor)."""
+
+    @staticmethod
+    def forward(ctx, mean, var, *counts):
+        ctx.shapes = (mean.shape, var.shape)
+        mean, var = _prep(mean.reshape(-1)), _prep(var.reshape(-1))
+        if sum(counts) != mean.numel() or var.numel() != mean.numel():
+            raise _lib.MobocmfError("split_rows: the counts must add up to the number of rows")
+        ctx.counts = tuple(int(c) for c in counts)
+        ctx.set_materialize_grads(False)
+        outs, off = [], 0
+        for t in (mean, var):
+            off = 0
+            for c in ctx.counts:
+                outs.append(t[off:off + c])
+                off += c
+        ctx.dev = mean.device
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        lib = _lib.require_device()
+        k, n = len(ctx.counts), sum(ctx.counts)
+        if all(g is None for g in gs):
+            return (None, None) + (None,) * k
+        gs = [None if g is None else _prep(g.reshape(-1)) for g in gs]
+        out = _empty(2 * n, device=ctx.dev)
+        sizes = (ctypes.c_int64 * (2 * k))(*(list(ctx.counts) * 2))
+        _lib.check(lib.mobocmf_gather_segments(2 * k, _ptr_table(gs), sizes, _ptr(out), _stream()), "mobocmf_gather_segments")
+        return (out[:n].view(ctx.shapes[0]), out[n:].view(ctx.shapes[1])) + (None,) * k
+
+
+def split_rows(mean, var, counts):
+    """Consecutive row ranges of (mean, var): returns ([mean ranges], [var ranges])."""
+    outs = _SplitRowsFn.apply(mean, var, *counts)
+    k = len(counts)
+    return list(outs[:k]), list(outs[k:])
+
+
+class _CondFactorsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, front, thr, *rows):
+        lib = _lib.require_device()
+        n_obj, n_con, P, T, coef_c, coef_1mc = meta
+        rows = [_prep(r.reshape(-1)) for r in rows]
+        if len(rows) != 2 * (n_obj + n_con) or any(r.numel() != T for r in rows):
+            raise _lib.MobocmfError("cond_factors: one mean and one variance row of T entries per objective / constraint")
+        dev = rows[0].device
+        fm, fv = rows[:n_obj], rows[n_obj:2 * n_obj]
+        cm, cv = rows[2 * n_obj:2 * n_obj + n_con], rows[2 * n_obj + n_con:]
+        grads = _empty(len(rows), T, device=dev)
+        g = [grads[i] for i in range(len(rows))]
+        loss = _empty((), device=dev)
+        front = None if front is None else _prep(front)
+        thr = None if thr is None else _prep(thr)
+        rc = lib.mobocmf_cond_factors_forward(n_obj, n_con, P, T, _ptr_table(fm), _ptr_table(fv), _ptr_table(cm), _ptr_table(cv),
+                                              _ptr(front), _ptr(thr), coef_c, coef_1mc, _ptr(loss),
+                                              _ptr_table(g[:n_obj]), _ptr_table(g[n_obj:2 * n_obj]),
+                                              _ptr_table(g[2 * n_obj:2 * n_obj + n_con]), _ptr_table(g[2 * n_obj + n_con:]),
+                                              _stream())
+        _lib.check(rc, "mobocmf_cond_factors_forward")
+        ctx.save_for_backward(grads)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.require_device()
+        (grads,) = ctx.saved_tensors
+        n, T = grads.shape
+        out = _empty(n, T, device=grads.device)
+        one = (ctypes.c_int64 * 1)(n * T)
+        _lib.check(lib.mobocmf_scale_segments(1, _ptr_table([grads]), _ptr_table([out]), one, None, _ptr(_prep(g)), _stream()),
+                   "mobocmf_scale_segments")
+        return (None, None, None) + tuple(out[i] for i in range(n))
+
+
+def cond_factors(fs_mean, fs_var, cs_mean, cs_var, front, thr, coef_c, coef_1mc):
+    """sum_{p, t} [coef_c c + coef_1mc (1 - c)], c(p, t) = prod_k Phi((cs_mean_k[t] - thr_k) / sd) prod_j Phi((front[p, j] -
+    fs_mean_j[t]) / sd): the omega factors (blackbox_mfdgp_fitter.py:235-243; coef_c = log eps) and, with no objective rows and
+    P = 1, the theta factors (:227-233; coef_c = log(1 - eps)).  Lists of row tensors (T entries each); one launch forward
+    (which also forms the gradients), one backward."""
+    n_obj, n_con = len(fs_mean), len(cs_mean)
+    T = (fs_mean[0] if n_obj else cs_mean[0]).numel()
+    P = front.shape[0] if (front is not None and n_obj) else 1
+    meta = (n_obj, n_con, int(P), int(T), float(coef_c), float(coef_1mc))
+    return _CondFactorsFn.apply(meta, front if n_obj else None, thr if n_con else None,
+                                *(list(fs_mean) + list(fs_var) + list(cs_mean) + list(cs_var)))
+
+
+class _ScalarCombineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coefs, *terms):
+        lib = _lib.require_device()
+        terms = [_prep(t.reshape(1)) for t in terms]
+        n = len(terms)
+        out = _empty((), device=terms[0].device)
+        ctx.coefs, ctx.dev = tuple(float(c) for c in coefs), terms[0].device
+        _lib.check(lib.mobocmf_scalar_combine(n, _ptr_table(terms), (ctypes.c_double * n)(*ctx.coefs), _ptr(out), _stream()),
+                   "mobocmf_scalar_combine")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.require_device()
+        n = len(ctx.coefs)
+        one = _ones_scalar(ctx.dev)
+        out = _empty(n, device=ctx.dev)
+        sizes = (ctypes.c_int64 * n)(*([1] * n))
+        _lib.check(lib.mobocmf_scale_segments(n, _ptr_table([one] * n), _ptr_table([out[i:i + 1] for i in range(n)]), sizes,
+                                              (ctypes.c_double * n)(*ctx.coefs), _ptr(_prep(g)), _stream()),
+                   "mobocmf_scale_segments")
+        return (None,) + tuple(out[i] for i in range(n))
+
+
+_ones = {}
+
+
+def _ones_scalar(dev):
+    t = _ones.get(dev)
+    if t is None:
+        t = torch.ones(1, dtype=torch.float64, device=dev)
+        _ones[dev] = t
+    return t
+
+
+def scalar_combine(terms, coefs):
+    """sum_i coefs[i] * terms[i] for 0-dim device tensors: one launch (and one for all the terms' gradients)."""
+    return _ScalarCombineFn.apply(tuple(coefs), *terms)
+
+
 class _AcqMomentsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu_t, var_t, S):

@@ -323,18 +323,34 @@ class BlackBoxMFDGPFitter:
         return local_index if getattr(h, "global_index", None) is None else h.global_index
 
     def loss_theta_factors(self, cs_mean, cs_var, threshold):
-        """:227-233."""
+        """:227-233.  On the GPU one launch (functional.cond_factors); host tensors: the plain torch statement."""
+        if cs_mean.is_cuda:
+            from .. import functional as F
+            thr = threshold.reshape(1) if torch.is_tensor(threshold) else torch.tensor([float(threshold)], dtype=cs_mean.dtype,
+                                                                                     device=cs_mean.device)
+            return F.cond_factors([], [], [cs_mean.reshape(-1)], [cs_var.reshape(-1)], None, thr,
+                                  float(np.log(1.0 - self.eps)), float(np.log(self.eps)))
         c = _ncdf((cs_mean - threshold) / torch.sqrt(cs_var))
         return torch.sum(np.log(1.0 - self.eps) * c + np.log(self.eps) * (1.0 - c))
 
     def loss_omega_factors(self, fs_mean, fs_var, cs_mean, cs_var, pareto_front):
-        """:235-243.  fs_* (n_obj, T), cs_* (n_con, T)."""
-        thr = self._thresholds_on(fs_mean.device, all_constraints=True)
-        if thr.numel() != cs_mean.shape[0]:
+        """:235-243.  fs_* (n_obj, T), cs_* (n_con, T) -- stacked tensors or lists of rows.  On the GPU one launch
+        (functional.cond_factors: forward, gradients included); host tensors: the plain torch statement."""
+        rows = lambda t: list(t) if isinstance(t, (list, tuple)) else list(t.unbind(0))
+        fm, fv, cm, cv = rows(fs_mean), rows(fs_var), rows(cs_mean), rows(cs_var)
+        ref = fm[0] if fm else cm[0]
+        thr = self._thresholds_on(ref.device, all_constraints=True)
+        if thr.numel() != len(cm):
             raise ValueError("omega factors: %d constraint rows but %d thresholds (sharded surrogates need "
-                             "set_global_constraint_thresholds)" % (cs_mean.shape[0], thr.numel()))
+                             "set_global_constraint_thresholds)" % (len(cm), thr.numel()))
+        if ref.is_cuda and len(fm) <= 8 and len(cm) <= 8:
+            from .. import functional as F
+            front = self._cached_const(("front", id(pareto_front)), lambda: pareto_front.contiguous())
+            return F.cond_factors(fm, fv, cm, cv, front, thr, float(np.log(self.eps)), float(np.log(1.0 - self.eps)))
+        fs_mean, fs_var = torch.stack(fm), torch.stack(fv)
         c = torch.ones(fs_mean.shape[-1], dtype=fs_mean.dtype, device=fs_mean.device)
-        if cs_mean.numel():
+        if cm:
+            cs_mean, cs_var = torch.stack(cm), torch.stack(cv)
             c = _prod(_ncdf((cs_mean - thr[:, None]) / torch.sqrt(cs_var)), 0)
         c = c * _prod(_ncdf((pareto_front[:, :, None] - fs_mean) / torch.sqrt(fs_var)), 1)
         return torch.sum(np.log(self.eps) * c + np.log(1 - self.eps) * (1.0 - c))
@@ -361,45 +377,69 @@ class BlackBoxMFDGPFitter:
         With surrogates sharded over ranks the omega factors need every model's (mean, var) at x_tilde: the local ones
         carry gradient, the others arrive as constants through one all-gather (mobocmf_amd.parallel)."""
         from .. import parallel
+        from .. import functional as F
+        from ..gp import MultivariateNormal as MVN
         P, T = self.pareto_set.shape[0], x_tilde.shape[0]
-        loss = 0.0
+        # The loss is a signed sum of scalar terms.  They are collected and combined in ONE launch at the end, the rows of every
+        # layer's moments are split into their three ranges (training batch | Pareto set | x~) by one autograd node per layer,
+        # and the theta / omega factors are one launch each: as framework ops (a subtraction per term, slice / stack backward
+        # per range, cdf / product / sum chains) this glue was ~100 element-wise launches per iteration of a loop whose cost IS
+        # its launch count.
+        terms, coefs = [], []
         tilde = {}
         k = 0
+        log_e, log_1me = float(np.log(self.eps)), float(np.log(1.0 - self.eps))
         for tag, i, h in self._handlers():
             xb, yb, fb = batches[(tag, i)] if batches is not None else self.next_conditioned_batch(h)
             B = xb.shape[0]
             S = h.mfdgp.num_samples_for_training
             top = h.num_fidelities - 1
             out = h.mfdgp(torch.cat([xb, self.pareto_set, x_tilde], 0), eps=None if eps is None else eps[(tag, i)])
-            def sl(dist, a, b):          # rows [a, b) of the concatenated input (x rows-per-input-row of the layer)
-                rpb = dist.mean.numel() // (B + P + T)
-                return dist.mean.reshape(-1)[a * rpb:b * rpb], dist.variance.reshape(-1)[a * rpb:b * rpb]
-
-            from ..gp import MultivariateNormal as MVN
-            batch = [MVN(*sl(d, 0, B)) for d in out]
-            loss = loss - h.elbo(batch, yb.T, fb)[0] / B * h.num_data
-            mu_p, var_p = sl(out[top], B, B + P)
+            parts = []
+            for d in out:
+                rpb = d.mean.numel() // (B + P + T)      # rows of the layer per input row
+                parts.append(F.split_rows(d.mean, d.variance, [B * rpb, P * rpb, T * rpb]))
+            batch = [MVN(pm[0], pv[0]) for pm, pv in parts]
+            terms.append(h.elbo(batch, yb.T, fb)[0])
+            coefs.append(-float(h.num_data) / B)
+            mu_p, var_p = parts[top][0][1], parts[top][1][1]
             if tag == "OBJ":
-                pf = torch.full((P, 1), float(top), dtype=xb.dtype, device=xb.device)
+                pf = self._cached_const(("pf", top, P), lambda: torch.full((P, 1), float(top), dtype=xb.dtype, device=xb.device))
                 pl = [None] * top + [MVN(mu_p, var_p)]
                 gi = self._global_index(h, i)                 # the front's columns follow the GLOBAL objective order
-                loss = loss - h.elbo(pl, self.pareto_front[:, gi:gi + 1].T, pf, include_kl_term=False)
+                col = self._cached_const(("front_col", gi), lambda: self.pareto_front[:, gi:gi + 1].T.contiguous())
+                terms.append(h.elbo(pl, col, pf, include_kl_term=False))
+                coefs.append(-1.0)
             else:
                 if S > 1:
                     raise NotImplementedError("theta factors are defined for one sample per row (reference: S = 1)")
-                loss = loss - self.loss_theta_factors(mu_p, var_p, self._thresholds_on(xb.device)[k])
+                thr_k = self._thresholds_on(xb.device)[k:k + 1]
+                terms.append(F.cond_factors([], [], [mu_p], [var_p], None, thr_k, log_1me, log_e))      # :227-233
+                coefs.append(-1.0)
                 k += 1
-            tilde[(tag, i)] = sl(out[top], B + P, B + P + T)
-        fm = torch.stack([tilde[(t, i)][0] for t, i, _ in self._handlers() if t == "OBJ"])
-        fv = torch.stack([tilde[(t, i)][1] for t, i, _ in self._handlers() if t == "OBJ"])
-        cons = [(tilde[(t, i)][0], tilde[(t, i)][1]) for t, i, _ in self._handlers() if t == "CON"]
-        cm = torch.stack([c[0] for c in cons]) if cons else fm.new_zeros((0, T))
-        cv = torch.stack([c[1] for c in cons]) if cons else fm.new_zeros((0, T))
+            tilde[(tag, i)] = (parts[top][0][2], parts[top][1][2])
+        fm = [tilde[(t, i)][0] for t, i, _ in self._handlers() if t == "OBJ"]
+        fv = [tilde[(t, i)][1] for t, i, _ in self._handlers() if t == "OBJ"]
+        cm = [tilde[(t, i)][0] for t, i, _ in self._handlers() if t == "CON"]
+        cv = [tilde[(t, i)][1] for t, i, _ in self._handlers() if t == "CON"]
         if parallel.world()[1] > 1:
             oi = [self._global_index(h, i) for t, i, h in self._handlers() if t == "OBJ"]
             ci = [self._global_index(h, i) for t, i, h in self._handlers() if t == "CON"]
-            fm, fv, cm, cv = parallel.gather_with_local_grad(fm, fv, cm, cv, oi, ci)
-        return loss - self.loss_omega_factors(fm, fv, cm, cv, self.pareto_front)
+            stk = lambda rows: torch.stack(rows) if rows else x_tilde.new_zeros((0, T))
+            gfm, gfv, gcm, gcv = parallel.gather_with_local_grad(stk(fm), stk(fv), stk(cm), stk(cv), oi, ci)
+            fm, fv, cm, cv = list(gfm.unbind(0)), list(gfv.unbind(0)), list(gcm.unbind(0)), list(gcv.unbind(0))
+        terms.append(self.loss_omega_factors(fm, fv, cm, cv, self.pareto_front))
+        coefs.append(-1.0)
+        return F.scalar_combine(terms, coefs)
+
+    def _cached_const(self, key, make):
+        """Small constant device tensors of the conditioned loss, built once (a fill / copy launch per iteration otherwise)."""
+        c = self.__dict__.setdefault("_const_cache", {})
+        hit = c.get(key)
+        if hit is None or hit[0] is not self.pareto_front:
+            hit = (self.pareto_front, make())
+            c[key] = hit
+        return hit[1]
 
     def train_conditioned_mfdgps(self, num_iters=None, use_graphs=None):
         """ONE Adam over all models' parameters, kernel hyper-parameters frozen (:245-268, :345-354).  On the GPU the

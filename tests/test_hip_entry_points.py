@@ -295,3 +295,58 @@ def _mid_gemm_cases(F, Mr, Nc, Kd):
             finally:
                 F.set_mid_gemm_max(1024)
             assert rel(C2, want) < 1e-12 and rel(C, C2) < 1e-12, (tri, tb, alpha)
+
+
+@pytest.mark.parametrize("n_obj,n_con,P,T", [(2, 1, 50, 10), (1, 0, 7, 3), (3, 2, 33, 300), (8, 8, 5, 17)])
+def test_conditioned_factor_losses_match_oracle(n_obj, n_con, P, T):
+    """mobocmf_cond_factors_forward (omega factors, blackbox_mfdgp_fitter.py:235-243; theta factors :227-233) and the segment
+    glue of the conditioned loss vs the oracle's torch statement: value and the gradient w.r.t. every mean / variance entry."""
+    from mobocmf_amd import functional as F
+    from oracle import mfdgp_oracle as O
+    rng = np.random.default_rng(n_obj * 100 + n_con * 10 + T)
+    t = lambda a: torch.tensor(a, dtype=torch.float64)
+    fm, fv = t(rng.standard_normal((n_obj, T))), t(0.2 + rng.random((n_obj, T)))
+    cm, cv = t(rng.standard_normal((n_con, T))), t(0.2 + rng.random((n_con, T)))
+    front, thr = t(rng.standard_normal((P, n_obj))), t(0.3 * rng.standard_normal(n_con))
+    eps = 1e-8
+    leaves_o = [x.clone().requires_grad_(True) for x in (fm, fv, cm, cv)]
+    lo = O.loss_omega_factors(leaves_o[0], leaves_o[1], leaves_o[2], leaves_o[3], front, thr, eps)
+    lo.backward()
+    leaves = [x.clone().to(DEV).requires_grad_(True) for x in (fm, fv, cm, cv)]
+    rows = lambda x: list(x.unbind(0))
+    lh = F.cond_factors(rows(leaves[0]), rows(leaves[1]), rows(leaves[2]), rows(leaves[3]), front.to(DEV), thr.to(DEV),
+                        float(np.log(eps)), float(np.log(1 - eps)))
+    (2.5 * lh).backward()
+    assert rel(lh, lo) < 1e-12
+    for a, b in zip(leaves, leaves_o):
+        if b.numel():
+            assert rel(a.grad, 2.5 * b.grad) < 1e-11
+    if n_con:      # theta factors of the first constraint (no objective rows, P = 1)
+        mu, var = cm[0].clone().requires_grad_(True), cv[0].clone().requires_grad_(True)
+        lt_o = O.loss_theta_factors(mu, var, thr[0], eps)
+        lt_o.backward()
+        mu_h, var_h = cm[0].clone().to(DEV).requires_grad_(True), cv[0].clone().to(DEV).requires_grad_(True)
+        lt = F.cond_factors([], [], [mu_h], [var_h], None, thr[:1].to(DEV), float(np.log(1 - eps)), float(np.log(eps)))
+        lt.backward()
+        assert rel(lt, lt_o) < 1e-12 and rel(mu_h.grad, mu.grad) < 1e-11 and rel(var_h.grad, var.grad) < 1e-11
+
+
+def test_split_rows_and_scalar_combine_are_exact():
+    """The glue nodes of the conditioned loss: row ranges as views with a one-launch backward (zeros where a range got no
+    gradient), and a signed sum of scalar terms."""
+    from mobocmf_amd import functional as F
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    m = torch.randn(37, dtype=torch.float64, device=DEV, generator=g, requires_grad=True)
+    v = torch.rand(37, dtype=torch.float64, device=DEV, generator=g).requires_grad_(True)
+    (m0, m1, m2), (v0, v1, v2) = F.split_rows(m, v, [5, 20, 12])
+    assert torch.equal(m1, m.detach()[5:25]) and torch.equal(v2, v.detach()[25:])
+    terms = [(m0 * m0).sum(), (m2 * v2).sum(), v1.sum()]            # m1 and v0 get no gradient at all
+    loss = F.scalar_combine(terms, [-2.0, 0.5, 3.0])
+    loss.backward()
+    md, vd = m.detach(), v.detach()
+    want = -2.0 * (md[:5] ** 2).sum() + 0.5 * (md[25:] * vd[25:]).sum() + 3.0 * vd[5:25].sum()
+    assert abs(float(loss) - float(want)) < 1e-12 * max(1.0, abs(float(want)))
+    gm = torch.cat([-4.0 * md[:5], torch.zeros(20, dtype=torch.float64, device=DEV), 0.5 * vd[25:]])
+    gv = torch.cat([torch.zeros(5, dtype=torch.float64, device=DEV), 3.0 * torch.ones(20, dtype=torch.float64, device=DEV), 0.5 * md[25:]])
+    assert torch.equal(m.grad, gm) and torch.equal(v.grad, gv)
