@@ -10,6 +10,8 @@ import sys
 
 R = "r" + (sys.argv[1] if len(sys.argv) > 1 else "02")
 F, P = "gpurun_out/final", "profiles"
+FB = "gpurun_out/finalb" if os.path.isdir("gpurun_out/finalb") else F      # round 4: the collection runs as two gpurun calls
+                                                                         # (tools/collect_profiles_a.sh / _b.sh)
 cp = lambda a, b: shutil.copy(a, os.path.join(P, R + "_" + b))
 clean = lambda path: "".join(l for l in open(path) if "amdgpu.ids" not in l and "run_backward" not in l)
 cp(F + "/bench_C3.json", "bench_C3.json")
@@ -21,8 +23,8 @@ cp(F + "/single_stream_step_timeline.txt", "single_stream_step_timeline.txt")
 cp(F + "/C5_step_timeline.txt", "C5_step_timeline.txt")
 cp(F + "/gemm_variants_kernel_summary.md", "gemm_variants_isolated_rocprof_summary.md")
 cp(glob.glob(F + "/rk/*/*kernel_stats.csv")[0], "gemm_variants_isolated_kernel_stats.csv")
-cp(F + "/pmc_gemm.json", "pmc_gemm.json")
-for name in ("instep_clock.md", "tile_sweep.txt", "C2_step_timeline.txt", "C1_step_timeline.txt"):
+cp(FB + "/pmc_gemm.json", "pmc_gemm.json")
+for name in ("instep_clock.md", "tile_sweep.txt", "C2_step_timeline.txt", "C1_step_timeline.txt", "cond_iteration_timeline.txt"):
     if os.path.exists(F + "/" + name):
         cp(F + "/" + name, name)
 if os.path.exists(F + "/gemm_stamps.txt"):
@@ -37,24 +39,25 @@ with open(os.path.join(P, R + "_gemm_variants.txt"), "w") as o:
         o.write("# tools/gemm_variants.py -- %s; HIP events, 20 launches per timing, three interleaved rounds after 0.3 s of load\n" % title)
         o.write(clean(F + "/" + name) + "\n")
 with open(os.path.join(P, R + "_other_measurements.txt"), "w") as o:
-    o.write("# bench.py on the other configurations (same harness; steps/s, whole job)\n" + open(F + "/other_configs.txt").read() + "\n")
-    o.write("# tools/size_sweep.py -- one surrogate, M = N, S = 1, two fidelities, rows shuffled (general branch)\n" + clean(F + "/size_sweep.txt") + "\n")
-    o.write("# tools/acq_bench.py 50\n" + clean(F + "/acq_bench.txt") + "\n")
-    o.write("# tools/cond_bench.py 400\n" + clean(F + "/cond_bench.txt") + "\n")
-    o.write("# examples/example_acquisition_mfdgp_forrester.py (the reference's walk-through at its own schedule)\n" + clean(F + "/forrester_walkthrough.txt") + "\n")
-    o.write("# tools/mfma_peak (pure instruction streams, no memory traffic)\n" + open(F + "/mfma_peak.txt").read())
+    o.write("# bench.py on the other configurations (same harness; steps/s, whole job)\n" + open(FB + "/other_configs.txt").read() + "\n")
+    o.write("# tools/size_sweep.py -- one surrogate, M = N, S = 1, two fidelities, rows shuffled (general branch)\n" + clean(FB + "/size_sweep.txt") + "\n")
+    o.write("# tools/acq_bench.py 50\n" + clean(FB + "/acq_bench.txt") + "\n")
+    o.write("# tools/cond_bench.py 400\n" + clean(FB + "/cond_bench.txt") + "\n")
+    o.write("# examples/example_acquisition_mfdgp_forrester.py (the reference's walk-through at its own schedule)\n" + clean(FB + "/forrester_walkthrough.txt") + "\n")
+    if os.path.exists(F + "/mfma_peak.txt"):
+        o.write("# tools/mfma_peak (pure instruction streams, no memory traffic)\n" + open(F + "/mfma_peak.txt").read())
 # SQ counters of the dominant kernel
 acc = {}
-for r in csv.DictReader(open(glob.glob(F + "/pmc_sq/*/*counter_collection.csv")[0])):
+for r in csv.DictReader(open(glob.glob(FB + "/pmc_sq/*/*counter_collection.csv")[0])):
     if "gemm_f64" in r["Kernel_Name"]:
         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-     for r in csv.DictReader(open(glob.glob(F + "/pmc_sq/*/*kernel_trace.csv")[0])) if "gemm_f64" in r["Kernel_Name"]]
+     for r in csv.DictReader(open(glob.glob(FB + "/pmc_sq/*/*kernel_trace.csv")[0])) if "gemm_f64" in r["Kernel_Name"]]
 dur = sum(d) / len(d)
 mf = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(acc["SQ_VALU_MFMA_BUSY_CYCLES"])
 clk = sum(acc["GRBM_GUI_ACTIVE"]) / len(acc["GRBM_GUI_ACTIVE"]) / 8 / dur / 1e3
 ms = json.load(open(F + "/bench_C3.json"))["roofline"]["kernel_ms"]
-shape = json.load(open(F + "/pmc_gemm.json"))["shape"]
+shape = json.load(open(FB + "/pmc_gemm.json"))["shape"]
 alg = shape[0] * shape[0] * shape[1] / 1e9
 open(os.path.join(P, R + "_pmc_sq_counters.md"), "w").write(("# SQ counters of the dominant kernel (A = L^-1 K_mn with the "
     "column-statistics epilogue, %d x %d x %d)\n" % tuple(shape)) + """
