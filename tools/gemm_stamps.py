@@ -18,7 +18,8 @@ from mobocmf_amd import functional as F  # noqa: E402
 dev = torch.device("cuda")
 lib = _lib.load()
 raw = ctypes.CDLL(_lib.LIB_PATH)
-M, N = 512, 65536
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 A = torch.tril(torch.randn(M, M, dtype=torch.float64, device=dev))
 B = torch.randn(M, N, dtype=torch.float64, device=dev)
 C = torch.empty(M, N, dtype=torch.float64, device=dev)
