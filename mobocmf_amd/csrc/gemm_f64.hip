@@ -258,7 +258,10 @@ __global__ __launch_bounds__(256, RM == 64 ? 3 : 2) void gemm_f64_kernel(GemmArg
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // wave-uniform, and told so: the LDS destinations of the stage's DMA instructions (M0) and the wavefront's tile offsets are
+    // then scalar arithmetic instead of a vector computation + v_readfirstlane per DMA instruction and K step (round 4: -10
+    // VGPRs, 1-4 % per launch at the 512-row shapes, C3 996 -> 1006 steps/s in a same-box A/B)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
 
