@@ -28,7 +28,8 @@ for cfg in C5 C2 C1; do
   rm -rf $O/p_$cfg
 done
 EPOCHS=60 rocprofv3 --kernel-trace --output-format csv -d $O/p_cond -- python3 tools/cond_bench.py 40 > /dev/null 2>&1
-python tools/step_timeline.py $(ls $O/p_cond/*/*kernel_trace.csv | head -1) 60 > $O/cond_iteration_timeline.txt || true
+# cond_bench.py ends with 40 graph-replayed then 40 eager conditioned iterations: -60 lands in the replayed ones
+python tools/step_timeline.py $(ls $O/p_cond/*/*kernel_trace.csv | head -1) -60 > $O/cond_iteration_timeline.txt || true
 rm -rf $O/p_cond
 rm -rf $O/prof/*/*agent_info.csv $O/prof1/*/*agent_info.csv
 du -sh $O

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One step of a single-stream run as a timeline: kernels in launch order between two Adam updates, with start offset,
 duration and the idle gap in front of each (rocprofv3 --kernel-trace CSV).
-usage: python tools/step_timeline.py <kernel_trace.csv> [step_index]"""
+usage: python tools/step_timeline.py <kernel_trace.csv> [step_index, negative = from the end]"""
 import csv
 import re
 import sys
@@ -9,6 +9,8 @@ import sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adam_multi" in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) - 2
+if k < 0:  # counted from the end of the run
+    k += len(idx)
 a, b = idx[k] + 1, idx[k + 1] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
