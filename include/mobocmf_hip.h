@@ -363,6 +363,62 @@ int mobocmf_scale_segments(int32_t n, const double* const* in, double* const* ou
 int mobocmf_gather_segments(int32_t n, const double* const* in, const int64_t* sizes, double* out, mobocmf_stream_t stream);
 int mobocmf_scalar_combine(int32_t n, const double* const* x, const double* coef, double* out, mobocmf_stream_t stream);
 
+/* ---- The whole ELBO step of SMALL surrogates in ONE launch (blackbox_mfdgp_fitter.py:161-171 at the reference's own sizes:
+ * M = N = tens of points, examples/example_acquisition_mfdgp_forrester/...py:51-62).  At those sizes a step through the layer
+ * entry points above is ~50 dependent launches of ~4.7 us each whatever they compute.  Here ONE workgroup per surrogate runs
+ * zero_grad + MFDGP.forward + VariationalELBOMF + backward + Adam (torch.optim.Adam semantics) as a sequence of
+ * workgroup-barrier-separated phases: the M x M chain lives in LDS, the M x N' panels in `work`; several surrogates = several
+ * workgroups of the same launch.  Same algebra and the same results as the layer path, rows ordered by DESCENDING
+ * fidelity with layer l evaluated on the first rows[l] of them.
+ *
+ * Limits: L <= 3 layers, M <= 32 inducing points shared by all layers (Z~_l = [Zx, m_{l-1}], mfdgp_hidden_layer.py:555-556),
+ * d <= 8, train branch only.  mobocmf_tiny_model is read by the kernel from DEVICE memory (`dev_models`: the caller uploads the
+ * array once); `host_models` is the same array in host memory, used for validation and launch geometry only.
+ *   raw[l][s]: the raw (unconstrained, softplus) kernel parameters in the packed order of the hyper-parameter vector above --
+ *     layer 0: s = 0 outputscale (1), s = 1 lengthscales (d); layers >= 1: s = 0..4 a1, af, nu, a2, lsf (1 each), s = 5 ls1 (d),
+ *     s = 6 ls2 (d).  m[l] (M), L_S[l] (M x M row-major, lower triangle used), raw_noise[l] (Interval(noise_lo, noise_hi)).
+ *   trainable[l]: bit s (< 7) raw[l][s], bit 7 m, bit 8 L_S, bit 9 raw_noise -- cleared bits are left untouched by the update.
+ *   rng[l] (l >= 1): {seed, calls, ticket} of the layer's eps stream as in mobocmf_propagate_rng_forward (same draws for the
+ *     same state; `calls` advances by one per step); eps[l] != NULL replaces the draw (rows[l] * S values).
+ *   Flat layout of grad / adam_m / adam_v (mobocmf_tiny_flat_len doubles): per layer [packed hyper-parameters | m | L_S], then
+ *     raw_noise of every layer.  grad (optional) receives d(-ELBO)/d(raw parameters) of the step.
+ *   out[0] = ELBO, out[1] = scaled KL, out[2] = -ELBO (before the update); info[l] = 0 or the failed Cholesky pivot (1-based).
+ * do_update = 0: gradients only (no parameter, optimiser or rng-counter write). */
+#define MOBOCMF_TINY_MAX_LAYERS 3
+#define MOBOCMF_TINY_MAX_M 32
+#define MOBOCMF_TINY_MAX_D 8
+typedef struct mobocmf_tiny_model {
+    int32_t L, M, d, S;
+    int32_t N;                               /* batch rows, ordered by descending fidelity */
+    int32_t rows[MOBOCMF_TINY_MAX_LAYERS];   /* rows[0] == N >= rows[1] >= ... >= 1 */
+    uint32_t trainable[MOBOCMF_TINY_MAX_LAYERS];
+    int32_t reserved;
+    const double* x;                         /* N x d */
+    const double* y;                         /* N */
+    const double* fid;                       /* N (levels as doubles, as VariationalELBOMF compares them) */
+    const double* Zx;                        /* M x d */
+    double* raw[MOBOCMF_TINY_MAX_LAYERS][7];
+    double* m[MOBOCMF_TINY_MAX_LAYERS];
+    double* L_S[MOBOCMF_TINY_MAX_LAYERS];
+    double* raw_noise[MOBOCMF_TINY_MAX_LAYERS];
+    double noise_lo[MOBOCMF_TINY_MAX_LAYERS], noise_hi[MOBOCMF_TINY_MAX_LAYERS];
+    int64_t* rng[MOBOCMF_TINY_MAX_LAYERS];
+    const double* eps[MOBOCMF_TINY_MAX_LAYERS];
+    double* adam_m;
+    double* adam_v;
+    int64_t* steps_done;                     /* completed Adam steps (device word, advanced by the launch) */
+    double* work;                            /* mobocmf_tiny_work_bytes */
+    double* grad;                            /* optional */
+    double* out;                             /* 3 doubles */
+    int32_t* info;                           /* L words */
+    double kl_scale;                         /* batch / num_data (variational_elbo_mf.py:44-47) */
+    double jitter;
+} mobocmf_tiny_model;
+int mobocmf_tiny_flat_len(const mobocmf_tiny_model* model, int64_t* len);
+int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes);
+int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
+                           double lr, double beta1, double beta2, double eps, int32_t do_update, mobocmf_stream_t stream);
+
 /* ---- Exact-GP comparison baselines (mobocmf/models/mfgp.py:24-141,145-184; mfgp_lin.py:101-189) on the layer's kernels.
  * The reference inherits exact inference from GPyTorch's ExactGP; here the Gram matrices come from mobocmf_gram_forward,
  * the multi-fidelity combination is one element-wise launch, the factorisation / triangular inverse are the variational

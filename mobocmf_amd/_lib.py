@@ -38,6 +38,24 @@ class LayerDesc(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("tuning", ctypes.POINTER(Tuning)), ("probe_events", ctypes.c_void_p)]
 
 
+TINY_MAX_LAYERS, TINY_MAX_M, TINY_MAX_D = 3, 32, 8      # MOBOCMF_TINY_MAX_* of include/mobocmf_hip.h
+
+
+class TinyModel(ctypes.Structure):
+    """mobocmf_tiny_model: one small surrogate of mobocmf_tiny_elbo_step (the kernel reads the array from DEVICE memory)."""
+    _L = TINY_MAX_LAYERS
+    _fields_ = [("L", ctypes.c_int32), ("M", ctypes.c_int32), ("d", ctypes.c_int32), ("S", ctypes.c_int32),
+                ("N", ctypes.c_int32), ("rows", ctypes.c_int32 * _L), ("trainable", ctypes.c_uint32 * _L),
+                ("reserved", ctypes.c_int32),
+                ("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("fid", ctypes.c_void_p), ("Zx", ctypes.c_void_p),
+                ("raw", (ctypes.c_void_p * 7) * _L), ("m", ctypes.c_void_p * _L), ("L_S", ctypes.c_void_p * _L),
+                ("raw_noise", ctypes.c_void_p * _L), ("noise_lo", ctypes.c_double * _L), ("noise_hi", ctypes.c_double * _L),
+                ("rng", ctypes.c_void_p * _L), ("eps", ctypes.c_void_p * _L),
+                ("adam_m", ctypes.c_void_p), ("adam_v", ctypes.c_void_p), ("steps_done", ctypes.c_void_p),
+                ("work", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("out", ctypes.c_void_p), ("info", ctypes.c_void_p),
+                ("kl_scale", ctypes.c_double), ("jitter", ctypes.c_double)]
+
+
 class MobocmfError(RuntimeError):
     pass
 
@@ -101,6 +119,9 @@ SYMBOLS = {
     "mobocmf_scale_segments": [_I32, _P, _P, _P, _P, _P, _P],
     "mobocmf_gather_segments": [_I32, _P, _P, _P, _P],
     "mobocmf_scalar_combine": [_I32, _P, _P, _P, _P],
+    "mobocmf_tiny_flat_len": [ctypes.POINTER(TinyModel), ctypes.POINTER(_I64)],
+    "mobocmf_tiny_work_bytes": [ctypes.POINTER(TinyModel), ctypes.POINTER(_SZ)],
+    "mobocmf_tiny_elbo_step": [_P, _P, _I32, _D, _D, _D, _D, _I32, _P],
     "mobocmf_rff_eval": [_I32, _I32, _I32, _I64] + [_P] * 8 + [_D, _D, _D, _P, _P],
     "mobocmf_gram_forward": [_I32, _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P],
     "mobocmf_check_info": [_P, ctypes.POINTER(_I32), _P],

@@ -165,3 +165,27 @@ struct GramArgs {
 // kind 1: [a1, af, nu, a2, lsf, ls1[0..d), ls2[0..d)]         (5 + 2d doubles)
 static inline int hyp_len(int kind, int d) { return kind == 0 ? 1 + d : 5 + 2 * d; }
 #define MAX_D MOBOCMF_MAX_D
+
+// ------------------------------------------------------------------ eps of the training branch (elementwise.hip, tiny_step.hip)
+// counter-based Philox4x32-10 keyed by (seed, call counter, row) + Box-Muller in float64: the draw of
+// mobocmf_propagate_rng_forward, shared with the one-launch step so that both produce the same eps from the same state
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t call, uint64_t idx) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)call, (uint32_t)(call >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    // two uniforms in (0, 1) with 53 random bits each, then Box-Muller (the cosine branch)
+    const double u1 = ((double)(((uint64_t)(r[0] >> 5) << 26) | (uint64_t)(r[1] >> 6)) + 0.5) * 1.1102230246251565e-16;
+    const double u2 = ((double)(((uint64_t)(r[2] >> 5) << 26) | (uint64_t)(r[3] >> 6)) + 0.5) * 1.1102230246251565e-16;
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}

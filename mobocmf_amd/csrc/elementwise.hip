@@ -714,26 +714,6 @@ __global__ void propagate_fwd_kernel(const double* mean, const double* var, cons
 // x 3, owned by the layer): every block reads `calls`, the block that takes the last ticket advances it -- a captured step
 // replays with fresh eps and without torch's generator (whose graph support costs two fill launches per replay and one
 // launch for the draw).  eps is written out for the backward pass.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                              uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t call, uint64_t idx) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)call, (uint32_t)(call >> 32), (uint32_t)seed,
-                  (uint32_t)(seed >> 32), r);
-    // two uniforms in (0, 1) with 53 random bits each, then Box-Muller (the cosine branch)
-    const double u1 = ((double)(((uint64_t)(r[0] >> 5) << 26) | (uint64_t)(r[1] >> 6)) + 0.5) * 1.1102230246251565e-16;
-    const double u2 = ((double)(((uint64_t)(r[2] >> 5) << 26) | (uint64_t)(r[3] >> 6)) + 0.5) * 1.1102230246251565e-16;
-    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
-}
 __global__ void propagate_rng_fwd_kernel(const double* mean, const double* var, int64_t* rng_state, double* f, double* eps_out,
                                          int64_t n, int div) {
     const uint64_t seed = (uint64_t)rng_state[0], call = (uint64_t)__atomic_load_n(&rng_state[1], __ATOMIC_RELAXED);

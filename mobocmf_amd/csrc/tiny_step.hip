@@ -1,0 +1,756 @@
+// The whole ELBO step of a SMALL surrogate in one launch (include/mobocmf_hip.h: mobocmf_tiny_elbo_step), gfx950.
+//
+// At the reference's own sizes (M = N = tens of points, examples/example_acquisition_mfdgp_forrester/...py:51-62) a step
+// through the layer entry points is ~50 dependent launches of ~4.7 us each whatever they compute.  Here ONE
+// workgroup of 256 threads runs zero_grad + MFDGP.forward (mfdgp.py:174-196) + VariationalELBOMF (variational_elbo_mf.py:
+// 24-51) + backward + Adam (blackbox_mfdgp_fitter.py:161-171) as ~45 phases separated by workgroup barriers (~0.1 us each
+// instead of a kernel boundary); several surrogates are several workgroups of the same launch.  The algebra is DESIGN.md 1
+// line for line -- explicit L^-1, A = L^-1 K, C = U^T A, the single weighted syrk H, Murray's Cholesky backward -- as
+// element-parallel products: a thread owns an output element and walks its (triangular) contraction range.  The M x M chain
+// state of every layer lives in LDS; the M x N' panels in `work` (a workgroup reads its own global writes after a barrier:
+// one CU, one L1).  Only the Cholesky + triangular inverse is serial: one wavefront per layer, the matrix row-per-lane in
+// registers, pivots and multipliers broadcast by v_readlane (no LDS round trip, no barrier), the layers side by side.
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 256;                          // threads per workgroup
+constexpr int TLM = MOBOCMF_TINY_MAX_LAYERS;
+constexpr int DBT = MOBOCMF_TINY_MAX_D;          // x columns of a staged inducing row (zero-padded)
+constexpr int ZW = DBT + 1;                      // + the f column
+constexpr int HS = 5 + 2 * DBT;                  // packed hyper-parameters of a layer, at most
+constexpr int NVEC = 11;                         // per-column vectors of a layer kept in `work`
+constexpr double MINV = 1e-10;                   // gpytorch.settings.min_variance (float64)
+constexpr double LOG2PI = 1.8378770664093453;
+
+struct Geom {
+    int L, M, d, S;
+    int ncol[TLM], H[TLM];
+    int64_t flat_off[TLM], flat_noise, flat_len;
+    int64_t work_off[TLM], scratch_off, work_len;
+    int ncmax;
+};
+__host__ __device__ inline void geom_of(const mobocmf_tiny_model& md, Geom& g) {
+    g.L = md.L; g.M = md.M; g.d = md.d; g.S = md.S;
+    int64_t fo = 0;
+    g.ncmax = 0;
+    for (int l = 0; l < TLM; ++l) {
+        g.ncol[l] = l < md.L ? md.rows[l] * (l ? md.S : 1) : 0;
+        g.H[l] = l == 0 ? 1 + md.d : 5 + 2 * md.d;
+        g.flat_off[l] = fo;
+        if (l < md.L) fo += g.H[l] + md.M + (int64_t)md.M * md.M;
+        if (g.ncol[l] > g.ncmax) g.ncmax = g.ncol[l];
+    }
+    g.flat_noise = fo;
+    g.flat_len = fo + md.L;
+    int64_t wo = (g.flat_len + 1) & ~(int64_t)1;
+    for (int l = 0; l < TLM; ++l) {
+        g.work_off[l] = wo;
+        wo += (int64_t)g.ncol[l] * (2 * md.M + NVEC);
+    }
+    g.scratch_off = wo;
+    g.work_len = wo + 3 * (int64_t)md.M * g.ncmax;
+}
+
+__device__ __forceinline__ double wsum(double v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+}
+// sum over the workgroup, handed to every thread (two barriers; sh: 4 doubles nobody else touches meanwhile)
+__device__ __forceinline__ double bsum(double v, double* sh) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__device__ __forceinline__ double rdlane(double v, int l) {      // l: wave-uniform
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return u.d;
+}
+
+// Cholesky of the MM x MM matrix in Lm (lower part used; identity beyond the real size) and the inverse of the factor, by ONE
+// wavefront: lane i holds row i in registers.  Right-looking: column j's multipliers l_ij = a_ij / sqrt(a_jj) are formed in
+// every lane at once, lane k's multiplier is broadcast (v_readlane, compile-time lane) for the update of column k.  The
+// inverse is a forward substitution with lane c owning column c of L^-1 (L_ik broadcast the same way).  No LDS traffic
+// inside, no barrier; Lm / Li receive L and L^-1 (zeros above the diagonal) at the end.
+template <int MM>
+__device__ void chol_inv_wave(double* Lm, double* Li, int LD, int lane, int32_t* info) {
+    double row[MM];
+    const int ln = lane < MM ? lane : 0;
+#pragma unroll
+    for (int k = 0; k < MM; ++k) row[k] = Lm[ln * LD + k];
+    int fail = 0;
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+        const double djj = rdlane(row[j], j);
+        if (!(djj > 0.0) && !fail) fail = j + 1;
+        const double r = 1.0 / sqrt(djj);
+        const double lij = lane == j ? djj * r : row[j] * r;
+        row[j] = lij;
+#pragma unroll
+        for (int k = j + 1; k < MM; ++k) row[k] -= lij * rdlane(lij, k);
+    }
+    double x[MM];
+#pragma unroll
+    for (int i = 0; i < MM; ++i) {
+        double s = i == lane ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= rdlane(row[k], i) * x[k];
+        x[i] = s / rdlane(row[i], i);
+    }
+    if (lane < MM) {
+#pragma unroll
+        for (int k = 0; k < MM; ++k) {
+            Lm[lane * LD + k] = k <= lane ? row[k] : 0.0;
+            Li[k * LD + lane] = x[k];
+        }
+    }
+    if (lane == 0) info[0] = fail;
+}
+
+struct KV { double k, E1, E2, Ef, fd; };
+// k(a, b) of DESIGN.md / gram.hip: a = (xa[0..d), fa), b = the staged inducing row zb (x part zero-padded to DBT, then f at
+// zb[DBT]).  hy: packed constrained hyper-parameters, il: inverse lengthscales (il[k], il[DBT + k]; zero for k >= d, so the
+// distance loops run over all DBT columns without a test)
+__device__ __forceinline__ void kern_eval(int kind, int d, const double* xa, double fa, const double* zb, const double* hy,
+                                          const double* il, KV& o) {
+    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DBT; ++k) {
+        const double df = (k < d ? xa[k] : 0.0) - zb[k];
+        const double t1 = df * il[k], t2 = df * il[DBT + k];
+        d1 += t1 * t1;
+        d2 += t2 * t2;
+    }
+    o.E1 = exp(-0.5 * d1);
+    if (!kind) { o.E2 = o.Ef = o.fd = 0.0; o.k = hy[0] * o.E1; return; }
+    o.E2 = exp(-0.5 * d2);
+    const double zf = zb[DBT];
+    o.fd = (fa - zf) / hy[4];
+    o.Ef = exp(-0.5 * o.fd * o.fd);
+    o.k = hy[0] * o.E1 * (hy[2] * fa * zf + hy[1] * o.Ef) + hy[3] * o.E2;
+}
+// Gradient terms of one kernel value with upstream G: hyper-parameters accumulated into h[] in the FIXED layout
+// [a1 | af | nu | a2 | lsf | ls1[DBT] | ls2[DBT]] (kind 0: alpha in slot 0, its lengthscales in the ls1 slots) -- compile-time
+// indices, so h[] stays in registers; slot_of() maps a packed position to its slot.  dfa = dk/dfa, dzf = dk/dzf (times G).
+__device__ __forceinline__ int slot_of(int kind, int d, int t) {
+    if (!kind) return t == 0 ? 0 : 5 + (t - 1);
+    return t < 5 ? t : (t < 5 + d ? t : 5 + DBT + (t - 5 - d));
+}
+__device__ __forceinline__ void kern_back(int kind, int d, const double* xa, double fa, const double* zb, const double* hy,
+                                          const double* il, double G, double (&h)[HS], double& dfa, double& dzf) {
+    KV o;
+    kern_eval(kind, d, xa, fa, zb, hy, il, o);
+    if (!kind) {
+        h[0] += G * o.E1;
+        const double W1 = G * hy[0] * o.E1;
+#pragma unroll
+        for (int k = 0; k < DBT; ++k) {
+            const double t = ((k < d ? xa[k] : 0.0) - zb[k]) * il[k];
+            h[5 + k] += W1 * t * t * il[k];
+        }
+        dfa = dzf = 0.0;
+        return;
+    }
+    const double a1 = hy[0], af = hy[1], nu = hy[2], a2 = hy[3], ilf = 1.0 / hy[4], zf = zb[DBT];
+    const double aE1 = a1 * o.E1, inner = nu * fa * zf + af * o.Ef, cb = aE1 * af * ilf, T = G * o.Ef * o.fd;
+    h[0] += G * o.E1 * inner;
+    h[1] += G * aE1 * o.Ef;
+    h[2] += G * aE1 * fa * zf;
+    h[3] += G * o.E2;
+    h[4] += cb * T * o.fd;
+    const double W1 = G * aE1 * inner, W2 = G * a2 * o.E2;
+#pragma unroll
+    for (int k = 0; k < DBT; ++k) {
+        const double df = (k < d ? xa[k] : 0.0) - zb[k];
+        const double t1 = df * il[k], t2 = df * il[DBT + k];
+        h[5 + k] += W1 * t1 * t1 * il[k];
+        h[5 + DBT + k] += W2 * t2 * t2 * il[DBT + k];
+    }
+    dfa = G * aE1 * nu * zf - T * cb;
+    dzf = G * aE1 * nu * fa + T * cb;
+}
+
+__device__ __forceinline__ int seg_len(int l, int s, int d) { return l == 0 ? (s == 0 ? 1 : d) : (s < 5 ? 1 : d); }
+
+template <int MR>
+__global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model* models, double lr, double b1, double b2,
+                                                       double aeps, int do_update) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const mobocmf_tiny_model& md = models[blockIdx.x];
+    constexpr int LD = MR + 1, MS = MR * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Geom g;
+    geom_of(md, g);
+    const int L = g.L, M = g.M, d = g.d, S = g.S;
+    double* Lm = lds;                       // [TLM][MS]  L
+    double* Li = Lm + TLM * MS;             // [TLM][MS]  L^-1
+    double* Um = Li + TLM * MS;             // [TLM][MS]  U = L^-1 L_S
+    double* W0 = Um + TLM * MS;             // three M x M temporaries of the backward
+    double* W1 = W0 + MS;
+    double* W2 = W1 + MS;
+    double* zt = W2 + MS;                   // [TLM][MR][ZW]  Z~_l
+    double* hy = zt + TLM * MR * ZW;        // [TLM][HS] constrained hyper-parameters
+    double* il = hy + TLM * HS;             // [TLM][2 DBT] inverse lengthscales
+    double* av = il + TLM * 2 * DBT;        // [TLM][MR]  a = L^-1 m
+    double* gmv = av + TLM * MR;            // [TLM][MR]  d loss / d m
+    double* ghy = gmv + TLM * MR;           // [TLM][HS]  d loss / d (constrained hyper-parameters)
+    double* dav = ghy + TLM * HS;           // [MR] da
+    double* dat = dav + MR;                 // [MR] da_tot
+    double* red = dat + MR;                 // [4][HS + 1] wavefront partials
+    double* sc = red + 4 * (HS + 1);        // [16]: tau[l] (0..2), g_noise[l] (4..6), bsum scratch (8..11)
+    double* work = md.work;
+    double* gflat = work;
+    double* Kb = work + g.scratch_off;      // M x ncmax scratch panels
+    double* S1 = Kb + (int64_t)M * g.ncmax;
+    double* S2 = S1 + (int64_t)M * g.ncmax;
+    const double gkl = md.kl_scale;         // d(-ELBO) / d KL_l
+    const double ge = -1.0;                 // d(-ELBO) / d ELBO
+
+    // ---- P0: constrained hyper-parameters, Z~, tau; gradient accumulators cleared
+    for (int e = tid; e < TLM * HS; e += TT) {
+        const int l = e / HS, t = e % HS;
+        double v = 0.0;
+        if (l < L && t < g.H[l]) {
+            int s = 0, off = 0;
+            while (t >= off + seg_len(l, s, d)) { off += seg_len(l, s, d); ++s; }
+            const double x = md.raw[l][s][t - off];
+            v = x > 20.0 ? x : log1p(exp(x));
+        }
+        hy[e] = v;
+        ghy[e] = 0.0;
+    }
+    for (int e = tid; e < TLM * MR; e += TT) gmv[e] = 0.0;
+    for (int e = tid; e < TLM * MR * ZW; e += TT) {
+        const int l = e / (MR * ZW), m = (e / ZW) % MR, k = e % ZW;
+        double v = 0.0;
+        if (l < L && m < M) {
+            if (k < d) v = md.Zx[m * d + k];
+            else if (k == DBT && l > 0) v = md.m[l - 1][m];
+        }
+        zt[e] = v;
+    }
+    if (tid < L) {
+        const double lo = md.noise_lo[tid], hi = md.noise_hi[tid], r = md.raw_noise[tid][0];
+        sc[tid] = hi > lo ? lo + (hi - lo) / (1.0 + exp(-r)) : r;
+    }
+    __syncthreads();
+    for (int e = tid; e < TLM * 2 * DBT; e += TT) {
+        const int l = e / (2 * DBT), k = e % (2 * DBT), kk = k % DBT;
+        double v = 0.0;
+        if (l < L && kk < d) {
+            if (l == 0) v = k < DBT ? 1.0 / hy[l * HS + 1 + kk] : 0.0;
+            else v = 1.0 / hy[l * HS + 5 + (k < DBT ? 0 : d) + kk];
+        }
+        il[e] = v;
+    }
+    __syncthreads();
+
+    // ---- P1: K_mm + jitter I of every layer (lower part; identity beyond M)
+    for (int e = tid; e < L * MR * MR; e += TT) {
+        const int l = e / (MR * MR), i = (e / MR) % MR, j = e % MR;
+        double v = 0.0;
+        if (i < M && j <= i) {
+            KV o;
+            kern_eval(l > 0, d, zt + (l * MR + i) * ZW, zt[(l * MR + i) * ZW + DBT], zt + (l * MR + j) * ZW, hy + l * HS,
+                      il + l * 2 * DBT, o);
+            v = o.k + (i == j ? md.jitter : 0.0);
+        } else if (i == j) {
+            v = 1.0;
+        }
+        Lm[l * MS + i * LD + j] = v;
+    }
+    __syncthreads();
+    // ---- P2: Cholesky + inverse, one wavefront per layer
+    if (wave < L) chol_inv_wave<MR>(Lm + wave * MS, Li + wave * MS, LD, lane, md.info + wave);
+    __syncthreads();
+    // ---- P3: U = L^-1 L_S, a = L^-1 m, KL = 1/2 [2 sum log L_ii - sum log L_S,ii^2 + |U|^2 + |a|^2 - M]
+    double klacc = 0.0;
+    for (int e = tid; e < L * M * M; e += TT) {
+        const int l = e / (M * M), i = (e / M) % M, j = e % M;
+        const double* li = Li + l * MS + i * LD;
+        double u = 0.0;
+        if (j <= i) {
+            const double* ls = md.L_S[l];
+            for (int k = j; k <= i; ++k) u += li[k] * ls[k * M + j];
+            klacc += 0.5 * u * u;
+        }
+        Um[l * MS + i * LD + j] = u;
+        if (j == 0) {
+            const double* mv = md.m[l];
+            double a = 0.0;
+            for (int k = 0; k <= i; ++k) a += li[k] * mv[k];
+            av[l * MR + i] = a;
+            const double lsii = md.L_S[l][i * M + i];
+            klacc += 0.5 * a * a + log(Lm[l * MS + i * LD + i]) - 0.5 * log(lsii * lsii) - 0.5;
+        }
+    }
+    __syncthreads();
+
+    // ---- forward, layer by layer
+    double dacc = 0.0;
+    for (int l = 0; l < L; ++l) {
+        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
+        double* wl = work + g.work_off[l];
+        double* A = wl;
+        double* C = A + (int64_t)M * nc;
+        double* vf = C + (int64_t)M * nc;      // f, eps, mean, var, knn, q, vraw, gmu, gv, cgv, gf
+        double *vmean = vf + 2 * nc, *vvar = vf + 3 * nc, *vknn = vf + 4 * nc, *vq = vf + 5 * nc, *vraw = vf + 6 * nc;
+        const double* hyl = hy + l * HS;
+        const double* ill = il + l * 2 * DBT;
+        // F1: K_mn
+        for (int e = tid; e < M * nc; e += TT) {
+            const int m = e / nc, c = e % nc, b = c / div;
+            const double fn = kind ? vf[c] : 0.0;
+            KV o;
+            kern_eval(kind, d, md.x + (int64_t)b * d, fn, zt + (l * MR + m) * ZW, hyl, ill, o);
+            Kb[(int64_t)m * nc + c] = o.k;
+            if (m == 0) vknn[c] = kind ? hyl[0] * (hyl[2] * fn * fn + hyl[1]) + hyl[3] : hyl[0];
+        }
+        __syncthreads();
+        // F2: A = L^-1 K
+        for (int e = tid; e < M * nc; e += TT) {
+            const int i = e / nc, c = e % nc;
+            const double* li = Li + l * MS + i * LD;
+            double s = 0.0;
+            for (int k = 0; k <= i; ++k) s += li[k] * Kb[(int64_t)k * nc + c];
+            A[(int64_t)i * nc + c] = s;
+        }
+        __syncthreads();
+        // F3: C = U^T A
+        for (int e = tid; e < M * nc; e += TT) {
+            const int j = e / nc, c = e % nc;
+            const double* u = Um + l * MS + j;
+            double s = 0.0;
+            for (int i = j; i < M; ++i) s += u[i * LD] * A[(int64_t)i * nc + c];
+            C[(int64_t)j * nc + c] = s;
+        }
+        __syncthreads();
+        // F4: moments, the layer's data term, the next layer's inputs
+        {
+            const double tau = sc[l], ltau = log(tau);
+            const int ncn = l + 1 < L ? g.ncol[l + 1] : 0, fdiv = l == 0 ? S : 1;
+            double* nf = l + 1 < L ? work + g.work_off[l + 1] + 2 * (int64_t)M * ncn : nullptr;
+            const double* xeps = l + 1 < L ? md.eps[l + 1] : nullptr;
+            const int64_t* rng = l + 1 < L ? md.rng[l + 1] : nullptr;
+            const uint64_t seed = rng ? (uint64_t)rng[0] : 0, call = rng ? (uint64_t)rng[1] : 0;
+            for (int c = tid; c < nc; c += TT) {
+                double q = 0.0, mu = 0.0, r = 0.0;
+                for (int i = 0; i < M; ++i) {
+                    const double a = A[(int64_t)i * nc + c], cc = C[(int64_t)i * nc + c];
+                    q += a * a;
+                    mu += av[l * MR + i] * a;
+                    r += cc * cc;
+                }
+                double sres = vknn[c] - q;
+                if (sres < 0.0) sres = 0.0;
+                const double vr = sres + r, var = vr < MINV ? MINV : vr;
+                vmean[c] = mu; vvar[c] = var; vq[c] = q; vraw[c] = vr;
+                const int b = c / div;
+                if (md.fid[b] == (double)l) {
+                    const double dlt = md.y[b] - mu;
+                    dacc += -0.5 * ((dlt * dlt + var) / tau + ltau + LOG2PI) / div;
+                }
+                for (int s = 0; s < fdiv; ++s) {
+                    const int cn = c * fdiv + s;
+                    if (cn < ncn) {
+                        const double ev = xeps ? xeps[cn] : philox_normal(seed, call, (uint64_t)cn);
+                        nf[cn] = mu + sqrt(var) * ev;
+                        nf[ncn + cn] = ev;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        const double data = bsum(dacc, sc + 8);
+        const double kl = bsum(klacc, sc + 8);
+        if (tid == 0) {
+            md.out[0] = data - gkl * kl;
+            md.out[1] = gkl * kl;
+            md.out[2] = -(data - gkl * kl);
+        }
+    }
+
+    // ---- backward, top layer first
+    for (int l = L - 1; l >= 0; --l) {
+        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l], Hl = g.H[l];
+        double* wl = work + g.work_off[l];
+        double* A = wl;
+        double* C = A + (int64_t)M * nc;
+        double* vf = C + (int64_t)M * nc;
+        double *vmean = vf + 2 * nc, *vvar = vf + 3 * nc, *vknn = vf + 4 * nc, *vq = vf + 5 * nc, *vraw = vf + 6 * nc;
+        double *vgmu = vf + 7 * nc, *vgv = vf + 8 * nc, *vcgv = vf + 9 * nc, *vgf = vf + 10 * nc;
+        const double* hyl = hy + l * HS;
+        const double* ill = il + l * 2 * DBT;
+        const double* Ul = Um + l * MS;
+        const double* Lil = Li + l * MS;
+        const double* Ll = Lm + l * MS;
+        const double* al = av + l * MR;
+        // B1: upstream gradients of the layer's moments: its own data term + what the next layer sent back through f
+        double st = 0.0;
+        {
+            const double tau = sc[l], gd = ge / div;
+            const int ncn = l + 1 < L ? g.ncol[l + 1] : 0, fdiv = l == 0 ? S : 1;
+            const double* nvf = l + 1 < L ? work + g.work_off[l + 1] + 2 * (int64_t)M * ncn : nullptr;
+            for (int c = tid; c < nc; c += TT) {
+                const int b = c / div;
+                double gm = 0.0, gvv = 0.0;
+                if (md.fid[b] == (double)l) {
+                    const double dlt = md.y[b] - vmean[c];
+                    gm = gd * dlt / tau;
+                    gvv = -0.5 * gd / tau;
+                    st += 0.5 * ((dlt * dlt + vvar[c]) / (tau * tau) - 1.0 / tau);
+                }
+                if (c * fdiv < ncn) {
+                    double sm = 0.0, sv = 0.0;
+                    for (int s = 0; s < fdiv; ++s) {
+                        const double g2 = nvf[10 * ncn + c * fdiv + s];
+                        sm += g2;
+                        sv += g2 * nvf[ncn + c * fdiv + s];
+                    }
+                    gm += sm;
+                    gvv += sv * 0.5 / sqrt(vvar[c]);
+                }
+                const double gvc = vraw[c] > MINV ? gvv : 0.0;
+                vgmu[c] = gm;
+                vgv[c] = gvc;
+                vcgv[c] = vknn[c] - vq[c] > 0.0 ? gvc : 0.0;
+            }
+        }
+        __syncthreads();
+        // B2: dA = 2 U (C diag gv) + a g_mean^T - 2 A diag(cgv)
+        for (int e = tid; e < M * nc; e += TT) {
+            const int i = e / nc, c = e % nc;
+            const double* u = Ul + i * LD;
+            double s = 0.0;
+            for (int j = 0; j <= i; ++j) s += u[j] * C[(int64_t)j * nc + c];
+            S1[(int64_t)i * nc + c] = 2.0 * s * vgv[c] + al[i] * vgmu[c] - 2.0 * A[(int64_t)i * nc + c] * vcgv[c];
+        }
+        __syncthreads();
+        // B3: dK = L^-T dA
+        for (int e = tid; e < M * nc; e += TT) {
+            const int m = e / nc, c = e % nc;
+            double s = 0.0;
+            for (int i = m; i < M; ++i) s += Lil[i * LD + m] * S1[(int64_t)i * nc + c];
+            Kb[(int64_t)m * nc + c] = s;
+        }
+        __syncthreads();
+        // B4: Gram backward of (dK, dk_nn = cgv), element by element; H = A diag(gv) A^T, Hc = A diag(cgv) A^T, da = A g_mean
+        double hacc[HS];
+#pragma unroll
+        for (int t = 0; t < HS; ++t) hacc[t] = 0.0;
+        for (int e = tid; e < M * nc; e += TT) {
+            const int m = e / nc, c = e % nc, b = c / div;
+            const double fn = kind ? vf[c] : 0.0;
+            double dfa, dzf;
+            kern_back(kind, d, md.x + (int64_t)b * d, fn, zt + (l * MR + m) * ZW, hyl, ill, Kb[(int64_t)m * nc + c], hacc, dfa, dzf);
+            S1[(int64_t)m * nc + c] = dfa;
+            S2[(int64_t)m * nc + c] = dzf;
+            if (m == 0) {
+                const double gk = vcgv[c];
+                if (!kind) hacc[0] += gk;
+                else {
+                    hacc[0] += gk * (hyl[2] * fn * fn + hyl[1]);
+                    hacc[1] += gk * hyl[0];
+                    hacc[2] += gk * hyl[0] * fn * fn;
+                    hacc[3] += gk;
+                }
+            }
+        }
+        for (int e = tid; e < M * M; e += TT) {
+            const int i = e / M, j = e % M;
+            if (j > i) continue;
+            double h = 0.0, hc = 0.0;
+            for (int c = 0; c < nc; ++c) {
+                const double p = A[(int64_t)i * nc + c] * A[(int64_t)j * nc + c];
+                h += p * vgv[c];
+                hc += p * vcgv[c];
+            }
+            W0[i * LD + j] = W0[j * LD + i] = h;
+            W1[i * LD + j] = W1[j * LD + i] = hc;
+            if (j == 0) {
+                double s = 0.0;
+                for (int c = 0; c < nc; ++c) s += A[(int64_t)i * nc + c] * vgmu[c];
+                dav[i] = s;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HS; ++t) {
+            const double v = wsum(hacc[t]);
+            if (lane == 0) red[wave * (HS + 1) + t] = v;
+        }
+        {
+            const double v = wsum(st);
+            if (lane == 0) red[wave * (HS + 1) + HS] = v;
+        }
+        __syncthreads();
+        // B5: column / row sums of the Gram backward; the wavefront partials
+        if (kind) {
+            for (int c = tid; c < nc; c += TT) {
+                double s = 0.0;
+                for (int m = 0; m < M; ++m) s += S1[(int64_t)m * nc + c];
+                vgf[c] = s + vcgv[c] * hyl[0] * 2.0 * hyl[2] * vf[c];
+            }
+            for (int m = tid; m < M; m += TT) {
+                double s = 0.0;
+                for (int c = 0; c < nc; ++c) s += S2[(int64_t)m * nc + c];
+                gmv[(l - 1) * MR + m] += s;
+            }
+        }
+        if (tid < Hl) {
+            const int t = slot_of(kind, d, tid);
+            ghy[l * HS + tid] += (red[t] + red[(HS + 1) + t]) + (red[2 * (HS + 1) + t] + red[3 * (HS + 1) + t]);
+        }
+        if (tid == TT - 1) {
+            const double s = (red[HS] + red[(HS + 1) + HS]) + (red[2 * (HS + 1) + HS] + red[3 * (HS + 1) + HS]);
+            double chain = 1.0;
+            if (md.noise_hi[l] > md.noise_lo[l]) {
+                const double sg = 1.0 / (1.0 + exp(-md.raw_noise[l][0]));
+                chain = (md.noise_hi[l] - md.noise_lo[l]) * sg * (1.0 - sg);
+            }
+            sc[4 + l] = s / div * ge * chain;
+        }
+        __syncthreads();
+        // ---- the M x M chain backward: W0 = H, W1 = Hc, dav = da
+        // CB1: G1 = U^T H
+        for (int e = tid; e < M * M; e += TT) {
+            const int i = e / M, j = e % M;
+            double s = 0.0;
+            for (int k = i; k < M; ++k) s += Ul[k * LD + i] * W0[k * LD + j];
+            W2[i * LD + j] = s;
+        }
+        __syncthreads();
+        // CB2: Y = 2 (U G1 - Hc) + a da^T + da_tot a^T (-> W1), dU_tot = 2 tril(G1^T) + gkl U (-> W0), da_tot
+        for (int e = tid; e < M * M; e += TT) {
+            const int i = e / M, j = e % M;
+            double s = 0.0;
+            for (int k = 0; k <= i; ++k) s += Ul[i * LD + k] * W2[k * LD + j];
+            const double dti = dav[i] + gkl * al[i];
+            W1[i * LD + j] = 2.0 * (s - W1[i * LD + j]) + al[i] * dav[j] + dti * al[j];
+            W0[i * LD + j] = j <= i ? 2.0 * W2[j * LD + i] + gkl * Ul[i * LD + j] : 0.0;
+            if (j == 0) dat[i] = dti;
+        }
+        __syncthreads();
+        // CB3: Y += dU_tot U^T;  g_LS = tril(L^-T dU_tot) - gkl diag(1 / L_S,ii);  g_m += L^-T da_tot
+        {
+            double* gls = gflat + g.flat_off[l] + Hl + M;
+            const double* ls = md.L_S[l];
+            for (int e = tid; e < M * M; e += TT) {
+                const int i = e / M, j = e % M, kmax = i < j ? i : j;
+                double s = 0.0;
+                for (int k = 0; k <= kmax; ++k) s += W0[i * LD + k] * Ul[j * LD + k];
+                W1[i * LD + j] += s;
+                double t = 0.0;
+                if (j <= i) {
+                    for (int k = i; k < M; ++k) t += Lil[k * LD + i] * W0[k * LD + j];
+                    if (i == j) t -= gkl / ls[i * M + i];
+                }
+                gls[i * M + j] = t;
+                if (j == 0) {
+                    double u = 0.0;
+                    for (int k = i; k < M; ++k) u += Lil[k * LD + i] * dat[k];
+                    gmv[l * MR + i] += u;
+                }
+            }
+        }
+        __syncthreads();
+        // CB4: dL = -tril(L^-T Y) + gkl diag(1 / L_ii)  (-> W2)
+        for (int e = tid; e < M * M; e += TT) {
+            const int i = e / M, j = e % M;
+            double v = 0.0;
+            if (j <= i) {
+                for (int k = i; k < M; ++k) v -= Lil[k * LD + i] * W1[k * LD + j];
+                if (i == j) v += gkl / Ll[i * LD + i];
+            }
+            W2[i * LD + j] = v;
+        }
+        __syncthreads();
+        // CB5: P = Phi(L^T dL)  (-> W0)
+        for (int e = tid; e < M * M; e += TT) {
+            const int i = e / M, j = e % M;
+            double v = 0.0;
+            if (j <= i) {
+                for (int k = i; k < M; ++k) v += Ll[k * LD + i] * W2[k * LD + j];
+                if (i == j) v *= 0.5;
+            }
+            W0[i * LD + j] = v;
+        }
+        __syncthreads();
+        // CB6: T4 = L^-T P  (-> W1)
+        for (int e = tid; e < M * M; e += TT) {
+            const int i = e / M, j = e % M;
+            double v = 0.0;
+            for (int k = i > j ? i : j; k < M; ++k) v += Lil[k * LD + i] * W0[k * LD + j];
+            W1[i * LD + j] = v;
+        }
+        __syncthreads();
+        // CB7: T5 = T4 L^-1  (-> W2)
+        for (int e = tid; e < M * M; e += TT) {
+            const int i = e / M, j = e % M;
+            double v = 0.0;
+            for (int k = j; k < M; ++k) v += W1[i * LD + k] * Lil[k * LD + j];
+            W2[i * LD + j] = v;
+        }
+        __syncthreads();
+        // CB8: Gram backward of dK_mm = sym(T5): both arguments are Z~ -- a pair's f gradient counts twice (-> W0)
+#pragma unroll
+        for (int t = 0; t < HS; ++t) hacc[t] = 0.0;
+        for (int e = tid; e < M * M; e += TT) {
+            const int i = e / M, j = e % M;
+            const double G = 0.5 * (W2[i * LD + j] + W2[j * LD + i]);
+            double dfa, dzf;
+            kern_back(kind, d, zt + (l * MR + i) * ZW, zt[(l * MR + i) * ZW + DBT], zt + (l * MR + j) * ZW, hyl, ill, G, hacc,
+                      dfa, dzf);
+            W0[i * LD + j] = dfa;
+        }
+#pragma unroll
+        for (int t = 0; t < HS; ++t) {
+            const double v = wsum(hacc[t]);
+            if (lane == 0) red[wave * (HS + 1) + t] = v;
+        }
+        __syncthreads();
+        if (tid < Hl) {
+            const int t = slot_of(kind, d, tid);
+            ghy[l * HS + tid] += (red[t] + red[(HS + 1) + t]) + (red[2 * (HS + 1) + t] + red[3 * (HS + 1) + t]);
+        }
+        if (kind)
+            for (int i = tid; i < M; i += TT) {
+                double s = 0.0;
+                for (int j = 0; j < M; ++j) s += W0[i * LD + j];
+                gmv[(l - 1) * MR + i] += 2.0 * s;
+            }
+        __syncthreads();
+    }
+
+    // ---- raw-parameter gradients into the flat vector (g_LS is there already)
+    for (int e = tid; e < L * HS; e += TT) {
+        const int l = e / HS, t = e % HS;
+        if (t < g.H[l]) {
+            int s = 0, off = 0;
+            while (t >= off + seg_len(l, s, d)) { off += seg_len(l, s, d); ++s; }
+            const double x = md.raw[l][s][t - off], gv = ghy[e];
+            gflat[g.flat_off[l] + t] = x > 20.0 ? gv : gv / (1.0 + exp(-x));
+        }
+    }
+    for (int e = tid; e < L * M; e += TT) gflat[g.flat_off[e / M] + g.H[e / M] + e % M] = gmv[(e / M) * MR + e % M];
+    if (tid < L) gflat[g.flat_noise + tid] = sc[4 + tid];
+    __syncthreads();
+    if (md.grad)
+        for (int64_t e = tid; e < g.flat_len; e += TT) md.grad[e] = gflat[e];
+    if (!do_update) return;
+    // ---- Adam (torch.optim.Adam: p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)), every trainable tensor
+    {
+        const int64_t step = md.steps_done[0] + 1;
+        const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
+        auto upd = [&](double* p, int64_t off, int len, bool on) {
+            if (!on) return;
+            for (int e = tid; e < len; e += TT) {
+                const double gi = gflat[off + e];
+                const double mi = b1 * md.adam_m[off + e] + (1.0 - b1) * gi;
+                const double vi = b2 * md.adam_v[off + e] + (1.0 - b2) * gi * gi;
+                md.adam_m[off + e] = mi;
+                md.adam_v[off + e] = vi;
+                p[e] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + aeps);
+            }
+        };
+        for (int l = 0; l < L; ++l) {
+            const uint32_t tr = md.trainable[l];
+            const int ns = l == 0 ? 2 : 7;
+            int off = 0;
+            for (int s = 0; s < ns; ++s) {
+                upd(md.raw[l][s], g.flat_off[l] + off, seg_len(l, s, d), (tr >> s) & 1u);
+                off += seg_len(l, s, d);
+            }
+            upd(md.m[l], g.flat_off[l] + g.H[l], M, (tr >> 7) & 1u);
+            upd(md.L_S[l], g.flat_off[l] + g.H[l] + M, M * M, (tr >> 8) & 1u);
+            upd(md.raw_noise[l], g.flat_noise + l, 1, (tr >> 9) & 1u);
+        }
+        __syncthreads();      // every thread has read steps_done / the rng call counters
+        if (tid == 0) {
+            md.steps_done[0] = step;
+            for (int l = 1; l < L; ++l)
+                if (!md.eps[l] && md.rng[l]) md.rng[l][1] += 1;
+        }
+    }
+}
+
+size_t lds_bytes(int MR) {
+    const int LD = MR + 1, MS = MR * LD;
+    const size_t n = (size_t)(3 * TLM + 3) * MS + (size_t)TLM * MR * ZW + 2 * (size_t)TLM * HS + (size_t)TLM * 2 * DBT +
+                     2 * (size_t)TLM * MR + 2 * (size_t)MR + 4 * (HS + 1) + 16;
+    return n * sizeof(double);
+}
+
+bool valid_model(const mobocmf_tiny_model& m) {
+    if (m.L < 1 || m.L > TLM || m.M < 1 || m.M > MOBOCMF_TINY_MAX_M || m.d < 1 || m.d > DBT || m.S < 1 || m.N < 1) return false;
+    if (m.rows[0] != m.N) return false;
+    for (int l = 0; l < m.L; ++l) {
+        if (m.rows[l] < 1 || (l && m.rows[l] > m.rows[l - 1])) return false;
+        if ((int64_t)m.rows[l] * m.S > (1 << 20)) return false;
+        const int ns = l == 0 ? 2 : 7;
+        for (int s = 0; s < ns; ++s)
+            if (!m.raw[l][s]) return false;
+        if (!m.m[l] || !m.L_S[l] || !m.raw_noise[l]) return false;
+        if (l && !m.eps[l] && !m.rng[l]) return false;
+    }
+    return m.x && m.y && m.fid && m.Zx && m.adam_m && m.adam_v && m.steps_done && m.work && m.out && m.info;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mobocmf_tiny_flat_len(const mobocmf_tiny_model* model, int64_t* len) {
+    if (!model || !len || model->L < 1 || model->L > TLM || model->M < 1 || model->d < 1) return MOBOCMF_BAD_ARG;
+    Geom g;
+    geom_of(*model, g);
+    *len = g.flat_len;
+    return MOBOCMF_OK;
+}
+
+int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes) {
+    if (!model || !bytes || model->L < 1 || model->L > TLM || model->M < 1 || model->d < 1 || model->S < 1) return MOBOCMF_BAD_ARG;
+    for (int l = 0; l < model->L; ++l)
+        if (model->rows[l] < 1) return MOBOCMF_BAD_ARG;
+    Geom g;
+    geom_of(*model, g);
+    *bytes = (size_t)g.work_len * sizeof(double);
+    return MOBOCMF_OK;
+}
+
+int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
+                           double lr, double beta1, double beta2, double eps, int32_t do_update, mobocmf_stream_t stream) {
+    if (!host_models || !dev_models || n_models < 1 || n_models > 65535) return MOBOCMF_BAD_ARG;
+    int mmax = 0;
+    for (int i = 0; i < n_models; ++i) {
+        if (!valid_model(host_models[i])) return MOBOCMF_BAD_ARG;
+        if (host_models[i].M > mmax) mmax = host_models[i].M;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (mmax <= 16) {
+        const size_t shm = lds_bytes(16);
+        hipLaunchKernelGGL(tiny_step_kernel<16>, dim3((unsigned)n_models), dim3(TT), shm, s, dev_models, lr, beta1, beta2, eps,
+                           do_update);
+    } else {
+        const size_t shm = lds_bytes(32);
+        static bool attr_set = false;      // idempotent per-function attribute (not a knob: the kernel cannot run without it)
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)tiny_step_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) !=
+                hipSuccess)
+                return MOBOCMF_HIP_ERROR;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(tiny_step_kernel<32>, dim3((unsigned)n_models), dim3(TT), shm, s, dev_models, lr, beta1, beta2, eps,
+                           do_update);
+    }
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+"""The ELBO step of SMALL surrogates (zero_grad + MFDGP.forward + VariationalELBOMF + backward + Adam,
+blackbox_mfdgp_fitter.py:161-171) as ONE launch for a whole group of models: mobocmf_tiny_elbo_step.
+
+At the reference's own sizes -- M = N = tens of points (examples/example_acquisition_mfdgp_forrester/...py:51-62) -- a step
+through the layer entry points is ~50 dependent launches of ~4.7 us whatever they compute; here one workgroup per surrogate
+runs the whole step as barrier-separated phases (csrc/tiny_step.hip).  ``TinyELBOStep`` has the surface of
+``GraphedELBOStep`` that the fitter's training loop uses (step / check / snapshot / loss), for several models at once.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .. import gp
+
+MAX_COLUMNS = 1024      # rows[l] * S per layer above which the layer path (grid-filling kernels) is the faster one
+
+
+def _hyper_params(layer):
+    return [getattr(m, n) for m, n in gp._hyper_sources(layer.covar_module, layer.kind)]
+
+
+def eligible(model, x, fidelities):
+    """True when ``model`` on the batch ``x`` fits the one-launch step: <= 3 layers sharing one set of <= 32 inducing inputs
+    (Z~_l = [Z_x, m_{l-1}]), d <= 8, softplus / Interval constraints, float64 parameters on the GPU, every fidelity's
+    prefix non-empty."""
+    try:
+        layers = model._layers()
+        L = len(layers)
+        if not (1 <= L <= _lib.TINY_MAX_LAYERS) or model.use_only_highest_fidelity or model._eval_mode:
+            return False
+        if not x.is_cuda or x.dtype != torch.float64 or x.dim() != 2 or not (1 <= x.shape[1] <= _lib.TINY_MAX_D):
+            return False
+        Z0 = layers[0].variational_strategy._inducing_points
+        M = Z0.shape[0]
+        if not (1 <= M <= _lib.TINY_MAX_M) or Z0.requires_grad or Z0.shape[1] != x.shape[1]:
+            return False
+        S = model.num_samples_for_training
+        fidv = fidelities.reshape(-1)
+        N = fidv.numel()
+        if N != x.shape[0] or N * max(S, 1) > MAX_COLUMNS:
+            return False
+        counts = [int((fidv >= l).sum()) for l in range(L)]
+        if counts[0] != N or counts[-1] < 1:
+            return False
+        jit = layers[0].variational_strategy.jitter_val
+        for l, layer in enumerate(layers):
+            vs = layer.variational_strategy
+            vd = vs._variational_distribution
+            if layer.kind != (0 if l == 0 else 1) or vs.jitter_val != jit or not layer.training:
+                return False
+            Zl = vs._inducing_points
+            if Zl.requires_grad or Zl.shape[0] != M:
+                return False
+            if l and not torch.equal(Zl[:, :-1], Z0):      # layers >= 1 share Z_x; their f column is m_{l-1} (F9)
+                return False
+            ps = _hyper_params(layer) + [vd.variational_mean, vd.chol_variational_covar]
+            lik = getattr(model, model.name_hidden_layer_likelihood + str(l))
+            c = lik.raw_noise_constraint
+            if type(c) is not gp.Interval or not (c.upper_bound > c.lower_bound) or c.upper_bound == float("inf"):
+                return False
+            ps.append(lik.raw_noise)
+            if not all(p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() for p in ps):
+                return False
+            if not all(type(getattr(m, n + "_constraint")) is gp.Positive
+                       for m, n in gp._hyper_sources(layer.covar_module, layer.kind)):
+                return False
+        return True
+    except AttributeError:
+        return False
+
+
+class TinyELBOStep:
+    """``step()`` == one full-batch ELBO step of EVERY model of the group, one launch.  ``models[i]`` trains on
+    ``(xs[i], ys[i], fids[i])`` (y: (N, 1) or (N,); fidelities as the ELBO takes them).  The rows are ordered once by
+    descending fidelity (``row_order[i]``; a full-batch ELBO is a sum over rows) and layer l runs on the rows of fidelity
+    >= l, as ``GraphedELBOStep(prune_rows=True)``.  ``losses`` is an (n, 3) device tensor: ELBO, scaled KL, -ELBO per model,
+    as of the last step (before its update)."""
+
+    def __init__(self, models, num_data, xs, ys, fids, lr, betas=(0.9, 0.999), eps=1e-8, stream=None, fixed_eps=None,
+                 want_grad=False):
+        lib = _lib.require_device()
+        self.models = list(models)
+        n = len(self.models)
+        dev = xs[0].device
+        self.device = dev
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.host = (_lib.TinyModel * n)()
+        self.losses = torch.zeros(n, 3, dtype=torch.float64, device=dev)
+        self.infos = torch.zeros(n, _lib.TINY_MAX_LAYERS, dtype=torch.int32, device=dev)
+        self.steps_done = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.row_order, self.layer_rows = [], []
+        self._keep = []          # tensors the descriptors point at
+        self.exp_avg, self.exp_avg_sq, self.grads, self._work = [], [], [], []
+        self._segments = []      # per model: [(parameter tensor, flat offset, length)]
+        for i, model in enumerate(self.models):
+            x, y, fid = xs[i], ys[i], fids[i]
+            if not eligible(model, x, fid):
+                raise _lib.MobocmfError("TinyELBOStep: model %d does not fit the one-launch step (see eligible())" % i)
+            layers = model._layers()
+            L, S = len(layers), model.num_samples_for_training
+            fidv = fid.reshape(-1).to(torch.float64)
+            N = fidv.numel()
+            counts = [int((fidv >= l).sum()) for l in range(L)]
+            order = torch.argsort(fidv, descending=True, stable=True)
+            xo, yo, fo = x[order].contiguous(), y.reshape(-1)[order].to(torch.float64).contiguous(), fidv[order].contiguous()
+            self.row_order.append(order)
+            self.layer_rows.append(counts)
+            T = self.host[i]
+            T.L, T.M, T.d, T.S, T.N = L, layers[0].variational_strategy._inducing_points.shape[0], x.shape[1], S, N
+            Zx = layers[0].variational_strategy._inducing_points.detach().contiguous()
+            T.x, T.y, T.fid, T.Zx = xo.data_ptr(), yo.data_ptr(), fo.data_ptr(), Zx.data_ptr()
+            self._keep += [xo, yo, fo, Zx]
+            T.kl_scale = N / float(num_data[i])
+            T.jitter = layers[0].variational_strategy.jitter_val
+            segs = []
+            off = 0
+            for l, layer in enumerate(layers):
+                vd = layer.variational_strategy._variational_distribution
+                lik = getattr(model, model.name_hidden_layer_likelihood + str(l))
+                T.rows[l] = counts[l]
+                tr = 0
+                for s, p in enumerate(_hyper_params(layer)):
+                    T.raw[l][s] = p.data_ptr()
+                    tr |= int(p.requires_grad) << s
+                    segs.append((p, off, p.numel()))
+                    off += p.numel()
+                for bit, p in ((7, vd.variational_mean), (8, vd.chol_variational_covar)):
+                    tr |= int(p.requires_grad) << bit
+                    segs.append((p, off, p.numel()))
+                    off += p.numel()
+                T.m[l], T.L_S[l] = vd.variational_mean.data_ptr(), vd.chol_variational_covar.data_ptr()
+                tr |= int(lik.raw_noise.requires_grad) << 9
+                T.trainable[l] = tr
+                T.raw_noise[l] = lik.raw_noise.data_ptr()
+                T.noise_lo[l], T.noise_hi[l] = lik.raw_noise_constraint.lower_bound, lik.raw_noise_constraint.upper_bound
+                if l:
+                    e = None if fixed_eps is None or fixed_eps[i] is None else fixed_eps[i][l]
+                    if e is not None:      # given for the batch as passed in (N * S values): follow the rows
+                        e = e.reshape(N, S)[order][:counts[l]].reshape(-1).contiguous()
+                        T.eps[l] = e.data_ptr()
+                        self._keep.append(e)
+                    rng = layer._rng(dev)
+                    T.rng[l] = rng.data_ptr()
+                    self._keep.append(rng)
+            for l in range(L):
+                lik = getattr(model, model.name_hidden_layer_likelihood + str(l))
+                segs.append((lik.raw_noise, off, 1))
+                off += 1
+            flat = ctypes.c_int64()
+            _lib.check(lib.mobocmf_tiny_flat_len(ctypes.byref(T), ctypes.byref(flat)), "mobocmf_tiny_flat_len")
+            assert flat.value == off, (flat.value, off)
+            wb = ctypes.c_size_t()
+            _lib.check(lib.mobocmf_tiny_work_bytes(ctypes.byref(T), ctypes.byref(wb)), "mobocmf_tiny_work_bytes")
+            work = torch.zeros(wb.value // 8, dtype=torch.float64, device=dev)
+            ea, eq = torch.zeros(off, dtype=torch.float64, device=dev), torch.zeros(off, dtype=torch.float64, device=dev)
+            self._work.append(work)
+            self.exp_avg.append(ea)
+            self.exp_avg_sq.append(eq)
+            T.work, T.adam_m, T.adam_v = work.data_ptr(), ea.data_ptr(), eq.data_ptr()
+            T.steps_done = self.steps_done[i:i + 1].data_ptr()
+            T.out = self.losses[i].data_ptr()
+            T.info = self.infos[i].data_ptr()
+            if want_grad:
+                gflat = torch.zeros(off, dtype=torch.float64, device=dev)
+                self.grads.append(gflat)
+                T.grad = gflat.data_ptr()
+            self._segments.append(segs)
+        raw = bytes(self.host)
+        self._dev_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self._snap = None
+
+    # ------------------------------------------------------------------ the step
+    def _launch(self, do_update):
+        lib = _lib.require_device()
+        _lib.check(lib.mobocmf_tiny_elbo_step(ctypes.cast(self.host, ctypes.c_void_p), ctypes.c_void_p(self._dev_table.data_ptr()),
+                                              len(self.models), self.lr, self.betas[0], self.betas[1], self.eps,
+                                              1 if do_update else 0, ctypes.c_void_p(self.stream.cuda_stream)),
+                   "mobocmf_tiny_elbo_step")
+
+    def step(self):
+        """Enqueues one step of every model on ``self.stream``."""
+        self._launch(True)
+        return self.losses
+
+    def gradients(self):
+        """-ELBO and its raw-parameter gradients at the current parameters, no update (``want_grad=True``): per model a dict
+        parameter -> gradient tensor of its shape."""
+        assert self.grads, "construct with want_grad=True"
+        self._launch(False)
+        self.stream.synchronize()
+        return [{p: self.grads[i][off:off + n].reshape(p.shape) for p, off, n in segs} for i, segs in enumerate(self._segments)]
+
+    @property
+    def loss(self):
+        return self.losses[:, 2]
+
+    @property
+    def kl(self):
+        return self.losses[:, 1]
+
+    # ------------------------------------------------------------------ verdicts / roll-back (as GraphedELBOStep)
+    def check(self):
+        """Synchronising: raises if a Cholesky of the last step failed or a loss is not finite."""
+        from ..layers.mfdgp_hidden_layer import NotPSDError
+        self.stream.synchronize()
+        if bool((self.infos != 0).any()):
+            i, l = [int(v) for v in torch.nonzero(self.infos)[0]]
+            raise NotPSDError("K_mm not positive definite in model %d layer %d" % (i, l))
+        if not bool(torch.isfinite(self.losses).all()):
+            raise FloatingPointError("non-finite ELBO")
+
+    def snapshot(self):
+        with torch.cuda.stream(self.stream):
+            self._snap = ([p.detach().clone() for m in self.models for p in m.parameters()],
+                          [t.clone() for t in self.exp_avg], [t.clone() for t in self.exp_avg_sq], self.steps_done.clone(),
+                          [l._rng(self.device).clone() for m in self.models for l in m._layers()])
+
+    def restore(self):
+        """Back to the last snapshot (parameters, optimiser state, eps streams)."""
+        self.stream.synchronize()
+        ps, ea, eq, steps, rngs = self._snap
+        with torch.no_grad():
+            for p, s0 in zip([p for m in self.models for p in m.parameters()], ps):
+                p.copy_(s0)
+            for t, s0 in zip(self.exp_avg, ea):
+                t.copy_(s0)
+            for t, s0 in zip(self.exp_avg_sq, eq):
+                t.copy_(s0)
+            self.steps_done.copy_(steps)
+            for layer, s0 in zip([l for m in self.models for l in m._layers()], rngs):
+                layer._rng(self.device).copy_(s0)
+
+    def export_adam_state(self, i, optimizer):
+        """Copies model i's moment estimates and step count into a FusedAdam over ``list(models[i].parameters())`` (the
+        layer-path step that takes over after a failed Cholesky keeps the optimiser's memory)."""
+        by_param = {id(p): (off, n) for p, off, n in self._segments[i]}
+        with torch.no_grad():
+            for k, p in enumerate(optimizer.params):
+                if id(p) in by_param:
+                    off, n = by_param[id(p)]
+                    optimizer.state[k]["exp_avg"].copy_(self.exp_avg[i][off:off + n].reshape(p.shape))
+                    optimizer.state[k]["exp_avg_sq"].copy_(self.exp_avg_sq[i][off:off + n].reshape(p.shape))
+            optimizer.steps_done.copy_(self.steps_done[i])

@@ -1,0 +1,168 @@
+"""mobocmf_tiny_elbo_step -- the whole ELBO step of small surrogates in ONE launch -- against the oracle
+(mfdgp.py:174-196 + variational_elbo_mf.py:24-51 + blackbox_mfdgp_fitter.py:161-171 restated) and against the layer path."""
+import numpy as np
+import pytest
+import torch
+
+from mobocmf_amd.util import synthetic
+from oracle import mfdgp_oracle as O
+from tests.test_hip_model import _model_param_for, _raw_from_model, rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CASES = [dict(d=1, L=2, M=16, N=16, S=1, seed=0), dict(d=1, L=2, M=16, N=16, S=4, seed=1),
+         dict(d=2, L=2, M=12, N=40, S=3, seed=2), dict(d=5, L=3, M=20, N=57, S=2, seed=3),
+         dict(d=8, L=3, M=32, N=64, S=4, seed=4), dict(d=3, L=1, M=9, N=30, S=1, seed=5),
+         dict(d=2, L=2, M=32, N=128, S=8, seed=6), dict(d=4, L=3, M=7, N=23, S=1, seed=7)]
+IDS = ["d%d_L%d_M%d_N%d_S%d" % (c["d"], c["L"], c["M"], c["N"], c["S"]) for c in CASES]
+
+
+def _problem(cfg, shuffle=True):
+    prob = synthetic.make_problem(**cfg)
+    N, S = cfg["N"], cfg["S"]
+    perm = np.random.default_rng(11).permutation(N) if shuffle else np.arange(N)
+    tc = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    x, y, fid = tc(prob["x"])[perm], tc(prob["y"])[perm], tc(prob["fid"])[perm]
+    eps = [None] + [tc(e).reshape(N, S)[perm].reshape(-1) for e in prob["eps"][1:]]
+    return prob, x, y, fid, eps
+
+
+def _tiny(models, xs, ys, fids, epss, lr=1e-2, want_grad=False):
+    from mobocmf_amd.util.tiny_step import TinyELBOStep
+    return TinyELBOStep(models, [x.shape[0] for x in xs], [x.to(DEV) for x in xs], [y.to(DEV) for y in ys],
+                        [f.to(DEV) for f in fids], lr=lr,
+                        fixed_eps=[None if e is None else [None if v is None else v.to(DEV) for v in e] for e in epss],
+                        want_grad=want_grad)
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=IDS)
+def test_tiny_step_gradients_match_oracle(cfg):
+    """ELBO, scaled KL and every raw-parameter gradient of one launch (no update) vs the oracle's autograd through its dense
+    evaluation of every layer at every row, on a shuffled batch."""
+    prob, x, y, fid, eps = _problem(cfg)
+    L, S = cfg["L"], cfg["S"]
+    model = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
+    raw = _raw_from_model(model, L)
+    e_o, skl_o = O.elbo(O.state_from_raw(raw), x, y, fid, eps=eps, S=S)
+    (-e_o).backward()
+    step = _tiny([model], [x], [y], [fid], [eps], want_grad=True)
+    grads = step.gradients()[0]
+    step.check()
+    out = step.losses[0].cpu()
+    assert rel(out[0], e_o) < 1e-9 and rel(out[1], skl_o) < 1e-9 and rel(out[2], -e_o) < 1e-9
+    for l in range(L):
+        for key, tt in raw["layers"][l].items():
+            p = _model_param_for(model, l, key)
+            gref = tt.grad if key != "L_S" else torch.tril(tt.grad)
+            assert rel(grads[p].reshape(gref.shape), gref) < 1e-6, (l, key, rel(grads[p].reshape(gref.shape), gref))
+        lk = getattr(model, f"hidden_layer_likelihood_{l}")
+        assert rel(grads[lk.raw_noise].reshape(()), raw["raw_noise"][l].grad) < 1e-6
+
+
+@pytest.mark.parametrize("cfg", CASES[:5], ids=IDS[:5])
+def test_tiny_step_trajectory_matches_oracle(cfg):
+    """Three fused steps (forward + ELBO + backward + Adam in one launch each) vs oracle.elbo_step with torch.optim.Adam:
+    the loss of every step and every parameter afterwards."""
+    prob, x, y, fid, eps = _problem(cfg)
+    L, S = cfg["L"], cfg["S"]
+    model = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
+    raw = _raw_from_model(model, L)
+    opt = torch.optim.Adam(O.flatten_raw(raw), lr=1e-2)
+    step = _tiny([model], [x], [y], [fid], [eps], lr=1e-2)
+    for k in range(3):
+        lo, klo = O.elbo_step(raw, opt, x, y, fid, eps, S, ref_equiv=False)
+        step.step()
+        step.check()
+        assert rel(step.loss[0], lo) < 1e-7, (k, rel(step.loss[0], lo))
+        assert rel(step.kl[0], klo) < 1e-7, k
+    assert int(step.steps_done[0]) == 3
+    for l in range(L):
+        for key, tt in raw["layers"][l].items():
+            p = _model_param_for(model, l, key)
+            assert rel(p.reshape(tt.shape), tt.detach()) < 1e-6, (l, key, rel(p.reshape(tt.shape), tt.detach()))
+        lk = getattr(model, f"hidden_layer_likelihood_{l}")
+        assert rel(lk.raw_noise.reshape(()), raw["raw_noise"][l].detach()) < 1e-6
+
+
+def test_tiny_step_group_equals_single_models_and_respects_frozen_parameters():
+    """Three surrogates in one launch == each alone; parameters with requires_grad = False (fix_variational_hypers(True):
+    noise and L_S, mfdgp.py:208-212) are left untouched."""
+    cfgs = [CASES[1], dict(CASES[1], seed=9), CASES[2]]
+    built = []
+    for cfg in cfgs:
+        prob, x, y, fid, eps = _problem(cfg)
+        a = synthetic.model_from_problem(prob, num_samples_for_training=cfg["S"], device=DEV)
+        b = synthetic.model_from_problem(prob, num_samples_for_training=cfg["S"], device=DEV)
+        for mdl in (a, b):
+            mdl.fix_variational_hypers(True)
+        built.append((a, b, x, y, fid, eps))
+    group = _tiny([t[0] for t in built], [t[2] for t in built], [t[3] for t in built], [t[4] for t in built],
+                  [t[5] for t in built])
+    singles = [_tiny([t[1]], [t[2]], [t[3]], [t[4]], [t[5]]) for t in built]
+    before = [t[0].hidden_layer_0.variational_strategy._variational_distribution.chol_variational_covar.clone() for t in built]
+    for _ in range(4):
+        group.step()
+        for s in singles:
+            s.step()
+    group.check()
+    for i, (a, b, *_r) in enumerate(built):
+        singles[i].check()
+        assert torch.equal(group.losses[i], singles[i].losses[0])
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa, pb)
+        assert torch.equal(a.hidden_layer_0.variational_strategy._variational_distribution.chol_variational_covar, before[i])
+        assert not torch.equal(a.hidden_layer_0.variational_strategy._variational_distribution.variational_mean,
+                               torch.zeros_like(a.hidden_layer_0.variational_strategy._variational_distribution.variational_mean))
+
+
+def test_tiny_step_draws_the_same_eps_as_the_layer_path():
+    """Without explicit eps both paths draw from the layers' Philox streams (seed, call counter, row): the same model state
+    gives the same trajectory through GraphedELBOStep (layer entry points, HIP graph) and through the one-launch step."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.util.graphed_step import GraphedELBOStep
+    cfg = dict(d=1, L=2, M=16, N=16, S=4, seed=3)
+    prob, x, y, fid, _ = _problem(cfg)
+    torch.manual_seed(5)
+    a = synthetic.model_from_problem(prob, num_samples_for_training=4, device=DEV)
+    torch.manual_seed(5)
+    b = synthetic.model_from_problem(prob, num_samples_for_training=4, device=DEV)
+    torch.manual_seed(77)
+    ga = GraphedELBOStep(a, VariationalELBOMF(a, 16, 2), x.to(DEV), y[:, None].to(DEV), fid[:, None].to(DEV), lr=3e-3)
+    for la, lb in zip(a._layers(), b._layers()):      # b's streams: a's seeds, counters at zero
+        lb._rng(torch.device(DEV, torch.cuda.current_device())).copy_(la._rng(la._rng_state.device))
+    tb = _tiny([b], [x], [y], [fid], [None], lr=3e-3)
+    for k in range(5):
+        loss, kl = ga.step()
+        tb.step()
+        ga.stream.synchronize()
+        tb.check()
+        assert rel(tb.loss[0], loss) < 1e-9, (k, rel(tb.loss[0], loss))
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert rel(pb, pa) < 1e-7
+
+
+def test_tiny_step_reports_a_failed_cholesky():
+    from mobocmf_amd.layers.mfdgp_hidden_layer import NotPSDError
+    cfg = CASES[0]
+    prob, x, y, fid, eps = _problem(cfg)
+    model = synthetic.model_from_problem(prob, num_samples_for_training=1, device=DEV)
+    with torch.no_grad():      # a negative output scale cannot come out of softplus; a NaN lengthscale makes K_mm NaN
+        model.hidden_layer_1.covar_module.kernels[1].base_kernel.raw_lengthscale.fill_(float("nan"))
+    step = _tiny([model], [x], [y], [fid], [eps])
+    step.step()
+    with pytest.raises((NotPSDError, FloatingPointError)):
+        step.check()
+
+
+def test_eligibility_rules():
+    from mobocmf_amd.util.tiny_step import eligible
+    cfg = CASES[0]
+    prob, x, y, fid, eps = _problem(cfg)
+    model = synthetic.model_from_problem(prob, num_samples_for_training=1, device=DEV)
+    assert eligible(model, x.to(DEV), fid.to(DEV))
+    assert not eligible(model, x, fid)                                  # host batch
+    assert not eligible(model, x.to(DEV), torch.zeros_like(fid).to(DEV))     # no row at the top fidelity
+    big = synthetic.make_problem(d=2, L=2, M=48, N=64, S=1, seed=0)
+    assert not eligible(synthetic.model_from_problem(big, num_samples_for_training=1, device=DEV),
+                        torch.as_tensor(big["x"]).to(DEV), torch.as_tensor(big["fid"]).to(DEV))
