@@ -10,6 +10,8 @@
 // state of every layer lives in LDS; the M x N' panels in `work` (a workgroup reads its own global writes after a barrier:
 // one CU, one L1).  Only the Cholesky + triangular inverse is serial: one wavefront per layer, the matrix row-per-lane in
 // registers, pivots and multipliers broadcast by v_readlane (no LDS round trip, no barrier), the layers side by side.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -27,7 +29,7 @@ struct Geom {
     int L, M, d, S;
     int ncol[TLM], H[TLM];
     int64_t flat_off[TLM], flat_noise, flat_len;
-    int64_t work_off[TLM], scratch_off, work_len;
+    int64_t work_off[TLM], scratch_off, pool_base, pool_len, work_len;
     int ncmax;
 };
 __host__ __device__ inline void geom_of(const mobocmf_tiny_model& md, Geom& g) {
@@ -43,25 +45,46 @@ __host__ __device__ inline void geom_of(const mobocmf_tiny_model& md, Geom& g) {
     }
     g.flat_noise = fo;
     g.flat_len = fo + md.L;
-    int64_t wo = (g.flat_len + 1) & ~(int64_t)1;
+    // the panel pool (every layer's A, C and per-column vectors, three scratch panels): in LDS when it fits the launch,
+    // otherwise in `work` behind the flat gradient; offsets are relative to the pool
+    g.pool_base = (g.flat_len + 1) & ~(int64_t)1;
+    int64_t wo = 0;
     for (int l = 0; l < TLM; ++l) {
         g.work_off[l] = wo;
         wo += (int64_t)g.ncol[l] * (2 * md.M + NVEC);
     }
     g.scratch_off = wo;
-    g.work_len = wo + 3 * (int64_t)md.M * g.ncmax;
+    g.pool_len = wo + 3 * (int64_t)md.M * g.ncmax;
+    g.work_len = g.pool_base + g.pool_len;
+#ifdef TINY_STAMPS
+    g.work_len += 128;      // phase stamps (tools/tiny_stamps.py): the last 128 doubles of `work`
+#endif
 }
 
-__device__ __forceinline__ double wsum(double v) {
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+// Sum over the wavefront by DPP moves (quad permutes, row shifts, row broadcasts: ~10 cycles a step; __shfl_xor is a
+// ds_bpermute round trip through LDS per step and half).  The total is valid in LANE 63 only.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, ROW_MASK, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, ROW_MASK, 0xf, true);
+    return v + r.d;
+}
+__device__ __forceinline__ double wsum63(double v) {
+    v = dpp_add<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x114, 0xf>(v);     // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);     // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1, 3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2, 3
     return v;
 }
 // sum over the workgroup, handed to every thread (two barriers; sh: 4 doubles nobody else touches meanwhile)
 __device__ __forceinline__ double bsum(double v, double* sh) {
-    v = wsum(v);
+    v = wsum63(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
@@ -85,12 +108,17 @@ __device__ void chol_inv_wave(double* Lm, double* Li, int LD, int lane, int32_t*
 #pragma unroll
     for (int k = 0; k < MM; ++k) row[k] = Lm[ln * LD + k];
     int fail = 0;
+    double rr[MM];      // 1 / L_jj (wave-uniform)
 #pragma unroll
     for (int j = 0; j < MM; ++j) {
         const double djj = rdlane(row[j], j);
         if (!(djj > 0.0) && !fail) fail = j + 1;
-        const double r = 1.0 / sqrt(djj);
-        const double lij = lane == j ? djj * r : row[j] * r;
+        // 1 / sqrt(d): v_rsq_f64 + two Newton steps (the IEEE sqrt + divide pair is ~200 dependent cycles per column)
+        double r = __builtin_amdgcn_rsq(djj);
+        r = r * (1.5 - (0.5 * djj) * r * r);
+        r = __builtin_fma(0.5 * r, __builtin_fma(-(djj * r), r, 1.0), r);      // residual form: ~1 ulp (chol.hip rsqrt_nr)
+        rr[j] = r;
+        const double lij = row[j] * r;      // lane j: d / sqrt(d) = L_jj
         row[j] = lij;
 #pragma unroll
         for (int k = j + 1; k < MM; ++k) row[k] -= lij * rdlane(lij, k);
@@ -101,7 +129,7 @@ __device__ void chol_inv_wave(double* Lm, double* Li, int LD, int lane, int32_t*
         double s = i == lane ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= rdlane(row[k], i) * x[k];
-        x[i] = s / rdlane(row[i], i);
+        x[i] = s * rr[i];
     }
     if (lane < MM) {
 #pragma unroll
@@ -142,6 +170,11 @@ __device__ __forceinline__ int slot_of(int kind, int d, int t) {
     if (!kind) return t == 0 ? 0 : 5 + (t - 1);
     return t < 5 ? t : (t < 5 + d ? t : 5 + DBT + (t - 5 - d));
 }
+__device__ __forceinline__ bool slot_used(int kind, int d, int t) {
+    if (t < 5) return kind ? true : t == 0;
+    if (t < 5 + DBT) return t - 5 < d;
+    return kind && t - 5 - DBT < d;
+}
 __device__ __forceinline__ void kern_back(int kind, int d, const double* xa, double fa, const double* zb, const double* hy,
                                           const double* il, double G, double (&h)[HS], double& dfa, double& dzf) {
     KV o;
@@ -180,7 +213,7 @@ __device__ __forceinline__ int seg_len(int l, int s, int d) { return l == 0 ? (s
 
 template <int MR>
 __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model* models, double lr, double b1, double b2,
-                                                       double aeps, int do_update) {
+                                                       double aeps, int do_update, int pool_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const mobocmf_tiny_model& md = models[blockIdx.x];
     constexpr int LD = MR + 1, MS = MR * LD;
@@ -202,13 +235,24 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     double* ghy = gmv + TLM * MR;           // [TLM][HS]  d loss / d (constrained hyper-parameters)
     double* dav = ghy + TLM * HS;           // [MR] da
     double* dat = dav + MR;                 // [MR] da_tot
-    double* red = dat + MR;                 // [4][HS + 1] wavefront partials
+    double* mst = dat + MR;                 // [TLM][MR] m of every layer (staged)
+    double* red = mst + TLM * MR;           // [4][HS + 1] wavefront partials
     double* sc = red + 4 * (HS + 1);        // [16]: tau[l] (0..2), g_noise[l] (4..6), bsum scratch (8..11)
-    double* work = md.work;
-    double* gflat = work;
+    double* gflat = md.work;
+    // the panels: LDS behind the chain state when the launch reserved room for them (a dependent global round trip per
+    // contraction step is what a phase costs otherwise), else the caller's workspace; generic pointers either way
+    double* work = pool_in_lds ? sc + 16 : md.work + g.pool_base;
     double* Kb = work + g.scratch_off;      // M x ncmax scratch panels
     double* S1 = Kb + (int64_t)M * g.ncmax;
     double* S2 = S1 + (int64_t)M * g.ncmax;
+#ifdef TINY_STAMPS
+    double* stamps = md.work + g.work_len - 128;
+    int n_stamp = 0;
+#define STAMP() do { if (tid == 0) stamps[n_stamp] = (double)wall_clock64(); ++n_stamp; } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+    STAMP();
     const double gkl = md.kl_scale;         // d(-ELBO) / d KL_l
     const double ge = -1.0;                 // d(-ELBO) / d ELBO
 
@@ -235,11 +279,18 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         }
         zt[e] = v;
     }
+    // L_S and m of every layer staged in LDS (W_l is free until the backward): P3 walks them k by k
+    for (int e = tid; e < L * M * M; e += TT) {
+        const int l = e / (M * M), i = (e / M) % M, j = e % M;
+        W0[l * MS + i * LD + j] = j <= i ? md.L_S[l][i * M + j] : 0.0;
+    }
+    for (int e = tid; e < L * M; e += TT) mst[(e / M) * MR + e % M] = md.m[e / M][e % M];
     if (tid < L) {
         const double lo = md.noise_lo[tid], hi = md.noise_hi[tid], r = md.raw_noise[tid][0];
         sc[tid] = hi > lo ? lo + (hi - lo) / (1.0 + exp(-r)) : r;
     }
     __syncthreads();
+    STAMP();
     for (int e = tid; e < TLM * 2 * DBT; e += TT) {
         const int l = e / (2 * DBT), k = e % (2 * DBT), kk = k % DBT;
         double v = 0.0;
@@ -250,6 +301,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         il[e] = v;
     }
     __syncthreads();
+    STAMP();
 
     // ---- P1: K_mm + jitter I of every layer (lower part; identity beyond M)
     for (int e = tid; e < L * MR * MR; e += TT) {
@@ -266,31 +318,36 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         Lm[l * MS + i * LD + j] = v;
     }
     __syncthreads();
+    STAMP();
     // ---- P2: Cholesky + inverse, one wavefront per layer
     if (wave < L) chol_inv_wave<MR>(Lm + wave * MS, Li + wave * MS, LD, lane, md.info + wave);
     __syncthreads();
+    STAMP();
     // ---- P3: U = L^-1 L_S, a = L^-1 m, KL = 1/2 [2 sum log L_ii - sum log L_S,ii^2 + |U|^2 + |a|^2 - M]
     double klacc = 0.0;
     for (int e = tid; e < L * M * M; e += TT) {
         const int l = e / (M * M), i = (e / M) % M, j = e % M;
         const double* li = Li + l * MS + i * LD;
+        const double* ls = W0 + l * MS;
         double u = 0.0;
         if (j <= i) {
-            const double* ls = md.L_S[l];
-            for (int k = j; k <= i; ++k) u += li[k] * ls[k * M + j];
+#pragma unroll 4
+            for (int k = j; k <= i; ++k) u += li[k] * ls[k * LD + j];
             klacc += 0.5 * u * u;
         }
         Um[l * MS + i * LD + j] = u;
         if (j == 0) {
-            const double* mv = md.m[l];
+            const double* mv = mst + l * MR;
             double a = 0.0;
+#pragma unroll 4
             for (int k = 0; k <= i; ++k) a += li[k] * mv[k];
             av[l * MR + i] = a;
-            const double lsii = md.L_S[l][i * M + i];
+            const double lsii = ls[i * LD + i];
             klacc += 0.5 * a * a + log(Lm[l * MS + i * LD + i]) - 0.5 * log(lsii * lsii) - 0.5;
         }
     }
     __syncthreads();
+    STAMP();
 
     // ---- forward, layer by layer
     double dacc = 0.0;
@@ -313,34 +370,35 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             if (m == 0) vknn[c] = kind ? hyl[0] * (hyl[2] * fn * fn + hyl[1]) + hyl[3] : hyl[0];
         }
         __syncthreads();
+        STAMP();
         // F2: A = L^-1 K
         for (int e = tid; e < M * nc; e += TT) {
             const int i = e / nc, c = e % nc;
             const double* li = Li + l * MS + i * LD;
             double s = 0.0;
+#pragma unroll 4
             for (int k = 0; k <= i; ++k) s += li[k] * Kb[(int64_t)k * nc + c];
             A[(int64_t)i * nc + c] = s;
         }
         __syncthreads();
+        STAMP();
         // F3: C = U^T A
         for (int e = tid; e < M * nc; e += TT) {
             const int j = e / nc, c = e % nc;
             const double* u = Um + l * MS + j;
             double s = 0.0;
+#pragma unroll 4
             for (int i = j; i < M; ++i) s += u[i * LD] * A[(int64_t)i * nc + c];
             C[(int64_t)j * nc + c] = s;
         }
         __syncthreads();
-        // F4: moments, the layer's data term, the next layer's inputs
+        STAMP();
+        // F4: moments and the layer's data term
         {
             const double tau = sc[l], ltau = log(tau);
-            const int ncn = l + 1 < L ? g.ncol[l + 1] : 0, fdiv = l == 0 ? S : 1;
-            double* nf = l + 1 < L ? work + g.work_off[l + 1] + 2 * (int64_t)M * ncn : nullptr;
-            const double* xeps = l + 1 < L ? md.eps[l + 1] : nullptr;
-            const int64_t* rng = l + 1 < L ? md.rng[l + 1] : nullptr;
-            const uint64_t seed = rng ? (uint64_t)rng[0] : 0, call = rng ? (uint64_t)rng[1] : 0;
             for (int c = tid; c < nc; c += TT) {
                 double q = 0.0, mu = 0.0, r = 0.0;
+#pragma unroll 4
                 for (int i = 0; i < M; ++i) {
                     const double a = A[(int64_t)i * nc + c], cc = C[(int64_t)i * nc + c];
                     q += a * a;
@@ -356,17 +414,26 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
                     const double dlt = md.y[b] - mu;
                     dacc += -0.5 * ((dlt * dlt + var) / tau + ltau + LOG2PI) / div;
                 }
-                for (int s = 0; s < fdiv; ++s) {
-                    const int cn = c * fdiv + s;
-                    if (cn < ncn) {
-                        const double ev = xeps ? xeps[cn] : philox_normal(seed, call, (uint64_t)cn);
-                        nf[cn] = mu + sqrt(var) * ev;
-                        nf[ncn + cn] = ev;
-                    }
-                }
             }
         }
         __syncthreads();
+        STAMP();
+        // F5: the next layer's inputs f = mean + sqrt(var) eps, one thread per column of the NEXT layer (one draw each)
+        if (l + 1 < L) {
+            const int ncn = g.ncol[l + 1], fdiv = l == 0 ? S : 1;
+            double* nf = work + g.work_off[l + 1] + 2 * (int64_t)M * ncn;
+            const double* xeps = md.eps[l + 1];
+            const int64_t* rng = md.rng[l + 1];
+            const uint64_t seed = rng ? (uint64_t)rng[0] : 0, call = rng ? (uint64_t)rng[1] : 0;
+            for (int cn = tid; cn < ncn; cn += TT) {
+                const int c = cn / fdiv;
+                const double ev = xeps ? xeps[cn] : philox_normal(seed, call, (uint64_t)cn);
+                nf[cn] = vmean[c] + sqrt(vvar[c]) * ev;
+                nf[ncn + cn] = ev;
+            }
+            __syncthreads();
+            STAMP();
+        }
     }
     {
         const double data = bsum(dacc, sc + 8);
@@ -425,23 +492,28 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             }
         }
         __syncthreads();
+        STAMP();
         // B2: dA = 2 U (C diag gv) + a g_mean^T - 2 A diag(cgv)
         for (int e = tid; e < M * nc; e += TT) {
             const int i = e / nc, c = e % nc;
             const double* u = Ul + i * LD;
             double s = 0.0;
+#pragma unroll 4
             for (int j = 0; j <= i; ++j) s += u[j] * C[(int64_t)j * nc + c];
             S1[(int64_t)i * nc + c] = 2.0 * s * vgv[c] + al[i] * vgmu[c] - 2.0 * A[(int64_t)i * nc + c] * vcgv[c];
         }
         __syncthreads();
+        STAMP();
         // B3: dK = L^-T dA
         for (int e = tid; e < M * nc; e += TT) {
             const int m = e / nc, c = e % nc;
             double s = 0.0;
+#pragma unroll 4
             for (int i = m; i < M; ++i) s += Lil[i * LD + m] * S1[(int64_t)i * nc + c];
             Kb[(int64_t)m * nc + c] = s;
         }
         __syncthreads();
+        STAMP();
         // B4: Gram backward of (dK, dk_nn = cgv), element by element; H = A diag(gv) A^T, Hc = A diag(cgv) A^T, da = A g_mean
         double hacc[HS];
 #pragma unroll
@@ -468,6 +540,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             const int i = e / M, j = e % M;
             if (j > i) continue;
             double h = 0.0, hc = 0.0;
+#pragma unroll 4
             for (int c = 0; c < nc; ++c) {
                 const double p = A[(int64_t)i * nc + c] * A[(int64_t)j * nc + c];
                 h += p * vgv[c];
@@ -477,29 +550,35 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             W1[i * LD + j] = W1[j * LD + i] = hc;
             if (j == 0) {
                 double s = 0.0;
+#pragma unroll 4
                 for (int c = 0; c < nc; ++c) s += A[(int64_t)i * nc + c] * vgmu[c];
                 dav[i] = s;
             }
         }
 #pragma unroll
         for (int t = 0; t < HS; ++t) {
-            const double v = wsum(hacc[t]);
-            if (lane == 0) red[wave * (HS + 1) + t] = v;
+            if (slot_used(kind, d, t)) {      // uniform
+                const double v = wsum63(hacc[t]);
+                if (lane == 63) red[wave * (HS + 1) + t] = v;
+            }
         }
         {
-            const double v = wsum(st);
-            if (lane == 0) red[wave * (HS + 1) + HS] = v;
+            const double v = wsum63(st);
+            if (lane == 63) red[wave * (HS + 1) + HS] = v;
         }
         __syncthreads();
+        STAMP();
         // B5: column / row sums of the Gram backward; the wavefront partials
         if (kind) {
             for (int c = tid; c < nc; c += TT) {
                 double s = 0.0;
+#pragma unroll 4
                 for (int m = 0; m < M; ++m) s += S1[(int64_t)m * nc + c];
                 vgf[c] = s + vcgv[c] * hyl[0] * 2.0 * hyl[2] * vf[c];
             }
             for (int m = tid; m < M; m += TT) {
                 double s = 0.0;
+#pragma unroll 4
                 for (int c = 0; c < nc; ++c) s += S2[(int64_t)m * nc + c];
                 gmv[(l - 1) * MR + m] += s;
             }
@@ -518,19 +597,23 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             sc[4 + l] = s / div * ge * chain;
         }
         __syncthreads();
+        STAMP();
         // ---- the M x M chain backward: W0 = H, W1 = Hc, dav = da
         // CB1: G1 = U^T H
         for (int e = tid; e < M * M; e += TT) {
             const int i = e / M, j = e % M;
             double s = 0.0;
+#pragma unroll 4
             for (int k = i; k < M; ++k) s += Ul[k * LD + i] * W0[k * LD + j];
             W2[i * LD + j] = s;
         }
         __syncthreads();
+        STAMP();
         // CB2: Y = 2 (U G1 - Hc) + a da^T + da_tot a^T (-> W1), dU_tot = 2 tril(G1^T) + gkl U (-> W0), da_tot
         for (int e = tid; e < M * M; e += TT) {
             const int i = e / M, j = e % M;
             double s = 0.0;
+#pragma unroll 4
             for (int k = 0; k <= i; ++k) s += Ul[i * LD + k] * W2[k * LD + j];
             const double dti = dav[i] + gkl * al[i];
             W1[i * LD + j] = 2.0 * (s - W1[i * LD + j]) + al[i] * dav[j] + dti * al[j];
@@ -538,6 +621,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             if (j == 0) dat[i] = dti;
         }
         __syncthreads();
+        STAMP();
         // CB3: Y += dU_tot U^T;  g_LS = tril(L^-T dU_tot) - gkl diag(1 / L_S,ii);  g_m += L^-T da_tot
         {
             double* gls = gflat + g.flat_off[l] + Hl + M;
@@ -545,60 +629,72 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             for (int e = tid; e < M * M; e += TT) {
                 const int i = e / M, j = e % M, kmax = i < j ? i : j;
                 double s = 0.0;
+#pragma unroll 4
                 for (int k = 0; k <= kmax; ++k) s += W0[i * LD + k] * Ul[j * LD + k];
                 W1[i * LD + j] += s;
                 double t = 0.0;
                 if (j <= i) {
+#pragma unroll 4
                     for (int k = i; k < M; ++k) t += Lil[k * LD + i] * W0[k * LD + j];
                     if (i == j) t -= gkl / ls[i * M + i];
                 }
                 gls[i * M + j] = t;
                 if (j == 0) {
                     double u = 0.0;
+#pragma unroll 4
                     for (int k = i; k < M; ++k) u += Lil[k * LD + i] * dat[k];
                     gmv[l * MR + i] += u;
                 }
             }
         }
         __syncthreads();
+        STAMP();
         // CB4: dL = -tril(L^-T Y) + gkl diag(1 / L_ii)  (-> W2)
         for (int e = tid; e < M * M; e += TT) {
             const int i = e / M, j = e % M;
             double v = 0.0;
             if (j <= i) {
+#pragma unroll 4
                 for (int k = i; k < M; ++k) v -= Lil[k * LD + i] * W1[k * LD + j];
                 if (i == j) v += gkl / Ll[i * LD + i];
             }
             W2[i * LD + j] = v;
         }
         __syncthreads();
+        STAMP();
         // CB5: P = Phi(L^T dL)  (-> W0)
         for (int e = tid; e < M * M; e += TT) {
             const int i = e / M, j = e % M;
             double v = 0.0;
             if (j <= i) {
+#pragma unroll 4
                 for (int k = i; k < M; ++k) v += Ll[k * LD + i] * W2[k * LD + j];
                 if (i == j) v *= 0.5;
             }
             W0[i * LD + j] = v;
         }
         __syncthreads();
+        STAMP();
         // CB6: T4 = L^-T P  (-> W1)
         for (int e = tid; e < M * M; e += TT) {
             const int i = e / M, j = e % M;
             double v = 0.0;
+#pragma unroll 4
             for (int k = i > j ? i : j; k < M; ++k) v += Lil[k * LD + i] * W0[k * LD + j];
             W1[i * LD + j] = v;
         }
         __syncthreads();
+        STAMP();
         // CB7: T5 = T4 L^-1  (-> W2)
         for (int e = tid; e < M * M; e += TT) {
             const int i = e / M, j = e % M;
             double v = 0.0;
+#pragma unroll 4
             for (int k = j; k < M; ++k) v += W1[i * LD + k] * Lil[k * LD + j];
             W2[i * LD + j] = v;
         }
         __syncthreads();
+        STAMP();
         // CB8: Gram backward of dK_mm = sym(T5): both arguments are Z~ -- a pair's f gradient counts twice (-> W0)
 #pragma unroll
         for (int t = 0; t < HS; ++t) hacc[t] = 0.0;
@@ -612,10 +708,13 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         }
 #pragma unroll
         for (int t = 0; t < HS; ++t) {
-            const double v = wsum(hacc[t]);
-            if (lane == 0) red[wave * (HS + 1) + t] = v;
+            if (slot_used(kind, d, t)) {
+                const double v = wsum63(hacc[t]);
+                if (lane == 63) red[wave * (HS + 1) + t] = v;
+            }
         }
         __syncthreads();
+        STAMP();
         if (tid < Hl) {
             const int t = slot_of(kind, d, tid);
             ghy[l * HS + tid] += (red[t] + red[(HS + 1) + t]) + (red[2 * (HS + 1) + t] + red[3 * (HS + 1) + t]);
@@ -623,10 +722,12 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         if (kind)
             for (int i = tid; i < M; i += TT) {
                 double s = 0.0;
+#pragma unroll 4
                 for (int j = 0; j < M; ++j) s += W0[i * LD + j];
                 gmv[(l - 1) * MR + i] += 2.0 * s;
             }
         __syncthreads();
+        STAMP();
     }
 
     // ---- raw-parameter gradients into the flat vector (g_LS is there already)
@@ -642,6 +743,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     for (int e = tid; e < L * M; e += TT) gflat[g.flat_off[e / M] + g.H[e / M] + e % M] = gmv[(e / M) * MR + e % M];
     if (tid < L) gflat[g.flat_noise + tid] = sc[4 + tid];
     __syncthreads();
+    STAMP();
     if (md.grad)
         for (int64_t e = tid; e < g.flat_len; e += TT) md.grad[e] = gflat[e];
     if (!do_update) return;
@@ -681,10 +783,11 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     }
 }
 
+constexpr size_t LDS_BUDGET = 160 * 1024;      // LDS of a gfx950 CU; one workgroup per CU may hold all of it
 size_t lds_bytes(int MR) {
     const int LD = MR + 1, MS = MR * LD;
     const size_t n = (size_t)(3 * TLM + 3) * MS + (size_t)TLM * MR * ZW + 2 * (size_t)TLM * HS + (size_t)TLM * 2 * DBT +
-                     2 * (size_t)TLM * MR + 2 * (size_t)MR + 4 * (HS + 1) + 16;
+                     3 * (size_t)TLM * MR + 2 * (size_t)MR + 4 * (HS + 1) + 16;
     return n * sizeof(double);
 }
 
@@ -729,27 +832,34 @@ int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
                            double lr, double beta1, double beta2, double eps, int32_t do_update, mobocmf_stream_t stream) {
     if (!host_models || !dev_models || n_models < 1 || n_models > 65535) return MOBOCMF_BAD_ARG;
     int mmax = 0;
+    int64_t pmax = 0;
     for (int i = 0; i < n_models; ++i) {
         if (!valid_model(host_models[i])) return MOBOCMF_BAD_ARG;
         if (host_models[i].M > mmax) mmax = host_models[i].M;
+        Geom g;
+        geom_of(host_models[i], g);
+        if (g.pool_len > pmax) pmax = g.pool_len;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (mmax <= 16) {
-        const size_t shm = lds_bytes(16);
-        hipLaunchKernelGGL(tiny_step_kernel<16>, dim3((unsigned)n_models), dim3(TT), shm, s, dev_models, lr, beta1, beta2, eps,
-                           do_update);
-    } else {
-        const size_t shm = lds_bytes(32);
-        static bool attr_set = false;      // idempotent per-function attribute (not a knob: the kernel cannot run without it)
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)tiny_step_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) !=
-                hipSuccess)
-                return MOBOCMF_HIP_ERROR;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(tiny_step_kernel<32>, dim3((unsigned)n_models), dim3(TT), shm, s, dev_models, lr, beta1, beta2, eps,
-                           do_update);
+    const int MR = mmax <= 16 ? 16 : 32;
+    size_t shm = lds_bytes(MR);
+    const size_t pool = (size_t)pmax * sizeof(double);
+    const int pool_in_lds = shm + pool <= LDS_BUDGET ? 1 : 0;
+    if (pool_in_lds) shm += pool;
+    // more than the default 64 KB of dynamic LDS needs the function attribute (idempotent; raised, never lowered)
+    static std::atomic<size_t> granted[2] = {{64 * 1024}, {64 * 1024}};
+    const void* fn = MR == 16 ? (const void*)tiny_step_kernel<16> : (const void*)tiny_step_kernel<32>;
+    if (shm > granted[MR == 32].load()) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
+            return MOBOCMF_HIP_ERROR;
+        granted[MR == 32].store(LDS_BUDGET);
     }
+    if (MR == 16)
+        hipLaunchKernelGGL(tiny_step_kernel<16>, dim3((unsigned)n_models), dim3(TT), shm, s, dev_models, lr, beta1, beta2, eps,
+                           do_update, pool_in_lds);
+    else
+        hipLaunchKernelGGL(tiny_step_kernel<32>, dim3((unsigned)n_models), dim3(TT), shm, s, dev_models, lr, beta1, beta2, eps,
+                           do_update, pool_in_lds);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 

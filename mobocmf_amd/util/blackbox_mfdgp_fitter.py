@@ -203,6 +203,11 @@ class BlackBoxMFDGPFitter:
         The rows are shuffled once (see the module docstring): the step runs GPyTorch's general branch, as the
         reference's shuffled batches do."""
         from .graphed_step import GraphedELBOStep
+        # the reference's own sizes (M = N = tens of points): every surrogate's whole step in ONE launch per epoch
+        done, tiny = self._train_mfdgp_tiny(fix_variational_hypers, num_epochs, lr)
+        if done >= num_epochs:
+            return
+        num_epochs -= done
         steps = []
         for slot, (tag, n, h) in enumerate(self._handlers()):
             h.mfdgp.fix_variational_hypers(fix_variational_hypers)
@@ -210,6 +215,8 @@ class BlackBoxMFDGPFitter:
             perm = self.shuffled_rows(x.shape[0], x.device)
             steps.append((tag, n, GraphedELBOStep(h.mfdgp, h.elbo, x[perm].contiguous(), y[perm].contiguous(),
                                                   fid[perm].contiguous(), lr=lr, stream=self._stream_for(slot, x.device))))
+            if tiny is not None:      # a Cholesky failed in the one-launch step: this path (jitter ladder) takes over its state
+                tiny.export_adam_state(slot, steps[-1][2].optimizer)
         from ..layers.mfdgp_hidden_layer import NotPSDError
         for _, _, g in steps:
             g.snapshot()
@@ -243,6 +250,50 @@ class BlackBoxMFDGPFitter:
             g.stream.synchronize()
             g.model.set_check_pd(True)
             g.retire()
+
+    use_tiny_step = True      # False: always the layer path (A/B, tests)
+
+    def _train_mfdgp_tiny(self, fix_variational_hypers, num_epochs, lr):
+        """The training phase through mobocmf_tiny_elbo_step (util/tiny_step.py) when EVERY surrogate fits it: one launch
+        per epoch for all of them.  Returns (epochs completed, step object or None): fewer than ``num_epochs`` when the
+        surrogates do not fit (0, None) or when a Cholesky failed -- the state is then rolled back to the last verified epoch
+        and the layer path, which can retry with more jitter as the reference does at every step, continues from there."""
+        from .tiny_step import TinyELBOStep, eligible
+        from ..layers.mfdgp_hidden_layer import NotPSDError
+        hs = self._handlers()
+        if not self.use_tiny_step or not hs:
+            return 0, None
+        for _, _, h in hs:
+            h.mfdgp.fix_variational_hypers(fix_variational_hypers)
+        data = [h.train_dataset.tensors for _, _, h in hs]
+        if not all(x.is_cuda and eligible(h.mfdgp, x, fid) for (_, _, h), (x, _, fid) in zip(hs, data)):
+            return 0, None
+        dev = data[0][0].device
+        step = TinyELBOStep([h.mfdgp for _, _, h in hs], [h.num_data for _, _, h in hs], [t[0] for t in data],
+                            [t[1] for t in data], [t[2] for t in data], lr=lr, stream=self._stream_for(0, dev))
+        step.stream.wait_stream(torch.cuda.current_stream(dev))
+        step.snapshot()
+        last_good = -1
+        for i in range(num_epochs):
+            step.step()
+            if (i % ITER_PRINT) == 0 or (i + 1) == num_epochs:
+                try:
+                    step.check()
+                except (NotPSDError, FloatingPointError) as err:
+                    warnings.warn("%s -- rolling back %d epochs; the layer path continues" % (err, i - last_good))
+                    step.restore()
+                    torch.cuda.current_stream(dev).wait_stream(step.stream)
+                    return last_good + 1, step
+                step.snapshot()
+                last_good = i
+                if self.verbose:
+                    out = step.losses.cpu()
+                    for k, (tag, n, _) in enumerate(hs):
+                        print("[%s: " % tag, n, "] Epoch:", i, "/", num_epochs, ". Avg. Neg. ELBO per epoch:",
+                              out[k, 2].item(), "\t KL per epoch:", out[k, 1].item())
+                    sys.stdout.flush()
+        step.stream.synchronize()
+        return num_epochs, step
 
     def train_mfdgps(self, use_graphs=None):
         """2-phase Adam schedule of the reference (:175-176).  ``use_graphs`` (default: automatically when every

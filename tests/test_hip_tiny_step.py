@@ -39,7 +39,8 @@ def _tiny(models, xs, ys, fids, epss, lr=1e-2, want_grad=False):
 @pytest.mark.parametrize("cfg", CASES, ids=IDS)
 def test_tiny_step_gradients_match_oracle(cfg):
     """ELBO, scaled KL and every raw-parameter gradient of one launch (no update) vs the oracle's autograd through its dense
-    evaluation of every layer at every row, on a shuffled batch."""
+    evaluation of every layer at every row, on a shuffled batch.  Gradient gate 1e-5 as for the layer path
+    (test_hip_pruned_oracle.py): at d = 1 cond(K_mm + 1e-6 I) ~ 1e9 and either implementation carries ~cond * eps."""
     prob, x, y, fid, eps = _problem(cfg)
     L, S = cfg["L"], cfg["S"]
     model = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
@@ -55,9 +56,9 @@ def test_tiny_step_gradients_match_oracle(cfg):
         for key, tt in raw["layers"][l].items():
             p = _model_param_for(model, l, key)
             gref = tt.grad if key != "L_S" else torch.tril(tt.grad)
-            assert rel(grads[p].reshape(gref.shape), gref) < 1e-6, (l, key, rel(grads[p].reshape(gref.shape), gref))
+            assert rel(grads[p].reshape(gref.shape), gref) < 1e-5, (l, key, rel(grads[p].reshape(gref.shape), gref))
         lk = getattr(model, f"hidden_layer_likelihood_{l}")
-        assert rel(grads[lk.raw_noise].reshape(()), raw["raw_noise"][l].grad) < 1e-6
+        assert rel(grads[lk.raw_noise].reshape(()), raw["raw_noise"][l].grad) < 1e-5
 
 
 @pytest.mark.parametrize("cfg", CASES[:5], ids=IDS[:5])
