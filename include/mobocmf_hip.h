@@ -383,7 +383,8 @@ int mobocmf_scalar_combine(int32_t n, const double* const* x, const double* coef
  *   Flat layout of grad / adam_m / adam_v (mobocmf_tiny_flat_len doubles): per layer [packed hyper-parameters | m | L_S], then
  *     raw_noise of every layer.  grad (optional) receives d(-ELBO)/d(raw parameters) of the step.
  *   out[0] = ELBO, out[1] = scaled KL, out[2] = -ELBO (before the update); info[l] = 0 or the failed Cholesky pivot (1-based).
- * do_update = 0: gradients only (no parameter, optimiser or rng-counter write). */
+ * do_update = 0: gradients only (no parameter, optimiser or rng-counter write); 1: the step; 2: forward only (out, top_mean /
+ * top_var; draws the random rows of x) -- a conditioned iteration is mode 2, the factor launches on top_mean / top_var, mode 1. */
 #define MOBOCMF_TINY_MAX_LAYERS 3
 #define MOBOCMF_TINY_MAX_M 32
 #define MOBOCMF_TINY_MAX_D 8
@@ -411,8 +412,21 @@ typedef struct mobocmf_tiny_model {
     double* grad;                            /* optional */
     double* out;                             /* 3 doubles */
     int32_t* info;                           /* L words */
-    double kl_scale;                         /* batch / num_data (variational_elbo_mf.py:44-47) */
+    double kl_scale;                         /* d loss / d KL_l: batch / num_data (variational_elbo_mf.py:44-47) */
     double jitter;
+    /* Conditioned training (blackbox_mfdgp_fitter.py:270-343), all optional (NULL / 0: the plain ELBO step).  The loss of a
+     * model is  -sum_rows row_weight[b] E_q[log p(y_b | f)] + kl_scale sum_l KL_l  + <seeds, top-layer moments>: rows scored
+     * with another weight (the batch term's num_data / B, a Pareto point's 1) or not at all (weight 0: x~ rows, the Pareto
+     * rows of a constraint), and gradients of terms formed OUTSIDE the launch (the theta / omega factors,
+     * mobocmf_cond_factors_forward) entering at the top layer's columns. */
+    const double* row_weight;                /* N (NULL: 1) */
+    const double* seed_gmean;                /* rows[L-1] * S: d(outside term) / d mean of the top layer's columns (NULL: none) */
+    const double* seed_gvar;
+    double seed_scale;                       /* the outside term's coefficient in the loss (the fitter's -1) */
+    double* top_mean;                        /* rows[L-1] * S: the top layer's moments, written by every mode (NULL: not) */
+    double* top_var;
+    int64_t* xrng;                           /* {seed, calls}: mode 2 draws rows [rand_row0, rand_row0 + rand_rows) of x from */
+    int32_t rand_row0, rand_rows;            /* U(0,1) (the x~ of :276; x must be writable); mode 1 of model 0 advances calls */
 } mobocmf_tiny_model;
 int mobocmf_tiny_flat_len(const mobocmf_tiny_model* model, int64_t* len);
 int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes);

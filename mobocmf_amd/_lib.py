@@ -53,7 +53,10 @@ class TinyModel(ctypes.Structure):
                 ("rng", ctypes.c_void_p * _L), ("eps", ctypes.c_void_p * _L),
                 ("adam_m", ctypes.c_void_p), ("adam_v", ctypes.c_void_p), ("steps_done", ctypes.c_void_p),
                 ("work", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("out", ctypes.c_void_p), ("info", ctypes.c_void_p),
-                ("kl_scale", ctypes.c_double), ("jitter", ctypes.c_double)]
+                ("kl_scale", ctypes.c_double), ("jitter", ctypes.c_double),
+                ("row_weight", ctypes.c_void_p), ("seed_gmean", ctypes.c_void_p), ("seed_gvar", ctypes.c_void_p),
+                ("seed_scale", ctypes.c_double), ("top_mean", ctypes.c_void_p), ("top_var", ctypes.c_void_p),
+                ("xrng", ctypes.c_void_p), ("rand_row0", ctypes.c_int32), ("rand_rows", ctypes.c_int32)]
 
 
 class MobocmfError(RuntimeError):

@@ -189,3 +189,9 @@ __device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t call, ui
     const double u2 = ((double)(((uint64_t)(r[2] >> 5) << 26) | (uint64_t)(r[3] >> 6)) + 0.5) * 1.1102230246251565e-16;
     return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
+__device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t call, uint64_t idx) {      // (0, 1), 53 random bits
+    uint32_t r[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)call, (uint32_t)(call >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    return ((double)(((uint64_t)(r[0] >> 5) << 26) | (uint64_t)(r[1] >> 6)) + 0.5) * 1.1102230246251565e-16;
+}

@@ -285,6 +285,12 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         W0[l * MS + i * LD + j] = j <= i ? md.L_S[l][i * M + j] : 0.0;
     }
     for (int e = tid; e < L * M; e += TT) mst[(e / M) * MR + e % M] = md.m[e / M][e % M];
+    if (do_update == 2 && md.xrng && md.rand_rows > 0) {
+        // the x~ of this iteration (:276): every model of the launch draws the SAME points from the shared stream
+        const uint64_t seed = (uint64_t)md.xrng[0], call = (uint64_t)md.xrng[1];
+        double* xw = const_cast<double*>(md.x) + (int64_t)md.rand_row0 * d;
+        for (int e = tid; e < md.rand_rows * d; e += TT) xw[e] = philox_uniform(seed, call, (uint64_t)e);
+    }
     if (tid < L) {
         const double lo = md.noise_lo[tid], hi = md.noise_hi[tid], r = md.raw_noise[tid][0];
         sc[tid] = hi > lo ? lo + (hi - lo) / (1.0 + exp(-r)) : r;
@@ -411,9 +417,10 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
                 vmean[c] = mu; vvar[c] = var; vq[c] = q; vraw[c] = vr;
                 const int b = c / div;
                 if (md.fid[b] == (double)l) {
-                    const double dlt = md.y[b] - mu;
-                    dacc += -0.5 * ((dlt * dlt + var) / tau + ltau + LOG2PI) / div;
+                    const double dlt = md.y[b] - mu, w = md.row_weight ? md.row_weight[b] : 1.0;
+                    dacc += w * (-0.5 * ((dlt * dlt + var) / tau + ltau + LOG2PI)) / div;
                 }
+                if (l == L - 1 && md.top_mean) { md.top_mean[c] = mu; md.top_var[c] = var; }
             }
         }
         __syncthreads();
@@ -445,6 +452,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         }
     }
 
+    if (do_update == 2) return;
     // ---- backward, top layer first
     for (int l = L - 1; l >= 0; --l) {
         const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l], Hl = g.H[l];
@@ -470,10 +478,14 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
                 const int b = c / div;
                 double gm = 0.0, gvv = 0.0;
                 if (md.fid[b] == (double)l) {
-                    const double dlt = md.y[b] - vmean[c];
-                    gm = gd * dlt / tau;
-                    gvv = -0.5 * gd / tau;
-                    st += 0.5 * ((dlt * dlt + vvar[c]) / (tau * tau) - 1.0 / tau);
+                    const double dlt = md.y[b] - vmean[c], w = md.row_weight ? md.row_weight[b] : 1.0;
+                    gm = w * gd * dlt / tau;
+                    gvv = -0.5 * w * gd / tau;
+                    st += w * 0.5 * ((dlt * dlt + vvar[c]) / (tau * tau) - 1.0 / tau);
+                }
+                if (l == L - 1 && md.seed_gmean) {
+                    gm += md.seed_scale * md.seed_gmean[c];
+                    gvv += md.seed_scale * md.seed_gvar[c];
                 }
                 if (c * fdiv < ncn) {
                     double sm = 0.0, sv = 0.0;
@@ -779,6 +791,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             md.steps_done[0] = step;
             for (int l = 1; l < L; ++l)
                 if (!md.eps[l] && md.rng[l]) md.rng[l][1] += 1;
+            if (blockIdx.x == 0 && md.xrng) md.xrng[1] += 1;
         }
     }
 }
@@ -803,6 +816,8 @@ bool valid_model(const mobocmf_tiny_model& m) {
         if (!m.m[l] || !m.L_S[l] || !m.raw_noise[l]) return false;
         if (l && !m.eps[l] && !m.rng[l]) return false;
     }
+    if ((m.seed_gmean == nullptr) != (m.seed_gvar == nullptr) || (m.top_mean == nullptr) != (m.top_var == nullptr)) return false;
+    if (m.xrng && (m.rand_row0 < 0 || m.rand_rows < 0 || m.rand_row0 + m.rand_rows > m.N)) return false;
     return m.x && m.y && m.fid && m.Zx && m.adam_m && m.adam_v && m.steps_done && m.work && m.out && m.info;
 }
 
@@ -830,7 +845,7 @@ int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes) {
 
 int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
                            double lr, double beta1, double beta2, double eps, int32_t do_update, mobocmf_stream_t stream) {
-    if (!host_models || !dev_models || n_models < 1 || n_models > 65535) return MOBOCMF_BAD_ARG;
+    if (!host_models || !dev_models || n_models < 1 || n_models > 65535 || do_update < 0 || do_update > 2) return MOBOCMF_BAD_ARG;
     int mmax = 0;
     int64_t pmax = 0;
     for (int i = 0; i < n_models; ++i) {

@@ -508,9 +508,18 @@ class BlackBoxMFDGPFitter:
         if use_graphs and not full_batch:
             raise ValueError("a captured conditioned step needs batch_size >= number of training points (mini-batches come "
                              "from a host-side loader)")
-        step = GraphedConditionedStep(self, lr=self.lr_2, use_graph=use_graphs,
-                                      stream=self._stream_for(0, self.pareto_set.device) if self.pareto_set.is_cuda else None)
-        step.snapshot()
+        tiny = None
+        if use_graphs and self.use_tiny_step and parallel.world()[1] == 1:
+            # the reference's own sizes: the whole iteration in 3 + n_con launches (util/tiny_step.py)
+            done, tiny = self._train_conditioned_tiny(num_iters)
+            num_iters -= done
+        if num_iters > 0:
+            step = GraphedConditionedStep(self, lr=self.lr_2, use_graph=use_graphs,
+                                          stream=self._stream_for(0, self.pareto_set.device) if self.pareto_set.is_cuda else None)
+            if tiny is not None:      # a Cholesky failed there: this path (jitter ladder) continues with its optimiser state
+                for k in range(len(tiny.models)):
+                    tiny.export_adam_state(k, step.optimizer)
+            step.snapshot()
         last_good = -1
         for i in range(num_iters):
             step.step()
@@ -530,12 +539,48 @@ class BlackBoxMFDGPFitter:
                 if self.verbose:
                     print("Iter:", i, "/", num_iters, ". Neg. ELBO per iter:", step.loss.item())
                     sys.stdout.flush()
-        step.stream.synchronize()
-        torch.cuda.current_stream(self.pareto_set.device).wait_stream(step.stream)
-        step.retire()
+        if num_iters > 0:
+            step.stream.synchronize()
+            torch.cuda.current_stream(self.pareto_set.device).wait_stream(step.stream)
+            step.retire()
         for _, _, h in self._handlers():
             h.iter_train_loader = None
             h.mfdgp.set_check_pd(True)
+
+    def _train_conditioned_tiny(self, num_iters):
+        """Conditioned training through TinyConditionedStep when every surrogate fits it.  Returns (iterations completed, step
+        or None): fewer than ``num_iters`` when the surrogates do not fit (0, None) or after a failed Cholesky (state rolled
+        back to the last verified iteration; the layer path continues)."""
+        from .. import _lib
+        from ..layers.mfdgp_hidden_layer import NotPSDError
+        from .tiny_step import TinyConditionedStep
+        dev = self.pareto_set.device
+        try:
+            step = TinyConditionedStep(self, lr=self.lr_2, stream=self._stream_for(0, dev))
+        except _lib.MobocmfError:
+            return 0, None
+        step.stream.wait_stream(torch.cuda.current_stream(dev))
+        step.snapshot()
+        last_good = -1
+        for i in range(num_iters):
+            step.step()
+            if (i % ITER_PRINT) == 0 or (i + 1) == num_iters:
+                try:
+                    step.check()
+                except (NotPSDError, FloatingPointError) as err:
+                    warnings.warn("conditioned training: %s -- rolling back %d iterations; the layer path continues" %
+                                  (err, i - last_good))
+                    step.restore()
+                    torch.cuda.current_stream(dev).wait_stream(step.stream)
+                    return last_good + 1, step
+                step.snapshot()
+                last_good = i
+                if self.verbose:
+                    print("Iter:", i, "/", num_iters, ". Neg. ELBO per iter:", step.loss.item())
+                    sys.stdout.flush()
+        step.stream.synchronize()
+        torch.cuda.current_stream(dev).wait_stream(step.stream)
+        return num_iters, step
 
     def mfdgps_to_train_mode(self):
         for _, _, h in self._handlers():

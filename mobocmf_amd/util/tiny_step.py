@@ -78,11 +78,14 @@ class TinyELBOStep:
     as of the last step (before its update)."""
 
     def __init__(self, models, num_data, xs, ys, fids, lr, betas=(0.9, 0.999), eps=1e-8, stream=None, fixed_eps=None,
-                 want_grad=False):
+                 want_grad=False, prepared=None):
+        """``prepared`` (TinyConditionedStep): per model a dict with the rows ALREADY in the kernel's order and the optional
+        fields of mobocmf_tiny_model -- x, y, fid, rows, row_weight, kl_scale, seeds (bool), rand (row0, rows), xrng, eps
+        (per layer, prefix columns)."""
         lib = _lib.require_device()
         self.models = list(models)
         n = len(self.models)
-        dev = xs[0].device
+        dev = (xs[0] if prepared is None else prepared[0]["x"]).device
         self.device = dev
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
@@ -94,17 +97,23 @@ class TinyELBOStep:
         self._keep = []          # tensors the descriptors point at
         self.exp_avg, self.exp_avg_sq, self.grads, self._work = [], [], [], []
         self._segments = []      # per model: [(parameter tensor, flat offset, length)]
+        self.top_moments, self.seeds, self.x_rows = [], [], []      # prepared models: (2, ncol_top) tensors, the x array
         for i, model in enumerate(self.models):
-            x, y, fid = xs[i], ys[i], fids[i]
+            prep = None if prepared is None else prepared[i]
+            x, y, fid = (xs[i], ys[i], fids[i]) if prep is None else (prep["x"], prep["y"], prep["fid"])
             if not eligible(model, x, fid):
                 raise _lib.MobocmfError("TinyELBOStep: model %d does not fit the one-launch step (see eligible())" % i)
             layers = model._layers()
             L, S = len(layers), model.num_samples_for_training
             fidv = fid.reshape(-1).to(torch.float64)
             N = fidv.numel()
-            counts = [int((fidv >= l).sum()) for l in range(L)]
-            order = torch.argsort(fidv, descending=True, stable=True)
-            xo, yo, fo = x[order].contiguous(), y.reshape(-1)[order].to(torch.float64).contiguous(), fidv[order].contiguous()
+            if prep is None:
+                counts = [int((fidv >= l).sum()) for l in range(L)]
+                order = torch.argsort(fidv, descending=True, stable=True)
+                xo, yo, fo = x[order].contiguous(), y.reshape(-1)[order].to(torch.float64).contiguous(), fidv[order].contiguous()
+            else:
+                counts, order = [int(r) for r in prep["rows"]], None
+                xo, yo, fo = x.contiguous(), y.reshape(-1).to(torch.float64).contiguous(), fidv.contiguous()
             self.row_order.append(order)
             self.layer_rows.append(counts)
             T = self.host[i]
@@ -112,8 +121,26 @@ class TinyELBOStep:
             Zx = layers[0].variational_strategy._inducing_points.detach().contiguous()
             T.x, T.y, T.fid, T.Zx = xo.data_ptr(), yo.data_ptr(), fo.data_ptr(), Zx.data_ptr()
             self._keep += [xo, yo, fo, Zx]
-            T.kl_scale = N / float(num_data[i])
+            T.kl_scale = N / float(num_data[i]) if prep is None else float(prep["kl_scale"])
             T.jitter = layers[0].variational_strategy.jitter_val
+            if prep is not None:
+                ntop = counts[-1] * (S if L > 1 else 1)
+                if prep.get("row_weight") is not None:
+                    w = prep["row_weight"].to(torch.float64).contiguous()
+                    T.row_weight = w.data_ptr()
+                    self._keep.append(w)
+                tm = torch.zeros(2, ntop, dtype=torch.float64, device=dev)
+                T.top_mean, T.top_var = tm[0].data_ptr(), tm[1].data_ptr()
+                self.top_moments.append(tm)
+                if prep.get("seeds"):
+                    sd = torch.zeros(2, ntop, dtype=torch.float64, device=dev)
+                    T.seed_gmean, T.seed_gvar, T.seed_scale = sd[0].data_ptr(), sd[1].data_ptr(), float(prep.get("seed_scale", 1.0))
+                    self.seeds.append(sd)
+                if prep.get("xrng") is not None:
+                    T.xrng = prep["xrng"].data_ptr()
+                    T.rand_row0, T.rand_rows = prep["rand"]
+                    self._keep.append(prep["xrng"])
+                self.x_rows.append(xo)
             segs = []
             off = 0
             for l, layer in enumerate(layers):
@@ -136,9 +163,15 @@ class TinyELBOStep:
                 T.raw_noise[l] = lik.raw_noise.data_ptr()
                 T.noise_lo[l], T.noise_hi[l] = lik.raw_noise_constraint.lower_bound, lik.raw_noise_constraint.upper_bound
                 if l:
-                    e = None if fixed_eps is None or fixed_eps[i] is None else fixed_eps[i][l]
-                    if e is not None:      # given for the batch as passed in (N * S values): follow the rows
-                        e = e.reshape(N, S)[order][:counts[l]].reshape(-1).contiguous()
+                    if prep is not None:
+                        e = None if prep.get("eps") is None else prep["eps"][l]
+                        if e is not None:
+                            e = e.reshape(-1)[:counts[l] * S].contiguous()
+                    else:
+                        e = None if fixed_eps is None or fixed_eps[i] is None else fixed_eps[i][l]
+                        if e is not None:      # given for the batch as passed in (N * S values): follow the rows
+                            e = e.reshape(N, S)[order][:counts[l]].reshape(-1).contiguous()
+                    if e is not None:
                         T.eps[l] = e.data_ptr()
                         self._keep.append(e)
                     rng = layer._rng(dev)
@@ -172,23 +205,24 @@ class TinyELBOStep:
         self._snap = None
 
     # ------------------------------------------------------------------ the step
-    def _launch(self, do_update):
+    def _launch(self, mode):
+        """mode: 0 gradients only, 1 the step, 2 forward only (mobocmf_tiny_elbo_step's do_update)."""
         lib = _lib.require_device()
         _lib.check(lib.mobocmf_tiny_elbo_step(ctypes.cast(self.host, ctypes.c_void_p), ctypes.c_void_p(self._dev_table.data_ptr()),
                                               len(self.models), self.lr, self.betas[0], self.betas[1], self.eps,
-                                              1 if do_update else 0, ctypes.c_void_p(self.stream.cuda_stream)),
+                                              int(mode), ctypes.c_void_p(self.stream.cuda_stream)),
                    "mobocmf_tiny_elbo_step")
 
     def step(self):
         """Enqueues one step of every model on ``self.stream``."""
-        self._launch(True)
+        self._launch(1)
         return self.losses
 
     def gradients(self):
         """-ELBO and its raw-parameter gradients at the current parameters, no update (``want_grad=True``): per model a dict
         parameter -> gradient tensor of its shape."""
         assert self.grads, "construct with want_grad=True"
-        self._launch(False)
+        self._launch(0)
         self.stream.synchronize()
         return [{p: self.grads[i][off:off + n].reshape(p.shape) for p, off, n in segs} for i, segs in enumerate(self._segments)]
 
@@ -243,3 +277,127 @@ class TinyELBOStep:
                     optimizer.state[k]["exp_avg"].copy_(self.exp_avg[i][off:off + n].reshape(p.shape))
                     optimizer.state[k]["exp_avg_sq"].copy_(self.exp_avg_sq[i][off:off + n].reshape(p.shape))
             optimizer.steps_done.copy_(self.steps_done[i])
+
+
+def _ptrs(vals):
+    return (ctypes.c_void_p * len(vals))(*vals) if vals else None
+
+
+class TinyConditionedStep(TinyELBOStep):
+    """One iteration of the conditioned training (blackbox_mfdgp_fitter.py:245-354: fresh x~ ~ U[0,1]^(n_tilde x d), the joint
+    loss over ALL surrogates, one Adam) in 3 + n_con launches instead of ~180: mobocmf_tiny_elbo_step forward-only (every
+    model on [Pareto set | x~ | its batch]; draws x~), the theta factors of every constraint and the omega factors
+    (mobocmf_cond_factors_forward, which also forms their gradients) on the top layers' moments, then
+    mobocmf_tiny_elbo_step as the step, the factor gradients entering at the top layers' columns.
+    Rows per model: the P Pareto points (objectives: scored against their column of the Pareto front, weight 1, :288-291;
+    constraints: weight 0, theta factors :227-233), the x~ (weight 0, omega factors :235-243), the batch (weight num_data / B,
+    KL weight 1: -elbo / B * num_data, :281-303).  One sample per row (the reference's S = 1)."""
+
+    def __init__(self, fitter, lr, betas=(0.9, 0.999), eps=1e-8, stream=None, n_tilde=10, fixed_x_tilde=None, fixed_eps=None,
+                 want_grad=False):
+        hs = fitter._handlers()
+        dev = fitter.pareto_set.device
+        P, d = fitter.pareto_set.shape
+        Tn = n_tilde if fixed_x_tilde is None else fixed_x_tilde.shape[0]
+        self.fitter, self.P, self.T = fitter, P, Tn
+        self.xrng = None
+        if fixed_x_tilde is None:
+            self.xrng = torch.tensor([int(torch.randint(1, 2 ** 62, (), dtype=torch.int64)), 0], dtype=torch.int64, device=dev)
+        prepared, self._orders = [], []
+        for tag, i, h in hs:
+            xb, yb, fb = h.train_dataset.tensors
+            if h.mfdgp.num_samples_for_training != 1:
+                raise _lib.MobocmfError("TinyConditionedStep: one training sample per row (the reference's S = 1)")
+            B, top = xb.shape[0], h.num_fidelities - 1
+            fv = fb.reshape(-1).to(torch.float64)
+            order = torch.argsort(fv, descending=True, stable=True)
+            self._orders.append(order)
+            xt = torch.zeros(Tn, d, dtype=torch.float64, device=dev) if fixed_x_tilde is None else fixed_x_tilde.to(dev).double()
+            z = lambda n: torch.zeros(n, dtype=torch.float64, device=dev)
+            if tag == "OBJ":
+                gi = fitter._global_index(h, i)
+                yp, wp = fitter.pareto_front[:, gi].to(torch.float64), torch.ones(P, dtype=torch.float64, device=dev)
+            else:
+                yp, wp = z(P), z(P)
+            e = None
+            if fixed_eps is not None and fixed_eps.get((tag, i)) is not None:
+                # given for the rows [batch | Pareto | x~] (fitter.conditioned_loss): into this step's [Pareto | x~ | batch sorted]
+                idx = torch.cat([torch.arange(B, B + P + Tn, device=dev), order])
+                e = [None if v is None else v.reshape(-1)[idx] for v in fixed_eps[(tag, i)]]
+            prepared.append(dict(
+                x=torch.cat([fitter.pareto_set.double(), xt, xb[order].double()], 0),
+                y=torch.cat([yp, z(Tn), yb.reshape(-1)[order].double()]),
+                fid=torch.cat([torch.full((P + Tn,), float(top), dtype=torch.float64, device=dev), fv[order]]),
+                rows=[P + Tn + int((fv >= l).sum()) for l in range(h.num_fidelities)],
+                row_weight=torch.cat([wp, z(Tn), torch.full((B,), float(h.num_data) / B, dtype=torch.float64, device=dev)]),
+                kl_scale=1.0, seeds=True, seed_scale=-1.0, xrng=self.xrng, rand=(P, Tn), eps=e))
+        super().__init__([h.mfdgp for _, _, h in hs], None, None, None, None, lr, betas=betas, eps=eps, stream=stream,
+                         want_grad=want_grad, prepared=prepared)
+        # the factor launches: pointer tables into the models' top-layer moments / seed arrays, built once
+        obj = [k for k, (tag, _, _) in enumerate(hs) if tag == "OBJ"]
+        con = [k for k, (tag, _, _) in enumerate(hs) if tag == "CON"]
+        if len(obj) > 8 or len(con) > 8:
+            raise _lib.MobocmfError("TinyConditionedStep: at most 8 objectives and 8 constraints")
+        self._obj, self._con = obj, con
+        self.factor_losses = torch.zeros(len(con) + 1, dtype=torch.float64, device=dev)
+        log_e, log_1me = float(torch.log(torch.tensor(fitter.eps, dtype=torch.float64))), \
+            float(torch.log1p(torch.tensor(-fitter.eps, dtype=torch.float64)))
+        thr = fitter._thresholds_on(dev).to(torch.float64).contiguous()
+        front = fitter.pareto_front.to(torch.float64).contiguous()
+        self._keep += [thr, front]
+        mom = lambda k, r, off: self.top_moments[k][r].data_ptr() + 8 * off
+        sd = lambda k, r, off: self.seeds[k][r].data_ptr() + 8 * off
+        self._theta = []
+        for j, k in enumerate(con):      # theta factors of constraint j at the Pareto points (columns [0, P) of its top layer)
+            self._theta.append((0, 1, 1, P, None, None, _ptrs([mom(k, 0, 0)]), _ptrs([mom(k, 1, 0)]), None,
+                                ctypes.c_void_p(thr.data_ptr() + 8 * j), log_1me, log_e,
+                                ctypes.c_void_p(self.factor_losses[j:j + 1].data_ptr()), None, None,
+                                _ptrs([sd(k, 0, 0)]), _ptrs([sd(k, 1, 0)])))
+        # omega factors at the x~ (columns [P, P + T)) over all objectives and constraints
+        self._omega = (len(obj), len(con), P, Tn, _ptrs([mom(k, 0, P) for k in obj]), _ptrs([mom(k, 1, P) for k in obj]),
+                       _ptrs([mom(k, 0, P) for k in con]), _ptrs([mom(k, 1, P) for k in con]),
+                       ctypes.c_void_p(front.data_ptr()), ctypes.c_void_p(thr.data_ptr()), log_e, log_1me,
+                       ctypes.c_void_p(self.factor_losses[len(con):].data_ptr()),
+                       _ptrs([sd(k, 0, P) for k in obj]), _ptrs([sd(k, 1, P) for k in obj]),
+                       _ptrs([sd(k, 0, P) for k in con]), _ptrs([sd(k, 1, P) for k in con]))
+
+    def _factors(self):
+        lib = _lib.require_device()
+        st = ctypes.c_void_p(self.stream.cuda_stream)
+        for a in self._theta + [self._omega]:
+            _lib.check(lib.mobocmf_cond_factors_forward(*a, st), "mobocmf_cond_factors_forward")
+
+    def step(self):
+        self._launch(2)
+        self._factors()
+        self._launch(1)
+        return self.losses
+
+    def gradients(self):
+        assert self.grads, "construct with want_grad=True"
+        self._launch(2)
+        self._factors()
+        self._launch(0)
+        self.stream.synchronize()
+        return [{p: self.grads[i][off:off + n].reshape(p.shape) for p, off, n in segs} for i, segs in enumerate(self._segments)]
+
+    @property
+    def loss(self):
+        """The joint loss of the last iteration (:270-343): the models' terms minus the factor terms (0-dim device tensor)."""
+        return self.losses[:, 2].sum() - self.factor_losses.sum()
+
+    @property
+    def x_tilde(self):
+        return self.x_rows[0][self.P:self.P + self.T]
+
+    def snapshot(self):
+        super().snapshot()
+        self._snap = self._snap + (None if self.xrng is None else self.xrng.clone(),)
+
+    def restore(self):
+        xr = self._snap[-1]
+        self._snap = self._snap[:-1]
+        super().restore()
+        if xr is not None:
+            self.xrng.copy_(xr)
+        self._snap = self._snap + (xr,)

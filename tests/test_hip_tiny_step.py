@@ -167,3 +167,84 @@ def test_eligibility_rules():
     big = synthetic.make_problem(d=2, L=2, M=48, N=64, S=1, seed=0)
     assert not eligible(synthetic.model_from_problem(big, num_samples_for_training=1, device=DEV),
                         torch.as_tensor(big["x"]).to(DEV), torch.as_tensor(big["fid"]).to(DEV))
+
+
+# ------------------------------------------------------------------ conditioned training in 3 + n_con launches
+def test_tiny_conditioned_iteration_matches_oracle():
+    """TinyConditionedStep -- forward-only launch, theta / omega factor launches on the top layers' moments, step launch with
+    the factor gradients entering as seeds -- vs the oracle's joint loss (blackbox_mfdgp_fitter.py:270-343 restated): the
+    loss and d loss / d (m, L_S) of every layer of every surrogate, explicit x~ and eps."""
+    from mobocmf_amd.util.tiny_step import TinyConditionedStep
+    from tests.helpers import oracle_state, to_t
+    from tests.test_hip_conditioned import _fitter
+    n_obj, n_con, N, P, T, d = 2, 1, 12, 5, 10, 2
+    fitter, probs = _fitter(n_obj, n_con, N)
+    g = torch.Generator().manual_seed(0)
+    pareto_set = torch.rand(P, d, dtype=torch.float64, generator=g)
+    pareto_front = torch.randn(P, n_obj, dtype=torch.float64, generator=g) * 0.5
+    x_tilde = torch.rand(T, d, dtype=torch.float64, generator=g)
+    fitter.set_pareto_solution(pareto_set, pareto_front)
+    eps_all, objs, cons = {}, [], []
+    for idx, (tag, i, h) in enumerate(fitter._handlers()):
+        e = torch.randn(N + P + T, dtype=torch.float64, generator=g)
+        eps_all[(tag, i)] = [None, e.to(DEV)]
+        st = oracle_state(probs[idx], requires_grad=True)
+        rec = {"state": st, "x": to_t(probs[idx]["x"]), "y": to_t(probs[idx]["y"]), "fid": to_t(probs[idx]["fid"]),
+               "eps_batch": [None, e[:N]], "eps_pareto": [None, e[N:N + P]], "eps_tilde": [None, e[N + P:]]}
+        (objs if tag == "OBJ" else cons).append(rec)
+        h.mfdgp.fix_variational_hypers_cond(True)
+    loss_o = O.conditioned_loss(objs, cons, pareto_set, pareto_front, x_tilde, fitter.thresholds_cons, fitter.eps)
+    loss_o.backward()
+    step = TinyConditionedStep(fitter, lr=1e-3, fixed_x_tilde=x_tilde.to(DEV), fixed_eps=eps_all, want_grad=True)
+    grads = step.gradients()
+    step.check()
+    assert rel(step.loss, loss_o) < 1e-8, rel(step.loss, loss_o)
+    for k, (rec, (tag, i, h)) in enumerate(zip(objs + cons, fitter._handlers())):
+        for l in range(2):
+            vd = getattr(h.mfdgp, f"hidden_layer_{l}").variational_strategy._variational_distribution
+            assert rel(grads[k][vd.variational_mean], rec["state"]["layers"][l]["m"].grad) < 1e-6, (tag, i, l)
+            assert rel(grads[k][vd.chol_variational_covar], torch.tril(rec["state"]["layers"][l]["L_S"].grad)) < 1e-6, (tag, i, l)
+    # the step itself: only m and L_S move (fix_variational_hypers_cond), by Adam's first step = lr * sign(gradient)
+    before = [[p.detach().clone() for p in h.mfdgp.parameters()] for _, _, h in fitter._handlers()]
+    step.step()
+    step.check()
+    for k, (_, _, h) in enumerate(fitter._handlers()):
+        for p, p0 in zip(h.mfdgp.parameters(), before[k]):
+            if p.requires_grad:
+                gk = grads[k][p]
+                moved = (p.detach() - p0)
+                assert torch.allclose(moved[gk != 0], -1e-3 * torch.sign(gk[gk != 0]), rtol=1e-5, atol=0)
+            else:
+                assert torch.equal(p.detach(), p0)
+
+
+def test_tiny_conditioned_step_draws_fresh_shared_x_tilde():
+    """Without fixed x~ the forward-only launch draws it (U(0,1), Philox keyed by the step's seed and iteration counter):
+    inside (0, 1), the same points for every surrogate, new ones at every iteration; the joint loss stays finite and the
+    fitter's conditioned training runs through this step."""
+    from mobocmf_amd.util.tiny_step import TinyConditionedStep
+    from tests.test_hip_conditioned import _fitter
+    fitter, _ = _fitter(2, 1, 12)
+    g = torch.Generator().manual_seed(1)
+    fitter.set_pareto_solution(torch.rand(5, 2, dtype=torch.float64, generator=g),
+                               torch.randn(5, 2, dtype=torch.float64, generator=g) * 0.3)
+    for _, _, h in fitter._handlers():
+        h.mfdgp.fix_variational_hypers_cond(True)
+    step = TinyConditionedStep(fitter, lr=1e-3)
+    seen = []
+    for _ in range(3):
+        step.step()
+        step.check()
+        xt = [xr[step.P:step.P + step.T].clone() for xr in step.x_rows]
+        assert all(torch.equal(xt[0], v) for v in xt[1:])
+        assert bool(((xt[0] > 0) & (xt[0] < 1)).all())
+        assert all(not torch.equal(xt[0], s) for s in seen)
+        seen.append(xt[0])
+        assert bool(torch.isfinite(step.loss))
+    assert int(step.xrng[1]) == 3
+    fitter.lr_2 = 5e-3
+    l0 = float(step.loss)
+    fitter.train_conditioned_mfdgps(num_iters=150)
+    xt = torch.rand(10, 2, dtype=torch.float64, generator=g).to(DEV)
+    torch.manual_seed(0)
+    assert float(fitter.conditioned_loss(xt)) < l0
