@@ -22,6 +22,7 @@ constexpr int DBT = MOBOCMF_TINY_MAX_D;          // x columns of a staged induci
 constexpr int ZW = DBT + 1;                      // + the f column
 constexpr int HS = 5 + 2 * DBT;                  // packed hyper-parameters of a layer, at most
 constexpr int NVEC = 11;                         // per-column vectors of a layer kept in `work`
+constexpr int NSEG = 32;                         // parameter tensors of a model, at most (3 layers x 9 + 3 noise)
 constexpr double MINV = 1e-10;                   // gpytorch.settings.min_variance (float64)
 constexpr double LOG2PI = 1.8378770664093453;
 
@@ -237,11 +238,13 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     double* dat = dav + MR;                 // [MR] da_tot
     double* mst = dat + MR;                 // [TLM][MR] m of every layer (staged)
     double* red = mst + TLM * MR;           // [4][HS + 1] wavefront partials
-    double* sc = red + 4 * (HS + 1);        // [16]: tau[l] (0..2), g_noise[l] (4..6), bsum scratch (8..11)
+    double* sc = red + 4 * (HS + 1);        // [16]: tau[l] (0..2), g_noise[l] (4..6), bsum scratch (8..11), Adam's bias terms
+    double** seg_ptr = (double**)(sc + 16); // [NSEG] parameter tensors in flat-vector order (trainable ones; else null)
+    int* seg_end = (int*)(seg_ptr + NSEG);  // [NSEG] end offset of each tensor in the flat vector
     double* gflat = md.work;
     // the panels: LDS behind the chain state when the launch reserved room for them (a dependent global round trip per
     // contraction step is what a phase costs otherwise), else the caller's workspace; generic pointers either way
-    double* work = pool_in_lds ? sc + 16 : md.work + g.pool_base;
+    double* work = pool_in_lds ? sc + 16 + NSEG + NSEG / 2 : md.work + g.pool_base;
     double* Kb = work + g.scratch_off;      // M x ncmax scratch panels
     double* S1 = Kb + (int64_t)M * g.ncmax;
     double* S2 = S1 + (int64_t)M * g.ncmax;
@@ -290,6 +293,33 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         const uint64_t seed = (uint64_t)md.xrng[0], call = (uint64_t)md.xrng[1];
         double* xw = const_cast<double*>(md.x) + (int64_t)md.rand_row0 * d;
         for (int e = tid; e < md.rand_rows * d; e += TT) xw[e] = philox_uniform(seed, call, (uint64_t)e);
+    }
+    if (tid >= 64 && tid < 64 + NSEG) {      // the parameter tensors in flat-vector order: thread 64 + k fills entry k
+        const int k = tid - 64;
+        double* ptr = nullptr;
+        int end = 0x7fffffff, j = 0;
+        for (int l = 0; l < L; ++l) {
+            const uint32_t tr = md.trainable[l];
+            const int ns = l == 0 ? 2 : 7;
+            int off = (int)g.flat_off[l];
+            for (int s2 = 0; s2 < ns; ++s2, ++j) {
+                off += seg_len(l, s2, d);
+                if (j == k) { ptr = ((tr >> s2) & 1u) ? md.raw[l][s2] : nullptr; end = off; }
+            }
+            off += M;
+            if (j++ == k) { ptr = ((tr >> 7) & 1u) ? md.m[l] : nullptr; end = off; }
+            off += M * M;
+            if (j++ == k) { ptr = ((tr >> 8) & 1u) ? md.L_S[l] : nullptr; end = off; }
+        }
+        for (int l = 0; l < L; ++l)
+            if (j++ == k) { ptr = ((md.trainable[l] >> 9) & 1u) ? md.raw_noise[l] : nullptr; end = (int)g.flat_noise + l + 1; }
+        seg_ptr[k] = ptr;
+        seg_end[k] = end;
+    }
+    if (tid == TT - 1 && do_update == 1) {      // Adam's bias corrections (two pow calls): once, off the critical path
+        const double step = (double)(md.steps_done[0] + 1);
+        sc[12] = 1.0 - pow(b1, step);
+        sc[13] = sqrt(1.0 - pow(b2, step));
     }
     if (tid < L) {
         const double lo = md.noise_lo[tid], hi = md.noise_hi[tid], r = md.raw_noise[tid][0];
@@ -349,7 +379,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
             for (int k = 0; k <= i; ++k) a += li[k] * mv[k];
             av[l * MR + i] = a;
             const double lsii = ls[i * LD + i];
-            klacc += 0.5 * a * a + log(Lm[l * MS + i * LD + i]) - 0.5 * log(lsii * lsii) - 0.5;
+            klacc += 0.5 * a * a + log(Lm[l * MS + i * LD + i] / fabs(lsii)) - 0.5;      // log L_ii - 1/2 log L_S,ii^2
         }
     }
     __syncthreads();
@@ -762,30 +792,24 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     // ---- Adam (torch.optim.Adam: p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)), every trainable tensor
     {
         const int64_t step = md.steps_done[0] + 1;
-        const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
-        auto upd = [&](double* p, int64_t off, int len, bool on) {
-            if (!on) return;
-            for (int e = tid; e < len; e += TT) {
-                const double gi = gflat[off + e];
-                const double mi = b1 * md.adam_m[off + e] + (1.0 - b1) * gi;
-                const double vi = b2 * md.adam_v[off + e] + (1.0 - b2) * gi * gi;
-                md.adam_m[off + e] = mi;
-                md.adam_v[off + e] = vi;
-                p[e] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + aeps);
-            }
-        };
-        for (int l = 0; l < L; ++l) {
-            const uint32_t tr = md.trainable[l];
-            const int ns = l == 0 ? 2 : 7;
-            int off = 0;
-            for (int s = 0; s < ns; ++s) {
-                upd(md.raw[l][s], g.flat_off[l] + off, seg_len(l, s, d), (tr >> s) & 1u);
-                off += seg_len(l, s, d);
-            }
-            upd(md.m[l], g.flat_off[l] + g.H[l], M, (tr >> 7) & 1u);
-            upd(md.L_S[l], g.flat_off[l] + g.H[l] + M, M * M, (tr >> 8) & 1u);
-            upd(md.raw_noise[l], g.flat_noise + l, 1, (tr >> 9) & 1u);
+        const double bc1 = sc[12], bc2s = sc[13];
+        // one pass over the flat vector (a pass per tensor is a dependent global round trip per tensor: 7 us for 15 tensors)
+        for (int e = tid; e < (int)g.flat_len; e += TT) {
+            int k = 0;
+#pragma unroll
+            for (int sft = NSEG / 2; sft > 0; sft >>= 1)      // first tensor whose end lies beyond e
+                if (seg_end[k + sft - 1] <= e) k += sft;
+            double* p = seg_ptr[k];
+            if (!p) continue;
+            const int start = k ? seg_end[k - 1] : 0;
+            const double gi = gflat[e];
+            const double mi = b1 * md.adam_m[e] + (1.0 - b1) * gi;
+            const double vi = b2 * md.adam_v[e] + (1.0 - b2) * gi * gi;
+            md.adam_m[e] = mi;
+            md.adam_v[e] = vi;
+            p[e - start] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + aeps);
         }
+        STAMP();
         __syncthreads();      // every thread has read steps_done / the rng call counters
         if (tid == 0) {
             md.steps_done[0] = step;
@@ -800,7 +824,7 @@ constexpr size_t LDS_BUDGET = 160 * 1024;      // LDS of a gfx950 CU; one workgr
 size_t lds_bytes(int MR) {
     const int LD = MR + 1, MS = MR * LD;
     const size_t n = (size_t)(3 * TLM + 3) * MS + (size_t)TLM * MR * ZW + 2 * (size_t)TLM * HS + (size_t)TLM * 2 * DBT +
-                     3 * (size_t)TLM * MR + 2 * (size_t)MR + 4 * (HS + 1) + 16;
+                     3 * (size_t)TLM * MR + 2 * (size_t)MR + 4 * (HS + 1) + 16 + NSEG + NSEG / 2;
     return n * sizeof(double);
 }
 

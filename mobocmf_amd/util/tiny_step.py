@@ -13,17 +13,25 @@ import torch
 from .. import _lib
 from .. import gp
 
-MAX_COLUMNS = 1024      # rows[l] * S per layer above which the layer path (grid-filling kernels) is the faster one
+MAX_COLUMNS = 1024      # rows[l] * S per layer: hard limit of this binding
+LAYER_PATH_US = 240.0   # what a step of a small surrogate costs through the layer entry points (HIP-graph replay, MI355X)
+
+
+def estimated_us(M, columns):
+    """Duration of one launch, from tools/tiny_sweep.py on MI355X (profiles/r04_tiny_step.txt): a fixed part that grows with
+    the chain (M^2) and a part per panel column -- one workgroup does everything, so beyond a few dozen columns at M = 32
+    (a few hundred at M = 16) the grid-filling kernels of the layer path win and ``eligible`` says no."""
+    return 20.0 + 0.15 * M * M + (M * M / 900.0) * float(sum(columns))
 
 
 def _hyper_params(layer):
     return [getattr(m, n) for m, n in gp._hyper_sources(layer.covar_module, layer.kind)]
 
 
-def eligible(model, x, fidelities):
+def eligible(model, x, fidelities, speed_rule=True):
     """True when ``model`` on the batch ``x`` fits the one-launch step: <= 3 layers sharing one set of <= 32 inducing inputs
     (Z~_l = [Z_x, m_{l-1}]), d <= 8, softplus / Interval constraints, float64 parameters on the GPU, every fidelity's
-    prefix non-empty."""
+    prefix non-empty -- and, with ``speed_rule``, small enough for one workgroup to beat the layer path (estimated_us)."""
     try:
         layers = model._layers()
         L = len(layers)
@@ -42,6 +50,8 @@ def eligible(model, x, fidelities):
             return False
         counts = [int((fidv >= l).sum()) for l in range(L)]
         if counts[0] != N or counts[-1] < 1:
+            return False
+        if speed_rule and estimated_us(M, [c * (S if l else 1) for l, c in enumerate(counts)]) > LAYER_PATH_US:
             return False
         jit = layers[0].variational_strategy.jitter_val
         for l, layer in enumerate(layers):
@@ -78,8 +88,9 @@ class TinyELBOStep:
     as of the last step (before its update)."""
 
     def __init__(self, models, num_data, xs, ys, fids, lr, betas=(0.9, 0.999), eps=1e-8, stream=None, fixed_eps=None,
-                 want_grad=False, prepared=None):
-        """``prepared`` (TinyConditionedStep): per model a dict with the rows ALREADY in the kernel's order and the optional
+                 want_grad=False, prepared=None, force=False):
+        """``force``: take every size the kernel accepts, also those where the layer path is faster (tests, sweeps).
+        ``prepared`` (TinyConditionedStep): per model a dict with the rows ALREADY in the kernel's order and the optional
         fields of mobocmf_tiny_model -- x, y, fid, rows, row_weight, kl_scale, seeds (bool), rand (row0, rows), xrng, eps
         (per layer, prefix columns)."""
         lib = _lib.require_device()
@@ -101,7 +112,7 @@ class TinyELBOStep:
         for i, model in enumerate(self.models):
             prep = None if prepared is None else prepared[i]
             x, y, fid = (xs[i], ys[i], fids[i]) if prep is None else (prep["x"], prep["y"], prep["fid"])
-            if not eligible(model, x, fid):
+            if not eligible(model, x, fid, speed_rule=not force):
                 raise _lib.MobocmfError("TinyELBOStep: model %d does not fit the one-launch step (see eligible())" % i)
             layers = model._layers()
             L, S = len(layers), model.num_samples_for_training

@@ -56,6 +56,7 @@ def test_fitter_graph_captures_the_general_branch():
     x, y, fid = synthetic.forrester_problem(0)
     fitter = BlackBoxMFDGPFitter(2, 16, num_epochs_1=3, num_epochs_2=3, device=DEV)
     fitter.verbose = False
+    fitter.use_tiny_step = False      # the layer path is what is under test (the one-launch step has no shortcut branch at all)
     fitter.initialize_mfdgp(to_t(x), to_t(y)[:, None], to_t(fid)[:, None], "obj1")
     layer0 = fitter.get_model("obj1").hidden_layer_0
     layer0._shortcut_last = True

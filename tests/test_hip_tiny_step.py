@@ -33,7 +33,7 @@ def _tiny(models, xs, ys, fids, epss, lr=1e-2, want_grad=False):
     return TinyELBOStep(models, [x.shape[0] for x in xs], [x.to(DEV) for x in xs], [y.to(DEV) for y in ys],
                         [f.to(DEV) for f in fids], lr=lr,
                         fixed_eps=[None if e is None else [None if v is None else v.to(DEV) for v in e] for e in epss],
-                        want_grad=want_grad)
+                        want_grad=want_grad, force=True)
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=IDS)
@@ -167,6 +167,11 @@ def test_eligibility_rules():
     big = synthetic.make_problem(d=2, L=2, M=48, N=64, S=1, seed=0)
     assert not eligible(synthetic.model_from_problem(big, num_samples_for_training=1, device=DEV),
                         torch.as_tensor(big["x"]).to(DEV), torch.as_tensor(big["fid"]).to(DEV))
+    # accepted by the kernel, but one workgroup would be slower than the layer path's grid-filling launches: the speed rule
+    wide = synthetic.make_problem(d=2, L=2, M=32, N=256, S=4, seed=0)
+    mw = synthetic.model_from_problem(wide, num_samples_for_training=4, device=DEV)
+    xw, fw = torch.as_tensor(wide["x"]).to(DEV), torch.as_tensor(wide["fid"]).to(DEV)
+    assert eligible(mw, xw, fw, speed_rule=False) and not eligible(mw, xw, fw)
 
 
 # ------------------------------------------------------------------ conditioned training in 3 + n_con launches

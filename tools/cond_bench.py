@@ -27,11 +27,12 @@ fitter.train_mfdgps()
 g = torch.Generator().manual_seed(0)
 fitter.set_pareto_solution(torch.rand(50, 1, dtype=torch.float64, generator=g),
                            torch.randn(50, 2, dtype=torch.float64, generator=g) * 0.3)
-for use_graphs in (True, False):
+for label, tiny, use_graphs in (("one-launch step + factor launches (default at these sizes)", True, True),
+                                ("layer path, HIP-graph replay", False, True), ("layer path, eager", False, False)):
+    fitter.use_tiny_step = tiny
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fitter.train_conditioned_mfdgps(num_iters=iters, use_graphs=use_graphs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("conditioned training, %s: %.3f ms per iteration (%d iterations incl. set-up)" %
-          ("HIP-graph replay" if use_graphs else "eager", dt / iters * 1e3, iters))
+    print("conditioned training, %s: %.3f ms per iteration (%d iterations incl. set-up)" % (label, dt / iters * 1e3, iters))

@@ -18,7 +18,7 @@ busy = 0.0
 groups = {}
 for r in rows[a:b]:
     st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")[:60]
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")[:60]
     wg = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) * max(int(r["Grid_Size_Y"]), 1) * max(int(r["Grid_Size_Z"]), 1)
     print("%9.1f us  +%6.1f gap  %7.1f us  %5d wg  %s" % ((st - t0) / 1e3, (st - prev_end) / 1e3, (en - st) / 1e3, wg, name))
     busy += (en - st) / 1e3

@@ -8,7 +8,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
     name = re.sub(r"^void ", "", name)
     if len(name) > 70:
         name = name[:67] + "..."
