@@ -7,6 +7,7 @@ runs the whole step as barrier-separated phases (csrc/tiny_step.hip).  ``TinyELB
 ``GraphedELBOStep`` that the fitter's training loop uses (step / check / snapshot / loss), for several models at once.
 """
 import ctypes
+import os
 
 import torch
 
@@ -197,7 +198,9 @@ class TinyELBOStep:
             assert flat.value == off, (flat.value, off)
             wb = ctypes.c_size_t()
             _lib.check(lib.mobocmf_tiny_work_bytes(ctypes.byref(T), ctypes.byref(wb)), "mobocmf_tiny_work_bytes")
-            work = torch.zeros(wb.value // 8, dtype=torch.float64, device=dev)
+            # MOBOCMF_POISON (as functional._scratch): NaN-filled workspace, so a read of anything the launch did not write shows
+            work = torch.full((wb.value // 8,), float("nan") if os.environ.get("MOBOCMF_POISON") else 0.0,
+                              dtype=torch.float64, device=dev)
             ea, eq = torch.zeros(off, dtype=torch.float64, device=dev), torch.zeros(off, dtype=torch.float64, device=dev)
             self._work.append(work)
             self.exp_avg.append(ea)

@@ -267,3 +267,36 @@ def test_bench_accounting_of_dead_rows_and_active_blocks():
     fid3[:256], fid3[256:512] = 2.0, 1.0
     assert bench.backward_active_fractions(cfg3, fid3, None, True) == [1.0, 0.5, 0.25]
     assert bench.panel_columns(cfg3, [1024, 512, 256]) == [1024, 2048, 1024]
+
+
+def test_tiny_step_descriptor_layout_and_argument_checks():
+    """mobocmf_tiny_model as ctypes sees it == as the library sees it (the size queries read fields on both sides of the
+    pointer block), the flat-vector / workspace sizes follow the documented layout, and a malformed descriptor is refused on
+    the HOST, before any launch (no GPU needed)."""
+    import ctypes
+    from mobocmf_amd import _lib
+    lib = _lib.load()
+    T = _lib.TinyModel()
+    T.L, T.M, T.d, T.S, T.N = 3, 20, 5, 2, 57
+    T.rows[0], T.rows[1], T.rows[2] = 57, 30, 11
+    flat, wb = ctypes.c_int64(), ctypes.c_size_t()
+    assert lib.mobocmf_tiny_flat_len(ctypes.byref(T), ctypes.byref(flat)) == _lib.OK
+    H = [1 + 5, 5 + 10, 5 + 10]
+    assert flat.value == sum(h + 20 + 400 for h in H) + 3
+    assert lib.mobocmf_tiny_work_bytes(ctypes.byref(T), ctypes.byref(wb)) == _lib.OK
+    cols = [57, 60, 22]
+    pool = sum(c * (2 * 20 + 11) for c in cols) + 3 * 20 * max(cols)
+    assert wb.value == 8 * (((flat.value + 1) // 2) * 2 + pool)
+    for field, bad in (("L", 0), ("L", 4), ("M", 0), ("d", 0), ("S", 0)):
+        B = _lib.TinyModel.from_buffer_copy(T)
+        setattr(B, field, bad)
+        assert lib.mobocmf_tiny_work_bytes(ctypes.byref(B), ctypes.byref(wb)) == _lib.BAD_ARG, field
+    assert lib.mobocmf_tiny_flat_len(None, ctypes.byref(flat)) == _lib.BAD_ARG
+    # the step itself: every check below fails before a launch could happen
+    arr = (_lib.TinyModel * 1)(T)
+    host = ctypes.cast(arr, ctypes.c_void_p)
+    step = lambda n, mode, h=host: lib.mobocmf_tiny_elbo_step(h, host, n, 1e-3, 0.9, 0.999, 1e-8, mode, None)
+    assert step(1, 1) == _lib.BAD_ARG              # no pointers set
+    assert step(0, 1) == _lib.BAD_ARG and step(1, 3) == _lib.BAD_ARG and step(1, 1, None) == _lib.BAD_ARG
+    arr[0].M = 33                                  # beyond MOBOCMF_TINY_MAX_M
+    assert step(1, 1) == _lib.BAD_ARG

@@ -113,6 +113,43 @@ int main(int argc, char** argv) {
         REQUIRE(mobocmf_debug_touch_workspaces(&d, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, cov.data(), cv - 256,
                                                &regions) == MOBOCMF_WORKSPACE_TOO_SMALL);
     }
+    // the one-launch step's descriptor (mobocmf_tiny_model): size queries over random shapes -- the workspace must hold the
+    // flat gradient and the documented panel pool, whatever the row counts -- and the step's argument checks, which refuse
+    // every descriptor below on the host (no data pointers are set: nothing can be launched from here)
+    int tiny_ok = 0, tiny_bad = 0;
+    for (int icase = 0; icase < ncases; ++icase) {
+        mobocmf_tiny_model t = {};
+        t.L = (int32_t)U(-1, 4); t.M = (int32_t)U(-1, 40); t.d = (int32_t)U(-1, 10); t.S = (int32_t)U(-1, 30);
+        t.N = (int32_t)U(-5, 1 << 18);
+        int32_t r = t.N;
+        bool rows_ok = true;
+        for (int l = 0; l < MOBOCMF_TINY_MAX_LAYERS; ++l) {
+            t.rows[l] = r;
+            if (l < t.L && r < 1) rows_ok = false;
+            r = (int32_t)U(-2, r > 1 ? r : 1);
+        }
+        int64_t flat = -1;
+        size_t wb = 0;
+        const int rc1 = mobocmf_tiny_flat_len(&t, &flat), rc2 = mobocmf_tiny_work_bytes(&t, &wb);
+        const bool shape_ok = t.L >= 1 && t.L <= MOBOCMF_TINY_MAX_LAYERS && t.M >= 1 && t.d >= 1;
+        REQUIRE((rc1 == MOBOCMF_OK) == shape_ok);
+        REQUIRE((rc2 == MOBOCMF_OK) == (shape_ok && t.S >= 1 && rows_ok));
+        if (rc2 == MOBOCMF_OK) {
+            int64_t pool = 0, cmax = 0;
+            for (int l = 0; l < t.L; ++l) {
+                const int64_t c = (int64_t)t.rows[l] * (l ? t.S : 1);
+                pool += c * (2 * t.M + 11);
+                cmax = c > cmax ? c : cmax;
+            }
+            REQUIRE((int64_t)wb == 8 * (((flat + 1) & ~(int64_t)1) + pool + 3 * (int64_t)t.M * cmax));
+            ++tiny_ok;
+        } else {
+            ++tiny_bad;
+        }
+        REQUIRE(mobocmf_tiny_elbo_step(&t, &t, 1, 1e-3, 0.9, 0.999, 1e-8, (int32_t)U(-1, 3), nullptr) == MOBOCMF_BAD_ARG);
+    }
+    std::printf("fuzz_workspaces: mobocmf_tiny_model: %d descriptors sized, %d refused, every step call refused on the host\n",
+                tiny_ok, tiny_bad);
     std::printf("fuzz_workspaces: %d cases: %d valid (%d carved out of exact-size host buffers, %lld regions written, %d above the "
                 "%zu MB host budget: sizes only), %d invalid (all refused with BAD_ARG) -- no sanitizer report\n",
                 ncases, valid, touched, (long long)regions_total, skipped_big, budget >> 20, invalid);
