@@ -384,7 +384,10 @@ int mobocmf_scalar_combine(int32_t n, const double* const* x, const double* coef
  *     raw_noise of every layer.  grad (optional) receives d(-ELBO)/d(raw parameters) of the step.
  *   out[0] = ELBO, out[1] = scaled KL, out[2] = -ELBO (before the update); info[l] = 0 or the failed Cholesky pivot (1-based).
  * do_update = 0: gradients only (no parameter, optimiser or rng-counter write); 1: the step; 2: forward only (out, top_mean /
- * top_var; draws the random rows of x) -- a conditioned iteration is mode 2, the factor launches on top_mean / top_var, mode 1. */
+ * top_var; draws the random rows of x) -- a conditioned iteration is mode 2, the factor launches on top_mean / top_var, mode 1;
+ * 3: input gradients (the parameters are constants -- acquisition search, JESMOC_MFDGP.py:38-52): `grad` receives d / d x
+ * (N x d) of <seed_gmean, top mean> + <seed_gvar, top var> (times seed_scale) and nothing else is written -- predictive
+ * moments of fitted models are mode 2 with branch = 1, eps[l] = the layer's fixed samples tiled over the test points. */
 #define MOBOCMF_TINY_MAX_LAYERS 3
 #define MOBOCMF_TINY_MAX_M 32
 #define MOBOCMF_TINY_MAX_D 8
@@ -393,7 +396,7 @@ typedef struct mobocmf_tiny_model {
     int32_t N;                               /* batch rows, ordered by descending fidelity */
     int32_t rows[MOBOCMF_TINY_MAX_LAYERS];   /* rows[0] == N >= rows[1] >= ... >= 1 */
     uint32_t trainable[MOBOCMF_TINY_MAX_LAYERS];
-    int32_t reserved;
+    int32_t branch;                          /* 0: train branch (clamp(k_nn - q, 0)), 1: eval branch (no clamp), as the layers */
     const double* x;                         /* N x d */
     const double* y;                         /* N */
     const double* fid;                       /* N (levels as doubles, as VariationalELBOMF compares them) */

@@ -46,7 +46,7 @@ class TinyModel(ctypes.Structure):
     _L = TINY_MAX_LAYERS
     _fields_ = [("L", ctypes.c_int32), ("M", ctypes.c_int32), ("d", ctypes.c_int32), ("S", ctypes.c_int32),
                 ("N", ctypes.c_int32), ("rows", ctypes.c_int32 * _L), ("trainable", ctypes.c_uint32 * _L),
-                ("reserved", ctypes.c_int32),
+                ("branch", ctypes.c_int32),
                 ("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("fid", ctypes.c_void_p), ("Zx", ctypes.c_void_p),
                 ("raw", (ctypes.c_void_p * 7) * _L), ("m", ctypes.c_void_p * _L), ("L_S", ctypes.c_void_p * _L),
                 ("raw_noise", ctypes.c_void_p * _L), ("noise_lo", ctypes.c_double * _L), ("noise_hi", ctypes.c_double * _L),

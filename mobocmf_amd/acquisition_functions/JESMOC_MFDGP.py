@@ -112,9 +112,39 @@ class JESMOC_MFDGP:
         d = self.constraints if is_constraint else self.objectives
         return d[fidelity][blackbox_name](X.double())
 
+    use_tiny_step = True      # False: always the layer path (A/B, tests)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_tiny_groups", None)      # device descriptors: rebuilt on first use
+        return state
+
+    def _tiny_group(self, jess, fidelity, T, d):
+        """TinyPredictGroup over (uncond, cond) of every black-box of ``fidelity`` for T test points -- when all of them are
+        small enough for the one-launch kernel (util/tiny_step.py) -- else None.  Built once per (fidelity, T)."""
+        cache = self.__dict__.setdefault("_tiny_groups", {})
+        key = (fidelity, T, d)
+        if key not in cache:
+            from ..util import tiny_step as TS
+            models = [m for jes in jess for m in (jes.mfdgp_uncond, jes.mfdgp_cond)]
+            ok = bool(models) and all(p.is_cuda for p in models[0].parameters()) and \
+                all(TS.fits_predict(m, fidelity, T, d) for m in models)
+            cache[key] = TS.TinyPredictGroup(models, fidelity, T, d) if ok else None
+        return cache[key]
+
     def coupled_acq(self, X, fidelity):
-        """Sum over all black-boxes (:125-135).  Sharded surrogates: each rank adds its own, one all-gather sums."""
+        """Sum over all black-boxes (:125-135).  Sharded surrogates: each rank adds its own, one all-gather sums.
+        Small surrogates (the reference's own sizes): the predictive moments of ALL models -- unconditioned and conditioned,
+        every black-box -- come from one launch, their gradient w.r.t. X from one more (TinyPredictGroup); the JES value
+        0.5 clamp(log v_uncond - log v_cond, 0) (:38-52) is then a handful of element-wise operations over all of them."""
         X = X.double()
+        jess = list(self.objectives[fidelity].values()) + list(self.constraints[fidelity].values())
+        if self.use_tiny_step and jess and X.is_cuda and parallel.world()[1] == 1:
+            X2 = X[:, 0, :] if X.dim() > 2 else X
+            grp = self._tiny_group(jess, fidelity, X2.shape[0], X2.shape[1])
+            if grp is not None:
+                _, v = grp.acquisition_moments(X2)
+                return (0.5 * torch.clamp(torch.log(v[0::2]) - torch.log(v[1::2]), min=0.0)).sum(0)
         local = [obj(X) for obj in self.objectives[fidelity].values()] + \
                 [con(X) for con in self.constraints[fidelity].values()]
         if not local:

@@ -31,7 +31,7 @@ struct Geom {
     int ncol[TLM], H[TLM];
     int64_t flat_off[TLM], flat_noise, flat_len;
     int64_t work_off[TLM], scratch_off, pool_base, pool_len, work_len;
-    int ncmax;
+    int ncmax, srows;
 };
 __host__ __device__ inline void geom_of(const mobocmf_tiny_model& md, Geom& g) {
     g.L = md.L; g.M = md.M; g.d = md.d; g.S = md.S;
@@ -55,7 +55,8 @@ __host__ __device__ inline void geom_of(const mobocmf_tiny_model& md, Geom& g) {
         wo += (int64_t)g.ncol[l] * (2 * md.M + NVEC);
     }
     g.scratch_off = wo;
-    g.pool_len = wo + 3 * (int64_t)md.M * g.ncmax;
+    g.srows = md.M > DBT ? md.M : DBT;      // rows of a scratch panel (mode 3 keeps DBT values per column in one)
+    g.pool_len = wo + 3 * (int64_t)g.srows * g.ncmax;
     g.work_len = g.pool_base + g.pool_len;
 #ifdef TINY_STAMPS
     g.work_len += 128;      // phase stamps (tools/tiny_stamps.py): the last 128 doubles of `work`
@@ -210,6 +211,27 @@ __device__ __forceinline__ void kern_back(int kind, int d, const double* xa, dou
     dzf = G * aE1 * nu * fa + T * cb;
 }
 
+// the same for the INPUTS of the data side only: dxa[k] += G dk/dx_k, dfa += G dk/dfa (parameters are constants)
+__device__ __forceinline__ void kern_back_in(int kind, int d, const double* xa, double fa, const double* zb, const double* hy,
+                                             const double* il, double G, double (&dxa)[DBT], double& dfa) {
+    KV o;
+    kern_eval(kind, d, xa, fa, zb, hy, il, o);
+    double W1, W2 = 0.0;
+    if (!kind) {
+        W1 = G * hy[0] * o.E1;
+    } else {
+        const double aE1 = hy[0] * o.E1, zf = zb[DBT];
+        W1 = G * aE1 * (hy[2] * fa * zf + hy[1] * o.Ef);
+        W2 = G * hy[3] * o.E2;
+        dfa += G * aE1 * hy[2] * zf - G * o.Ef * o.fd * aE1 * hy[1] / hy[4];
+    }
+#pragma unroll
+    for (int k = 0; k < DBT; ++k) {
+        const double df = (k < d ? xa[k] : 0.0) - zb[k];
+        dxa[k] -= W1 * df * il[k] * il[k] + W2 * df * il[DBT + k] * il[DBT + k];
+    }
+}
+
 __device__ __forceinline__ int seg_len(int l, int s, int d) { return l == 0 ? (s == 0 ? 1 : d) : (s < 5 ? 1 : d); }
 
 template <int MR>
@@ -246,8 +268,8 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     // contraction step is what a phase costs otherwise), else the caller's workspace; generic pointers either way
     double* work = pool_in_lds ? sc + 16 + NSEG + NSEG / 2 : md.work + g.pool_base;
     double* Kb = work + g.scratch_off;      // M x ncmax scratch panels
-    double* S1 = Kb + (int64_t)M * g.ncmax;
-    double* S2 = S1 + (int64_t)M * g.ncmax;
+    double* S1 = Kb + (int64_t)g.srows * g.ncmax;
+    double* S2 = S1 + (int64_t)g.srows * g.ncmax;
 #ifdef TINY_STAMPS
     double* stamps = md.work + g.work_len - 128;
     int n_stamp = 0;
@@ -288,6 +310,8 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         W0[l * MS + i * LD + j] = j <= i ? md.L_S[l][i * M + j] : 0.0;
     }
     for (int e = tid; e < L * M; e += TT) mst[(e / M) * MR + e % M] = md.m[e / M][e % M];
+    if (do_update == 3)
+        for (int e = tid; e < md.N * d; e += TT) md.grad[e] = 0.0;
     if (do_update == 2 && md.xrng && md.rand_rows > 0) {
         // the x~ of this iteration (:276): every model of the launch draws the SAME points from the shared stream
         const uint64_t seed = (uint64_t)md.xrng[0], call = (uint64_t)md.xrng[1];
@@ -442,7 +466,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
                     r += cc * cc;
                 }
                 double sres = vknn[c] - q;
-                if (sres < 0.0) sres = 0.0;
+                if (!md.branch && sres < 0.0) sres = 0.0;      // train branch: clamp(k_nn - q, 0); eval branch: none
                 const double vr = sres + r, var = vr < MINV ? MINV : vr;
                 vmean[c] = mu; vvar[c] = var; vq[c] = q; vraw[c] = vr;
                 const int b = c / div;
@@ -530,7 +554,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
                 const double gvc = vraw[c] > MINV ? gvv : 0.0;
                 vgmu[c] = gm;
                 vgv[c] = gvc;
-                vcgv[c] = vknn[c] - vq[c] > 0.0 ? gvc : 0.0;
+                vcgv[c] = (md.branch || vknn[c] - vq[c] > 0.0) ? gvc : 0.0;
             }
         }
         __syncthreads();
@@ -556,6 +580,31 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         }
         __syncthreads();
         STAMP();
+        if (do_update == 3) {
+            // input gradients only (the parameters are constants: acquisition search): per column d loss / d f, handed to
+            // the layer below, and d loss / d x, summed over the row's columns into grad[b][k]
+            for (int c = tid; c < nc; c += TT) {
+                const int b = c / div;
+                const double fn = kind ? vf[c] : 0.0;
+                double dxa[DBT], dfs = 0.0;
+#pragma unroll
+                for (int k = 0; k < DBT; ++k) dxa[k] = 0.0;
+                for (int m = 0; m < M; ++m)
+                    kern_back_in(kind, d, md.x + (int64_t)b * d, fn, zt + (l * MR + m) * ZW, hyl, ill, Kb[(int64_t)m * nc + c], dxa, dfs);
+                if (kind) vgf[c] = dfs + vcgv[c] * hyl[0] * 2.0 * hyl[2] * fn;
+#pragma unroll
+                for (int k = 0; k < DBT; ++k) S1[(int64_t)c * DBT + k] = dxa[k];
+            }
+            __syncthreads();
+            for (int e = tid; e < md.rows[l] * d; e += TT) {
+                const int b = e / d, k = e % d;
+                double sx = 0.0;
+                for (int s2 = 0; s2 < div; ++s2) sx += S1[(int64_t)(b * div + s2) * DBT + k];
+                md.grad[e] += sx;
+            }
+            __syncthreads();
+            continue;
+        }
         // B4: Gram backward of (dK, dk_nn = cgv), element by element; H = A diag(gv) A^T, Hc = A diag(cgv) A^T, da = A g_mean
         double hacc[HS];
 #pragma unroll
@@ -772,6 +821,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         STAMP();
     }
 
+    if (do_update == 3) return;
     // ---- raw-parameter gradients into the flat vector (g_LS is there already)
     for (int e = tid; e < L * HS; e += TT) {
         const int l = e / HS, t = e % HS;
@@ -842,6 +892,7 @@ bool valid_model(const mobocmf_tiny_model& m) {
     }
     if ((m.seed_gmean == nullptr) != (m.seed_gvar == nullptr) || (m.top_mean == nullptr) != (m.top_var == nullptr)) return false;
     if (m.xrng && (m.rand_row0 < 0 || m.rand_rows < 0 || m.rand_row0 + m.rand_rows > m.N)) return false;
+    if (m.branch != 0 && m.branch != 1) return false;
     return m.x && m.y && m.fid && m.Zx && m.adam_m && m.adam_v && m.steps_done && m.work && m.out && m.info;
 }
 
@@ -869,11 +920,11 @@ int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes) {
 
 int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
                            double lr, double beta1, double beta2, double eps, int32_t do_update, mobocmf_stream_t stream) {
-    if (!host_models || !dev_models || n_models < 1 || n_models > 65535 || do_update < 0 || do_update > 2) return MOBOCMF_BAD_ARG;
+    if (!host_models || !dev_models || n_models < 1 || n_models > 65535 || do_update < 0 || do_update > 3) return MOBOCMF_BAD_ARG;
     int mmax = 0;
     int64_t pmax = 0;
     for (int i = 0; i < n_models; ++i) {
-        if (!valid_model(host_models[i])) return MOBOCMF_BAD_ARG;
+        if (!valid_model(host_models[i]) || (do_update == 3 && !host_models[i].grad)) return MOBOCMF_BAD_ARG;
         if (host_models[i].M > mmax) mmax = host_models[i].M;
         Geom g;
         geom_of(host_models[i], g);

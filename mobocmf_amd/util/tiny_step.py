@@ -29,6 +29,45 @@ def _hyper_params(layer):
     return [getattr(m, n) for m, n in gp._hyper_sources(layer.covar_module, layer.kind)]
 
 
+def fits_predict(model, fidelity, T, d, speed_rule=True):
+    """True when ``model``'s predictive moments at T test points up to layer ``fidelity`` fit the one-launch kernel (the
+    structural limits of ``eligible``; the training flags do not matter: prediction runs the eval branch)."""
+    try:
+        layers = model._layers()[:fidelity + 1]
+        if not (1 <= len(layers) <= _lib.TINY_MAX_LAYERS) or model.use_only_highest_fidelity or not (1 <= d <= _lib.TINY_MAX_D):
+            return False
+        Z0 = layers[0].variational_strategy._inducing_points
+        M = Z0.shape[0]
+        if not (1 <= M <= _lib.TINY_MAX_M) or Z0.shape[1] != d or not Z0.is_cuda:
+            return False
+        S = model.num_samples_for_acquisition
+        cols = [T] + [T * S] * (len(layers) - 1)
+        if max(cols) > MAX_COLUMNS * 4 or (speed_rule and estimated_us(M, cols) > LAYER_PATH_US):
+            return False
+        jit = layers[0].variational_strategy.jitter_val
+        for l, layer in enumerate(layers):
+            vs = layer.variational_strategy
+            vd = vs._variational_distribution
+            Zl = vs._inducing_points
+            if layer.kind != (0 if l == 0 else 1) or vs.jitter_val != jit or Zl.shape[0] != M:
+                return False
+            if l and (not torch.equal(Zl[:, :-1], Z0) or layer.samples.numel() != S):
+                return False
+            lik = getattr(model, model.name_hidden_layer_likelihood + str(l))
+            c = lik.raw_noise_constraint
+            if type(c) is not gp.Interval or not (c.upper_bound > c.lower_bound) or c.upper_bound == float("inf"):
+                return False
+            ps = _hyper_params(layer) + [vd.variational_mean, vd.chol_variational_covar, lik.raw_noise]
+            if not all(p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() for p in ps):
+                return False
+            if not all(type(getattr(m, n + "_constraint")) is gp.Positive
+                       for m, n in gp._hyper_sources(layer.covar_module, layer.kind)):
+                return False
+        return True
+    except AttributeError:
+        return False
+
+
 def eligible(model, x, fidelities, speed_rule=True):
     """True when ``model`` on the batch ``x`` fits the one-launch step: <= 3 layers sharing one set of <= 32 inducing inputs
     (Z~_l = [Z_x, m_{l-1}]), d <= 8, softplus / Interval constraints, float64 parameters on the GPU, every fidelity's
@@ -415,3 +454,127 @@ class TinyConditionedStep(TinyELBOStep):
         if xr is not None:
             self.xrng.copy_(xr)
         self._snap = self._snap + (xr,)
+
+
+class _TinyMomentsFn(torch.autograd.Function):
+    """(n_models, 2, columns) top-layer moments of a TinyPredictGroup at X; backward: d / d X through every model, one launch."""
+
+    @staticmethod
+    def forward(ctx, group, X):
+        ctx.group = group
+        ctx.save_for_backward(X.detach())
+        group.x.copy_(X.detach().reshape(group.T, group.d))
+        group._launch(2)
+        return group.moments.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        group = ctx.group
+        (X,) = ctx.saved_tensors
+        group.x.copy_(X.reshape(group.T, group.d))      # (another evaluation may have used the group since the forward)
+        group.seeds.copy_(g)
+        group._launch(3)
+        return None, group.gx.sum(0).reshape(X.shape)
+
+
+class TinyPredictGroup:
+    """Predictive moments of SEVERAL fitted small models at the same T test points (eval branch, the layers' fixed
+    ``samples``: MFDGP.predict_for_acquisition, mfdgp.py:237-262) in ONE launch -- mobocmf_tiny_elbo_step in its forward-only
+    mode -- and their gradient w.r.t. the test points in one more (mode 3): what an acquisition search evaluates hundreds of
+    times against constant parameters (JESMOC_MFDGP.py:137-184).  ``moments_at(X)`` -> (n_models, 2, T * S) (T for
+    fidelity 0): mean and variance of the top layer's columns, WITHOUT the likelihood noise; differentiable w.r.t. X."""
+
+    def __init__(self, models, fidelity, T, d, stream=None):
+        lib = _lib.require_device()
+        self.models, self.fidelity, self.T, self.d = list(models), fidelity, int(T), int(d)
+        n = len(self.models)
+        dev = next(self.models[0].parameters()).device
+        self.device = dev
+        L = fidelity + 1
+        self.S = self.models[0].num_samples_for_acquisition if L > 1 else 1
+        ncol = self.T * self.S
+        self.x = torch.zeros(self.T, d, dtype=torch.float64, device=dev)
+        self.moments = torch.zeros(n, 2, ncol, dtype=torch.float64, device=dev)
+        self.seeds = torch.zeros(n, 2, ncol, dtype=torch.float64, device=dev)
+        self.gx = torch.zeros(n, self.T, d, dtype=torch.float64, device=dev)
+        self.host = (_lib.TinyModel * n)()
+        self._keep = []
+        zrow = torch.zeros(self.T, dtype=torch.float64, device=dev)
+        nofid = torch.full((self.T,), -1.0, dtype=torch.float64, device=dev)      # no row is scored: moments only
+        self._keep += [zrow, nofid]
+        for i, model in enumerate(self.models):
+            if not fits_predict(model, fidelity, self.T, d, speed_rule=False) or \
+                    (L > 1 and model.num_samples_for_acquisition != self.S):
+                raise _lib.MobocmfError("TinyPredictGroup: model %d does not fit the one-launch kernel" % i)
+            layers = model._layers()[:L]
+            Tm = self.host[i]
+            Tm.L, Tm.M, Tm.d, Tm.S, Tm.N = L, layers[0].variational_strategy._inducing_points.shape[0], d, self.S, self.T
+            Tm.branch = 1
+            Zx = layers[0].variational_strategy._inducing_points.detach().contiguous()
+            Tm.x, Tm.y, Tm.fid, Tm.Zx = self.x.data_ptr(), zrow.data_ptr(), nofid.data_ptr(), Zx.data_ptr()
+            Tm.kl_scale, Tm.jitter = 0.0, layers[0].variational_strategy.jitter_val
+            self._keep.append(Zx)
+            for l, layer in enumerate(layers):
+                vd = layer.variational_strategy._variational_distribution
+                lik = getattr(model, model.name_hidden_layer_likelihood + str(l))
+                Tm.rows[l] = self.T
+                for s, p in enumerate(_hyper_params(layer)):
+                    Tm.raw[l][s] = p.data_ptr()
+                Tm.m[l], Tm.L_S[l] = vd.variational_mean.data_ptr(), vd.chol_variational_covar.data_ptr()
+                Tm.raw_noise[l] = lik.raw_noise.data_ptr()
+                Tm.noise_lo[l], Tm.noise_hi[l] = lik.raw_noise_constraint.lower_bound, lik.raw_noise_constraint.upper_bound
+                if l:      # eval_mode's draws: the layer's fixed samples, tiled over the test points (mfdgp_hidden_layer.py:263-270)
+                    e = layer.samples.reshape(-1).to(torch.float64).repeat(self.T).contiguous()
+                    Tm.eps[l] = e.data_ptr()
+                    self._keep.append(e)
+            flat, wb = ctypes.c_int64(), ctypes.c_size_t()
+            _lib.check(lib.mobocmf_tiny_flat_len(ctypes.byref(Tm), ctypes.byref(flat)), "mobocmf_tiny_flat_len")
+            _lib.check(lib.mobocmf_tiny_work_bytes(ctypes.byref(Tm), ctypes.byref(wb)), "mobocmf_tiny_work_bytes")
+            work = torch.zeros(wb.value // 8, dtype=torch.float64, device=dev)
+            dummy = torch.zeros(2, flat.value, dtype=torch.float64, device=dev)      # (never written: modes 2 / 3 only)
+            misc = torch.zeros(8, dtype=torch.int64, device=dev)
+            out = torch.zeros(3, dtype=torch.float64, device=dev)
+            self._keep += [work, dummy, misc, out]
+            Tm.work, Tm.adam_m, Tm.adam_v = work.data_ptr(), dummy[0].data_ptr(), dummy[1].data_ptr()
+            Tm.steps_done, Tm.info, Tm.out = misc.data_ptr(), misc[4:].data_ptr(), out.data_ptr()
+            Tm.top_mean, Tm.top_var = self.moments[i, 0].data_ptr(), self.moments[i, 1].data_ptr()
+            Tm.seed_gmean, Tm.seed_gvar, Tm.seed_scale = self.seeds[i, 0].data_ptr(), self.seeds[i, 1].data_ptr(), 1.0
+            Tm.grad = self.gx[i].data_ptr()
+        self._dev_table = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(dev)
+
+    def _launch(self, mode):
+        lib = _lib.require_device()
+        _lib.check(lib.mobocmf_tiny_elbo_step(ctypes.cast(self.host, ctypes.c_void_p), ctypes.c_void_p(self._dev_table.data_ptr()),
+                                              len(self.models), 0.0, 0.9, 0.999, 1e-8, int(mode),
+                                              ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                   "mobocmf_tiny_elbo_step")
+
+    def moments_at(self, X):
+        X = X.reshape(self.T, self.d)
+        if X.requires_grad and torch.is_grad_enabled():
+            return _TinyMomentsFn.apply(self, X)
+        self.x.copy_(X.detach())
+        self._launch(2)
+        return self.moments.clone()
+
+    def noise(self, refresh=False):
+        """(n_models,) likelihood noise of the top layer (constrained values).  The parameters are constants while a group is
+        in use (an acquisition search against fitted models), so the values are formed once; ``refresh=True`` re-reads them."""
+        if refresh or self.__dict__.get("_noise") is None:
+            with torch.no_grad():
+                self._noise = torch.stack([getattr(m, m.name_hidden_layer_likelihood + str(self.fidelity)).noise.reshape(())
+                                           for m in self.models])
+        return self._noise
+
+    def acquisition_moments(self, X):
+        """(mus, vars), each (n_models, T): MFDGP.predict_for_acquisition of every model (noise added, moments over the S
+        fixed samples, mfdgp.py:237-262)."""
+        mom = self.moments_at(X)
+        mean, var = mom[:, 0], mom[:, 1] + self.noise()[:, None]
+        if self.fidelity == 0:
+            return mean, var
+        n = mean.shape[0]
+        mu = mean.reshape(n, self.T, self.S)
+        mus = mu.mean(2)
+        second = (var.reshape(n, self.T, self.S) + mu * mu).mean(2)
+        return mus, second - mus * mus

@@ -253,3 +253,78 @@ def test_tiny_conditioned_step_draws_fresh_shared_x_tilde():
     xt = torch.rand(10, 2, dtype=torch.float64, generator=g).to(DEV)
     torch.manual_seed(0)
     assert float(fitter.conditioned_loss(xt)) < l0
+
+
+# ------------------------------------------------------------------ acquisition: moments + dX in two launches
+def _two_fitters(seed=0):
+    """An 'unconditioned' and a 'conditioned' fitter over the same three small problems (different variational parameters)."""
+    from tests.test_hip_conditioned import _fitter
+    fu, _ = _fitter(2, 1, 12)
+    fc, _ = _fitter(2, 1, 12)
+    g = torch.Generator().manual_seed(seed)
+    for _, _, h in fc._handlers():
+        for layer in h.mfdgp._layers():
+            vd = layer.variational_strategy._variational_distribution
+            with torch.no_grad():
+                vd.variational_mean.add_(0.05 * torch.randn(vd.variational_mean.shape, dtype=torch.float64, generator=g).to(DEV))
+                vd.chol_variational_covar.mul_(0.7)
+    return fu, fc
+
+
+@pytest.mark.parametrize("fidelity", [0, 1])
+def test_tiny_predict_group_matches_predict_for_acquisition_and_its_input_gradient(fidelity):
+    """TinyPredictGroup (forward-only launch for all models; mode-3 launch for d/dX) vs MFDGP.predict_for_acquisition through
+    the layer entry points (itself pinned to the oracle in test_hip_model.py): moments to 1e-9, d(sum of weighted moments)/dX
+    to 1e-7, for T = 7 points, S = 25 fixed samples."""
+    from mobocmf_amd.util.tiny_step import TinyPredictGroup
+    fu, fc = _two_fitters()
+    models = [h.mfdgp for _, _, h in fu._handlers()] + [h.mfdgp for _, _, h in fc._handlers()]
+    g = torch.Generator().manual_seed(3)
+    X = torch.rand(7, 2, dtype=torch.float64, generator=g).to(DEV)
+    wm = torch.randn(len(models), 7, dtype=torch.float64, generator=g).to(DEV)
+    wv = torch.randn(len(models), 7, dtype=torch.float64, generator=g).to(DEV)
+    Xa = X.clone().requires_grad_(True)
+    ref_m, ref_v = [], []
+    for m in models:
+        m.eval()
+        mu, v = m.predict_for_acquisition(Xa, fidelity)
+        m.train()
+        ref_m.append(mu), ref_v.append(v)
+    ref_m, ref_v = torch.stack(ref_m), torch.stack(ref_v)
+    ((ref_m * wm).sum() + (ref_v * wv).sum()).backward()
+    grp = TinyPredictGroup(models, fidelity, 7, 2)
+    Xb = X.clone().requires_grad_(True)
+    mus, v = grp.acquisition_moments(Xb)
+    ((mus * wm).sum() + (v * wv).sum()).backward()
+    assert rel(mus, ref_m) < 1e-9 and rel(v, ref_v) < 1e-8, (rel(mus, ref_m), rel(v, ref_v))
+    assert rel(Xb.grad, Xa.grad) < 1e-7, rel(Xb.grad, Xa.grad)
+
+
+def test_coupled_jes_through_the_one_launch_kernel_equals_the_layer_path():
+    """JESMOC_MFDGP.coupled_acq (sum over black-boxes of 0.5 clamp(log v_uncond - log v_cond, 0), JESMOC_MFDGP.py:38-52,
+    125-135) and its gradient w.r.t. the candidates, both fidelities: one-launch kernel vs layer entry points."""
+    from mobocmf_amd.acquisition_functions.JESMOC_MFDGP import JESMOC_MFDGP
+    fu, fc = _two_fitters(1)
+    fc.pareto_set = torch.zeros(1, 2, dtype=torch.float64, device=DEV)
+    fc.pareto_front = torch.zeros(1, 2, dtype=torch.float64, device=DEV)
+    acq = JESMOC_MFDGP.__new__(JESMOC_MFDGP)
+    acq.blackbox_mfdgp_fitter_uncond, acq.blackbox_mfdgp_fitter_cond = fu, fc
+    acq.num_fidelities, acq.eval_highest_fidelity = 2, False
+    acq.standard_bounds = torch.tensor([[0.0, 0.0], [1.0, 1.0]], dtype=torch.float64, device=DEV)
+    acq.objectives, acq.constraints, acq.costs_blackboxes = {0: {}, 1: {}}, {0: {}, 1: {}}, {0: {"total": 0.0}, 1: {"total": 0.0}}
+    for f in (0, 1):
+        for name, is_con in (("bb0", False), ("bb1", False), ("bb2", True)):
+            acq.add_blackbox(f, name, is_constraint=is_con)
+    X = torch.rand(5, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(9)).to(DEV)
+    for f in (0, 1):
+        res = {}
+        for tiny in (True, False):
+            acq.use_tiny_step = tiny
+            Xg = X.clone().requires_grad_(True)
+            v = acq.coupled_acq(Xg, fidelity=f)
+            v.sum().backward()
+            res[tiny] = (v.detach(), Xg.grad)
+        assert acq._tiny_groups[(f, 5, 2)] is not None
+        assert float(res[False][0].abs().max()) > 0
+        assert rel(res[True][0], res[False][0]) < 1e-8, (f, rel(res[True][0], res[False][0]))
+        assert rel(res[True][1], res[False][1]) < 1e-6, (f, rel(res[True][1], res[False][1]))

@@ -19,6 +19,9 @@ echo
 echo "== tools/cond_bench.py 400: conditioned training (N1), Forrester sizes, 3 surrogates, 50 Pareto points, 10 x~"
 python tools/cond_bench.py 400 2>/dev/null
 echo
+echo "== tools/acq_small_bench.py: acquisition phase at Forrester sizes (search = 200 projected-Adam iterations x 5 restarts, 2 evaluations of 6 models each)"
+python tools/acq_small_bench.py 2>/dev/null
+echo
 echo "== examples/example_acquisition_mfdgp_forrester.py (the reference's walk-through at its own schedule)"
 python examples/example_acquisition_mfdgp_forrester.py 2>/dev/null | grep -E "schedule|seconds|Pareto set|next evaluation"
 } > $O/tiny_step.txt 2>&1
