@@ -420,7 +420,25 @@ class TinyConditionedStep(TinyELBOStep):
         for a in self._theta + [self._omega]:
             _lib.check(lib.mobocmf_cond_factors_forward(*a, st), "mobocmf_cond_factors_forward")
 
+    use_graph = True      # the iteration's 3 + n_con launches replayed from one HIP graph (host issue is half their duration)
+
+    def _capture(self):
+        """The launches of an iteration captured once: every argument is static (pointers, sizes, the learning rate), x~ and
+        eps come from device-side counters, so a replay IS the next iteration.  The capture pass itself executes nothing."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+            self._launch(2)
+            self._factors()
+            self._launch(1)
+        self._graph = g
+
     def step(self):
+        if self.use_graph:
+            if self.__dict__.get("_graph") is None:
+                self._capture()
+            with torch.cuda.stream(self.stream):
+                self._graph.replay()
+            return self.losses
         self._launch(2)
         self._factors()
         self._launch(1)
