@@ -1276,48 +1276,71 @@ __device__ __forceinline__ double npdf(double z) { return 0.3989422804014327 * e
 // loss = sum_{p < P, t < T} [ coef_c c(p,t) + coef_1mc (1 - c(p,t)) ],
 //   c(p,t) = prod_k Phi((cm_k[t] - thr[k]) / sqrt(cv_k[t])) * prod_j Phi((front[p][j] - fm_j[t]) / sqrt(fv_j[t]));
 // the gradients w.r.t. every fm_j[t], fv_j[t], cm_k[t], cv_k[t] (for an upstream gradient of 1) come out of the same pass.
-__global__ void cond_factors_kernel(FactTable tb, int n_obj, int n_con, int P, int T, const double* front, const double* thr,
-                                    double coef_c, double coef_1mc, double* loss) {
+// Threads are spread over (t, p): NG = 256 / min(T, 256) groups share a point t and split the Pareto points p among them (the
+// omega factors are 10 points x 50 Pareto points x n_obj erf / exp pairs: one thread per t walked all 50 serially, 80 us --
+// longer than the whole one-launch step that feeds it); the groups' partial sums over p meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void cond_factors_kernel(FactTable tb, int n_obj, int n_con, int P, int T, const double* front,
+                                                           const double* thr, double coef_c, double coef_1mc, double* loss) {
     __shared__ double sh[4];
+    __shared__ double part[256][2 * FACT_MAX + 1];      // per (group, t): sum_p O, gm[j], gv[j]
     double acc = 0.0;
     const double dldc = coef_c - coef_1mc;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        double phic[FACT_MAX], dzm[FACT_MAX], dzv[FACT_MAX];      // Phi(z_k), dPhi/dcm_k, dPhi/dcv_k
-        double C = 1.0;
-        for (int k = 0; k < n_con; ++k) {
-            const double sd = sqrt(tb.cv[k][t]), z = (tb.cm[k][t] - thr[k]) / sd, pd = npdf(z);
-            phic[k] = ncdf(z);
-            dzm[k] = pd / sd;
-            dzv[k] = -0.5 * pd * z / tb.cv[k][t];
-            C *= phic[k];
-        }
-        double isd[FACT_MAX], gm[FACT_MAX], gv[FACT_MAX];
-        for (int j = 0; j < n_obj; ++j) { isd[j] = 1.0 / sqrt(tb.fv[j][t]); gm[j] = 0.0; gv[j] = 0.0; }
-        double osum = 0.0;      // sum_p O(p,t)
-        for (int p = 0; p < P; ++p) {
-            double ph[FACT_MAX], u[FACT_MAX], O = 1.0;
-            for (int j = 0; j < n_obj; ++j) {
-                u[j] = (front[(int64_t)p * n_obj + j] - tb.fm[j][t]) * isd[j];
-                ph[j] = ncdf(u[j]);
-                O *= ph[j];
+    const int Tt = T < 256 ? T : 256;                   // points of a tile
+    int NG = 256 / Tt;
+    if (NG > P) NG = P;
+    const int tl = threadIdx.x % Tt, grp = threadIdx.x / Tt;
+    for (int t0 = 0; t0 < T; t0 += Tt) {
+        const int t = t0 + tl;
+        const bool on = grp < NG && t < T;
+        double isd[FACT_MAX], gm[FACT_MAX], gv[FACT_MAX], osum = 0.0;
+        if (on) {
+            for (int j = 0; j < n_obj; ++j) { isd[j] = 1.0 / sqrt(tb.fv[j][t]); gm[j] = 0.0; gv[j] = 0.0; }
+            for (int p = grp; p < P; p += NG) {
+                double ph[FACT_MAX], u[FACT_MAX], O = 1.0;
+                for (int j = 0; j < n_obj; ++j) {
+                    u[j] = (front[(int64_t)p * n_obj + j] - tb.fm[j][t]) * isd[j];
+                    ph[j] = ncdf(u[j]);
+                    O *= ph[j];
+                }
+                osum += O;
+                for (int j = 0; j < n_obj; ++j) {
+                    double rest = 1.0;      // O / Phi(u_j), formed without the division
+                    for (int q = 0; q < n_obj; ++q) rest *= q == j ? 1.0 : ph[q];
+                    const double pd = npdf(u[j]);
+                    gm[j] += rest * pd * (-isd[j]);
+                    gv[j] += rest * pd * (-0.5 * u[j] / tb.fv[j][t]);
+                }
             }
-            osum += O;
-            for (int j = 0; j < n_obj; ++j) {
-                double rest = C;      // c / Phi(u_j), formed without the division
-                for (int q = 0; q < n_obj; ++q) rest *= q == j ? 1.0 : ph[q];
-                const double pd = npdf(u[j]);
-                gm[j] += rest * pd * (-isd[j]);
-                gv[j] += rest * pd * (-0.5 * u[j] / tb.fv[j][t]);
+            double* pp = part[grp * Tt + tl];
+            pp[0] = osum;
+            for (int j = 0; j < n_obj; ++j) { pp[1 + j] = gm[j]; pp[1 + FACT_MAX + j] = gv[j]; }
+        }
+        __syncthreads();
+        if (on && grp == 0) {
+            for (int g2 = 1; g2 < NG; ++g2) {
+                const double* pp = part[g2 * Tt + tl];
+                osum += pp[0];
+                for (int j = 0; j < n_obj; ++j) { gm[j] += pp[1 + j]; gv[j] += pp[1 + FACT_MAX + j]; }
+            }
+            double phic[FACT_MAX], dzm[FACT_MAX], dzv[FACT_MAX];      // Phi(z_k), dPhi/dcm_k, dPhi/dcv_k
+            double C = 1.0;
+            for (int k = 0; k < n_con; ++k) {
+                const double sd = sqrt(tb.cv[k][t]), z = (tb.cm[k][t] - thr[k]) / sd, pd = npdf(z);
+                phic[k] = ncdf(z);
+                dzm[k] = pd / sd;
+                dzv[k] = -0.5 * pd * z / tb.cv[k][t];
+                C *= phic[k];
+            }
+            acc += dldc * C * osum + coef_1mc * (double)P;
+            for (int j = 0; j < n_obj; ++j) { tb.gfm[j][t] = dldc * C * gm[j]; tb.gfv[j][t] = dldc * C * gv[j]; }
+            for (int k = 0; k < n_con; ++k) {
+                double rest = osum;
+                for (int q = 0; q < n_con; ++q) rest *= q == k ? 1.0 : phic[q];
+                tb.gcm[k][t] = dldc * rest * dzm[k];
+                tb.gcv[k][t] = dldc * rest * dzv[k];
             }
         }
-        acc += dldc * C * osum + coef_1mc * (double)P;
-        for (int j = 0; j < n_obj; ++j) { tb.gfm[j][t] = dldc * gm[j]; tb.gfv[j][t] = dldc * gv[j]; }
-        for (int k = 0; k < n_con; ++k) {
-            double rest = osum;
-            for (int q = 0; q < n_con; ++q) rest *= q == k ? 1.0 : phic[q];
-            tb.gcm[k][t] = dldc * rest * dzm[k];
-            tb.gcv[k][t] = dldc * rest * dzv[k];
-        }
+        __syncthreads();
     }
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0) loss[0] = acc;
