@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int TT = 256;                          // threads per workgroup
+constexpr int NWMAX = 8;                         // wavefronts per workgroup, at most (256 or 512 threads)
 constexpr int TLM = MOBOCMF_TINY_MAX_LAYERS;
 constexpr int DBT = MOBOCMF_TINY_MAX_D;          // x columns of a staged inducing row (zero-padded)
 constexpr int ZW = DBT + 1;                      // + the f column
@@ -82,13 +82,24 @@ __device__ __forceinline__ double wsum63(double v) {
     v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2, 3
     return v;
 }
-// sum over the workgroup, handed to every thread (two barriers; sh: 4 doubles nobody else touches meanwhile)
+// sum over the workgroup's NW wavefronts, handed to every thread (two barriers; sh: NW doubles nobody else touches meanwhile)
+template <int NW>
 __device__ __forceinline__ double bsum(double v, double* sh) {
     v = wsum63(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += sh[w];
+    return t;
+}
+template <int NW>
+__device__ __forceinline__ double red_sum(const double* red, int stride, int t) {      // the wavefronts' partials of slot t
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w * stride + t];
+    return v;
 }
 __device__ __forceinline__ double rdlane(double v, int l) {      // l: wave-uniform
     union { double d; int i[2]; } u;
@@ -234,12 +245,13 @@ __device__ __forceinline__ void kern_back_in(int kind, int d, const double* xa, 
 
 __device__ __forceinline__ int seg_len(int l, int s, int d) { return l == 0 ? (s == 0 ? 1 : d) : (s < 5 ? 1 : d); }
 
-template <int MR>
+template <int MR, int TT>
 __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model* models, double lr, double b1, double b2,
                                                        double aeps, int do_update, int pool_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const mobocmf_tiny_model& md = models[blockIdx.x];
     constexpr int LD = MR + 1, MS = MR * LD;
+    constexpr int NW = TT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Geom g;
     geom_of(md, g);
@@ -260,13 +272,13 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     double* dat = dav + MR;                 // [MR] da_tot
     double* mst = dat + MR;                 // [TLM][MR] m of every layer (staged)
     double* red = mst + TLM * MR;           // [4][HS + 1] wavefront partials
-    double* sc = red + 4 * (HS + 1);        // [16]: tau[l] (0..2), g_noise[l] (4..6), bsum scratch (8..11), Adam's bias terms
-    double** seg_ptr = (double**)(sc + 16); // [NSEG] parameter tensors in flat-vector order (trainable ones; else null)
+    double* sc = red + NWMAX * (HS + 1);    // [24]: tau[l] (0..2), g_noise[l] (4..6), Adam's bias terms (12, 13), bsum scratch (16..23)
+    double** seg_ptr = (double**)(sc + 24); // [NSEG] parameter tensors in flat-vector order (trainable ones; else null)
     int* seg_end = (int*)(seg_ptr + NSEG);  // [NSEG] end offset of each tensor in the flat vector
     double* gflat = md.work;
     // the panels: LDS behind the chain state when the launch reserved room for them (a dependent global round trip per
     // contraction step is what a phase costs otherwise), else the caller's workspace; generic pointers either way
-    double* work = pool_in_lds ? sc + 16 + NSEG + NSEG / 2 : md.work + g.pool_base;
+    double* work = pool_in_lds ? sc + 24 + NSEG + NSEG / 2 : md.work + g.pool_base;
     double* Kb = work + g.scratch_off;      // M x ncmax scratch panels
     double* S1 = Kb + (int64_t)g.srows * g.ncmax;
     double* S2 = S1 + (int64_t)g.srows * g.ncmax;
@@ -497,8 +509,8 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         }
     }
     {
-        const double data = bsum(dacc, sc + 8);
-        const double kl = bsum(klacc, sc + 8);
+        const double data = bsum<NW>(dacc, sc + 16);
+        const double kl = bsum<NW>(klacc, sc + 16);
         if (tid == 0) {
             md.out[0] = data - gkl * kl;
             md.out[1] = gkl * kl;
@@ -676,10 +688,10 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         }
         if (tid < Hl) {
             const int t = slot_of(kind, d, tid);
-            ghy[l * HS + tid] += (red[t] + red[(HS + 1) + t]) + (red[2 * (HS + 1) + t] + red[3 * (HS + 1) + t]);
+            ghy[l * HS + tid] += red_sum<NW>(red, HS + 1, t);
         }
         if (tid == TT - 1) {
-            const double s = (red[HS] + red[(HS + 1) + HS]) + (red[2 * (HS + 1) + HS] + red[3 * (HS + 1) + HS]);
+            const double s = red_sum<NW>(red, HS + 1, HS);
             double chain = 1.0;
             if (md.noise_hi[l] > md.noise_lo[l]) {
                 const double sg = 1.0 / (1.0 + exp(-md.raw_noise[l][0]));
@@ -808,7 +820,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         STAMP();
         if (tid < Hl) {
             const int t = slot_of(kind, d, tid);
-            ghy[l * HS + tid] += (red[t] + red[(HS + 1) + t]) + (red[2 * (HS + 1) + t] + red[3 * (HS + 1) + t]);
+            ghy[l * HS + tid] += red_sum<NW>(red, HS + 1, t);
         }
         if (kind)
             for (int i = tid; i < M; i += TT) {
@@ -874,7 +886,7 @@ constexpr size_t LDS_BUDGET = 160 * 1024;      // LDS of a gfx950 CU; one workgr
 size_t lds_bytes(int MR) {
     const int LD = MR + 1, MS = MR * LD;
     const size_t n = (size_t)(3 * TLM + 3) * MS + (size_t)TLM * MR * ZW + 2 * (size_t)TLM * HS + (size_t)TLM * 2 * DBT +
-                     3 * (size_t)TLM * MR + 2 * (size_t)MR + 4 * (HS + 1) + 16 + NSEG + NSEG / 2;
+                     3 * (size_t)TLM * MR + 2 * (size_t)MR + NWMAX * (HS + 1) + 24 + NSEG + NSEG / 2;
     return n * sizeof(double);
 }
 
@@ -923,12 +935,14 @@ int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
     if (!host_models || !dev_models || n_models < 1 || n_models > 65535 || do_update < 0 || do_update > 3) return MOBOCMF_BAD_ARG;
     int mmax = 0;
     int64_t pmax = 0;
+    int cmax = 0;
     for (int i = 0; i < n_models; ++i) {
         if (!valid_model(host_models[i]) || (do_update == 3 && !host_models[i].grad)) return MOBOCMF_BAD_ARG;
         if (host_models[i].M > mmax) mmax = host_models[i].M;
         Geom g;
         geom_of(host_models[i], g);
         if (g.pool_len > pmax) pmax = g.pool_len;
+        if (g.ncmax > cmax) cmax = g.ncmax;
     }
     hipStream_t s = (hipStream_t)stream;
     const int MR = mmax <= 16 ? 16 : 32;
@@ -937,19 +951,24 @@ int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
     const int pool_in_lds = shm + pool <= LDS_BUDGET ? 1 : 0;
     if (pool_in_lds) shm += pool;
     // more than the default 64 KB of dynamic LDS needs the function attribute (idempotent; raised, never lowered)
-    static std::atomic<size_t> granted[2] = {{64 * 1024}, {64 * 1024}};
-    const void* fn = MR == 16 ? (const void*)tiny_step_kernel<16> : (const void*)tiny_step_kernel<32>;
-    if (shm > granted[MR == 32].load()) {
+    static std::atomic<size_t> granted[4] = {{64 * 1024}, {64 * 1024}, {64 * 1024}, {64 * 1024}};
+    // 512 threads when a phase has more than two elements per thread of a 256-thread workgroup (wide panels: conditioned
+    // training, acquisition): the phases are latency-bound per thread, more threads walk more elements at once
+    const bool wide = (int64_t)mmax * cmax > 2 * 256;
+    const int slot = (MR == 32 ? 2 : 0) + (wide ? 1 : 0);
+    const void* fn = MR == 16 ? (wide ? (const void*)tiny_step_kernel<16, 512> : (const void*)tiny_step_kernel<16, 256>)
+                              : (wide ? (const void*)tiny_step_kernel<32, 512> : (const void*)tiny_step_kernel<32, 256>);
+    if (shm > granted[slot].load()) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
             return MOBOCMF_HIP_ERROR;
-        granted[MR == 32].store(LDS_BUDGET);
+        granted[slot].store(LDS_BUDGET);
     }
-    if (MR == 16)
-        hipLaunchKernelGGL(tiny_step_kernel<16>, dim3((unsigned)n_models), dim3(TT), shm, s, dev_models, lr, beta1, beta2, eps,
-                           do_update, pool_in_lds);
-    else
-        hipLaunchKernelGGL(tiny_step_kernel<32>, dim3((unsigned)n_models), dim3(TT), shm, s, dev_models, lr, beta1, beta2, eps,
-                           do_update, pool_in_lds);
+#define LAUNCH(MR_, TT_)                                                                                              \
+    hipLaunchKernelGGL((tiny_step_kernel<MR_, TT_>), dim3((unsigned)n_models), dim3(TT_), shm, s, dev_models, lr, beta1, \
+                       beta2, eps, do_update, pool_in_lds)
+    if (MR == 16) { if (wide) LAUNCH(16, 512); else LAUNCH(16, 256); }
+    else { if (wide) LAUNCH(32, 512); else LAUNCH(32, 256); }
+#undef LAUNCH
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
