@@ -375,3 +375,56 @@ def test_fitter_falls_back_to_the_layer_path_after_a_failed_cholesky(monkeypatch
     assert float(st["exp_avg_sq"].abs().sum()) > 0
     for p in fitter.get_model("obj1").parameters():
         assert bool(torch.isfinite(p).all())
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        L = int(rng.integers(1, 4))
+        d = int(rng.integers(1, 9))
+        M = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 31, 32]))
+        N = int(rng.integers(max(M, 4), 90))
+        S = int(rng.choice([1, 1, 2, 3, 5, 8]))
+        if N * S > 400:
+            continue
+        out.append(dict(d=d, L=L, M=M, N=N, S=S, seed=int(rng.integers(1 << 30))))
+    return out
+
+
+FUZZ = _fuzz_cases(24, seed=77)
+
+
+@pytest.mark.parametrize("cfg", FUZZ, ids=["d%d_L%d_M%d_N%d_S%d" % (c["d"], c["L"], c["M"], c["N"], c["S"]) for c in FUZZ])
+def test_fuzz_tiny_step_against_the_layer_path(cfg):
+    """Random shapes inside the kernel's limits (M = 1 ... 32 incl. non-powers of two, d = 1 ... 8, 1-3 layers, S = 1 ... 8,
+    ragged row counts): ELBO, scaled KL and every raw-parameter gradient of the one-launch step vs the layer entry points
+    (GraphedELBOStep's pruned forward / backward, themselves pinned to the oracle in test_hip_pruned_oracle.py)."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    prob, x, y, fid, eps = _problem(cfg)
+    L, S, N = cfg["L"], cfg["S"], cfg["N"]
+    if int((fid >= L - 1).sum()) < 1:
+        pytest.skip("no row at the top fidelity")
+    ma = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
+    mb = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
+    ma.set_check_pd(False)
+    fidv = fid.reshape(-1)
+    rows = [int((fidv >= l).sum()) for l in range(L)]
+    order = torch.argsort(fidv, descending=True, stable=True)
+    xo, yo, fo = x[order].to(DEV), y[order][:, None].to(DEV), fid[order][:, None].to(DEV)
+    eo = [None if e is None else e.reshape(N, S)[order][:rows[l]].reshape(-1).contiguous().to(DEV) for l, e in enumerate(eps)]
+    e_ref, skl_ref = VariationalELBOMF(ma, N, L)(ma(xo, eps=eo, rows=rows), yo.T, fo)
+    (-e_ref).backward()
+    step = _tiny([mb], [x], [y], [fid], [eps], want_grad=True)
+    grads = step.gradients()[0]
+    step.check()
+    out = step.losses[0]
+    assert rel(out[0], e_ref) < 1e-9 and rel(out[1], skl_ref) < 1e-9, (rel(out[0], e_ref), rel(out[1], skl_ref))
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        if pa.grad is None:
+            continue
+        ga, gb = pa.grad, grads[pb]
+        if pa.dim() == 2 and pa.shape[0] == pa.shape[1] and pa.shape[0] == cfg["M"]:
+            ga = torch.tril(ga)
+        scale = float(ga.abs().max())
+        assert scale == 0.0 or float((gb - ga).abs().max()) / scale < 1e-5, (tuple(pa.shape), float((gb - ga).abs().max()) / scale)
