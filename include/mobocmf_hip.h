@@ -387,7 +387,9 @@ int mobocmf_scalar_combine(int32_t n, const double* const* x, const double* coef
  * top_var; draws the random rows of x) -- a conditioned iteration is mode 2, the factor launches on top_mean / top_var, mode 1;
  * 3: input gradients (the parameters are constants -- acquisition search, JESMOC_MFDGP.py:38-52): `grad` receives d / d x
  * (N x d) of <seed_gmean, top mean> + <seed_gvar, top var> (times seed_scale) and nothing else is written -- predictive
- * moments of fitted models are mode 2 with branch = 1, eps[l] = the layer's fixed samples tiled over the test points. */
+ * moments of fitted models are mode 2 with branch = 1, eps[l] = the layer's fixed samples tiled over the test points;
+ * 4: mode 1 with the factor terms of the conditioned loss formed INSIDE the launch (mobocmf_tiny_coupling: ONE launch per
+ * conditioned iteration instead of mode 2 + factor launches + mode 1). */
 #define MOBOCMF_TINY_MAX_LAYERS 3
 #define MOBOCMF_TINY_MAX_M 32
 #define MOBOCMF_TINY_MAX_D 8
@@ -423,14 +425,32 @@ typedef struct mobocmf_tiny_model {
      * rows of a constraint), and gradients of terms formed OUTSIDE the launch (the theta / omega factors,
      * mobocmf_cond_factors_forward) entering at the top layer's columns. */
     const double* row_weight;                /* N (NULL: 1) */
-    const double* seed_gmean;                /* rows[L-1] * S: d(outside term) / d mean of the top layer's columns (NULL: none) */
+    const double* seed_gmean;                /* rows[L-1] * S: d(outside term) / d mean of the top layer's columns (NULL: none;
+                                              * mode 4 WRITES both arrays itself before its backward reads them) */
     const double* seed_gvar;
     double seed_scale;                       /* the outside term's coefficient in the loss (the fitter's -1) */
     double* top_mean;                        /* rows[L-1] * S: the top layer's moments, written by every mode (NULL: not) */
     double* top_var;
-    int64_t* xrng;                           /* {seed, calls}: mode 2 draws rows [rand_row0, rand_row0 + rand_rows) of x from */
-    int32_t rand_row0, rand_rows;            /* U(0,1) (the x~ of :276; x must be writable); mode 1 of model 0 advances calls */
+    int64_t* xrng;                           /* {seed, calls}: modes 2 / 4 draw rows [rand_row0, rand_row0 + rand_rows) of x from */
+    int32_t rand_row0, rand_rows;            /* U(0,1) (the x~ of :276; x must be writable); modes 1 / 4 of model 0 advance calls */
+    /* mode 4 (the whole conditioned iteration in ONE cooperative launch): what couples the models, and this model's part in it */
+    const struct mobocmf_tiny_coupling* coupling;
+    int32_t role, role_index;                /* 0: objective role_index of the coupling, 1: constraint role_index */
 } mobocmf_tiny_model;
+/* The theta / omega factors of blackbox_mfdgp_fitter.py:227-243 over the models of one launch (device-resident, shared).
+ * Every model holds, at its TOP layer with S = 1, the P Pareto points in columns [0, P) and the T points x~ in [P, P + T).
+ * After its forward every workgroup publishes its top-layer moments, the workgroups of the launch meet at a barrier (an arrival
+ * counter in device memory; n_models <= 64, T <= 256), and every workgroup forms the factor gradients of ITS model -- the omega factors from all models' moments at x~, a constraint's theta
+ * factors from its own at the Pareto points -- into its seed_gmean / seed_gvar before running its backward and update. */
+typedef struct mobocmf_tiny_coupling {
+    int32_t n_obj, n_con, P, T;
+    int32_t obj_model[8], con_model[8];      /* index in the launch's model array of every objective / constraint */
+    const double* front;                     /* P x n_obj (Pareto front, columns in objective order) */
+    const double* thresholds;                /* n_con */
+    double log_eps, log_1m_eps;
+    double* losses;                          /* n_con + 1: the theta factor term of every constraint, then the omega term */
+    int64_t* barrier;                        /* device word, zero-initialised ONCE by the caller: arrivals at the in-launch barrier */
+} mobocmf_tiny_coupling;
 int mobocmf_tiny_flat_len(const mobocmf_tiny_model* model, int64_t* len);
 int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes);
 int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,

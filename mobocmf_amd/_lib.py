@@ -56,7 +56,17 @@ class TinyModel(ctypes.Structure):
                 ("kl_scale", ctypes.c_double), ("jitter", ctypes.c_double),
                 ("row_weight", ctypes.c_void_p), ("seed_gmean", ctypes.c_void_p), ("seed_gvar", ctypes.c_void_p),
                 ("seed_scale", ctypes.c_double), ("top_mean", ctypes.c_void_p), ("top_var", ctypes.c_void_p),
-                ("xrng", ctypes.c_void_p), ("rand_row0", ctypes.c_int32), ("rand_rows", ctypes.c_int32)]
+                ("xrng", ctypes.c_void_p), ("rand_row0", ctypes.c_int32), ("rand_rows", ctypes.c_int32),
+                ("coupling", ctypes.c_void_p), ("role", ctypes.c_int32), ("role_index", ctypes.c_int32)]
+
+
+class TinyCoupling(ctypes.Structure):
+    """mobocmf_tiny_coupling: the theta / omega factors over the models of one mode-4 launch (device-resident)."""
+    _fields_ = [("n_obj", ctypes.c_int32), ("n_con", ctypes.c_int32), ("P", ctypes.c_int32), ("T", ctypes.c_int32),
+                ("obj_model", ctypes.c_int32 * 8), ("con_model", ctypes.c_int32 * 8),
+                ("front", ctypes.c_void_p), ("thresholds", ctypes.c_void_p),
+                ("log_eps", ctypes.c_double), ("log_1m_eps", ctypes.c_double), ("losses", ctypes.c_void_p),
+                ("barrier", ctypes.c_void_p)]
 
 
 class MobocmfError(RuntimeError):

@@ -22,6 +22,7 @@ constexpr int DBT = MOBOCMF_TINY_MAX_D;          // x columns of a staged induci
 constexpr int ZW = DBT + 1;                      // + the f column
 constexpr int HS = 5 + 2 * DBT;                  // packed hyper-parameters of a layer, at most
 constexpr int NVEC = 11;                         // per-column vectors of a layer kept in `work`
+constexpr int64_t CPL_DOUBLES = 256 * 17;           // scratch of coupling_seeds (mode 4)
 constexpr int NSEG = 32;                         // parameter tensors of a model, at most (3 layers x 9 + 3 noise)
 constexpr double MINV = 1e-10;                   // gpytorch.settings.min_variance (float64)
 constexpr double LOG2PI = 1.8378770664093453;
@@ -30,7 +31,7 @@ struct Geom {
     int L, M, d, S;
     int ncol[TLM], H[TLM];
     int64_t flat_off[TLM], flat_noise, flat_len;
-    int64_t work_off[TLM], scratch_off, pool_base, pool_len, work_len;
+    int64_t work_off[TLM], scratch_off, pool_base, pool_len, cpl_off, work_len;
     int ncmax, srows;
 };
 __host__ __device__ inline void geom_of(const mobocmf_tiny_model& md, Geom& g) {
@@ -57,7 +58,8 @@ __host__ __device__ inline void geom_of(const mobocmf_tiny_model& md, Geom& g) {
     g.scratch_off = wo;
     g.srows = md.M > DBT ? md.M : DBT;      // rows of a scratch panel (mode 3 keeps DBT values per column in one)
     g.pool_len = wo + 3 * (int64_t)g.srows * g.ncmax;
-    g.work_len = g.pool_base + g.pool_len;
+    g.cpl_off = g.pool_base + g.pool_len;      // mode 4: partial sums of the factor terms, 256 x (1 + 2 x 8) doubles
+    g.work_len = g.cpl_off + CPL_DOUBLES;
 #ifdef TINY_STAMPS
     g.work_len += 128;      // phase stamps (tools/tiny_stamps.py): the last 128 doubles of `work`
 #endif
@@ -243,6 +245,113 @@ __device__ __forceinline__ void kern_back_in(int kind, int d, const double* xa, 
     }
 }
 
+__device__ __forceinline__ double ncdf_t(double z) { return 0.5 * (1.0 + erf(z * 0.7071067811865476)); }
+__device__ __forceinline__ double npdf_t(double z) { return 0.3989422804014327 * exp(-0.5 * z * z); }
+// a value another workgroup of this launch wrote before the grid barrier (agent-scope load: not served from a stale line)
+__device__ __forceinline__ double peer(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Mode 4, after the grid barrier: the factor gradients of THIS model (blackbox_mfdgp_fitter.py:227-243; the algebra of
+// elementwise.hip cond_factors_kernel) into its seed arrays -- zero on the batch columns, the theta factors on a constraint's
+// Pareto columns, the omega factors (all models' moments at x~) on the x~ columns.  part: >= 256 * (1 + 2 n_obj) doubles of
+// workgroup scratch.  NT threads; all of them call it.
+template <int NT>
+__device__ void coupling_seeds(const mobocmf_tiny_model* models, const mobocmf_tiny_model& md, int ncol_top, double* part,
+                               double* sh) {
+    const mobocmf_tiny_coupling& cp = *md.coupling;
+    const int tid = threadIdx.x, P = cp.P, T = cp.T, no = cp.n_obj, nc = cp.n_con;
+    const int stride = 1 + 2 * no;
+    double* sgm = const_cast<double*>(md.seed_gmean);      // (inputs of modes 1 / 3; in mode 4 the launch fills them itself)
+    double* sgv = const_cast<double*>(md.seed_gvar);
+    for (int c = tid; c < ncol_top; c += NT) { sgm[c] = 0.0; sgv[c] = 0.0; }
+    // ---- omega: sum_p over the Pareto points, split among NG thread groups per point t (T <= NT)
+    int NG = 256 / T;      // (T <= 256: the binding's limit) NG T <= 256 rows of `part`
+    if (NG > P) NG = P;
+    const int tl = tid % T, grp = tid / T;
+    const bool on = grp < NG;
+    if (on) {
+        double isd[8], fmv[8], fvv[8], gm[8], gv[8], osum = 0.0;
+        for (int j = 0; j < no; ++j) {
+            const mobocmf_tiny_model& mj = models[cp.obj_model[j]];
+            fmv[j] = peer(mj.top_mean + P + tl);
+            fvv[j] = peer(mj.top_var + P + tl);
+            isd[j] = 1.0 / sqrt(fvv[j]);
+            gm[j] = gv[j] = 0.0;
+        }
+        for (int p = grp; p < P; p += NG) {
+            double ph[8], u[8], O = 1.0;
+            for (int j = 0; j < no; ++j) {
+                u[j] = (cp.front[(int64_t)p * no + j] - fmv[j]) * isd[j];
+                ph[j] = ncdf_t(u[j]);
+                O *= ph[j];
+            }
+            osum += O;
+            for (int j = 0; j < no; ++j) {
+                double rest = 1.0;
+                for (int q = 0; q < no; ++q) rest *= q == j ? 1.0 : ph[q];
+                const double pd = npdf_t(u[j]);
+                gm[j] += rest * pd * (-isd[j]);
+                gv[j] += rest * pd * (-0.5 * u[j] / fvv[j]);
+            }
+        }
+        double* pp = part + (int64_t)(grp * T + tl) * stride;
+        pp[0] = osum;
+        for (int j = 0; j < no; ++j) { pp[1 + j] = gm[j]; pp[1 + no + j] = gv[j]; }
+    }
+    __syncthreads();
+    const double dldc = cp.log_eps - cp.log_1m_eps;      // omega: coef_c = log eps, coef_1mc = log(1 - eps)
+    double acc = 0.0;
+    if (tid < T) {
+        const int t = tid;
+        double osum = 0.0, gm = 0.0, gv = 0.0;
+        const int j0 = md.role == 0 ? md.role_index : 0;
+        for (int g2 = 0; g2 < NG; ++g2) {
+            const double* pp = part + (int64_t)(g2 * T + t) * stride;
+            osum += pp[0];
+            if (no) { gm += pp[1 + j0]; gv += pp[1 + no + j0]; }
+        }
+        double phic[8], dzm[8], dzv[8], C = 1.0;
+        for (int k = 0; k < nc; ++k) {
+            const mobocmf_tiny_model& mk = models[cp.con_model[k]];
+            const double cm = peer(mk.top_mean + P + t), cv = peer(mk.top_var + P + t);
+            const double sd = sqrt(cv), z = (cm - cp.thresholds[k]) / sd, pd = npdf_t(z);
+            phic[k] = ncdf_t(z);
+            dzm[k] = pd / sd;
+            dzv[k] = -0.5 * pd * z / cv;
+            C *= phic[k];
+        }
+        acc = dldc * C * osum + cp.log_1m_eps * (double)P;
+        if (md.role == 0) {
+            sgm[P + t] = dldc * C * gm;
+            sgv[P + t] = dldc * C * gv;
+        } else {
+            double rest = osum;
+            for (int q = 0; q < nc; ++q) rest *= q == md.role_index ? 1.0 : phic[q];
+            sgm[P + t] = dldc * rest * dzm[md.role_index];
+            sgv[P + t] = dldc * rest * dzv[md.role_index];
+        }
+    }
+    if (blockIdx.x == 0) {      // (uniform) the omega term itself, once per launch
+        acc = bsum<NT / 64>(acc, sh);
+        if (tid == 0) cp.losses[nc] = acc;
+    }
+    // ---- theta (a constraint's own moments at the Pareto points): coef_c = log(1 - eps), coef_1mc = log eps
+    if (md.role == 1) {
+        double tacc = 0.0;
+        const double thr = cp.thresholds[md.role_index], dl = cp.log_1m_eps - cp.log_eps;
+        for (int pcol = tid; pcol < P; pcol += NT) {
+            const double mu = md.top_mean[pcol], var = md.top_var[pcol], sd = sqrt(var), z = (mu - thr) / sd, pd = npdf_t(z);
+            tacc += dl * ncdf_t(z) + cp.log_eps;
+            sgm[pcol] = dl * pd / sd;
+            sgv[pcol] = dl * (-0.5 * pd * z / var);
+        }
+        tacc = bsum<NT / 64>(tacc, sh);
+        if (tid == 0) cp.losses[md.role_index] = tacc;
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ int seg_len(int l, int s, int d) { return l == 0 ? (s == 0 ? 1 : d) : (s < 5 ? 1 : d); }
 
 template <int MR, int TT>
@@ -324,7 +433,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     for (int e = tid; e < L * M; e += TT) mst[(e / M) * MR + e % M] = md.m[e / M][e % M];
     if (do_update == 3)
         for (int e = tid; e < md.N * d; e += TT) md.grad[e] = 0.0;
-    if (do_update == 2 && md.xrng && md.rand_rows > 0) {
+    if ((do_update == 2 || do_update == 4) && md.xrng && md.rand_rows > 0) {
         // the x~ of this iteration (:276): every model of the launch draws the SAME points from the shared stream
         const uint64_t seed = (uint64_t)md.xrng[0], call = (uint64_t)md.xrng[1];
         double* xw = const_cast<double*>(md.x) + (int64_t)md.rand_row0 * d;
@@ -352,7 +461,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         seg_ptr[k] = ptr;
         seg_end[k] = end;
     }
-    if (tid == TT - 1 && do_update == 1) {      // Adam's bias corrections (two pow calls): once, off the critical path
+    if (tid == TT - 1 && (do_update == 1 || do_update == 4)) {      // Adam's bias corrections (two pow calls): once, off the critical path
         const double step = (double)(md.steps_done[0] + 1);
         sc[12] = 1.0 - pow(b1, step);
         sc[13] = sqrt(1.0 - pow(b2, step));
@@ -519,6 +628,32 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     }
 
     if (do_update == 2) return;
+    if (do_update == 4) {
+        // the conditioned iteration in one launch: every model's top-layer moments are published, the grid meets, every
+        // workgroup forms the theta / omega factor gradients of its own model (its own moments it reads back from L1 / LDS
+        // order; the others' with agent-scope loads)
+        // The barrier: a monotonic arrival counter in the coupling record (never reset: launch k waits for k n_models
+        // arrivals).  The n_models <= 64 workgroups of a launch are resident together on a 256-CU device whatever else runs
+        // (a waiting workgroup holds one CU's slot; the missing ones get theirs as soon as ANY slot frees), so the wait ends;
+        // should it not within ~0.2 s, the workgroup gives up, flags the model (info = -1) and poisons its loss instead of
+        // hanging the device.  (hipLaunchCooperativeKernel + grid.sync() does the same job with a 23 us dispatch gap per
+        // launch and cannot be captured into a graph.)
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            unsigned long long* cnt = (unsigned long long*)md.coupling->barrier;
+            const unsigned long long n = gridDim.x;
+            const unsigned long long old = atomicAdd(cnt, 1ull), target = (old / n + 1ull) * n;
+            int spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 21)) { md.info[0] = -1; md.out[2] = __builtin_nan(""); break; }
+            }
+            __threadfence();
+        }
+        __syncthreads();
+        coupling_seeds<TT>(models, md, g.ncol[L - 1], md.work + g.cpl_off, sc + 16);
+    }
     // ---- backward, top layer first
     for (int l = L - 1; l >= 0; --l) {
         const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l], Hl = g.H[l];
@@ -932,12 +1067,18 @@ int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes) {
 
 int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
                            double lr, double beta1, double beta2, double eps, int32_t do_update, mobocmf_stream_t stream) {
-    if (!host_models || !dev_models || n_models < 1 || n_models > 65535 || do_update < 0 || do_update > 3) return MOBOCMF_BAD_ARG;
+    if (!host_models || !dev_models || n_models < 1 || n_models > 65535 || do_update < 0 || do_update > 4) return MOBOCMF_BAD_ARG;
     int mmax = 0;
     int64_t pmax = 0;
     int cmax = 0;
     for (int i = 0; i < n_models; ++i) {
         if (!valid_model(host_models[i]) || (do_update == 3 && !host_models[i].grad)) return MOBOCMF_BAD_ARG;
+        if (do_update == 4) {      // S = 1, seeds and top moments present, a coupling (checked in depth by the caller's binding)
+            const mobocmf_tiny_model& m = host_models[i];
+            if (!m.coupling || m.S != 1 || !m.seed_gmean || !m.top_mean || m.role < 0 || m.role > 1 || m.role_index < 0 ||
+                m.role_index > 7 || m.coupling != host_models[0].coupling)
+                return MOBOCMF_BAD_ARG;
+        }
         if (host_models[i].M > mmax) mmax = host_models[i].M;
         Geom g;
         geom_of(host_models[i], g);
@@ -963,6 +1104,7 @@ int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
             return MOBOCMF_HIP_ERROR;
         granted[slot].store(LDS_BUDGET);
     }
+    if (do_update == 4 && n_models > 64) return MOBOCMF_BAD_ARG;      // (the in-launch barrier wants them resident together)
 #define LAUNCH(MR_, TT_)                                                                                              \
     hipLaunchKernelGGL((tiny_step_kernel<MR_, TT_>), dim3((unsigned)n_models), dim3(TT_), shm, s, dev_models, lr, beta1, \
                        beta2, eps, do_update, pool_in_lds)

@@ -338,10 +338,11 @@ def _ptrs(vals):
 
 class TinyConditionedStep(TinyELBOStep):
     """One iteration of the conditioned training (blackbox_mfdgp_fitter.py:245-354: fresh x~ ~ U[0,1]^(n_tilde x d), the joint
-    loss over ALL surrogates, one Adam) in 3 + n_con launches instead of ~180: mobocmf_tiny_elbo_step forward-only (every
-    model on [Pareto set | x~ | its batch]; draws x~), the theta factors of every constraint and the omega factors
-    (mobocmf_cond_factors_forward, which also forms their gradients) on the top layers' moments, then
-    mobocmf_tiny_elbo_step as the step, the factor gradients entering at the top layers' columns.
+    loss over ALL surrogates, one Adam) in ONE launch instead of ~180 (mobocmf_tiny_elbo_step mode 4: every model on [Pareto
+    set | x~ | its batch], x~ drawn in the launch; after the forward the models' workgroups meet at a barrier and each forms
+    the theta / omega factor gradients of its model from all models' top-layer moments), or, ``one_launch = False``, in
+    3 + n_con: forward-only launch, mobocmf_cond_factors_forward for the theta factors of every constraint and for the omega
+    factors on the top layers' moments, step launch with those gradients entering at the top layers' columns.
     Rows per model: the P Pareto points (objectives: scored against their column of the Pareto front, weight 1, :288-291;
     constraints: weight 0, theta factors :227-233), the x~ (weight 0, omega factors :235-243), the batch (weight num_data / B,
     KL weight 1: -elbo / B * num_data, :281-303).  One sample per row (the reference's S = 1)."""
@@ -384,6 +385,7 @@ class TinyConditionedStep(TinyELBOStep):
                 rows=[P + Tn + int((fv >= l).sum()) for l in range(h.num_fidelities)],
                 row_weight=torch.cat([wp, z(Tn), torch.full((B,), float(h.num_data) / B, dtype=torch.float64, device=dev)]),
                 kl_scale=1.0, seeds=True, seed_scale=-1.0, xrng=self.xrng, rand=(P, Tn), eps=e))
+        self._roles = [(0 if tag == "OBJ" else 1) for tag, _, _ in hs]
         super().__init__([h.mfdgp for _, _, h in hs], None, None, None, None, lr, betas=betas, eps=eps, stream=stream,
                          want_grad=want_grad, prepared=prepared)
         # the factor launches: pointer tables into the models' top-layer moments / seed arrays, built once
@@ -413,6 +415,28 @@ class TinyConditionedStep(TinyELBOStep):
                        ctypes.c_void_p(self.factor_losses[len(con):].data_ptr()),
                        _ptrs([sd(k, 0, P) for k in obj]), _ptrs([sd(k, 1, P) for k in obj]),
                        _ptrs([sd(k, 0, P) for k in con]), _ptrs([sd(k, 1, P) for k in con]))
+        self._setup_coupling(front, thr, log_e, log_1me)
+
+    def _setup_coupling(self, front, thr, log_e, log_1me):
+        """mobocmf_tiny_coupling for the one-launch iteration (mode 4) and every model's role in it; the descriptor table is
+        uploaded again with those fields set."""
+        cp = _lib.TinyCoupling()
+        cp.n_obj, cp.n_con, cp.P, cp.T = len(self._obj), len(self._con), self.P, self.T
+        for j, k in enumerate(self._obj):
+            cp.obj_model[j] = k
+            self.host[k].role, self.host[k].role_index = 0, j
+        for j, k in enumerate(self._con):
+            cp.con_model[j] = k
+            self.host[k].role, self.host[k].role_index = 1, j
+        cp.front, cp.thresholds = front.data_ptr(), thr.data_ptr()
+        cp.log_eps, cp.log_1m_eps = log_e, log_1me
+        cp.losses = self.factor_losses.data_ptr()
+        self._barrier = torch.zeros(1, dtype=torch.int64, device=self.device)
+        cp.barrier = self._barrier.data_ptr()
+        self._coupling = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).to(self.device)
+        for k in range(len(self.models)):
+            self.host[k].coupling = self._coupling.data_ptr()
+        self._dev_table = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(self.device)
 
     def _factors(self):
         lib = _lib.require_device()
@@ -420,17 +444,25 @@ class TinyConditionedStep(TinyELBOStep):
         for a in self._theta + [self._omega]:
             _lib.check(lib.mobocmf_cond_factors_forward(*a, st), "mobocmf_cond_factors_forward")
 
-    use_graph = True      # the iteration's 3 + n_con launches replayed from one HIP graph (host issue is half their duration)
+    use_graph = True      # the iteration's launch(es) replayed from one HIP graph
+    one_launch = True     # the whole iteration as ONE launch (mode 4: the factor terms formed inside, after an in-launch barrier
+    #                       of the models' workgroups); False: forward-only launch + factor launches + step launch
 
     def _capture(self):
-        """The launches of an iteration captured once: every argument is static (pointers, sizes, the learning rate), x~ and
+        """The launch(es) of an iteration captured once: every argument is static (pointers, sizes, the learning rate), x~ and
         eps come from device-side counters, so a replay IS the next iteration.  The capture pass itself executes nothing."""
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+            self._issue()
+        self._graph = g
+
+    def _issue(self):
+        if self.one_launch and self.T <= 256 and len(self.models) <= 64:
+            self._launch(4)
+        else:
             self._launch(2)
             self._factors()
             self._launch(1)
-        self._graph = g
 
     def step(self):
         if self.use_graph:
@@ -438,10 +470,8 @@ class TinyConditionedStep(TinyELBOStep):
                 self._capture()
             with torch.cuda.stream(self.stream):
                 self._graph.replay()
-            return self.losses
-        self._launch(2)
-        self._factors()
-        self._launch(1)
+        else:
+            self._issue()
         return self.losses
 
     def gradients(self):

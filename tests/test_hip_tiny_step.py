@@ -428,3 +428,38 @@ def test_fuzz_tiny_step_against_the_layer_path(cfg):
             ga = torch.tril(ga)
         scale = float(ga.abs().max())
         assert scale == 0.0 or float((gb - ga).abs().max()) / scale < 1e-5, (tuple(pa.shape), float((gb - ga).abs().max()) / scale)
+
+
+def test_one_launch_conditioned_iteration_equals_the_three_launch_form():
+    """Mode 4 -- forward, grid barrier, the theta / omega factor gradients formed by every workgroup for its own model,
+    backward, Adam: ONE cooperative launch -- vs forward-only launch + mobocmf_cond_factors_forward launches + step launch
+    (itself pinned to the oracle above): the same losses, factor terms and parameters over three iterations, explicit x~, eps."""
+    from mobocmf_amd.util.tiny_step import TinyConditionedStep
+    from tests.test_hip_conditioned import _fitter
+    g = torch.Generator().manual_seed(4)
+    P, T, N = 9, 10, 12
+    ps = torch.rand(P, 2, dtype=torch.float64, generator=g)
+    pf = torch.randn(P, 2, dtype=torch.float64, generator=g) * 0.4
+    xt = torch.rand(T, 2, dtype=torch.float64, generator=g).to(DEV)
+    runs = {}
+    for one in (True, False):
+        fitter, _ = _fitter(2, 1, N)
+        fitter.set_pareto_solution(ps, pf)
+        ge = torch.Generator().manual_seed(5)
+        eps_all = {}
+        for tag, i, h in fitter._handlers():
+            h.mfdgp.fix_variational_hypers_cond(True)
+            eps_all[(tag, i)] = [None, torch.randn(N + P + T, dtype=torch.float64, generator=ge).to(DEV)]
+        step = TinyConditionedStep(fitter, lr=2e-3, fixed_x_tilde=xt, fixed_eps=eps_all)
+        step.one_launch, step.use_graph = one, False
+        hist = []
+        for _ in range(3):
+            step.step()
+            step.check()
+            hist.append((step.losses.clone(), step.factor_losses.clone()))
+        assert step.one_launch is one      # the cooperative launch was accepted
+        runs[one] = (hist, [p.detach().clone() for _, _, h in fitter._handlers() for p in h.mfdgp.parameters()])
+    for (la, fa), (lb, fb) in zip(runs[True][0], runs[False][0]):
+        assert rel(la, lb) < 1e-11 and rel(fa, fb) < 1e-11, (rel(la, lb), rel(fa, fb))
+    for pa, pb in zip(runs[True][1], runs[False][1]):
+        assert rel(pa, pb) < 1e-10

@@ -286,7 +286,7 @@ def test_tiny_step_descriptor_layout_and_argument_checks():
     assert lib.mobocmf_tiny_work_bytes(ctypes.byref(T), ctypes.byref(wb)) == _lib.OK
     cols = [57, 60, 22]
     pool = sum(c * (2 * 20 + 11) for c in cols) + 3 * max(20, 8) * max(cols)
-    assert wb.value == 8 * (((flat.value + 1) // 2) * 2 + pool)
+    assert wb.value == 8 * (((flat.value + 1) // 2) * 2 + pool + 256 * 17)
     for field, bad in (("L", 0), ("L", 4), ("M", 0), ("d", 0), ("S", 0)):
         B = _lib.TinyModel.from_buffer_copy(T)
         setattr(B, field, bad)

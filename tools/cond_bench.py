@@ -27,7 +27,7 @@ fitter.train_mfdgps()
 g = torch.Generator().manual_seed(0)
 fitter.set_pareto_solution(torch.rand(50, 1, dtype=torch.float64, generator=g),
                            torch.randn(50, 2, dtype=torch.float64, generator=g) * 0.3)
-for label, tiny, use_graphs in (("one-launch step + factor launches (default at these sizes)", True, True),
+for label, tiny, use_graphs in (("ONE launch per iteration (mobocmf_tiny_elbo_step mode 4; default at these sizes)", True, True),
                                 ("layer path, HIP-graph replay", False, True), ("layer path, eager", False, False)):
     fitter.use_tiny_step = tiny
     torch.cuda.synchronize()

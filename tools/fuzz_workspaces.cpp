@@ -141,7 +141,7 @@ int main(int argc, char** argv) {
                 pool += c * (2 * t.M + 11);
                 cmax = c > cmax ? c : cmax;
             }
-            REQUIRE((int64_t)wb == 8 * (((flat + 1) & ~(int64_t)1) + pool + 3 * (int64_t)(t.M > 8 ? t.M : 8) * cmax));
+            REQUIRE((int64_t)wb == 8 * (((flat + 1) & ~(int64_t)1) + pool + 3 * (int64_t)(t.M > 8 ? t.M : 8) * cmax + 256 * 17));
             ++tiny_ok;
         } else {
             ++tiny_bad;
