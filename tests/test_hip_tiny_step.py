@@ -463,3 +463,35 @@ def test_one_launch_conditioned_iteration_equals_the_three_launch_form():
         assert rel(la, lb) < 1e-11 and rel(fa, fb) < 1e-11, (rel(la, lb), rel(fa, fb))
     for pa, pb in zip(runs[True][1], runs[False][1]):
         assert rel(pa, pb) < 1e-10
+
+
+def test_in_launch_barrier_gives_up_instead_of_hanging():
+    """The one-launch conditioned iteration waits for its models' workgroups at an arrival counter.  A wait that cannot end
+    (here: the counter is knocked out of step, so the last workgroup waits for arrivals that never come) is abandoned after
+    ~0.2-0.5 s: the model is flagged, its loss poisoned, ``check()`` raises -- the device is not hung, and the next launches
+    run (the fitter then rolls back and continues on the layer path)."""
+    import time
+    from mobocmf_amd.layers.mfdgp_hidden_layer import NotPSDError
+    from mobocmf_amd.util.tiny_step import TinyConditionedStep
+    from tests.test_hip_conditioned import _fitter
+    fitter, _ = _fitter(2, 1, 12)
+    g = torch.Generator().manual_seed(2)
+    fitter.set_pareto_solution(torch.rand(5, 2, dtype=torch.float64, generator=g), torch.randn(5, 2, dtype=torch.float64, generator=g) * 0.3)
+    for _, _, h in fitter._handlers():
+        h.mfdgp.fix_variational_hypers_cond(True)
+    step = TinyConditionedStep(fitter, lr=1e-3)
+    step.use_graph = False
+    step.step()
+    step.check()
+    step.snapshot()
+    step._barrier.fill_(1)               # 3 workgroups: arrivals 2, 3, 4 -- the third waits for a 6 that never comes
+    t0 = time.perf_counter()
+    step.step()
+    with pytest.raises((NotPSDError, FloatingPointError)):
+        step.check()
+    assert time.perf_counter() - t0 < 5.0
+    step.restore()
+    step._barrier.zero_()
+    step.infos.zero_()
+    step.step()
+    step.check()                          # the device is fine
