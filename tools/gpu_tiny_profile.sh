@@ -16,8 +16,8 @@ echo
 echo "== tools/tiny_stamps.py (library built with -DTINY_STAMPS): microseconds per phase of one C1 surrogate, launch order; the last entry is Adam"
 MOBOCMF_HIP_LIB=$PWD/abtest/libtstamps.so python tools/tiny_stamps.py C1 2>/dev/null
 echo
-echo "== tools/cond_bench.py 400: conditioned training (N1), Forrester sizes, 3 surrogates, 50 Pareto points, 10 x~"
-python tools/cond_bench.py 400 2>/dev/null
+echo "== tools/cond_bench.py 2000: conditioned training (N1), Forrester sizes, 3 surrogates, 50 Pareto points, 10 x~"
+python tools/cond_bench.py 2000 2>/dev/null
 echo
 echo "== tools/acq_small_bench.py: acquisition phase at Forrester sizes (search = 200 projected-Adam iterations x 5 restarts, 2 evaluations of 6 models each)"
 python tools/acq_small_bench.py 2>/dev/null
