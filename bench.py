@@ -246,6 +246,37 @@ PROBE_SPANS = (("Gram forward K_mn", 9, 0), ("A = L^-1 K (lower, colstats q+mean
                ("Gram backward of K_mn", 8, 10))
 
 
+def reference_sizes_leg(device, steps=2000):
+    """The reference's OWN problem size beside the headline (BASELINE.json configs[0]: Forrester 1D, 2 fidelities, M = N = 16,
+    S = 4; three surrogates): ELBO steps/s through the one-launch step (mobocmf_tiny_elbo_step) and through
+    the layer entry points (HIP-graph replay on three streams), same process.  A few tenths of a second."""
+    from mobocmf_amd.util import tiny_step as TS
+    cfg = dict(synthetic.CONFIGS["C1"])
+    gsteps = build_graphed(cfg, [0, 1, 2], device, use_graph=True)
+    out = {"workload": "C1: Forrester-sized, d=%d M=%d N=%d S=%d, 3 surrogates" % (cfg["d"], cfg["M"], cfg["N"], cfg["S"])}
+
+    def timed(fn, n):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 3 * n / (time.perf_counter() - t0)
+
+    out["layer_path_steps_per_s"] = timed(lambda: [g.step() for g in gsteps], max(steps // 8, 50))
+    if all(TS.eligible(g.model, g.x, g.fid) for g in gsteps):
+        tiny = TS.TinyELBOStep([g.model for g in gsteps], [cfg["N"]] * 3, [g.x for g in gsteps], [g.y for g in gsteps],
+                               [g.fid for g in gsteps], lr=1e-3)
+        out["one_launch_steps_per_s"] = timed(tiny.step, steps)
+        tiny.check()
+        out["finite"] = bool(torch.isfinite(tiny.losses).all())
+    for g in gsteps:
+        g.retire()
+    return out
+
+
 def measure_instep_kernels(gstep, cfg, steps=6, skip=2, layer=None):
     """Durations of one layer's grid-filling launches INSIDE a training step of one surrogate (the other surrogates idle): the
     library records caller-created HIP events around them (mobocmf_layer_desc.probe_events, attached to the PANEL calls of
@@ -623,6 +654,9 @@ def main():
             g.retire()
         del dsteps
 
+    small_leg = None
+    if world == 1 and rank == 0 and not args.no_dense_leg and args.config == "C3":
+        small_leg = reference_sizes_leg(device)
     if rank == 0:
         n_sur = n_out if rows else n_out * world
         value = n_sur * args.steps / elapsed
@@ -651,6 +685,7 @@ def main():
                           "what": "layer l runs on the rows of fidelity >= l (batch ordered once by descending fidelity); a "
                                   "layer backward skips 128-column blocks whose upstream gradients are all zero"},
             "reference_layout": dense_leg,
+            "reference_sizes": small_leg,
             "value_over_reference_layout": (value / dense_leg["value"]) if dense_leg else None,
             # SURVEY 8(d)'s F_step prices the reference's solve-based op sequence at every row (~5.7x the flops executed
             # here at C3): steps/s x F_step in TFLOP/s is what a chip running the REFERENCE's operation count would have to
