@@ -111,7 +111,7 @@ def test_tiny_step_group_equals_single_models_and_respects_frozen_parameters():
         singles[i].check()
         # (not bit-equal: the launch geometry follows the WIDEST model of the group -- 512 threads instead of 256 -- and
         # with it the order of the workgroup reductions)
-        assert rel(group.losses[i], singles[i].losses[0]) < 1e-11
+        assert rel(group.losses[i], singles[i].losses[0]) < 1e-9
         for pa, pb in zip(a.parameters(), b.parameters()):
             assert rel(pa, pb) < 1e-9
         assert torch.equal(a.hidden_layer_0.variational_strategy._variational_distribution.chol_variational_covar, before[i])
