@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised campaign for mobocmf_tiny_elbo_step: random shapes inside the kernel's limits (M 1..32, d 1..8, 1-3 layers,
+S 1..8, ragged fidelity mixes), ELBO / scaled KL / every raw-parameter gradient against the layer entry points (pruned forward
++ backward, themselves pinned to the oracle) -- the worst relative differences over the campaign.
+usage: python tools/fuzz_tiny_step.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mobocmf_amd.mlls import VariationalELBOMF  # noqa: E402
+from mobocmf_amd.util import synthetic  # noqa: E402
+from mobocmf_amd.util.tiny_step import TinyELBOStep  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+DEV = "cuda"
+rel = lambda a, b: float((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-300))
+worst = {"elbo": 0.0, "kl": 0.0, "grad": 0.0}
+worst_case = {}
+done = 0
+while done < n_cases:
+    L = int(rng.integers(1, 4)); d = int(rng.integers(1, 9)); M = int(rng.integers(1, 33))
+    N = int(rng.integers(max(M, 4), 120)); S = int(rng.choice([1, 1, 2, 3, 4, 8]))
+    if N * S > 600:
+        continue
+    seed = int(rng.integers(1 << 30))
+    prob = synthetic.make_problem(d=d, L=L, M=M, N=N, S=S, seed=seed, top_fraction=float(rng.choice([0.25, 0.1, 0.5])))
+    perm = rng.permutation(N)
+    tc = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    x, y, fid = tc(prob["x"])[perm], tc(prob["y"])[perm], tc(prob["fid"])[perm]
+    if any(int((fid == l).sum()) < 1 for l in range(L)):      # (the model's initialisation wants data at every fidelity)
+        continue
+    eps = [None] + [tc(e).reshape(N, S)[perm].reshape(-1) for e in prob["eps"][1:]]
+    ma = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
+    mb = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
+    ma.set_check_pd(False)
+    rows = [int((fid >= l).sum()) for l in range(L)]
+    order = torch.argsort(fid, descending=True, stable=True)
+    xo, yo, fo = x[order].to(DEV), y[order][:, None].to(DEV), fid[order][:, None].to(DEV)
+    eo = [None if e is None else e.reshape(N, S)[order][:rows[l]].reshape(-1).contiguous().to(DEV) for l, e in enumerate(eps)]
+    e_ref, skl_ref = VariationalELBOMF(ma, N, L)(ma(xo, eps=eo, rows=rows), yo.T, fo)
+    (-e_ref).backward()
+    step = TinyELBOStep([mb], [N], [x.to(DEV)], [y.to(DEV)], [fid.to(DEV)], lr=1e-3,
+                        fixed_eps=[[None if e is None else e.to(DEV) for e in eps]], want_grad=True, force=True)
+    grads = step.gradients()[0]
+    step.check()
+    out = step.losses[0]
+    errs = {"elbo": rel(out[0], e_ref), "kl": rel(out[1], skl_ref), "grad": 0.0}
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        if pa.grad is None:
+            continue
+        ga = torch.tril(pa.grad) if (pa.dim() == 2 and pa.shape[0] == pa.shape[1] == M) else pa.grad
+        sc = float(ga.abs().max())
+        if sc > 0:
+            errs["grad"] = max(errs["grad"], float((grads[pb] - ga).abs().max()) / sc)
+    for k, v in errs.items():
+        if not np.isfinite(v) or v > worst[k]:
+            worst[k], worst_case[k] = v, (d, L, M, N, S, seed)
+    done += 1
+    if done % 50 == 0:
+        print("%d cases: worst relative differences  ELBO %.2e  scaled KL %.2e  gradients %.2e" %
+              (done, worst["elbo"], worst["kl"], worst["grad"]), flush=True)
+print("worst cases (d, L, M, N, S, seed):", worst_case)
+assert worst["elbo"] < 1e-8 and worst["kl"] < 1e-8 and worst["grad"] < 1e-4, worst
+print("campaign passed: %d cases" % done)
