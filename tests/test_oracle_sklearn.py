@@ -79,3 +79,30 @@ def test_optimal_variational_posterior_predicts_like_sklearns_exact_gp(d, n, see
     elbo, _ = O.elbo(hyp_state, T(X), T(y), torch.zeros(n, dtype=torch.float64), shortcut=False)
     lml = gpr.log_marginal_likelihood_value_
     assert abs(float(elbo) - lml) < 2e-3 * max(1.0, abs(lml)), (float(elbo), lml)
+
+
+@pytest.mark.parametrize("M,d,seed", [(5, 1, 0), (12, 3, 1), (20, 2, 2)])
+def test_kl_term_is_torch_distributions_kl(M, d, seed):
+    """KL(q(u) || p(u)) of the oracle (kl_mvn_mvn restated) == torch.distributions.kl_divergence of the two
+    multivariate normals (PyTorch's own implementation)."""
+    rng = np.random.default_rng(seed)
+    Z = T(rng.random((M, d)))
+    hyp = {"ls": T(0.3 + rng.random(d)), "alpha": T(0.5 + rng.random())}
+    m = T(rng.standard_normal(M))
+    L_S = torch.tril(T(0.3 * rng.standard_normal((M, M)))) + torch.diag(T(0.5 + rng.random(M)))
+    K = O.gram(hyp, Z, Z) + O.JITTER * torch.eye(M, dtype=torch.float64)
+    ref = torch.distributions.kl_divergence(torch.distributions.MultivariateNormal(m, scale_tril=L_S),
+                                            torch.distributions.MultivariateNormal(torch.zeros(M, dtype=torch.float64), K))
+    assert abs(float(O.kl_layer(hyp, Z, m, L_S)) - float(ref)) < 1e-9 * max(1.0, abs(float(ref)))
+
+
+def test_expected_log_prob_is_the_gauss_hermite_integral():
+    """GaussianLikelihood.expected_log_prob restated: E_{f ~ N(mu, var)} log N(y | f, tau), against numpy's
+    Gauss-Hermite quadrature of torch.distributions.Normal.log_prob (exact for this quadratic integrand)."""
+    rng = np.random.default_rng(0)
+    y, mu = T(rng.standard_normal(9)), T(rng.standard_normal(9))
+    var, tau = T(0.05 + rng.random(9)), T(0.3)
+    t, w = np.polynomial.hermite.hermgauss(20)
+    f = mu[:, None] + torch.sqrt(2.0 * var)[:, None] * T(t)[None, :]
+    quad = (torch.distributions.Normal(f, torch.sqrt(tau)).log_prob(y[:, None]) * T(w)[None, :]).sum(1) / np.sqrt(np.pi)
+    assert float((O.expected_log_prob(y, mu, var, tau) - quad).abs().max()) < 1e-12
