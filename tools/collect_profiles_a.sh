@@ -23,7 +23,8 @@ python tools/gemm_variants.py 512 65536 > $O/gemm_variants_reflayout.txt 2>&1
 python tools/tile_sweep.py > $O/tile_sweep.txt 2>&1
 echo "variants done"
 for cfg in C5 C2 C1; do
-  rocprofv3 --kernel-trace --output-format csv -d $O/p_$cfg -- python3 bench.py --config $cfg --surrogates 1 --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-roofline --no-dense-leg > /dev/null 2>&1
+  # (--layer-path: C1 would otherwise run as one launch per step -- profiles/r04_tiny_step.txt covers that; the timeline is the layer path's)
+  rocprofv3 --kernel-trace --output-format csv -d $O/p_$cfg -- python3 bench.py --config $cfg --surrogates 1 --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-roofline --no-dense-leg --layer-path > /dev/null 2>&1
   python tools/step_timeline.py $(ls $O/p_$cfg/*/*kernel_trace.csv | head -1) > $O/${cfg}_step_timeline.txt
   rm -rf $O/p_$cfg
 done
