@@ -307,8 +307,8 @@ class TinyELBOStep:
     def restore(self):
         """Back to the last snapshot (parameters, optimiser state, eps streams)."""
         self.stream.synchronize()
-        ps, ea, eq, steps, rngs = self._snap
-        with torch.no_grad():
+        ps, ea, eq, steps, rngs = self._snap[:5]
+        with torch.no_grad(), torch.cuda.stream(self.stream):      # (ordered with the launches that follow on this stream)
             for p, s0 in zip([p for m in self.models for p in m.parameters()], ps):
                 p.copy_(s0)
             for t, s0 in zip(self.exp_avg, ea):
@@ -496,12 +496,11 @@ class TinyConditionedStep(TinyELBOStep):
         self._snap = self._snap + (None if self.xrng is None else self.xrng.clone(),)
 
     def restore(self):
-        xr = self._snap[-1]
-        self._snap = self._snap[:-1]
         super().restore()
+        xr = self._snap[-1]
         if xr is not None:
-            self.xrng.copy_(xr)
-        self._snap = self._snap + (xr,)
+            with torch.cuda.stream(self.stream):
+                self.xrng.copy_(xr)
 
 
 class _TinyMomentsFn(torch.autograd.Function):

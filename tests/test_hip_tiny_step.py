@@ -493,5 +493,6 @@ def test_in_launch_barrier_gives_up_instead_of_hanging():
     step.restore()
     step._barrier.zero_()
     step.infos.zero_()
+    torch.cuda.synchronize()
     step.step()
     step.check()                          # the device is fine
