@@ -2,14 +2,17 @@
 //
 // At the reference's own sizes (M = N = tens of points, examples/example_acquisition_mfdgp_forrester/...py:51-62) a step
 // through the layer entry points is ~50 dependent launches of ~4.7 us each whatever they compute.  Here ONE
-// workgroup of 256 threads runs zero_grad + MFDGP.forward (mfdgp.py:174-196) + VariationalELBOMF (variational_elbo_mf.py:
+// workgroup of 256 (wide panels: 512) threads runs zero_grad + MFDGP.forward (mfdgp.py:174-196) + VariationalELBOMF (variational_elbo_mf.py:
 // 24-51) + backward + Adam (blackbox_mfdgp_fitter.py:161-171) as ~45 phases separated by workgroup barriers (~0.1 us each
 // instead of a kernel boundary); several surrogates are several workgroups of the same launch.  The algebra is DESIGN.md 1
 // line for line -- explicit L^-1, A = L^-1 K, C = U^T A, the single weighted syrk H, Murray's Cholesky backward -- as
 // element-parallel products: a thread owns an output element and walks its (triangular) contraction range.  The M x M chain
-// state of every layer lives in LDS; the M x N' panels in `work` (a workgroup reads its own global writes after a barrier:
-// one CU, one L1).  Only the Cholesky + triangular inverse is serial: one wavefront per layer, the matrix row-per-lane in
+// state of every layer lives in LDS; the M x N' panels join it there when they fit, else they live in `work` (a workgroup
+// reads its own global writes after a barrier: one CU, one L1).  Only the Cholesky + triangular inverse is serial: one wavefront per layer, the matrix row-per-lane in
 // registers, pivots and multipliers broadcast by v_readlane (no LDS round trip, no barrier), the layers side by side.
+// Modes (do_update): 0 gradients only, 1 the step, 2 forward only (acquisition moments; the first launch of a three-launch
+// conditioned iteration), 3 input gradients (acquisition search), 4 the conditioned iteration in one launch (the models'
+// workgroups meet at an arrival counter after their forward and form the theta / omega factor gradients themselves).
 #include <atomic>
 
 #include "common.h"
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     double* dav = ghy + TLM * HS;           // [MR] da
     double* dat = dav + MR;                 // [MR] da_tot
     double* mst = dat + MR;                 // [TLM][MR] m of every layer (staged)
-    double* red = mst + TLM * MR;           // [4][HS + 1] wavefront partials
+    double* red = mst + TLM * MR;           // [NWMAX][HS + 1] wavefront partials
     double* sc = red + NWMAX * (HS + 1);    // [24]: tau[l] (0..2), g_noise[l] (4..6), Adam's bias terms (12, 13), bsum scratch (16..23)
     double** seg_ptr = (double**)(sc + 24); // [NSEG] parameter tensors in flat-vector order (trainable ones; else null)
     int* seg_end = (int*)(seg_ptr + NSEG);  // [NSEG] end offset of each tensor in the flat vector
