@@ -459,6 +459,7 @@ def main():
     ap.add_argument("--no-dense-leg", action="store_true",
                     help="skip the second timing of the step in the reference's layout (every layer at every row, dense backward)")
     ap.add_argument("--launch", action="store_true", help="go through the rank launcher even for --gpus 1")
+    ap.add_argument("--no-rccl", action="store_true", help="one GPU: do not create the one-rank process group")
     ap.add_argument("--layer-path", action="store_true",
                     help="small configurations: the layer entry points (HIP-graph replay) instead of the one-launch step")
     args = ap.parse_args()
@@ -512,6 +513,7 @@ def main():
         from mobocmf_amd import functional as F_
         F_.set_potrf_cols(args.potrf_cols)
     dist = None
+    rccl_error = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -519,6 +521,27 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    elif not args.no_rccl:
+        # one GPU: a process group of ONE rank on the nccl (= RCCL) backend all the same, so that the exchange below runs the
+        # collective an N-rank job runs (`rccl_ranks`, `exchange_ms` of the record) -- through the launcher's environment when
+        # there is one, else through a rendezvous file (no port to collide on).  A box whose RCCL cannot start is reported
+        # (`rccl_error`), the step timing does not depend on it.
+        import torch.distributed as dist
+        try:
+            if "MASTER_PORT" in os.environ and "RANK" in os.environ:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group(args.backend, rank=0, world_size=1,
+                                        **({"device_id": device} if args.backend == "nccl" else {}))
+            else:
+                import tempfile
+                rdv = tempfile.NamedTemporaryFile(prefix="mobocmf_rdv_", delete=False)
+                rdv.close()
+                os.unlink(rdv.name)
+                dist.init_process_group(args.backend, init_method="file://" + rdv.name, rank=0, world_size=1,
+                                        **({"device_id": device} if args.backend == "nccl" else {}))
+        except Exception as e:      # noqa: BLE001 -- whatever the backend raises: report, go on without a group
+            rccl_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+            dist = None
 
     cfg = dict(synthetic.CONFIGS[args.config])
     n_out = 3 if args.config == "C3" else min(cfg["outputs"], 3) if args.config != "C5" else 1
@@ -600,10 +623,21 @@ def main():
             mus, vs = model.predict_for_acquisition(Xg, cfg["L"] - 1)
             model.train()
             local.append(torch.stack([mus, vs]))
-        gathered = parallel.all_gather_moments(torch.stack(local))
-    torch.cuda.synchronize()
-    exchange_ms = (time.perf_counter() - t1) * 1e3
-    finite = finite and bool(torch.isfinite(gathered).all())
+        local = torch.stack(local)
+        gathered = parallel.all_gather_moments(local)      # (the warm call: communicator set-up, first-use allocations)
+        torch.cuda.synchronize()
+        exchange_first_ms = (time.perf_counter() - t1) * 1e3
+        ex = []
+        for _ in range(5):      # the collective alone: median of 5
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            gathered = parallel.all_gather_moments(local)
+            torch.cuda.synchronize()
+            ex.append((time.perf_counter() - t1) * 1e3)
+    exchange_ms = sorted(ex)[2]
+    rccl_loaded = any("librccl" in ln for ln in open("/proc/self/maps")) if os.path.exists("/proc/self/maps") else None
+    finite = finite and bool(torch.isfinite(gathered).all()) and gathered.shape[0] == world * local.shape[0] and \
+        bool(torch.equal(gathered[rank * local.shape[0]:(rank + 1) * local.shape[0]], local))
 
     # What the record says about rows / columns / executed flops is read off the STEP OBJECT (its layer_rows and the
     # fidelities of the rows it holds, in the order it holds them), never inferred from the CLI flags: with --shard rows every
@@ -692,8 +726,13 @@ def main():
             # sustain to match this step rate.  It exceeds the FP64 peak because work was removed, so it is reported as an
             # equivalent rate, not as a fraction of peak; the roofline figure of the whole step is step_executed_fp64_frac.
             "reference_equivalent_tflops": algorithmic_flops(cfg) * value / world / 1e12,
-            "exchange_ms": exchange_ms, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
-            "backend": (args.backend if dist is not None else None),
+            # the path's exchange: ONE all-gather of every surrogate's posterior moments on a 256-point grid;
+            # `exchange_ms` = that collective alone (median of 5 after a warm call), `exchange_first_ms` = the moments of this
+            # rank's surrogates + the first (warm-up) collective
+            "exchange_ms": exchange_ms, "exchange_first_ms": exchange_first_ms, "exchange_repeats_ms": ex,
+            "exchange_payload_bytes": int(local.numel() * 8),
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
+            "backend": (args.backend if dist is not None else None), "librccl_mapped": rccl_loaded, "rccl_error": rccl_error,
             "finite": finite, "step_issue": "eager" if args.eager else ("one launch per step for all surrogates "
                                                                         "(mobocmf_tiny_elbo_step)" if tiny is not None else "hip-graph replay"),
         }

@@ -22,8 +22,8 @@
  * travels with the call in a `mobocmf_tuning` (a pointer in the layer descriptor, or an argument of the standalone
  * product entry points; NULL = the compiled-in defaults), block-activity arrays and probe events are explicit arguments,
  * and the workspace-size queries take the same descriptor / tuning as the launch they size for.  Two host threads with
- * different tunings on different streams do not interact.  (One write-once per-device bit mask remembers that a kernel's
- * dynamic-LDS attribute was set.)  Return value: MOBOCMF_OK or an error
+ * different tunings on different streams do not interact.  (One write-once bit per kernel instantiation and device
+ * remembers that the kernel's dynamic-LDS attribute was set on that device.)  Return value: MOBOCMF_OK or an error
  * code; a non-positive-definite K_mm is reported through the device word `info` (0 = OK, k>0 = pivot k
  * failed), mirroring LAPACK potrf / torch.linalg.cholesky_ex, so the caller may retry with more jitter
  * (gpytorch psd_safe_cholesky semantics) without a sync on the fast path.
@@ -433,14 +433,15 @@ typedef struct mobocmf_tiny_model {
     double* top_var;
     int64_t* xrng;                           /* {seed, calls}: modes 2 / 4 draw rows [rand_row0, rand_row0 + rand_rows) of x from */
     int32_t rand_row0, rand_rows;            /* U(0,1) (the x~ of :276; x must be writable); modes 1 / 4 of model 0 advance calls */
-    /* mode 4 (the whole conditioned iteration in ONE cooperative launch): what couples the models, and this model's part in it */
+    /* mode 4 (the whole conditioned iteration in ONE launch with an in-launch barrier): what couples the models, and this model's part in it */
     const struct mobocmf_tiny_coupling* coupling;
     int32_t role, role_index;                /* 0: objective role_index of the coupling, 1: constraint role_index */
 } mobocmf_tiny_model;
 /* The theta / omega factors of blackbox_mfdgp_fitter.py:227-243 over the models of one launch (device-resident, shared).
  * Every model holds, at its TOP layer with S = 1, the P Pareto points in columns [0, P) and the T points x~ in [P, P + T).
  * After its forward every workgroup publishes its top-layer moments, the workgroups of the launch meet at a barrier (an arrival
- * counter in device memory; n_models <= 64, T <= 256), and every workgroup forms the factor gradients of ITS model -- the omega factors from all models' moments at x~, a constraint's theta
+ * counter in device memory -- an ordinary launch, not a cooperative one: mobocmf_tiny_elbo_step checks n_models against the
+ * device's occupancy for the kernel, n_models <= 64, 1 <= T <= 256), and every workgroup forms the factor gradients of ITS model -- the omega factors from all models' moments at x~, a constraint's theta
  * factors from its own at the Pareto points -- into its seed_gmean / seed_gvar before running its backward and update. */
 typedef struct mobocmf_tiny_coupling {
     int32_t n_obj, n_con, P, T;
@@ -449,7 +450,17 @@ typedef struct mobocmf_tiny_coupling {
     const double* thresholds;                /* n_con */
     double log_eps, log_1m_eps;
     double* losses;                          /* n_con + 1: the theta factor term of every constraint, then the omega term */
-    int64_t* barrier;                        /* device word, zero-initialised ONCE by the caller: arrivals at the in-launch barrier */
+    int64_t* barrier;                        /* device word, zero-initialised ONCE by the caller: arrivals at the in-launch barrier.
+                                              * Monotonic: launch k of the record waits for k * n_models arrivals, so ONE record
+                                              * serves ONE launch at a time (launches of a record are ordered on one stream) and
+                                              * always with the same n_models */
+    int32_t* status;                         /* device word, zero-initialised by the caller, only ever OR'd by the launches:
+                                              * bit 0 a workgroup gave up waiting at the barrier (it left its model untouched),
+                                              * bit 1 the launch did not match the record (n_models, T, P): nothing was updated.
+                                              * Sticky across launches -- the caller reads it whenever it checks (every 1000
+                                              * iterations in the fitter) and clears it after rolling back */
+    int32_t n_models;                        /* workgroups (= models) of the launches this record is for; the kernel checks */
+    int32_t reserved;
 } mobocmf_tiny_coupling;
 int mobocmf_tiny_flat_len(const mobocmf_tiny_model* model, int64_t* len);
 int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes);

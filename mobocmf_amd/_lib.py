@@ -66,7 +66,8 @@ class TinyCoupling(ctypes.Structure):
                 ("obj_model", ctypes.c_int32 * 8), ("con_model", ctypes.c_int32 * 8),
                 ("front", ctypes.c_void_p), ("thresholds", ctypes.c_void_p),
                 ("log_eps", ctypes.c_double), ("log_1m_eps", ctypes.c_double), ("losses", ctypes.c_void_p),
-                ("barrier", ctypes.c_void_p)]
+                ("barrier", ctypes.c_void_p), ("status", ctypes.c_void_p), ("n_models", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class MobocmfError(RuntimeError):

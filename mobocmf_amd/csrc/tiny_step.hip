@@ -638,23 +638,47 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
         // The barrier: a monotonic arrival counter in the coupling record (never reset: launch k waits for k n_models
         // arrivals).  The n_models <= 64 workgroups of a launch are resident together on a 256-CU device whatever else runs
         // (a waiting workgroup holds one CU's slot; the missing ones get theirs as soon as ANY slot frees), so the wait ends;
-        // should it not within ~0.2 s, the workgroup gives up, flags the model (info = -1) and poisons its loss instead of
-        // hanging the device.  (hipLaunchCooperativeKernel + grid.sync() does the same job with a 23 us dispatch gap per
-        // launch and cannot be captured into a graph.)
+        // should it not within ~0.2 s, the workgroup gives up, flags the model (info = -1, the coupling's sticky status word)
+        // and leaves without touching its parameters instead of hanging the device.  This is an ORDINARY launch, not a
+        // cooperative one (hipLaunchCooperativeKernel + grid.sync() does the same job with a 23 us dispatch gap per launch
+        // and cannot be captured into a graph): co-residency is checked on the host against the device's occupancy for this
+        // kernel and LDS size (mobocmf_tiny_elbo_step refuses mode 4 otherwise).
+        // A launch whose shape does not match the record (another n_models than the record was made for: the arrival counter
+        // would no longer be a multiple of the grid at launch start; T outside what coupling_seeds divides by) stops HERE, in
+        // every workgroup alike, before anyone arrives: nothing hangs, nothing is updated, the sticky status word says why.
+        const mobocmf_tiny_coupling& cpl = *md.coupling;
+        if (cpl.n_models != (int)gridDim.x || cpl.T < 1 || cpl.T > 256 || cpl.P < 1) {
+            if (tid == 0) {
+                atomicOr(cpl.status, 2);
+                md.info[0] = -2;
+                md.out[2] = __builtin_nan("");
+            }
+            return;
+        }
         __syncthreads();
         if (tid == 0) {
             __threadfence();
-            unsigned long long* cnt = (unsigned long long*)md.coupling->barrier;
+            unsigned long long* cnt = (unsigned long long*)cpl.barrier;
             const unsigned long long n = gridDim.x;
             const unsigned long long old = atomicAdd(cnt, 1ull), target = (old / n + 1ull) * n;
-            int spins = 0;
+            int spins = 0, gave_up = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 21)) { md.info[0] = -1; md.out[2] = __builtin_nan(""); break; }
+                if (++spins > (1 << 21)) { gave_up = 1; break; }
             }
             __threadfence();
+            sc[14] = gave_up ? 1.0 : 0.0;
+            if (gave_up) {      // sticky (only ever OR'd; the next launch rewrites info / out): TinyConditionedStep.check() reads it
+                atomicOr(cpl.status, 1);
+                md.info[0] = -1;
+                md.out[2] = __builtin_nan("");
+            }
         }
         __syncthreads();
+        // a workgroup that gave up has no right to its peers' moments: it leaves BEFORE the backward and the update -- its
+        // parameters, optimiser state, step count and random streams stay as they were (its peers may still complete: they
+        // read what this workgroup published before it arrived)
+        if (sc[14] != 0.0) return;
         coupling_seeds<TT>(models, md, g.ncol[L - 1], md.work + g.cpl_off, sc + 16);
     }
     // ---- backward, top layer first
@@ -1094,20 +1118,33 @@ int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
     const size_t pool = (size_t)pmax * sizeof(double);
     const int pool_in_lds = shm + pool <= LDS_BUDGET ? 1 : 0;
     if (pool_in_lds) shm += pool;
-    // more than the default 64 KB of dynamic LDS needs the function attribute (idempotent; raised, never lowered)
-    static std::atomic<size_t> granted[4] = {{64 * 1024}, {64 * 1024}, {64 * 1024}, {64 * 1024}};
     // 512 threads when a phase has more than two elements per thread of a 256-thread workgroup (wide panels: conditioned
     // training, acquisition): the phases are latency-bound per thread, more threads walk more elements at once
     const bool wide = (int64_t)mmax * cmax > 2 * 256;
     const int slot = (MR == 32 ? 2 : 0) + (wide ? 1 : 0);
     const void* fn = MR == 16 ? (wide ? (const void*)tiny_step_kernel<16, 512> : (const void*)tiny_step_kernel<16, 256>)
                               : (wide ? (const void*)tiny_step_kernel<32, 512> : (const void*)tiny_step_kernel<32, 256>);
-    if (shm > granted[slot].load()) {
+    // more than the default 64 KB of dynamic LDS needs the function attribute, which is per DEVICE: one write-once bit per
+    // (kernel instantiation, device) remembers that it was set (devices beyond 63: set on every call, it is idempotent)
+    static std::atomic<uint64_t> granted[4] = {{0}, {0}, {0}, {0}};
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return MOBOCMF_HIP_ERROR;
+    const uint64_t bit = devid >= 0 && devid < 64 ? 1ull << devid : 0ull;
+    if (shm > 64 * 1024 && !(granted[slot].load() & bit)) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
             return MOBOCMF_HIP_ERROR;
-        granted[slot].store(LDS_BUDGET);
+        granted[slot].fetch_or(bit);
     }
-    if (do_update == 4 && n_models > 64) return MOBOCMF_BAD_ARG;      // (the in-launch barrier wants them resident together)
+    if (do_update == 4) {
+        // the in-launch barrier needs every workgroup of the launch resident at once: bound the grid by what THIS device holds
+        // of this kernel with this much LDS (a partitioned or smaller device holds fewer; MOBOCMF_BAD_ARG sends the caller to
+        // the three-launch form)
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, wide ? 512 : 256, shm) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess)
+            return MOBOCMF_HIP_ERROR;
+        if (n_models > 64 || (int64_t)n_models > (int64_t)per_cu * cus) return MOBOCMF_BAD_ARG;
+    }
 #define LAUNCH(MR_, TT_)                                                                                              \
     hipLaunchKernelGGL((tiny_step_kernel<MR_, TT_>), dim3((unsigned)n_models), dim3(TT_), shm, s, dev_models, lr, beta1, \
                        beta2, eps, do_update, pool_in_lds)

@@ -1134,8 +1134,16 @@ def _ones_scalar(dev):
     return t
 
 
+SEG_MAX = 32      # segments one mobocmf_scalar_combine / _scale_segments / _gather_segments launch takes
+
+
 def scalar_combine(terms, coefs):
-    """sum_i coefs[i] * terms[i] for 0-dim device tensors: one launch (and one for all the terms' gradients)."""
+    """sum_i coefs[i] * terms[i] for 0-dim device tensors: one launch (and one for all the terms' gradients); more than
+    SEG_MAX terms (a conditioned loss over 16+ black-boxes on one rank) are combined in chunks, then the chunk sums."""
+    terms, coefs = list(terms), list(coefs)
+    while len(terms) > SEG_MAX:
+        part = [_ScalarCombineFn.apply(tuple(coefs[i:i + SEG_MAX]), *terms[i:i + SEG_MAX]) for i in range(0, len(terms), SEG_MAX)]
+        terms, coefs = part, [1.0] * len(part)
     return _ScalarCombineFn.apply(tuple(coefs), *terms)
 
 

@@ -15,6 +15,14 @@ def world():
     return 0, 1
 
 
+def _no_group():
+    """True when no process group exists: the exchanges below are then identities.  With a group -- also one of a single
+    rank -- every exchange runs its collective: a one-rank run (bench.py through the launcher, tests/test_hip_rccl_single_rank.py)
+    executes exactly the RCCL calls an N-rank run does."""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized())
+
+
 def _free_port():
     import socket
     sk = socket.socket()
@@ -162,10 +170,10 @@ def _collective_device(t):
 
 def all_gather_moments(local):
     """local: (k, ...) tensor of this rank's k surrogates (the SAME k on every rank) -> (world*k, ...) in rank order.
-    World size 1 degenerates to the identity (no communicator needed)."""
+    Without a process group: the identity (no communicator needed)."""
     import torch.distributed as dist
     _, w = world()
-    if w == 1:
+    if _no_group():
         return local
     dev = local.device
     local = local.contiguous().to(_collective_device(local))
@@ -180,7 +188,7 @@ def all_gather_ragged(local):
     count is -- a rank that skipped the call because it holds no rows would leave the others waiting."""
     import torch.distributed as dist
     _, w = world()
-    if w == 1:
+    if _no_group():
         return [local]
     dev = local.device
     cdev = _collective_device(local)
@@ -199,10 +207,9 @@ def all_gather_ragged(local):
 
 def broadcast_(t, src=0):
     """In-place broadcast from ``src`` (points every rank must agree on: x~ of the conditioned training, acquisition
-    candidates).  World size 1: no-op."""
+    candidates).  Without a process group: no-op."""
     import torch.distributed as dist
-    _, w = world()
-    if w == 1:
+    if _no_group():
         return t
     cdev = _collective_device(t)
     if cdev != t.device:
@@ -238,10 +245,12 @@ def _group_key():
 
 
 def _layout_hash(k_obj, k_con, oi, ci):
+    """48 bits: its two 24-bit halves are exactly representable in float32 as well as float64 (the header row of
+    ``gather_with_local_grad`` travels in the moments' dtype)."""
     h = 1469598103934665603
     for v in (k_obj, k_con, -1 if oi is None else len(oi)) + (oi or ()) + (-2 if ci is None else len(ci),) + (ci or ()):
         h = ((h ^ (int(v) & 0xFFFFFFFF)) * 1099511628211) & 0x7FFFFFFFFFFFFFF
-    return h
+    return (h ^ (h >> 48)) & 0xFFFFFFFFFFFF
 
 
 def _gather_plan(k_obj, k_con, obj_index, con_index, device):
@@ -312,10 +321,10 @@ def gather_with_local_grad(fm, fv, cm, cv, obj_index=None, con_index=None):
     on every rank after the collective, instead of slicing stale rows or hanging.  Ranks may hold different numbers of
     objectives / constraints, none included.  ``obj_index`` / ``con_index``: the GLOBAL position of each local row (the
     column of the Pareto front / the entry of the threshold vector it belongs to); the result is ordered by it.  Without
-    them the rows come back in rank order.  World size 1: identity."""
+    them the rows come back in rank order.  Without a process group: identity."""
     import torch.distributed as dist
     r, w = world()
-    if w == 1:
+    if _no_group():
         return fm, fv, cm, cv
     k_obj, k_con = fm.shape[0], cm.shape[0]
     plan = _gather_plan(k_obj, k_con, obj_index, con_index, fm.device)
@@ -324,17 +333,21 @@ def gather_with_local_grad(fm, fv, cm, cv, obj_index=None, con_index=None):
     oi = None if obj_index is None else tuple(int(i) for i in obj_index)
     ci = None if con_index is None else tuple(int(i) for i in con_index)
     local = torch.cat([torch.stack([fm, fv], 1), torch.stack([cm, cv], 1)], 0)        # (k_obj + k_con, 2, T), with gradient
-    # row 0 = header (the layout hash, split into two exactly representable halves), rows 1.. = the moments, zero padded
-    pad = torch.zeros(kmax + 1, 2, T, dtype=local.dtype, device=cdev)
+    # row 0 = header (the layout hash, split into two 24-bit halves: exact in float32 and float64), rows 1.. = the moments,
+    # zero padded
     h = _layout_hash(k_obj, k_con, oi, ci)
-    pad[0, 0, 0], pad[0, 1, 0] = float(h >> 30), float(h & ((1 << 30) - 1))
+    head = torch.zeros(1, 2, T, dtype=local.dtype)
+    head[0, 0, 0], head[0, 1, 0] = float(h >> 24), float(h & ((1 << 24) - 1))
+    pad = torch.zeros(kmax + 1, 2, T, dtype=local.dtype, device=cdev)
+    pad[:1] = head.to(cdev, non_blocking=True)
     nfit = min(local.shape[0], kmax)
     if nfit:
         pad[1:1 + nfit] = local.detach()[:nfit].to(cdev)
     out = torch.empty(w * (kmax + 1), 2, T, dtype=local.dtype, device=cdev)
     dist.all_gather_into_tensor(out, pad)
     out = out.to(dev).reshape(w, kmax + 1, 2, T)
-    got = [(int(out[q, 0, 0, 0]) << 30) | int(out[q, 0, 1, 0]) for q in range(w)]
+    hdr = out[:, 0, :, 0].to("cpu", torch.float64)      # ONE device-to-host copy for all ranks' headers
+    got = [(int(hdr[q, 0]) << 24) | int(hdr[q, 1]) for q in range(w)]
     if got != plan["hashes"]:
         raise ValueError("gather_with_local_grad: the row layout of rank(s) %s differs from the one negotiated for this "
                          "process group; call parallel.reset_gather_plans() on every rank before changing the sharding" %
@@ -371,8 +384,7 @@ def shard_rows(n, rank=None, world_size=None, device=None):
 def all_reduce_sum_(buf):
     """In-place sum over the ranks (RCCL on HBM buffers; the gloo rehearsal hops through the host)."""
     import torch.distributed as dist
-    _, w = world()
-    if w == 1:
+    if _no_group():
         return buf
     if buf.device.type == "cuda" and dist.get_backend() == "gloo":
         host = buf.cpu()

@@ -353,6 +353,8 @@ class TinyConditionedStep(TinyELBOStep):
         dev = fitter.pareto_set.device
         P, d = fitter.pareto_set.shape
         Tn = n_tilde if fixed_x_tilde is None else fixed_x_tilde.shape[0]
+        if Tn < 1 or P < 1:
+            raise _lib.MobocmfError("TinyConditionedStep: at least one x~ point and one Pareto point (got %d, %d)" % (Tn, P))
         self.fitter, self.P, self.T = fitter, P, Tn
         self.xrng = None
         if fixed_x_tilde is None:
@@ -433,6 +435,9 @@ class TinyConditionedStep(TinyELBOStep):
         cp.losses = self.factor_losses.data_ptr()
         self._barrier = torch.zeros(1, dtype=torch.int64, device=self.device)
         cp.barrier = self._barrier.data_ptr()
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)      # sticky: OR'd by the launches, read by check()
+        cp.status = self._status.data_ptr()
+        cp.n_models = len(self.models)
         self._coupling = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).to(self.device)
         for k in range(len(self.models)):
             self.host[k].coupling = self._coupling.data_ptr()
@@ -458,11 +463,28 @@ class TinyConditionedStep(TinyELBOStep):
 
     def _issue(self):
         if self.one_launch and self.T <= 256 and len(self.models) <= 64:
-            self._launch(4)
-        else:
-            self._launch(2)
-            self._factors()
-            self._launch(1)
+            try:
+                self._launch(4)
+                return
+            except _lib.MobocmfError:
+                # refused (MOBOCMF_BAD_ARG: more models than this device keeps resident at once -- the in-launch barrier
+                # needs them all): nothing was enqueued; the three-launch form has no such requirement
+                self.one_launch = False
+        self._launch(2)
+        self._factors()
+        self._launch(1)
+
+    def check(self):
+        """As TinyELBOStep.check, plus the sticky status word of the one-launch form: a workgroup that gave up waiting at the
+        in-launch barrier -- in ANY iteration since the last check, not only the last one -- left its model untouched while its
+        peers moved on; that is reported like a failed Cholesky (the fitter rolls back to its last snapshot)."""
+        super().check()
+        st = int(self._status.item())
+        if st:
+            self._status.zero_()
+            raise FloatingPointError("one-launch conditioned iteration: %s (status %d)" %
+                                     ("a workgroup timed out at the in-launch barrier" if st & 1 else
+                                      "the launch did not match its coupling record", st))
 
     def step(self):
         if self.use_graph:
@@ -498,9 +520,10 @@ class TinyConditionedStep(TinyELBOStep):
     def restore(self):
         super().restore()
         xr = self._snap[-1]
-        if xr is not None:
-            with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(self.stream):
+            if xr is not None:
                 self.xrng.copy_(xr)
+            self._status.zero_()
 
 
 class _TinyMomentsFn(torch.autograd.Function):

@@ -350,3 +350,8 @@ def test_split_rows_and_scalar_combine_are_exact():
     gm = torch.cat([-4.0 * md[:5], torch.zeros(20, dtype=torch.float64, device=DEV), 0.5 * vd[25:]])
     gv = torch.cat([torch.zeros(5, dtype=torch.float64, device=DEV), 3.0 * torch.ones(20, dtype=torch.float64, device=DEV), 0.5 * md[25:]])
     assert torch.equal(m.grad, gm) and torch.equal(v.grad, gv)
+    # more terms than one launch takes (a conditioned loss over 16+ black-boxes on a rank: 2 * handlers + 1 terms): chunked
+    w = torch.randn(71, dtype=torch.float64, device=DEV, generator=g, requires_grad=True)
+    cs = [float(c) for c in torch.linspace(-1.5, 2.0, 71)]
+    F.scalar_combine([w[i] * w[i] for i in range(71)], cs).backward()
+    assert rel(w.grad, 2.0 * torch.tensor(cs, dtype=torch.float64, device=DEV) * w.detach()) < 1e-14

@@ -496,3 +496,84 @@ def test_in_launch_barrier_gives_up_instead_of_hanging():
     torch.cuda.synchronize()
     step.step()
     step.check()                          # the device is fine
+
+
+def test_barrier_timeout_at_a_non_check_iteration_is_sticky_and_leaves_the_model_untouched():
+    """The fitter checks every 1000 iterations only (blackbox_mfdgp_fitter.ITER_PRINT).  A workgroup that gives up at the
+    in-launch barrier in iteration k must (i) not update its model from its peers' unpublished moments -- parameters, Adam
+    state, step count and random streams stay as they were -- and (ii) still be reported by a check() many iterations later,
+    although the launches in between rewrite ``info`` and the losses: the coupling's status word is only ever OR'd."""
+    from mobocmf_amd.util.tiny_step import TinyConditionedStep
+    from tests.test_hip_conditioned import _fitter
+    fitter, _ = _fitter(2, 1, 12)
+    g = torch.Generator().manual_seed(2)
+    fitter.set_pareto_solution(torch.rand(5, 2, dtype=torch.float64, generator=g), torch.randn(5, 2, dtype=torch.float64, generator=g) * 0.3)
+    for _, _, h in fitter._handlers():
+        h.mfdgp.fix_variational_hypers_cond(True)
+    step = TinyConditionedStep(fitter, lr=1e-3)
+    step.use_graph = False
+    step.step()
+    step.check()
+    step.snapshot()
+    torch.cuda.synchronize()
+    before = [[p.detach().clone() for p in m.parameters()] for m in step.models]
+    adam_before = [t.clone() for t in step.exp_avg]
+    steps_before = step.steps_done.clone()
+    step._barrier.fill_(1)               # the last of the 3 workgroups waits for arrivals that never come
+    step.step()
+    torch.cuda.synchronize()
+    gave_up = [i for i in range(len(step.models)) if int(step.infos[i, 0]) == -1]
+    assert len(gave_up) == 1 and int(step._status.item()) == 1
+    k = gave_up[0]
+    for pa, pb in zip(step.models[k].parameters(), before[k]):
+        assert torch.equal(pa, pb)                      # the model that timed out was not touched ...
+    assert torch.equal(step.exp_avg[k], adam_before[k]) and int(step.steps_done[k]) == int(steps_before[k])
+    other = [i for i in range(len(step.models)) if i != k]
+    assert all(int(step.steps_done[i]) == int(steps_before[i]) + 1 for i in other)      # ... its peers completed
+    step._barrier.zero_()                # the disturbance was transient: the following iterations run normally
+    for _ in range(3):
+        step.step()
+    torch.cuda.synchronize()
+    assert not bool((step.infos != 0).any()) and bool(torch.isfinite(step.losses).all())      # overwritten by now
+    with pytest.raises(FloatingPointError):
+        step.check()                     # ... but the status word remembers
+    step.restore()
+    step.step()
+    step.check()
+
+
+def test_one_launch_iteration_refused_beyond_the_devices_residency_falls_back():
+    """mobocmf_tiny_elbo_step refuses mode 4 for more models than the device keeps resident at once (bounded by 64 and by
+    hipOccupancyMaxActiveBlocksPerMultiprocessor x CU count for the kernel and its LDS size): MOBOCMF_BAD_ARG, nothing enqueued;
+    TinyConditionedStep then issues the three-launch form."""
+    import ctypes
+    from mobocmf_amd import _lib
+    from mobocmf_amd.util.tiny_step import TinyConditionedStep
+    from tests.test_hip_conditioned import _fitter
+    fitter, _ = _fitter(2, 1, 12)
+    g = torch.Generator().manual_seed(2)
+    fitter.set_pareto_solution(torch.rand(5, 2, dtype=torch.float64, generator=g), torch.randn(5, 2, dtype=torch.float64, generator=g) * 0.3)
+    for _, _, h in fitter._handlers():
+        h.mfdgp.fix_variational_hypers_cond(True)
+    step = TinyConditionedStep(fitter, lr=1e-3)
+    lib = _lib.require_device()
+    n = len(step.models)
+    big = (_lib.TinyModel * 65)(*[step.host[i % n] for i in range(65)])
+    dev = torch.frombuffer(bytearray(bytes(big)), dtype=torch.uint8).to(step.device)
+    rc = lib.mobocmf_tiny_elbo_step(ctypes.cast(big, ctypes.c_void_p), ctypes.c_void_p(dev.data_ptr()), 65, 1e-3, 0.9, 0.999, 1e-8,
+                                    4, ctypes.c_void_p(step.stream.cuda_stream))
+    assert rc == _lib.BAD_ARG
+    # a launch that does not match its coupling record (here: fewer workgroups than the record was made for) stops in every
+    # workgroup before anyone arrives at the barrier: status bit 1, nothing updated, nothing hangs
+    torch.cuda.synchronize()
+    sd = step.steps_done.clone()
+    rc = lib.mobocmf_tiny_elbo_step(ctypes.cast(step.host, ctypes.c_void_p), ctypes.c_void_p(step._dev_table.data_ptr()), n - 1,
+                                    1e-3, 0.9, 0.999, 1e-8, 4, ctypes.c_void_p(step.stream.cuda_stream))
+    assert rc == _lib.OK
+    torch.cuda.synchronize()
+    assert int(step._status.item()) == 2 and torch.equal(step.steps_done, sd) and int(step._barrier.item()) == 0
+    step._status.zero_()
+    step.infos.zero_()
+    step.use_graph = False
+    step.step()
+    step.check()
