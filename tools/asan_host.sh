@@ -10,7 +10,7 @@ rm -rf $B && mkdir -p $B
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -O1 -g"
 pids=""
-for f in gemm_f64 chol gram elementwise rff tiny_step api; do
+for f in gemm_f64 chol gram elementwise rff tiny_step coop_step api; do
   $HIPCC --offload-arch=gfx950 -fno-gpu-sanitize $SAN -DMOBOCMF_HOST_FUZZ -fPIC -std=c++17 -Wno-unused-result -c mobocmf_amd/csrc/$f.hip -o $B/$f.o &
   pids="$pids $!"
 done

@@ -8,7 +8,7 @@ name=$1; shift
 mkdir -p abtest/obj_$name
 objs=""
 pids=""
-for f in gemm_f64 chol gram elementwise rff tiny_step api; do
+for f in gemm_f64 chol gram elementwise rff tiny_step coop_step api; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result "$@" -c mobocmf_amd/csrc/$f.hip -o abtest/obj_$name/$f.o &
   pids="$pids $!"
   objs="$objs abtest/obj_$name/$f.o"
