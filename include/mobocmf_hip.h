@@ -467,6 +467,28 @@ int mobocmf_tiny_work_bytes(const mobocmf_tiny_model* model, size_t* bytes);
 int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
                            double lr, double beta1, double beta2, double eps, int32_t do_update, mobocmf_stream_t stream);
 
+/* ---- The same step for MID-SIZE surrogates (M <= 128 inducing points: the reference's own BO loop runs M = N from 15 to 75,
+ * examples/toy_synthetic_2D_JESMOCMF/toy_synthetic_2D_JESMOCMF.py:25,102-103,305-331 with mfdgp.py:295-298; BASELINE config 2 has
+ * M = 128), still ONE launch per step for a whole group of surrogates, by SEVERAL workgroups per surrogate: the step is ~11
+ * phases separated by an in-launch barrier of the surrogate's workgroups (arrival counter + agent-scope fences); every product
+ * runs on v_mfma_f64_16x16x4_f64.  Same descriptor (mobocmf_tiny_model; M <= MOBOCMF_COOP_MAX_M, d <= 8, L <= 3), same flat
+ * layout of grad / adam_m / adam_v (mobocmf_tiny_flat_len), same draws, same results as the layer path up to summation order;
+ * `work` is sized by mobocmf_coop_work_bytes.  do_update: 0 gradients only | 1 the step | 2 forward only | 4 the conditioned
+ * iteration in one launch (mobocmf_tiny_coupling with n_models = the models of the launch; the barrier of its record is not
+ * used: the whole grid meets on the launch's own sync words).
+ * wgs_per_model: workgroups sharing one surrogate, 1..64, or 0 = chosen from the widest phase (at most 16); *wgs_used (may be
+ * NULL) receives the choice.  Every workgroup of the launch must be resident at once (n_models * wgs_per_model <= what the
+ * device holds of this kernel: checked, MOBOCMF_BAD_ARG otherwise -- an ordinary launch, not a cooperative one, so that it can
+ * be captured into a graph).  sync_words: 16 * (n_models + 1) device int64, zero-initialised ONCE by the caller and then left to
+ * the launches (monotonic arrival counters: a group of words serves one launch at a time, always with the same wgs_per_model
+ * and n_models).  A wait that does not end within ~0.3 s is abandoned: info[0] = -1, out[2] = NaN, nothing is updated by that
+ * workgroup. */
+#define MOBOCMF_COOP_MAX_M 128
+int mobocmf_coop_work_bytes(const mobocmf_tiny_model* model, size_t* bytes);
+int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
+                           int32_t wgs_per_model, int64_t* sync_words, double lr, double beta1, double beta2, double eps,
+                           int32_t do_update, int32_t* wgs_used, mobocmf_stream_t stream);
+
 /* ---- Exact-GP comparison baselines (mobocmf/models/mfgp.py:24-141,145-184; mfgp_lin.py:101-189) on the layer's kernels.
  * The reference inherits exact inference from GPyTorch's ExactGP; here the Gram matrices come from mobocmf_gram_forward,
  * the multi-fidelity combination is one element-wise launch, the factorisation / triangular inverse are the variational

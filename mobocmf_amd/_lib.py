@@ -39,6 +39,7 @@ class LayerDesc(ctypes.Structure):
 
 
 TINY_MAX_LAYERS, TINY_MAX_M, TINY_MAX_D = 3, 32, 8      # MOBOCMF_TINY_MAX_* of include/mobocmf_hip.h
+COOP_MAX_M = 128                                         # MOBOCMF_COOP_MAX_M
 
 
 class TinyModel(ctypes.Structure):
@@ -136,6 +137,8 @@ SYMBOLS = {
     "mobocmf_tiny_flat_len": [ctypes.POINTER(TinyModel), ctypes.POINTER(_I64)],
     "mobocmf_tiny_work_bytes": [ctypes.POINTER(TinyModel), ctypes.POINTER(_SZ)],
     "mobocmf_tiny_elbo_step": [_P, _P, _I32, _D, _D, _D, _D, _I32, _P],
+    "mobocmf_coop_work_bytes": [ctypes.POINTER(TinyModel), ctypes.POINTER(_SZ)],
+    "mobocmf_coop_elbo_step": [_P, _P, _I32, _I32, _P, _D, _D, _D, _D, _I32, ctypes.POINTER(_I32), _P],
     "mobocmf_rff_eval": [_I32, _I32, _I32, _I64] + [_P] * 8 + [_D, _D, _D, _P, _P],
     "mobocmf_gram_forward": [_I32, _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P],
     "mobocmf_check_info": [_P, ctypes.POINTER(_I32), _P],

@@ -211,6 +211,1043 @@ __device__ __forceinline__ void tile_of(int t, int& ti, int& tj) {      // index
 
 constexpr int XFW = DBT + 2;      // a staged data row of a column block: x (zero padded), f, valid flag
 
-//KERNEL//
+#ifdef COOP_STAMPS
+#define CSTAMP() do { if (tid == 0 && wj == 0) stamps[n_stamp] = (double)wall_clock64(); ++n_stamp; } while (0)
+#else
+#define CSTAMP() do { } while (0)
+#endif
+#define MODEL_BARRIER() do { if (!group_barrier(mcnt, (unsigned)k, flag)) { if (tid == 0) { md.info[0] = -1; md.out[2] = __builtin_nan(""); } return; } CSTAMP(); } while (0)
+
+__global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model* models, int k, unsigned long long* sync_words,
+                                                       double lr, double b1, double b2, double aeps, int do_update) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int mi = blockIdx.x / k, wj = blockIdx.x % k;
+    const mobocmf_tiny_model& md = models[mi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    CGeom g;
+    cgeom_of(md, g);
+    const int L = g.L, M = g.M, Mp = g.Mp, nt = g.nt, d = g.d, S = g.S;
+    const int64_t mm = (int64_t)Mp * Mp;
+    unsigned long long* mcnt = sync_words + 16 * (int64_t)mi;
+    unsigned long long* gcnt = sync_words + 16 * (int64_t)(gridDim.x / k);
+    double* W = md.work;
+    double* gflat = W;
+    // ---- LDS
+    double* hy = lds;                          // [TLM][HS] constrained hyper-parameters
+    double* il = hy + TLM * HS;                // [TLM][2 DBT] inverse lengthscales
+    double* sc = il + TLM * 2 * DBT;           // [32]: tau[l] 0..2, Adam's bias terms 12, 13, bsum scratch 16..23, barrier flag 30
+    int* flag = (int*)(sc + 30);
+    double** seg_ptr = (double**)(sc + 32);    // [NSEG] parameter tensors in flat-vector order (trainable ones; else null)
+    int* seg_end = (int*)(seg_ptr + NSEG);     // [NSEG]
+    double* big = sc + 32 + NSEG + NSEG / 2;
+    // chain view of `big`
+    double* ztc = big;                         // [Mp][ZW]  Z~ of the layer; later m (0..Mp) and diag(L) (Mp..2Mp)
+    double* Lp = ztc + Mp * ZW;                // packed swizzled tiles of L (later: of tril(L_S))
+    double* Lip = Lp + g.ntri * 256;           // ... of L^-1
+    // column-block view of `big`
+    double* zt = big;                          // [Mp][ZW]
+    double* X0 = zt + Mp * ZW;                 // three [Mp][XLD] column blocks
+    double* X1 = X0 + Mp * XLD;
+    double* X2 = X1 + Mp * XLD;
+    double* avl = X2 + Mp * XLD;               // [Mp] a = L^-1 m of the layer
+    double* xf = avl + Mp;                     // [16][XFW] the block's data rows
+    double* gcol = xf + 16 * XFW;              // [4][16] per-column scalars of the block
+    double* red = gcol + 64;                   // [16][16][3] partial column sums
+    double* redh = red + 768;                  // [CNW][HS + 1] wavefront partials
+#ifdef COOP_STAMPS
+    double* stamps = W + g.work_len;
+    int n_stamp = 0;
+#endif
+    CSTAMP();
+    const double gkl = md.kl_scale, ge = -1.0;
+    auto MAT = [&](int l, int m) -> double* { return W + g.mat[l] + (int64_t)m * mm; };
+    auto VEC = [&](int l, int v) -> double* { return W + g.vec[l] + (int64_t)v * g.ncp[l]; };
+    auto SML = [&](int l, int v) -> double* { return W + g.sml[l] + (int64_t)v * Mp; };
+    auto PART = [&](int l, int cb) -> double* { return W + g.part[l] + (int64_t)cb * g.pstr; };
+
+    // ---- P0 (every workgroup for itself): constrained hyper-parameters, inverse lengthscales, noise, parameter table
+    for (int e = tid; e < TLM * HS; e += CT) {
+        const int l = e / HS, t = e % HS;
+        double v = 0.0;
+        if (l < L && t < g.H[l]) {
+            int s = 0, off = 0;
+            while (t >= off + seg_len(l, s, d)) { off += seg_len(l, s, d); ++s; }
+            const double x = md.raw[l][s][t - off];
+            v = x > 20.0 ? x : log1p(exp(x));
+        }
+        hy[e] = v;
+    }
+    if (tid >= 64 && tid < 64 + NSEG) {
+        const int kk = tid - 64;
+        double* ptr = nullptr;
+        int end = 0x7fffffff, j = 0;
+        for (int l = 0; l < L; ++l) {
+            const uint32_t tr = md.trainable[l];
+            const int ns = l == 0 ? 2 : 7;
+            int off = (int)g.flat_off[l];
+            for (int s2 = 0; s2 < ns; ++s2, ++j) {
+                off += seg_len(l, s2, d);
+                if (j == kk) { ptr = ((tr >> s2) & 1u) ? md.raw[l][s2] : nullptr; end = off; }
+            }
+            off += M;
+            if (j++ == kk) { ptr = ((tr >> 7) & 1u) ? md.m[l] : nullptr; end = off; }
+            off += M * M;
+            if (j++ == kk) { ptr = ((tr >> 8) & 1u) ? md.L_S[l] : nullptr; end = off; }
+        }
+        for (int l = 0; l < L; ++l)
+            if (j++ == kk) { ptr = ((md.trainable[l] >> 9) & 1u) ? md.raw_noise[l] : nullptr; end = (int)g.flat_noise + l + 1; }
+        seg_ptr[kk] = ptr;
+        seg_end[kk] = end;
+    }
+    if (tid == CT - 1 && (do_update == 1 || do_update == 4)) {
+        const double step = (double)(md.steps_done[0] + 1);
+        sc[12] = 1.0 - pow(b1, step);
+        sc[13] = sqrt(1.0 - pow(b2, step));
+    }
+    if (tid < L) {
+        const double lo = md.noise_lo[tid], hi = md.noise_hi[tid], r = md.raw_noise[tid][0];
+        sc[tid] = hi > lo ? lo + (hi - lo) / (1.0 + exp(-r)) : r;
+    }
+    if ((do_update == 2 || do_update == 4) && md.xrng && md.rand_rows > 0 && wj == 0) {
+        // the x~ of this iteration (blackbox_mfdgp_fitter.py:276): every model of the launch draws the SAME points
+        const uint64_t seed = (uint64_t)md.xrng[0], call = (uint64_t)md.xrng[1];
+        double* xw = const_cast<double*>(md.x) + (int64_t)md.rand_row0 * d;
+        for (int e = tid; e < md.rand_rows * d; e += CT) xw[e] = philox_uniform(seed, call, (uint64_t)e);
+    }
+    __syncthreads();
+    for (int e = tid; e < TLM * 2 * DBT; e += CT) {
+        const int l = e / (2 * DBT), kk = e % (2 * DBT), k2 = kk % DBT;
+        double v = 0.0;
+        if (l < L && k2 < d) {
+            if (l == 0) v = kk < DBT ? 1.0 / hy[l * HS + 1 + k2] : 0.0;
+            else v = 1.0 / hy[l * HS + 5 + (kk < DBT ? 0 : d) + k2];
+        }
+        il[e] = v;
+    }
+    __syncthreads();
+
+    // ---- P1: the M x M chain forward of layer l by ONE workgroup, L and L^-1 in LDS
+    for (int l = wj; l < L; l += k) {
+        const int kind = l > 0;
+        const double* hyl = hy + l * HS;
+        const double* ill = il + l * 2 * DBT;
+        for (int e = tid; e < Mp * ZW; e += CT) {
+            const int m = e / ZW, kk = e % ZW;
+            double v = 0.0;
+            if (m < M) {
+                if (kk < d) v = md.Zx[m * d + kk];
+                else if (kk == DBT && l > 0) v = md.m[l - 1][m];
+            }
+            ztc[e] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < g.ntri * 256; e += CT) {      // K_mm + jitter I, lower tiles (identity beyond M)
+            const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            int ti, tj;
+            tile_of(t, ti, tj);
+            const int i = ti * 16 + r, j = tj * 16 + c;
+            double v = 0.0;
+            if (i < M && j <= i) {
+                KV o;
+                kern_eval(kind, d, ztc + i * ZW, ztc[i * ZW + DBT], ztc + j * ZW, hyl, ill, o);
+                v = o.k + (i == j ? md.jitter : 0.0);
+            } else if (i == j) {
+                v = 1.0;
+            }
+            Lp[t * 256 + tel(r, c)] = v;
+        }
+        __syncthreads();
+        // blocked right-looking Cholesky, 16-wide: diagonal tile in registers (one wavefront), panel and trailing update on the MFMA
+        int fail = 0;
+        for (int s = 0; s < nt; ++s) {
+            if (wave == 0) {
+                const int f = chol_inv_tile16(Lp + tix(s, s), Lip + tix(s, s), lane);
+                if (f && !fail) fail = s * 16 + f;
+            }
+            __syncthreads();
+            for (int i = s + 1 + wave; i < nt; i += CNW) {      // L_is = A_is L_ss^-T
+                double* A = Lp + tix(i, s);
+                const double* B = Lip + tix(s, s);
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = mfma(A[tel(li, 4 * q + lk)], B[tel(li, 4 * q + lk)], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[tel(4 * r + lk, li)] = acc[r];
+            }
+            __syncthreads();
+            const int nrem = nt - s - 1, ntr = nrem * (nrem + 1) / 2;
+            for (int u = wave; u < ntr; u += CNW) {      // A_ij -= L_is L_js^T
+                int a, b;
+                tile_of(u, a, b);
+                const double* P = Lp + tix(s + 1 + a, s);
+                const double* Q = Lp + tix(s + 1 + b, s);
+                double* D = Lp + tix(s + 1 + a, s + 1 + b);
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = D[tel(4 * r + lk, li)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = mfma(-P[tel(li, 4 * q + lk)], Q[tel(li, 4 * q + lk)], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) D[tel(4 * r + lk, li)] = acc[r];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) md.info[l] = fail;
+        // off-diagonal tiles of L^-1, one block column per wavefront: X_is = -L_ii^-1 sum_{t = s .. i-1} L_it X_ts
+        for (int p = wave; p < (nt + 1) / 2; p += CNW) {
+            for (int h = 0; h < 2; ++h) {
+                const int s = h ? nt - 1 - p : p;
+                if (h && s == p) break;
+                for (int i = s + 1; i < nt; ++i) {
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int t = s; t < i; ++t) {
+                        const double* A = Lp + tix(i, t);
+                        const double* B = Lip + tix(t, s);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = mfma(A[tel(li, 4 * q + lk)], B[tel(4 * q + lk, li)], acc);
+                    }
+                    const double* Aii = Lip + tix(i, i);
+                    v4d d2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d2 = mfma(Aii[tel(li, 4 * q + lk)], acc[q], d2);      // the accumulator IS the B fragment
+                    double* X = Lip + tix(i, s);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[tel(4 * r + lk, li)] = -d2[r];
+                }
+            }
+        }
+        __syncthreads();
+        // L, L^-1, L^-T to global (the other workgroups read them k-major); diag(L) and m kept; L's tiles then hold tril(L_S)
+        {
+            double* Lg = MAT(l, M_L);
+            double* Lig = MAT(l, M_LI);
+            double* LiTg = MAT(l, M_LIT);
+            for (int e = tid; e < g.ntri * 256; e += CT) {
+                const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
+                int ti, tj;
+                tile_of(t, ti, tj);
+                Lg[(int64_t)(ti * 16 + r) * Mp + tj * 16 + c] = Lp[t * 256 + tel(r, c)];
+                Lig[(int64_t)(ti * 16 + r) * Mp + tj * 16 + c] = Lip[t * 256 + tel(r, c)];
+                LiTg[(int64_t)(tj * 16 + r) * Mp + ti * 16 + c] = Lip[t * 256 + tel(c, r)];
+            }
+            for (int i = tid; i < Mp; i += CT) {
+                ztc[i] = i < M ? md.m[l][i] : 0.0;
+                ztc[Mp + i] = Lp[tix(i >> 4, i >> 4) + tel(i & 15, i & 15)];
+            }
+        }
+        __syncthreads();
+        {
+            const double* ls = md.L_S[l];
+            for (int e = tid; e < g.ntri * 256; e += CT) {
+                const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
+                int ti, tj;
+                tile_of(t, ti, tj);
+                const int i = ti * 16 + r, j = tj * 16 + c;
+                Lp[t * 256 + tel(r, c)] = (i < M && j <= i) ? ls[(int64_t)i * M + j] : 0.0;
+            }
+        }
+        __syncthreads();
+        // U = L^-1 L_S (lower tiles), both orientations to global; a = L^-1 m; KL = 1/2 [2 sum log L_ii - sum log L_S,ii^2 + |U|^2 + |a|^2 - M]
+        double klacc = 0.0;
+        {
+            double* Ug = MAT(l, M_U);
+            double* UTg = MAT(l, M_UT);
+            for (int u = wave; u < g.ntri; u += CNW) {
+                int ti, tj;
+                tile_of(u, ti, tj);
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                for (int tk = tj; tk <= ti; ++tk) {
+                    const double* A = Lip + tix(ti, tk);
+                    const double* B = Lp + tix(tk, tj);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = mfma(A[tel(li, 4 * q + lk)], B[tel(4 * q + lk, li)], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ti * 16 + 4 * r + lk, j = tj * 16 + li;
+                    Ug[(int64_t)i * Mp + j] = acc[r];
+                    UTg[(int64_t)j * Mp + i] = acc[r];
+                    klacc += 0.5 * acc[r] * acc[r];
+                }
+            }
+            double* avg = SML(l, S_AV);
+            for (int i = tid; i < Mp; i += CT) {
+                double a = 0.0;
+                const int ti = i >> 4, r = i & 15;
+                for (int kk = 0; kk <= i; ++kk) a += Lip[tix(ti, kk >> 4) + tel(r, kk & 15)] * ztc[kk];
+                avg[i] = a;
+                if (i < M) klacc += 0.5 * a * a + log(ztc[Mp + i] / fabs(Lp[tix(ti, ti) + tel(r, r)])) - 0.5;
+            }
+        }
+        const double kl = bsum<CNW>(klacc, sc + 16);
+        if (tid == 0) W[g.sml[l] + 5 * Mp] = kl;
+        __syncthreads();
+    }
+    CSTAMP();
+    MODEL_BARRIER();
+
+    // ---- forward, layer by layer: a workgroup per block of 16 columns
+    int zt_layer = -1;
+    auto stage_layer = [&](int l) {      // Z~_l and a_l into LDS (all threads; ends with a barrier)
+        if (zt_layer == l) return;
+        __syncthreads();
+        for (int e = tid; e < Mp * ZW; e += CT) {
+            const int m = e / ZW, kk = e % ZW;
+            double v = 0.0;
+            if (m < M) {
+                if (kk < d) v = md.Zx[m * d + kk];
+                else if (kk == DBT && l > 0) v = md.m[l - 1][m];
+            }
+            zt[e] = v;
+        }
+        const double* avg = SML(l, S_AV);
+        for (int i = tid; i < Mp; i += CT) avl[i] = avg[i];
+        zt_layer = l;
+        __syncthreads();
+    };
+    // the block's data rows: x (zero padded to DBT), f, valid flag; layer >= 1 draws / reads f = mean + sqrt(var) eps
+    auto stage_rows = [&](int l, int c0, bool forward) {
+        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
+        if (tid < 16) {
+            const int c = c0 + tid;
+            const bool valid = c < nc;
+            double f = 0.0;
+            if (kind && valid) {
+                if (forward) {
+                    const int fdiv = l == 1 ? S : 1, cp = c / fdiv;
+                    const int64_t* rng = md.rng[l];
+                    const double ev = md.eps[l] ? md.eps[l][c] : philox_normal((uint64_t)rng[0], (uint64_t)rng[1], (uint64_t)c);
+                    f = VEC(l - 1, V_MEAN)[cp] + sqrt(VEC(l - 1, V_VAR)[cp]) * ev;
+                    VEC(l, V_F)[c] = f;
+                    VEC(l, V_EPS)[c] = ev;
+                } else {
+                    f = VEC(l, V_F)[c];
+                }
+            }
+            xf[tid * XFW + DBT] = f;
+            xf[tid * XFW + DBT + 1] = valid ? 1.0 : 0.0;
+        }
+        if (tid >= 64 && tid < 64 + 16 * DBT) {
+            const int j = (tid - 64) / DBT, kk = (tid - 64) % DBT, c = c0 + j;
+            xf[j * XFW + kk] = (c < nc && kk < d) ? md.x[(int64_t)(c / div) * d + kk] : 0.0;
+        }
+    };
+    for (int l = 0; l < L; ++l) {
+        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
+        const double* hyl = hy + l * HS;
+        const double* ill = il + l * 2 * DBT;
+        const double* LiTg = MAT(l, M_LIT);
+        const double* Ug = MAT(l, M_U);
+        double* ATg = W + g.pan[l];
+        double* CTg = ATg + (int64_t)g.ncp[l] * Mp;
+        for (int cb = wj; cb < g.ncb[l]; cb += k) {
+            stage_layer(l);
+            const int c0 = cb * 16;
+            stage_rows(l, c0, true);
+            __syncthreads();
+            // F1: K block
+            for (int e = tid; e < Mp * 16; e += CT) {
+                const int m = e >> 4, j = e & 15;
+                double v = 0.0;
+                if (m < M && xf[j * XFW + DBT + 1] != 0.0) {
+                    KV o;
+                    kern_eval(kind, d, xf + j * XFW, xf[j * XFW + DBT], zt + m * ZW, hyl, ill, o);
+                    v = o.k;
+                }
+                X0[m * XLD + j] = v;
+            }
+            __syncthreads();
+            int tl[2];
+            const int ntl = wave_tiles(wave, nt, tl);
+            // F2: A = L^-1 K
+            for (int h = 0; h < ntl; ++h) store_x(X1, tl[h], lane, tile_tx(LiTg, Mp, X0, tl[h], 0, tl[h] + 1, lane));
+            __syncthreads();
+            // F3: C = U^T A
+            for (int h = 0; h < ntl; ++h) store_x(X2, tl[h], lane, tile_tx(Ug, Mp, X1, tl[h], tl[h], nt, lane));
+            __syncthreads();
+            // F4: moments, the block's share of the data term; A, C to global (column-major: the backward's operand layout)
+            {
+                const int j = tid & 15, part = tid >> 4;
+                double q = 0.0, mu = 0.0, r = 0.0;
+                for (int m = part; m < Mp; m += 16) {
+                    const double a = X1[m * XLD + j], c = X2[m * XLD + j];
+                    q += a * a;
+                    mu += avl[m] * a;
+                    r += c * c;
+                }
+                red[(part * 16 + j) * 3 + 0] = q;
+                red[(part * 16 + j) * 3 + 1] = mu;
+                red[(part * 16 + j) * 3 + 2] = r;
+            }
+            for (int e = tid; e < 16 * Mp; e += CT) {
+                const int j = e / Mp, m = e % Mp;
+                ATg[(int64_t)(c0 + j) * Mp + m] = X1[m * XLD + j];
+                CTg[(int64_t)(c0 + j) * Mp + m] = X2[m * XLD + j];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                double dterm = 0.0;
+                if (lane < 16 && c0 + lane < nc) {
+                    const int c = c0 + lane;
+                    double q = 0.0, mu = 0.0, r = 0.0;
+                    for (int p = 0; p < 16; ++p) {
+                        q += red[(p * 16 + lane) * 3 + 0];
+                        mu += red[(p * 16 + lane) * 3 + 1];
+                        r += red[(p * 16 + lane) * 3 + 2];
+                    }
+                    const double fn = xf[lane * XFW + DBT];
+                    const double knn = kind ? hyl[0] * (hyl[2] * fn * fn + hyl[1]) + hyl[3] : hyl[0];
+                    double sres = knn - q;
+                    if (!md.branch && sres < 0.0) sres = 0.0;
+                    const double vr = sres + r, var = vr < MINV ? MINV : vr;
+                    VEC(l, V_MEAN)[c] = mu; VEC(l, V_VAR)[c] = var; VEC(l, V_KNN)[c] = knn; VEC(l, V_Q)[c] = q; VEC(l, V_RAW)[c] = vr;
+                    const int b = c / div;
+                    if (md.fid[b] == (double)l) {
+                        const double tau = sc[l], dlt = md.y[b] - mu, w = md.row_weight ? md.row_weight[b] : 1.0;
+                        dterm = w * (-0.5 * ((dlt * dlt + var) / tau + log(tau) + LOG2PI)) / div;
+                    }
+                    if (l == L - 1 && md.top_mean) { md.top_mean[c] = mu; md.top_var[c] = var; }
+                }
+                dterm = wsum63(dterm);
+                if (lane == 63) PART(l, cb)[0] = dterm;
+            }
+            __syncthreads();
+        }
+        MODEL_BARRIER();
+    }
+    // ---- the ELBO (one wavefront of the surrogate's first workgroup; nobody waits for it)
+    if (wj == 0 && wave == 0) {
+        double data = 0.0, kl = 0.0;
+        for (int l = 0; l < L; ++l) {
+            for (int cb = lane; cb < g.ncb[l]; cb += 64) data += PART(l, cb)[0];
+            if (lane == 0) kl += W[g.sml[l] + 5 * Mp];
+        }
+        data = wsum63(data);
+        kl = wsum63(kl);
+        if (lane == 63) {
+            md.out[0] = data - gkl * kl;
+            md.out[1] = gkl * kl;
+            md.out[2] = -(data - gkl * kl);
+        }
+    }
+    if (do_update == 2) return;
+    if (do_update == 4) {
+        // the conditioned iteration in one launch: all models' top-layer moments are in memory; the whole grid meets, the first
+        // workgroup of every model forms the theta / omega factor gradients of its model (tiny_step.hip coupling_seeds), the
+        // model's workgroups meet again
+        const mobocmf_tiny_coupling& cpl = *md.coupling;
+        if (cpl.n_models * k != (int)gridDim.x || cpl.T < 1 || cpl.T > 256 || cpl.P < 1) {
+            if (tid == 0 && wj == 0) { atomicOr(cpl.status, 2); md.info[0] = -2; md.out[2] = __builtin_nan(""); }
+            return;
+        }
+        if (!group_barrier(gcnt, gridDim.x, flag)) {
+            if (tid == 0 && wj == 0) { atomicOr(cpl.status, 1); md.info[0] = -1; md.out[2] = __builtin_nan(""); }
+            return;
+        }
+        if (wj == 0) coupling_seeds<CT>(models, md, g.ncol[L - 1], W + g.cpl_off, sc + 16);
+        MODEL_BARRIER();
+    }
+
+    // ---- the weighted syrk H = A diag(gv) A^T, Hc = A diag(cgv) A^T of layer lh, k-sliced: one (tile, slice) per wavefront
+    auto h_tasks = [&](int lh) {
+        const double* ATg = W + g.pan[lh];
+        const double* vgv = VEC(lh, V_GV);
+        const double* vcg = VEC(lh, V_CGV);
+        const int ks = g.ks[lh], ncp = g.ncp[lh];
+        const int len = ((ncp / 16 + ks - 1) / ks) * 16;
+        for (int u = wj * CNW + wave; u < g.ntri * ks; u += k * CNW) {
+            const int ch = u / g.ntri;
+            int ti, tj;
+            tile_of(u % g.ntri, ti, tj);
+            const int cbeg = ch * len, cend = cbeg + len < ncp ? cbeg + len : ncp;
+            v4d ah = {0.0, 0.0, 0.0, 0.0}, ac = {0.0, 0.0, 0.0, 0.0};
+            const double* pa = ATg + (int64_t)lk * Mp + ti * 16 + li;
+            const double* pb = ATg + (int64_t)lk * Mp + tj * 16 + li;
+            double a[4], b[4], w1[4], w2[4];
+            if (cbeg < cend) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = pa[(int64_t)(cbeg + 4 * q) * Mp]; b[q] = pb[(int64_t)(cbeg + 4 * q) * Mp];
+                    w1[q] = vgv[cbeg + 4 * q + lk]; w2[q] = vcg[cbeg + 4 * q + lk];
+                }
+            }
+            for (int c = cbeg; c < cend; c += 16) {
+                double an[4], bn[4], w1n[4], w2n[4];
+                const int cn = c + 16 < cend ? c + 16 : c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    an[q] = pa[(int64_t)(cn + 4 * q) * Mp]; bn[q] = pb[(int64_t)(cn + 4 * q) * Mp];
+                    w1n[q] = vgv[cn + 4 * q + lk]; w2n[q] = vcg[cn + 4 * q + lk];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ah = mfma(a[q], b[q] * w1[q], ah);
+                    ac = mfma(a[q], b[q] * w2[q], ac);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a[q] = an[q]; b[q] = bn[q]; w1[q] = w1n[q]; w2[q] = w2n[q]; }
+            }
+            double* Hs = MAT(lh, M_HS + ch);
+            double* Hcs = MAT(lh, M_HCS + ch);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + 4 * r + lk, j = tj * 16 + li;
+                Hs[(int64_t)i * Mp + j] = ah[r];
+                Hcs[(int64_t)i * Mp + j] = ac[r];
+                if (ti != tj) {
+                    Hs[(int64_t)j * Mp + i] = ah[r];
+                    Hcs[(int64_t)j * Mp + i] = ac[r];
+                }
+            }
+        }
+        // da = A g_mean of the layer: the column blocks' partial rows added up (one wavefront)
+        if (wj * CNW + wave == (g.ntri * ks) % (k * CNW)) {
+            double* dav = SML(lh, S_DAV);
+            double* dat = SML(lh, S_DAT);
+            const double* avg = SML(lh, S_AV);
+            for (int i = lane; i < Mp; i += 64) {
+                double s = 0.0;
+                for (int cb = 0; cb < g.ncb[lh]; ++cb) s += PART(lh, cb)[PHEAD + HS + Mp + i];
+                dav[i] = s;
+                dat[i] = s + gkl * avg[i];
+            }
+        }
+    };
+
+    // ---- backward, top layer first: a workgroup per block of 16 columns; the syrk of the layer above rides along
+    for (int l = L - 1; l >= 0; --l) {
+        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
+        const double* hyl = hy + l * HS;
+        const double* ill = il + l * 2 * DBT;
+        const double* Lig = MAT(l, M_LI);
+        const double* UTg = MAT(l, M_UT);
+        const double* ATg = W + g.pan[l];
+        const double* CTg = ATg + (int64_t)g.ncp[l] * Mp;
+        for (int cb = wj; cb < g.ncb[l]; cb += k) {
+            stage_layer(l);
+            const int c0 = cb * 16;
+            stage_rows(l, c0, false);
+            for (int e = tid; e < 16 * Mp; e += CT) {
+                const int j = e / Mp, m = e % Mp;
+                X1[m * XLD + j] = ATg[(int64_t)(c0 + j) * Mp + m];
+                X2[m * XLD + j] = CTg[(int64_t)(c0 + j) * Mp + m];
+            }
+            // B1: upstream gradients of the block's moments: its own data term + what the next layer sent back through f
+            if (wave == 1) {
+                double st = 0.0;
+                if (lane < 16) {
+                    const int c = c0 + lane;
+                    double gm = 0.0, gvc = 0.0, cg = 0.0;
+                    if (c < nc) {
+                        const int b = c / div;
+                        const double tau = sc[l], gd = ge / div, vmean = VEC(l, V_MEAN)[c], vvar = VEC(l, V_VAR)[c];
+                        double gvv = 0.0;
+                        if (md.fid[b] == (double)l) {
+                            const double dlt = md.y[b] - vmean, w = md.row_weight ? md.row_weight[b] : 1.0;
+                            gm = w * gd * dlt / tau;
+                            gvv = -0.5 * w * gd / tau;
+                            st = w * 0.5 * ((dlt * dlt + vvar) / (tau * tau) - 1.0 / tau);
+                        }
+                        if (l == L - 1 && md.seed_gmean) {
+                            gm += md.seed_scale * md.seed_gmean[c];
+                            gvv += md.seed_scale * md.seed_gvar[c];
+                        }
+                        if (l + 1 < L) {
+                            const int ncn = g.ncol[l + 1], fdiv = l == 0 ? S : 1;
+                            if (c * fdiv < ncn) {
+                                const double* ngf = VEC(l + 1, V_GF);
+                                const double* nep = VEC(l + 1, V_EPS);
+                                double sm = 0.0, sv = 0.0;
+                                for (int s2 = 0; s2 < fdiv; ++s2) {
+                                    const double g2 = ngf[c * fdiv + s2];
+                                    sm += g2;
+                                    sv += g2 * nep[c * fdiv + s2];
+                                }
+                                gm += sm;
+                                gvv += sv * 0.5 / sqrt(vvar);
+                            }
+                        }
+                        gvc = VEC(l, V_RAW)[c] > MINV ? gvv : 0.0;
+                        cg = (md.branch || VEC(l, V_KNN)[c] - VEC(l, V_Q)[c] > 0.0) ? gvc : 0.0;
+                    }
+                    VEC(l, V_GMU)[c] = gm; VEC(l, V_GV)[c] = gvc; VEC(l, V_CGV)[c] = cg;
+                    gcol[lane] = gm; gcol[16 + lane] = gvc; gcol[32 + lane] = cg;
+                }
+                st = wsum63(st);
+                if (lane == 63) PART(l, cb)[1] = st;
+            }
+            __syncthreads();
+            int tl[2];
+            const int ntl = wave_tiles(wave, nt, tl);
+            // B2: dA = 2 U (C diag gv) + a g_mean^T - 2 A diag(cgv)   (the column scale commutes with the product)
+            for (int h = 0; h < ntl; ++h) {
+                const v4d acc = tile_tx(UTg, Mp, X2, tl[h], 0, tl[h] + 1, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = tl[h] * 16 + 4 * r + lk;
+                    X0[i * XLD + li] = 2.0 * gcol[16 + li] * acc[r] + avl[i] * gcol[li] - 2.0 * X1[i * XLD + li] * gcol[32 + li];
+                }
+            }
+            for (int i = tid; i < Mp; i += CT) {      // the block's share of da = A g_mean
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s += X1[i * XLD + j] * gcol[j];
+                PART(l, cb)[PHEAD + HS + Mp + i] = s;
+            }
+            __syncthreads();
+            // B3: dK = L^-T dA
+            for (int h = 0; h < ntl; ++h) store_x(X2, tl[h], lane, tile_tx(Lig, Mp, X0, tl[h], tl[h], nt, lane));
+            __syncthreads();
+            // B4: Gram backward of (dK, dk_nn = cgv), element by element
+            double hacc[HS];
+#pragma unroll
+            for (int t = 0; t < HS; ++t) hacc[t] = 0.0;
+            for (int e = tid; e < Mp * 16; e += CT) {
+                const int m = e >> 4, j = e & 15;
+                double dfa = 0.0, dzf = 0.0;
+                if (m < M && xf[j * XFW + DBT + 1] != 0.0) {
+                    const double fn = xf[j * XFW + DBT];
+                    kern_back(kind, d, xf + j * XFW, fn, zt + m * ZW, hyl, ill, X2[m * XLD + j], hacc, dfa, dzf);
+                    if (m == 0) {
+                        const double gk = gcol[32 + j];
+                        if (!kind) hacc[0] += gk;
+                        else {
+                            hacc[0] += gk * (hyl[2] * fn * fn + hyl[1]);
+                            hacc[1] += gk * hyl[0];
+                            hacc[2] += gk * hyl[0] * fn * fn;
+                            hacc[3] += gk;
+                        }
+                    }
+                }
+                X0[m * XLD + j] = dfa;
+                X1[m * XLD + j] = dzf;
+            }
+#pragma unroll
+            for (int t = 0; t < HS; ++t) {
+                if (slot_used(kind, d, t)) {
+                    const double v = wsum63(hacc[t]);
+                    if (lane == 63) redh[wave * (HS + 1) + t] = v;
+                }
+            }
+            __syncthreads();
+            // B5: the block's partial sums: hyper-parameters (fixed slot layout), d/df of its columns, d/dzf rows
+            if (tid < HS) PART(l, cb)[PHEAD + tid] = slot_used(kind, d, tid) ? red_sum<CNW>(redh, HS + 1, tid) : 0.0;
+            if (kind) {
+                {
+                    const int j = tid & 15, part = tid >> 4;
+                    double s = 0.0;
+                    for (int m = part; m < Mp; m += 16) s += X0[m * XLD + j];
+                    red[part * 16 + j] = s;
+                }
+                for (int m = tid; m < Mp; m += CT) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) s += X1[m * XLD + j];
+                    PART(l, cb)[PHEAD + HS + m] = s;
+                }
+                __syncthreads();
+                if (tid < 16) {
+                    const int c = c0 + tid;
+                    double s = 0.0;
+                    for (int p = 0; p < 16; ++p) s += red[p * 16 + tid];
+                    VEC(l, V_GF)[c] = c < nc ? s + gcol[32 + tid] * hyl[0] * 2.0 * hyl[2] * xf[tid * XFW + DBT] : 0.0;
+                }
+            }
+            __syncthreads();
+        }
+        if (l + 1 < L) h_tasks(l + 1);
+        MODEL_BARRIER();
+    }
+    h_tasks(0);
+    MODEL_BARRIER();
+
+    // ---- the M x M chain backward, every layer at once, tile-parallel: one 16 x 16 output tile per wavefront
+    const int gw = wj * CNW + wave, nwv = k * CNW, nt2 = nt * nt;
+    // k-major fragment of a matrix: rows k0 + 4 q + lk (q = 0..3), 16 contiguous columns from column x0
+#define FRAG(dst, P, k0, x0) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dst[q_] = (P)[(int64_t)((k0) + 4 * q_ + lk) * Mp + (x0) + li]
+    // CB1: G1 = U^T H, GT = H U (= G1^T: H is symmetric -- both orientations, so that every later read is k-major)
+    for (int u = gw; u < L * nt2; u += nwv) {
+        const int l = u / nt2, ti = (u % nt2) / nt, tj = u % nt;
+        const double* Ug = MAT(l, M_U);
+        const int ks = g.ks[l];
+        v4d a1 = {0.0, 0.0, 0.0, 0.0}, a2 = {0.0, 0.0, 0.0, 0.0};
+        for (int kt = ti < tj ? ti : tj; kt < nt; ++kt) {
+            double ui[4], uj[4], hi[4], hj[4], tmp[4];
+            FRAG(ui, Ug, kt * 16, ti * 16);
+            FRAG(uj, Ug, kt * 16, tj * 16);
+            FRAG(hi, MAT(l, M_HS), kt * 16, ti * 16);
+            FRAG(hj, MAT(l, M_HS), kt * 16, tj * 16);
+            for (int s2 = 1; s2 < ks; ++s2) {
+                FRAG(tmp, MAT(l, M_HS + s2), kt * 16, ti * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hi[q] += tmp[q];
+                FRAG(tmp, MAT(l, M_HS + s2), kt * 16, tj * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hj[q] += tmp[q];
+            }
+            if (kt >= ti) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a1 = mfma(ui[q], hj[q], a1);
+            }
+            if (kt >= tj) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a2 = mfma(hi[q], uj[q], a2);
+            }
+        }
+        double* G1 = MAT(l, M_G1);
+        double* GT = MAT(l, M_GT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            G1[(int64_t)(ti * 16 + 4 * r + lk) * Mp + tj * 16 + li] = a1[r];
+            GT[(int64_t)(ti * 16 + 4 * r + lk) * Mp + tj * 16 + li] = a2[r];
+        }
+    }
+    MODEL_BARRIER();
+    // CB2+3: Y = 2 (U G1 - Hc) + a da^T + da_tot a^T + dU_tot U^T with dU_tot = 2 tril(G1^T) + gkl U;
+    //        g_LS = tril(L^-T dU_tot) - gkl diag(1 / L_S,ii);  g_m += L^-T da_tot (one more wavefront task per layer)
+    for (int u = gw; u < L * nt2 + L; u += nwv) {
+        if (u >= L * nt2) {
+            const int l = u - L * nt2;
+            const double* Lig = MAT(l, M_LI);
+            const double* dat = SML(l, S_DAT);
+            double* gma = SML(l, S_GMA);
+            for (int i = lane; i < Mp; i += 64) {
+                double s = 0.0;
+                for (int kk = i; kk < Mp; ++kk) s += Lig[(int64_t)kk * Mp + i] * dat[kk];
+                gma[i] = s;
+            }
+            continue;
+        }
+        const int l = u / nt2, ti = (u % nt2) / nt, tj = u % nt;
+        const double* Ug = MAT(l, M_U);
+        const double* UTg = MAT(l, M_UT);
+        const double* G1 = MAT(l, M_G1);
+        const double* GT = MAT(l, M_GT);
+        const double* Lig = MAT(l, M_LI);
+        const int ks = g.ks[l];
+        v4d s1 = {0.0, 0.0, 0.0, 0.0}, s2 = {0.0, 0.0, 0.0, 0.0}, s3 = {0.0, 0.0, 0.0, 0.0};
+        const int kmin = ti < tj ? ti : tj;
+        for (int kt = 0; kt <= ti; ++kt) {
+            double ua[4], gb[4];
+            FRAG(ua, UTg, kt * 16, ti * 16);      // U[i][k]
+            FRAG(gb, G1, kt * 16, tj * 16);       // G1[k][j]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s1 = mfma(ua[q], gb[q], s1);
+            if (kt <= kmin) {
+                double gi[4], ub[4];
+                FRAG(gi, G1, kt * 16, ti * 16);   // G1[k][i]
+                FRAG(ub, UTg, kt * 16, tj * 16);  // U[j][k]
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = kt * 16 + 4 * q + lk, i = ti * 16 + li;
+                    const double du = kk <= i ? 2.0 * gi[q] + gkl * ua[q] : 0.0;      // dU_tot[i][k]
+                    s2 = mfma(du, ub[q], s2);
+                }
+            }
+        }
+        if (tj <= ti) {
+            for (int kt = ti; kt < nt; ++kt) {
+                double la[4], gt[4], ub[4];
+                FRAG(la, Lig, kt * 16, ti * 16);  // L^-1[k][i]
+                FRAG(gt, GT, kt * 16, tj * 16);   // G1[j][k]
+                FRAG(ub, Ug, kt * 16, tj * 16);   // U[k][j]
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = kt * 16 + 4 * q + lk, j = tj * 16 + li;
+                    const double du = j <= kk ? 2.0 * gt[q] + gkl * ub[q] : 0.0;      // dU_tot[k][j]
+                    s3 = mfma(la[q], du, s3);
+                }
+            }
+        }
+        const double* avg = SML(l, S_AV);
+        const double* dav = SML(l, S_DAV);
+        const double* dat = SML(l, S_DAT);
+        double* Y = MAT(l, M_Y);
+        double* gls = gflat + g.flat_off[l] + g.H[l] + M;
+        const double* ls = md.L_S[l];
+        const int j = tj * 16 + li;
+        const double aj = avg[j], dj = dav[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + 4 * r + lk;
+            double hc = 0.0;
+            for (int sl = 0; sl < ks; ++sl) hc += MAT(l, M_HCS + sl)[(int64_t)i * Mp + j];
+            // (Y overwrites slice 0 of H, which CB1 was the last to read; Hc is a different matrix)
+            Y[(int64_t)i * Mp + j] = 2.0 * (s1[r] - hc) + avg[i] * dj + dat[i] * aj + s2[r];
+            if (i < M && j < M) {
+                double t = 0.0;
+                if (j <= i) {
+                    t = s3[r];
+                    if (i == j) t -= gkl / ls[(int64_t)i * M + i];
+                }
+                gls[(int64_t)i * M + j] = t;
+            }
+        }
+    }
+    MODEL_BARRIER();
+    // CB4-6, one workgroup per block of 16 columns of Y: dL = -tril(L^-T Y) + gkl diag(1 / L_ii), P = Phi(L^T dL), T4 = L^-T P
+    for (int u = wj; u < L * nt; u += k) {
+        const int l = u / nt, cb = u % nt;
+        const double* Lg = MAT(l, M_L);
+        const double* Lig = MAT(l, M_LI);
+        const double* Y = MAT(l, M_Y);
+        __syncthreads();
+        for (int e = tid; e < Mp * 16; e += CT) X0[(e >> 4) * XLD + (e & 15)] = Y[(int64_t)(e >> 4) * Mp + cb * 16 + (e & 15)];
+        __syncthreads();
+        int tl[2];
+        const int ntl = wave_tiles(wave, nt, tl);
+        for (int h = 0; h < ntl; ++h) {
+            const v4d acc = tile_tx(Lig, Mp, X0, tl[h], tl[h], nt, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = tl[h] * 16 + 4 * r + lk, j = cb * 16 + li;
+                double v = j <= i ? -acc[r] : 0.0;
+                if (i == j && i < M) v += gkl / Lg[(int64_t)i * Mp + i];
+                X1[i * XLD + li] = v;
+            }
+        }
+        __syncthreads();
+        for (int h = 0; h < ntl; ++h) {
+            const v4d acc = tile_tx(Lg, Mp, X1, tl[h], tl[h], nt, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = tl[h] * 16 + 4 * r + lk, j = cb * 16 + li;
+                X2[i * XLD + li] = j < i ? acc[r] : (j == i ? 0.5 * acc[r] : 0.0);
+            }
+        }
+        __syncthreads();
+        for (int h = 0; h < ntl; ++h) {
+            const int t = tl[h];
+            store_x(X0, t, lane, tile_tx(Lig, Mp, X2, t, t > cb ? t : cb, nt, lane));
+        }
+        __syncthreads();
+        double* T4T = MAT(l, M_T4T);
+        for (int e = tid; e < 16 * Mp; e += CT) {
+            const int j = e / Mp, m = e % Mp;
+            T4T[(int64_t)(cb * 16 + j) * Mp + m] = X0[m * XLD + j];
+        }
+    }
+    MODEL_BARRIER();
+    // CB7: T5 = T4 L^-1
+    for (int u = gw; u < L * nt2; u += nwv) {
+        const int l = u / nt2, ti = (u % nt2) / nt, tj = u % nt;
+        const double* T4T = MAT(l, M_T4T);
+        const double* Lig = MAT(l, M_LI);
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kt = tj; kt < nt; ++kt) {
+            double a[4], b[4];
+            FRAG(a, T4T, kt * 16, ti * 16);
+            FRAG(b, Lig, kt * 16, tj * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = mfma(a[q], b[q], acc);
+        }
+        double* T5 = MAT(l, M_T5);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T5[(int64_t)(ti * 16 + 4 * r + lk) * Mp + tj * 16 + li] = acc[r];
+    }
+    MODEL_BARRIER();
+    // CB8: Gram backward of dK_mm = sym(T5), a workgroup per 16 rows (both arguments are Z~: a pair's f gradient counts twice)
+    for (int u = wj; u < L * nt; u += k) {
+        const int l = u / nt, ti = u % nt, kind = l > 0;
+        stage_layer(l);
+        const double* T5 = MAT(l, M_T5);
+        const double* hyl = hy + l * HS;
+        const double* ill = il + l * 2 * DBT;
+        double hacc[HS];
+#pragma unroll
+        for (int t = 0; t < HS; ++t) hacc[t] = 0.0;
+        const int i = ti * 16 + (tid & 15);
+        double rs = 0.0;
+        if (i < M) {
+            for (int j = tid >> 4; j < M; j += 16) {
+                const double G = 0.5 * (T5[(int64_t)i * Mp + j] + T5[(int64_t)j * Mp + i]);
+                double dfa, dzf;
+                kern_back(kind, d, zt + i * ZW, zt[i * ZW + DBT], zt + j * ZW, hyl, ill, G, hacc, dfa, dzf);
+                rs += dfa;
+            }
+        }
+        red[(tid >> 4) * 16 + (tid & 15)] = rs;
+#pragma unroll
+        for (int t = 0; t < HS; ++t) {
+            if (slot_used(kind, d, t)) {
+                const double v = wsum63(hacc[t]);
+                if (lane == 63) redh[wave * (HS + 1) + t] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < HS) W[g.hpart[l] + (int64_t)ti * HS + tid] = slot_used(kind, d, tid) ? red_sum<CNW>(redh, HS + 1, tid) : 0.0;
+        if (tid >= 64 && tid < 80) {
+            double s = 0.0;
+            for (int p = 0; p < 16; ++p) s += red[p * 16 + (tid - 64)];
+            SML(l, S_GMB)[ti * 16 + (tid - 64)] = 2.0 * s;
+        }
+        __syncthreads();
+    }
+    MODEL_BARRIER();
+
+    // ---- raw-parameter gradients assembled from the partial sums, element by element of the flat vector, and Adam
+    // (torch.optim.Adam: p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)); g_LS is in the flat vector already
+    {
+        const double bc1 = sc[12], bc2s = sc[13];
+        const bool upd = do_update == 1 || do_update == 4;
+        for (int e = wj * CT + tid; e < (int)g.flat_len; e += k * CT) {
+            int kk = 0;
+#pragma unroll
+            for (int sft = NSEG / 2; sft > 0; sft >>= 1)
+                if (seg_end[kk + sft - 1] <= e) kk += sft;
+            double gi;
+            if (e >= (int)g.flat_noise) {
+                const int l = e - (int)g.flat_noise, div = l ? S : 1;
+                double s = 0.0;
+                for (int cb = 0; cb < g.ncb[l]; ++cb) s += PART(l, cb)[1];
+                double chain = 1.0;
+                if (md.noise_hi[l] > md.noise_lo[l]) {
+                    const double sg = 1.0 / (1.0 + exp(-md.raw_noise[l][0]));
+                    chain = (md.noise_hi[l] - md.noise_lo[l]) * sg * (1.0 - sg);
+                }
+                gi = s / div * ge * chain;
+            } else {
+                int l = 0;
+                while (l + 1 < L && e >= (int)g.flat_off[l + 1]) ++l;
+                const int t = e - (int)g.flat_off[l], Hl = g.H[l];
+                if (t < Hl) {
+                    const int slot = slot_of(l > 0, d, t);
+                    double s = 0.0;
+                    for (int cb = 0; cb < g.ncb[l]; ++cb) s += PART(l, cb)[PHEAD + slot];
+                    for (int ti = 0; ti < nt; ++ti) s += W[g.hpart[l] + (int64_t)ti * HS + slot];
+                    int sgm = 0, off = 0;
+                    while (t >= off + seg_len(l, sgm, d)) { off += seg_len(l, sgm, d); ++sgm; }
+                    const double x = md.raw[l][sgm][t - off];
+                    gi = x > 20.0 ? s : s / (1.0 + exp(-x));
+                } else if (t < Hl + M) {
+                    const int i = t - Hl;
+                    double s = SML(l, S_GMA)[i];
+                    if (l + 1 < L) {
+                        s += SML(l + 1, S_GMB)[i];
+                        for (int cb = 0; cb < g.ncb[l + 1]; ++cb) s += PART(l + 1, cb)[PHEAD + HS + i];
+                    }
+                    gi = s;
+                } else {
+                    gi = gflat[e];
+                }
+            }
+            gflat[e] = gi;
+            if (md.grad) md.grad[e] = gi;
+            double* p = seg_ptr[kk];
+            if (!upd || !p) continue;
+            const int start = kk ? seg_end[kk - 1] : 0;
+            const double mi2 = b1 * md.adam_m[e] + (1.0 - b1) * gi;
+            const double vi = b2 * md.adam_v[e] + (1.0 - b2) * gi * gi;
+            md.adam_m[e] = mi2;
+            md.adam_v[e] = vi;
+            p[e - start] -= (lr / bc1) * mi2 / (sqrt(vi) / bc2s + aeps);
+        }
+        CSTAMP();
+        if (upd && wj == 0 && tid == 0) {
+            md.steps_done[0] += 1;
+            for (int l = 1; l < L; ++l)
+                if (!md.eps[l] && md.rng[l]) md.rng[l][1] += 1;
+            if (blockIdx.x == 0 && md.xrng) md.xrng[1] += 1;
+        }
+    }
+}
+#undef FRAG
+#undef MODEL_BARRIER
+#undef CSTAMP
+
+size_t coop_lds_bytes(int Mp) {
+    const int ntri = (Mp / 16) * (Mp / 16 + 1) / 2;
+    const size_t common = (size_t)TLM * HS + (size_t)TLM * 2 * DBT + 32 + NSEG + NSEG / 2;
+    const size_t chain = (size_t)Mp * ZW + 2 * (size_t)ntri * 256;
+    const size_t col = (size_t)Mp * ZW + 3 * (size_t)Mp * XLD + Mp + 16 * XFW + 64 + 768 + CNW * (HS + 1);
+    return (common + (chain > col ? chain : col)) * sizeof(double);
+}
+
+bool coop_valid_model(const mobocmf_tiny_model& m) {
+    if (m.L < 1 || m.L > TLM || m.M < 1 || m.M > CMAXM || m.d < 1 || m.d > DBT || m.S < 1 || m.N < 1) return false;
+    if (m.rows[0] != m.N) return false;
+    for (int l = 0; l < m.L; ++l) {
+        if (m.rows[l] < 1 || (l && m.rows[l] > m.rows[l - 1])) return false;
+        if ((int64_t)m.rows[l] * m.S > (1 << 20)) return false;
+        const int ns = l == 0 ? 2 : 7;
+        for (int s = 0; s < ns; ++s)
+            if (!m.raw[l][s]) return false;
+        if (!m.m[l] || !m.L_S[l] || !m.raw_noise[l]) return false;
+        if (l && !m.eps[l] && !m.rng[l]) return false;
+    }
+    if ((m.seed_gmean == nullptr) != (m.seed_gvar == nullptr) || (m.top_mean == nullptr) != (m.top_var == nullptr)) return false;
+    if (m.xrng && (m.rand_row0 < 0 || m.rand_rows < 0 || m.rand_row0 + m.rand_rows > m.N)) return false;
+    if (m.branch != 0 && m.branch != 1) return false;
+    return m.x && m.y && m.fid && m.Zx && m.adam_m && m.adam_v && m.steps_done && m.work && m.out && m.info;
+}
 
 }  // namespace
+
+extern "C" {
+
+int mobocmf_coop_work_bytes(const mobocmf_tiny_model* model, size_t* bytes) {
+    if (!model || !bytes || model->L < 1 || model->L > TLM || model->M < 1 || model->M > CMAXM || model->d < 1 || model->S < 1)
+        return MOBOCMF_BAD_ARG;
+    for (int l = 0; l < model->L; ++l)
+        if (model->rows[l] < 1) return MOBOCMF_BAD_ARG;
+    CGeom g;
+    cgeom_of(*model, g);
+    size_t n = (size_t)g.work_len;
+#ifdef COOP_STAMPS
+    n += 64;
+#endif
+    *bytes = n * sizeof(double);
+    return MOBOCMF_OK;
+}
+
+int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
+                           int32_t wgs_per_model, int64_t* sync_words, double lr, double beta1, double beta2, double eps,
+                           int32_t do_update, int32_t* wgs_used, mobocmf_stream_t stream) {
+    if (!host_models || !dev_models || !sync_words || n_models < 1 || n_models > 256 || wgs_per_model < 0 || wgs_per_model > 64)
+        return MOBOCMF_BAD_ARG;
+    if (do_update != 0 && do_update != 1 && do_update != 2 && do_update != 4) return MOBOCMF_BAD_ARG;
+    int mpmax = 0, want = 1;
+    for (int i = 0; i < n_models; ++i) {
+        const mobocmf_tiny_model& m = host_models[i];
+        if (!coop_valid_model(m)) return MOBOCMF_BAD_ARG;
+        if (do_update == 4) {
+            if (!m.coupling || m.S != 1 || !m.seed_gmean || !m.top_mean || m.role < 0 || m.role > 1 || m.role_index < 0 ||
+                m.role_index > 7 || m.coupling != host_models[0].coupling)
+                return MOBOCMF_BAD_ARG;
+        }
+        CGeom g;
+        cgeom_of(m, g);
+        if (g.Mp > mpmax) mpmax = g.Mp;
+        // the widest phase of this model: column blocks of a layer, the chain backward's column blocks of all layers
+        int w = m.L * g.nt;
+        for (int l = 0; l < m.L; ++l)
+            if (g.ncb[l] > w) w = g.ncb[l];
+        if (w > want) want = w;
+    }
+    const size_t shm = coop_lds_bytes(mpmax);
+    static std::atomic<uint64_t> granted{0};      // one write-once bit per device: the dynamic-LDS attribute was set there
+    int devid = 0;
+    HIP_TRY(hipGetDevice(&devid));
+    const uint64_t bit = devid >= 0 && devid < 64 ? 1ull << devid : 0ull;
+    if (shm > 64 * 1024 && !(granted.load() & bit)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)coop_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        granted.fetch_or(bit);
+    }
+    // every workgroup of the launch waits for its peers inside the launch: all of them must be resident at once
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)coop_step_kernel, CT, shm));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
+    const int64_t resident = (int64_t)per_cu * cus;
+    int k = wgs_per_model;
+    if (k == 0) {
+        k = want < 16 ? want : 16;
+        while (k > 1 && (int64_t)k * n_models > resident) --k;
+    }
+    if ((int64_t)k * n_models > resident || k < 1) return MOBOCMF_BAD_ARG;
+    if (wgs_used) *wgs_used = k;
+    hipLaunchKernelGGL(coop_step_kernel, dim3((unsigned)(n_models * k)), dim3(CT), shm, (hipStream_t)stream, dev_models, k,
+                       (unsigned long long*)sync_words, lr, beta1, beta2, eps, do_update);
+    return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
+}
+
+}  // extern "C"

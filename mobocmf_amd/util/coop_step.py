@@ -1,0 +1,80 @@
+"""The ELBO step of MID-SIZE surrogates (M <= 128 inducing points) as ONE launch for a whole group of models, several
+workgroups per surrogate: mobocmf_coop_elbo_step (csrc/coop_step.hip).
+
+The reference's own BO loop trains M = N from 15 to 75 points (examples/toy_synthetic_2D_JESMOCMF/...py:25,102-103,305-331 with
+mfdgp.py:295-298); the one-workgroup kernel (util/tiny_step.py) covers M <= 32, the layer path costs 57 launches per step there.
+``CoopELBOStep`` has the surface of ``TinyELBOStep`` / ``GraphedELBOStep`` that the fitter's loop uses (step / check / snapshot /
+restore / losses / export_adam_state); ``CoopConditionedStep`` is the conditioned iteration (blackbox_mfdgp_fitter.py:245-354).
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from . import tiny_step as TS
+
+MAX_COLUMNS = 16384      # rows[l] * S per layer this binding accepts
+
+
+def eligible(model, x, fidelities):
+    """The structural limits of the cooperative kernel: <= 3 layers sharing one set of <= 128 inducing inputs, d <= 8, softplus /
+    Interval constraints, float64 parameters on the GPU (``tiny_step.eligible`` with this kernel's limits; no speed rule: the
+    launch beats the layer path's ~57 launches per step wherever it applies)."""
+    return TS.eligible(model, x, fidelities, speed_rule=False, max_m=_lib.COOP_MAX_M, max_columns=MAX_COLUMNS)
+
+
+class _CoopLaunch:
+    """The launch of mobocmf_coop_elbo_step for the descriptor table a Tiny* step object built."""
+    _work_bytes_fn = "mobocmf_coop_work_bytes"
+    wgs_per_model = 0      # 0: chosen by the library from the widest phase
+
+    @staticmethod
+    def _eligible(model, x, fid, force):
+        return eligible(model, x, fid)
+
+    def _sync_words(self):
+        sw = self.__dict__.get("_sync")
+        if sw is None:
+            sw = torch.zeros(16 * (len(self.models) + 1), dtype=torch.int64, device=self.device)
+            self._sync = sw
+        return sw
+
+    def _launch(self, mode):
+        lib = _lib.require_device()
+        used = ctypes.c_int32(0)
+        _lib.check(lib.mobocmf_coop_elbo_step(ctypes.cast(self.host, ctypes.c_void_p), ctypes.c_void_p(self._dev_table.data_ptr()),
+                                              len(self.models), int(self.wgs_per_model), ctypes.c_void_p(self._sync_words().data_ptr()),
+                                              self.lr, self.betas[0], self.betas[1], self.eps, int(mode), ctypes.byref(used),
+                                              ctypes.c_void_p(self.stream.cuda_stream)),
+                   "mobocmf_coop_elbo_step")
+        self.wgs_used = used.value
+
+
+class CoopELBOStep(_CoopLaunch, TS.TinyELBOStep):
+    """``step()`` == one full-batch ELBO step of EVERY model of the group, one launch (see ``TinyELBOStep`` for the arguments)."""
+
+    def restore(self):
+        super().restore()
+        # a barrier that was abandoned leaves its arrival counter out of step: start the counters afresh
+        with torch.cuda.stream(self.stream):
+            self._sync_words().zero_()
+
+
+class CoopConditionedStep(_CoopLaunch, TS.TinyConditionedStep):
+    """One iteration of the conditioned training in ONE launch (mode 4), or forward-only launch + factor launches + step launch."""
+
+    def _issue(self):
+        if self.one_launch and self.T <= 256:
+            try:
+                self._launch(4)
+                return
+            except _lib.MobocmfError:
+                self.one_launch = False
+        self._launch(2)
+        self._factors()
+        self._launch(1)
+
+    def restore(self):
+        super().restore()
+        with torch.cuda.stream(self.stream):
+            self._sync_words().zero_()

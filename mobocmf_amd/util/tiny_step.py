@@ -68,8 +68,8 @@ def fits_predict(model, fidelity, T, d, speed_rule=True):
         return False
 
 
-def eligible(model, x, fidelities, speed_rule=True):
-    """True when ``model`` on the batch ``x`` fits the one-launch step: <= 3 layers sharing one set of <= 32 inducing inputs
+def eligible(model, x, fidelities, speed_rule=True, max_m=None, max_columns=None):
+    """(``max_m`` / ``max_columns``: the limits of the kernel asked about; default: the one-workgroup kernel's.)  True when ``model`` on the batch ``x`` fits the one-launch step: <= 3 layers sharing one set of <= 32 inducing inputs
     (Z~_l = [Z_x, m_{l-1}]), d <= 8, softplus / Interval constraints, float64 parameters on the GPU, every fidelity's
     prefix non-empty -- and, with ``speed_rule``, small enough for one workgroup to beat the layer path (estimated_us)."""
     try:
@@ -81,12 +81,12 @@ def eligible(model, x, fidelities, speed_rule=True):
             return False
         Z0 = layers[0].variational_strategy._inducing_points
         M = Z0.shape[0]
-        if not (1 <= M <= _lib.TINY_MAX_M) or Z0.requires_grad or Z0.shape[1] != x.shape[1]:
+        if not (1 <= M <= (max_m or _lib.TINY_MAX_M)) or Z0.requires_grad or Z0.shape[1] != x.shape[1]:
             return False
         S = model.num_samples_for_training
         fidv = fidelities.reshape(-1)
         N = fidv.numel()
-        if N != x.shape[0] or N * max(S, 1) > MAX_COLUMNS:
+        if N != x.shape[0] or N * max(S, 1) > (max_columns or MAX_COLUMNS):
             return False
         counts = [int((fidv >= l).sum()) for l in range(L)]
         if counts[0] != N or counts[-1] < 1:
@@ -152,8 +152,8 @@ class TinyELBOStep:
         for i, model in enumerate(self.models):
             prep = None if prepared is None else prepared[i]
             x, y, fid = (xs[i], ys[i], fids[i]) if prep is None else (prep["x"], prep["y"], prep["fid"])
-            if not eligible(model, x, fid, speed_rule=not force):
-                raise _lib.MobocmfError("TinyELBOStep: model %d does not fit the one-launch step (see eligible())" % i)
+            if not self._eligible(model, x, fid, force):
+                raise _lib.MobocmfError("%s: model %d does not fit the one-launch step (see eligible())" % (type(self).__name__, i))
             layers = model._layers()
             L, S = len(layers), model.num_samples_for_training
             fidv = fid.reshape(-1).to(torch.float64)
@@ -236,7 +236,7 @@ class TinyELBOStep:
             _lib.check(lib.mobocmf_tiny_flat_len(ctypes.byref(T), ctypes.byref(flat)), "mobocmf_tiny_flat_len")
             assert flat.value == off, (flat.value, off)
             wb = ctypes.c_size_t()
-            _lib.check(lib.mobocmf_tiny_work_bytes(ctypes.byref(T), ctypes.byref(wb)), "mobocmf_tiny_work_bytes")
+            _lib.check(getattr(lib, self._work_bytes_fn)(ctypes.byref(T), ctypes.byref(wb)), self._work_bytes_fn)
             # MOBOCMF_POISON (as functional._scratch): NaN-filled workspace, so a read of anything the launch did not write shows
             work = torch.full((wb.value // 8,), float("nan") if os.environ.get("MOBOCMF_POISON") else 0.0,
                               dtype=torch.float64, device=dev)
@@ -256,6 +256,13 @@ class TinyELBOStep:
         raw = bytes(self.host)
         self._dev_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._snap = None
+
+    # ------------------------------------------------------------------ the kernel this class drives
+    _work_bytes_fn = "mobocmf_tiny_work_bytes"
+
+    @staticmethod
+    def _eligible(model, x, fid, force):
+        return eligible(model, x, fid, speed_rule=not force)
 
     # ------------------------------------------------------------------ the step
     def _launch(self, mode):

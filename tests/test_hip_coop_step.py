@@ -1,0 +1,205 @@
+"""mobocmf_coop_elbo_step -- the whole ELBO step of mid-size surrogates (M <= 128) in ONE launch by several workgroups per
+surrogate -- against the oracle (mfdgp.py:174-196 + variational_elbo_mf.py:24-51 + blackbox_mfdgp_fitter.py:161-171 restated),
+against the one-workgroup kernel and against the layer path."""
+import numpy as np
+import pytest
+import torch
+
+from mobocmf_amd.util import synthetic
+from oracle import mfdgp_oracle as O
+from tests.test_hip_model import _model_param_for, _raw_from_model, rel
+from tests.test_hip_tiny_step import _problem
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (the reference's loop: M = N, S = 1, two fidelities; BASELINE config 2: d = 2, M = 128, N = 512, S = 8; plus ragged / small / 3-layer shapes)
+CASES = [dict(d=2, L=2, M=64, N=64, S=1, seed=0), dict(d=2, L=2, M=48, N=48, S=1, seed=1),
+         dict(d=2, L=2, M=96, N=120, S=2, seed=2), dict(d=2, L=2, M=128, N=256, S=4, seed=3),
+         dict(d=5, L=3, M=40, N=57, S=2, seed=4), dict(d=8, L=3, M=75, N=75, S=1, seed=5),
+         dict(d=3, L=1, M=33, N=50, S=1, seed=6), dict(d=1, L=2, M=16, N=16, S=4, seed=7),
+         dict(d=4, L=3, M=7, N=23, S=1, seed=8), dict(d=2, L=2, M=128, N=512, S=8, seed=9)]
+IDS = ["d%d_L%d_M%d_N%d_S%d" % (c["d"], c["L"], c["M"], c["N"], c["S"]) for c in CASES]
+
+
+def _coop(models, xs, ys, fids, epss, lr=1e-2, want_grad=False, wgs=0):
+    from mobocmf_amd.util.coop_step import CoopELBOStep
+    step = CoopELBOStep(models, [x.shape[0] for x in xs], [x.to(DEV) for x in xs], [y.to(DEV) for y in ys],
+                        [f.to(DEV) for f in fids], lr=lr,
+                        fixed_eps=[None if e is None else [None if v is None else v.to(DEV) for v in e] for e in epss],
+                        want_grad=want_grad, force=True)
+    step.wgs_per_model = wgs
+    return step
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=IDS)
+def test_coop_step_gradients_match_oracle(cfg):
+    """ELBO, scaled KL and every raw-parameter gradient of one launch (no update) vs the oracle's autograd through its dense
+    evaluation of every layer at every row, on a shuffled batch.  Gates as for the one-workgroup kernel and the layer path."""
+    prob, x, y, fid, eps = _problem(cfg)
+    L, S = cfg["L"], cfg["S"]
+    model = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
+    raw = _raw_from_model(model, L)
+    e_o, skl_o = O.elbo(O.state_from_raw(raw), x, y, fid, eps=eps, S=S)
+    (-e_o).backward()
+    step = _coop([model], [x], [y], [fid], [eps], want_grad=True)
+    grads = step.gradients()[0]
+    step.check()
+    out = step.losses[0].cpu()
+    assert rel(out[0], e_o) < 1e-9 and rel(out[1], skl_o) < 1e-9 and rel(out[2], -e_o) < 1e-9, (out, e_o, skl_o)
+    for l in range(L):
+        for key, tt in raw["layers"][l].items():
+            p = _model_param_for(model, l, key)
+            gref = tt.grad if key != "L_S" else torch.tril(tt.grad)
+            assert rel(grads[p].reshape(gref.shape), gref) < 1e-5, (l, key, rel(grads[p].reshape(gref.shape), gref))
+        lk = getattr(model, f"hidden_layer_likelihood_{l}")
+        assert rel(grads[lk.raw_noise].reshape(()), raw["raw_noise"][l].grad) < 1e-5
+
+
+@pytest.mark.parametrize("wgs", [1, 2, 3, 7, 16, 40])
+def test_any_number_of_workgroups_per_surrogate_gives_the_same_gradients(wgs):
+    """The phases deal their tiles / column blocks to whatever workgroups there are: 1 (no barrier traffic at all) ... 40 (more
+    than any phase has tasks) give the same ELBO and gradients up to summation order."""
+    cfg = CASES[2]
+    prob, x, y, fid, eps = _problem(cfg)
+    a = synthetic.model_from_problem(prob, num_samples_for_training=cfg["S"], device=DEV)
+    b = synthetic.model_from_problem(prob, num_samples_for_training=cfg["S"], device=DEV)
+    sa = _coop([a], [x], [y], [fid], [eps], want_grad=True, wgs=wgs)
+    sb = _coop([b], [x], [y], [fid], [eps], want_grad=True, wgs=4)
+    ga, gb = sa.gradients()[0], sb.gradients()[0]
+    sa.check()
+    assert sa.wgs_used == wgs
+    assert rel(sa.losses[0], sb.losses[0]) < 1e-12
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert rel(ga[pa], gb[pb]) < 1e-8, rel(ga[pa], gb[pb])
+
+
+@pytest.mark.parametrize("cfg", CASES[:5], ids=IDS[:5])
+def test_coop_step_trajectory_matches_oracle(cfg):
+    """Three fused steps vs oracle.elbo_step with torch.optim.Adam: the loss of every step and every parameter afterwards."""
+    prob, x, y, fid, eps = _problem(cfg)
+    L, S = cfg["L"], cfg["S"]
+    model = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
+    raw = _raw_from_model(model, L)
+    opt = torch.optim.Adam(O.flatten_raw(raw), lr=1e-2)
+    step = _coop([model], [x], [y], [fid], [eps], lr=1e-2)
+    for k in range(3):
+        lo, klo = O.elbo_step(raw, opt, x, y, fid, eps, S, ref_equiv=False)
+        step.step()
+        step.check()
+        assert rel(step.loss[0], lo) < 1e-7, (k, rel(step.loss[0], lo))
+        assert rel(step.kl[0], klo) < 1e-7, k
+    assert int(step.steps_done[0]) == 3
+    for l in range(L):
+        for key, tt in raw["layers"][l].items():
+            p = _model_param_for(model, l, key)
+            assert rel(p.reshape(tt.shape), tt.detach()) < 1e-6, (l, key, rel(p.reshape(tt.shape), tt.detach()))
+        lk = getattr(model, f"hidden_layer_likelihood_{l}")
+        assert rel(lk.raw_noise.reshape(()), raw["raw_noise"][l].detach()) < 1e-6
+
+
+def test_coop_group_equals_single_models_and_the_one_workgroup_kernel():
+    """Three surrogates of different shapes in one launch == each alone; and at a size both kernels take (M = 16) the
+    cooperative kernel follows the one-workgroup kernel's trajectory, frozen parameters untouched."""
+    from tests.test_hip_tiny_step import _tiny
+    cfgs = [CASES[1], CASES[4], CASES[7]]
+    built = []
+    for cfg in cfgs:
+        prob, x, y, fid, eps = _problem(cfg)
+        a = synthetic.model_from_problem(prob, num_samples_for_training=cfg["S"], device=DEV)
+        b = synthetic.model_from_problem(prob, num_samples_for_training=cfg["S"], device=DEV)
+        for mdl in (a, b):
+            mdl.fix_variational_hypers(True)
+        built.append((a, b, x, y, fid, eps))
+    group = _coop([t[0] for t in built], [t[2] for t in built], [t[3] for t in built], [t[4] for t in built], [t[5] for t in built])
+    singles = [_coop([t[1]], [t[2]], [t[3]], [t[4]], [t[5]]) for t in built[:2]] + \
+        [_tiny([built[2][1]], [built[2][2]], [built[2][3]], [built[2][4]], [built[2][5]])]
+    before = [t[0].hidden_layer_0.variational_strategy._variational_distribution.chol_variational_covar.clone() for t in built]
+    for _ in range(4):
+        group.step()
+        for s in singles:
+            s.step()
+    group.check()
+    for i, (a, b, *_r) in enumerate(built):
+        singles[i].check()
+        assert rel(group.losses[i], singles[i].losses[0]) < 1e-8, (i, rel(group.losses[i], singles[i].losses[0]))
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert rel(pa, pb) < 1e-8
+        assert torch.equal(a.hidden_layer_0.variational_strategy._variational_distribution.chol_variational_covar, before[i])
+
+
+def test_coop_step_draws_the_same_eps_as_the_layer_path():
+    """Without explicit eps both paths draw from the layers' Philox streams: the same model state gives the same trajectory
+    through GraphedELBOStep (layer entry points, HIP graph) and through the cooperative launch, at the reference's M = N = 64."""
+    from mobocmf_amd.mlls import VariationalELBOMF
+    from mobocmf_amd.util.graphed_step import GraphedELBOStep
+    cfg = dict(d=2, L=2, M=64, N=64, S=2, seed=3)
+    prob, x, y, fid, _ = _problem(cfg)
+    torch.manual_seed(5)
+    a = synthetic.model_from_problem(prob, num_samples_for_training=2, device=DEV)
+    torch.manual_seed(5)
+    b = synthetic.model_from_problem(prob, num_samples_for_training=2, device=DEV)
+    torch.manual_seed(77)
+    ga = GraphedELBOStep(a, VariationalELBOMF(a, 64, 2), x.to(DEV), y[:, None].to(DEV), fid[:, None].to(DEV), lr=3e-3)
+    for la, lb in zip(a._layers(), b._layers()):
+        lb._rng(torch.device(DEV, torch.cuda.current_device())).copy_(la._rng(la._rng_state.device))
+    tb = _coop([b], [x], [y], [fid], [None], lr=3e-3)
+    for k in range(5):
+        loss, kl = ga.step()
+        tb.step()
+        ga.stream.synchronize()
+        tb.check()
+        assert rel(tb.loss[0], loss) < 1e-9, (k, rel(tb.loss[0], loss))
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert rel(pb, pa) < 1e-7
+
+
+def test_coop_step_reports_a_failed_cholesky_and_replays_from_a_graph():
+    from mobocmf_amd.layers.mfdgp_hidden_layer import NotPSDError
+    cfg = CASES[1]
+    prob, x, y, fid, eps = _problem(cfg)
+    model = synthetic.model_from_problem(prob, num_samples_for_training=1, device=DEV)
+    ref = synthetic.model_from_problem(prob, num_samples_for_training=1, device=DEV)
+    step, sref = _coop([model], [x], [y], [fid], [eps]), _coop([ref], [x], [y], [fid], [eps])
+    g = torch.cuda.CUDAGraph()      # an ordinary launch: capturable
+    with torch.cuda.graph(g, stream=step.stream, capture_error_mode="thread_local"):
+        step.step()
+    for _ in range(3):
+        with torch.cuda.stream(step.stream):
+            g.replay()
+        sref.step()
+    step.check()
+    sref.check()
+    for pa, pb in zip(model.parameters(), ref.parameters()):
+        assert torch.equal(pa, pb)
+    with torch.no_grad():
+        model.hidden_layer_1.covar_module.kernels[1].base_kernel.raw_lengthscale.fill_(float("nan"))
+    step.step()
+    with pytest.raises((NotPSDError, FloatingPointError)):
+        step.check()
+
+
+def test_C2_seeds_match_oracle():
+    """BASELINE config 2 (d = 2, 2 fidelities, M = 128, N = 512, S = 8; SURVEY 8(d) inputs), seeds 0-2: ELBO, scaled KL and every
+    gradient of the cooperative launch vs the oracle's dense evaluation.  128 inducing points in 2-D: cond(K_mm + 1e-6 I) ~ 1e9,
+    either implementation carries ~cond * eps -- gates as test_hip_fullsize.py uses at C2 (north star: 1e-4)."""
+    for seed in (0, 1, 2):
+        cfg = dict(synthetic.CONFIGS["C2"])
+        prob = synthetic.make_problem(d=cfg["d"], L=cfg["L"], M=cfg["M"], N=cfg["N"], S=cfg["S"], seed=seed)
+        tc = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+        x, y, fid = tc(prob["x"]), tc(prob["y"]), tc(prob["fid"])
+        eps = [None] + [tc(e) for e in prob["eps"][1:]]
+        model = synthetic.model_from_problem(prob, num_samples_for_training=cfg["S"], device=DEV)
+        raw = _raw_from_model(model, cfg["L"])
+        e_o, skl_o = O.elbo(O.state_from_raw(raw), x, y, fid, eps=eps, S=cfg["S"])
+        (-e_o).backward()
+        step = _coop([model], [x], [y], [fid], [eps], want_grad=True)
+        grads = step.gradients()[0]
+        step.check()
+        out = step.losses[0].cpu()
+        assert rel(out[0], e_o) < 1e-7 and rel(out[1], skl_o) < 1e-7, (seed, out, e_o)
+        for l in range(cfg["L"]):
+            for key, tt in raw["layers"][l].items():
+                p = _model_param_for(model, l, key)
+                gref = tt.grad if key != "L_S" else torch.tril(tt.grad)
+                assert rel(grads[p].reshape(gref.shape), gref) < 1e-4, (seed, l, key, rel(grads[p].reshape(gref.shape), gref))
