@@ -29,7 +29,7 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-constexpr int CT = 256;                          // threads per workgroup
+constexpr int CT = 512;                          // threads per workgroup: two wavefronts per SIMD (the phases are latency-bound)
 constexpr int CNW = CT / 64;
 constexpr int CMAXM = MOBOCMF_COOP_MAX_M;
 constexpr int KSMAX = 4;                         // k-slices of the weighted syrk, at most
@@ -74,7 +74,7 @@ __host__ __device__ inline void cgeom_of(const mobocmf_tiny_model& md, CGeom& g)
         g.vec[l] = wo;
         wo += (int64_t)NVEC * g.ncp[l];
         g.sml[l] = wo;
-        if (l < md.L) wo += 5 * g.Mp + 16;
+        if (l < md.L) wo += 6 * g.Mp + HS + 24;
         g.part[l] = wo;
         wo += (int64_t)g.ncb[l] * g.pstr;
         g.hpart[l] = wo;
@@ -87,10 +87,32 @@ __host__ __device__ inline void cgeom_of(const mobocmf_tiny_model& md, CGeom& g)
 // matrices of a layer (offsets in units of Mp * Mp from mat[l])
 enum { M_L = 0, M_LI = 1, M_LIT = 2, M_U = 3, M_UT = 4, M_G1 = 5, M_GT = 6, M_HS = 7, M_HCS = 7 + KSMAX,
        M_Y = M_HS, M_T4T = M_G1, M_T5 = M_GT };
-// small vectors of a layer (offsets in units of Mp from sml[l]; the KL sits behind them)
-enum { S_AV = 0, S_DAV = 1, S_DAT = 2, S_GMA = 3, S_GMB = 4 };
+// small vectors of a layer (offsets in units of Mp from sml[l]): a, da, da_tot, L^-T da_tot, the K_mm Gram backward's share of
+// g_m[l-1], the column blocks' summed d/dzf rows (S_GZ); behind them the KL (1), and the summed hyper-parameter partials + the
+// noise-gradient sum (RED: HS + 1)
+enum { S_AV = 0, S_DAV = 1, S_DAT = 2, S_GMA = 3, S_GMB = 4, S_GZ = 5 };
 // per-column vectors of a layer (units of ncp from vec[l])
 enum { V_F = 0, V_EPS = 1, V_MEAN = 2, V_VAR = 3, V_KNN = 4, V_Q = 5, V_RAW = 6, V_GMU = 7, V_GV = 8, V_CGV = 9, V_GF = 10 };
+
+// global-memory views of generic pointers (global_load / global_store instead of flat accesses; and the compiler then knows
+// that they cannot alias LDS, so the loads of a batch are issued together instead of one per LDS store)
+typedef const __attribute__((address_space(1))) double* gcd;
+typedef __attribute__((address_space(1))) double* gwd;
+#define GC(p) ((gcd)(p))
+#define GW(p) ((gwd)(p))
+
+// n elements dealt to the CT threads, B per thread at a time: all B loads are issued before the first store (a loop that loads,
+// waits and stores element by element pays one L2 round trip per element: ~1 us each right after a barrier's invalidate)
+template <int B, class LoadF, class StoreF>
+__device__ __forceinline__ void batched(int n, int tid, LoadF ld, StoreF st) {
+    for (int base = tid; base < n; base += CT * B) {
+        double v[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) { const int e = base + b * CT; v[b] = ld(e < n ? e : n - 1); }
+#pragma unroll
+        for (int b = 0; b < B; ++b) { const int e = base + b * CT; if (e < n) st(e, v[b]); }
+    }
+}
 
 __device__ __forceinline__ v4d mfma(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
@@ -164,27 +186,59 @@ __device__ __forceinline__ bool group_barrier(unsigned long long* cnt, unsigned 
 }
 
 // One 16 x 16 tile of T X for a column block X [k][XLD] in LDS and a matrix T given k-major in global memory (Tk[k * ld + row]
-// = T[row][k]): k tiles kt0 .. kt1-1.  The 4 x 16 fragments of T are fetched one k tile ahead of their use.
-__device__ __forceinline__ v4d tile_tx(const double* Tk, int ld, const double* X, int t, int kt0, int kt1, int lane) {
+// = T[row][k]): k tiles kt0 .. kt1-1 (at most 8).  ALL 4 x 16 fragments of T are requested before the first MFMA: one L2 round
+// trip per tile instead of one per k tile.
+__device__ __forceinline__ v4d tile_tx(const double* Tk_, int ld, const double* X, int t, int kt0, int kt1, int lane) {
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     if (kt0 >= kt1) return acc;
-    const int li = lane & 15, lk = lane >> 4;
-    const double* tp = Tk + (int64_t)lk * ld + t * 16 + li;
+    const int li = lane & 15, lk = lane >> 4, nk = kt1 - kt0;
+    gcd tp = GC(Tk_) + (int64_t)lk * ld + t * 16 + li;
     const double* xp = X + lk * XLD + li;
-    double a[4], an[4];
+    double a[8][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = tp[(int64_t)(kt0 * 16 + 4 * q) * ld];
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int kn = kt + 1 < kt1 ? kt + 1 : kt;
+    for (int kk = 0; kk < 8; ++kk) {
+        if (kk < 4 || nk > 4) {      // (uniform)
+            const int kt = kk < nk ? kt0 + kk : kt1 - 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) an[q] = tp[(int64_t)(kn * 16 + 4 * q) * ld];
+            for (int q = 0; q < 4; ++q) a[kk][q] = tp[(int64_t)(kt * 16 + 4 * q) * ld];
+        }
+    }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = mfma(a[q], xp[(kt * 16 + 4 * q) * XLD], acc);
+    for (int kk = 0; kk < 8; ++kk) {
+        if (kk < nk) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = an[q];
+            for (int q = 0; q < 4; ++q) acc = mfma(a[kk][q], xp[((kt0 + kk) * 16 + 4 * q) * XLD], acc);
+        }
     }
     return acc;
 }
+// The same in two halves: the fragments of T's tile column t requested into registers (they depend on the layer only: a
+// workgroup that runs several column blocks of a layer keeps them), and the product with a column block.
+__device__ __forceinline__ void tile_load(const double* Tk_, int ld, int t, int kt0, int kt1, int lane, double (&a)[8][4]) {
+    const int li = lane & 15, lk = lane >> 4, nk = kt1 - kt0;
+    gcd tp = GC(Tk_) + (int64_t)lk * ld + t * 16 + li;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        if (kk < nk) {      // (uniform)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[kk][q] = tp[(int64_t)((kt0 + kk) * 16 + 4 * q) * ld];
+        }
+    }
+}
+__device__ __forceinline__ v4d tile_mma(const double (&a)[8][4], const double* X, int kt0, int kt1, int lane) {
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    const int li = lane & 15, lk = lane >> 4, nk = kt1 - kt0;
+    const double* xp = X + lk * XLD + li;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        if (kk < nk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = mfma(a[kk][q], xp[((kt0 + kk) * 16 + 4 * q) * XLD], acc);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ double xor_add(double v, int mask) { return v + __shfl_xor(v, mask); }
 __device__ __forceinline__ void store_x(double* X, int t, int lane, v4d acc) {      // accumulator tile t -> X[k][XLD]
     const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
@@ -203,68 +257,140 @@ __device__ __forceinline__ int wave_tiles(int wave, int nt, int (&t)[2]) {
     t[1] = nt - 1 - p;
     return t[1] != p ? 2 : 1;
 }
-__device__ __forceinline__ void tile_of(int t, int& ti, int& tj) {      // index in the packed lower triangle -> (ti, tj <= ti)
+__device__ __forceinline__ void tile_of_slow(int t, int& ti, int& tj) {      // index in the packed lower triangle -> (ti, tj <= ti)
     ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     tj = t - ti * (ti + 1) / 2;
 }
+#define tile_of(t, ti, tj) do { const int tm_ = tmap[t]; ti = tm_ >> 4; tj = tm_ & 15; } while (0)
 
-constexpr int XFW = DBT + 2;      // a staged data row of a column block: x (zero padded), f, valid flag
+constexpr int XFW = DBT + 5;      // a staged data row of a column block: x (zero padded), f, valid flag, y, fidelity, row weight
+
+
+// ---- Every phase is a function of its own with its own scope: as ONE 1400-line body the kernel made the compiler hoist the
+// address arithmetic of all phases to the top of every loop nest and spill it (hundreds of scratch round trips, ~15 us in front
+// of a phase).  What the phases share lives in LDS: the surrogate's descriptor, its geometry, and this context.
+// (PHASE_FN: inlined.  As functions of their own the phases each saved and restored ~110 callee-saved VGPRs through scratch
+// memory at entry and exit -- 4-7 us per call; inlined, they still get their own scopes, and nothing of one phase is live in
+// the next: what they share is re-read from LDS.)
+#define PHASE_FN __device__ __forceinline__
+// a wave-uniform value read from LDS lands in a VGPR (two for a pointer or a double); through v_readfirstlane it lives in SGPRs
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return u.d;
+}
+template <class T>
+__device__ __forceinline__ T* uni(T* p) {
+    union { T* p; int i[2]; } u;
+    u.p = p;
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return u.p;
+}
+struct Ctx {
+    const mobocmf_tiny_model* models;
+    double* lds;                        // behind descriptor, geometry and context
+    unsigned long long *mcnt, *gcnt;    // arrival counters: this surrogate's workgroups / the whole grid
+    double lr, b1, b2, aeps;
+    int k, wj, do_update, n_stamp;
+};
+constexpr int MDW = (sizeof(mobocmf_tiny_model) + 15) / 16 * 2;      // (doubles)
+constexpr int GEW = (sizeof(CGeom) + 15) / 16 * 2;
+constexpr int CXW = (sizeof(Ctx) + 15) / 16 * 2;
 
 #ifdef COOP_STAMPS
-#define CSTAMP() do { if (tid == 0 && wj == 0) stamps[n_stamp] = (double)wall_clock64(); ++n_stamp; } while (0)
+// (diagnostic build: workgroup 0 of a surrogate writes (id, 100 MHz wall clock) pairs behind its workspace; tools/coop_stamps.py)
+#define CSTAMP(id) do { if (tid == 0) { if (wj == 0 && cx->n_stamp < 120) { double* st_ = md.work + g.work_len; st_[2 * cx->n_stamp] = (double)(id); st_[2 * cx->n_stamp + 1] = (double)wall_clock64(); } cx->n_stamp += 1; } } while (0)
 #else
-#define CSTAMP() do { } while (0)
+#define CSTAMP(id) do { } while (0)
 #endif
-#define MODEL_BARRIER() do { if (!group_barrier(mcnt, (unsigned)k, flag)) { if (tid == 0) { md.info[0] = -1; md.out[2] = __builtin_nan(""); } return; } CSTAMP(); } while (0)
 
-__global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model* models, int k, unsigned long long* sync_words,
-                                                       double lr, double b1, double b2, double aeps, int do_update) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int mi = blockIdx.x / k, wj = blockIdx.x % k;
-    const mobocmf_tiny_model& md = models[mi];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-    CGeom g;
-    cgeom_of(md, g);
-    const int L = g.L, M = g.M, Mp = g.Mp, nt = g.nt, d = g.d, S = g.S;
-    const int64_t mm = (int64_t)Mp * Mp;
-    unsigned long long* mcnt = sync_words + 16 * (int64_t)mi;
-    unsigned long long* gcnt = sync_words + 16 * (int64_t)(gridDim.x / k);
-    double* W = md.work;
-    double* gflat = W;
-    // ---- LDS
-    double* hy = lds;                          // [TLM][HS] constrained hyper-parameters
-    double* il = hy + TLM * HS;                // [TLM][2 DBT] inverse lengthscales
-    double* sc = il + TLM * 2 * DBT;           // [32]: tau[l] 0..2, Adam's bias terms 12, 13, bsum scratch 16..23, barrier flag 30
-    int* flag = (int*)(sc + 30);
-    double** seg_ptr = (double**)(sc + 32);    // [NSEG] parameter tensors in flat-vector order (trainable ones; else null)
-    int* seg_end = (int*)(seg_ptr + NSEG);     // [NSEG]
-    double* big = sc + 32 + NSEG + NSEG / 2;
-    // chain view of `big`
-    double* ztc = big;                         // [Mp][ZW]  Z~ of the layer; later m (0..Mp) and diag(L) (Mp..2Mp)
-    double* Lp = ztc + Mp * ZW;                // packed swizzled tiles of L (later: of tril(L_S))
-    double* Lip = Lp + g.ntri * 256;           // ... of L^-1
-    // column-block view of `big`
-    double* zt = big;                          // [Mp][ZW]
-    double* X0 = zt + Mp * ZW;                 // three [Mp][XLD] column blocks
-    double* X1 = X0 + Mp * XLD;
-    double* X2 = X1 + Mp * XLD;
-    double* avl = X2 + Mp * XLD;               // [Mp] a = L^-1 m of the layer
-    double* xf = avl + Mp;                     // [16][XFW] the block's data rows
-    double* gcol = xf + 16 * XFW;              // [4][16] per-column scalars of the block
-    double* red = gcol + 64;                   // [16][16][3] partial column sums
-    double* redh = red + 768;                  // [CNW][HS + 1] wavefront partials
-#ifdef COOP_STAMPS
-    double* stamps = W + g.work_len;
-    int n_stamp = 0;
-#endif
-    CSTAMP();
-    const double gkl = md.kl_scale, ge = -1.0;
-    auto MAT = [&](int l, int m) -> double* { return W + g.mat[l] + (int64_t)m * mm; };
-    auto VEC = [&](int l, int v) -> double* { return W + g.vec[l] + (int64_t)v * g.ncp[l]; };
-    auto SML = [&](int l, int v) -> double* { return W + g.sml[l] + (int64_t)v * Mp; };
-    auto PART = [&](int l, int cb) -> double* { return W + g.part[l] + (int64_t)cb * g.pstr; };
+// the locals every phase starts from (what it does not use costs nothing)
+#define CTX_LOCALS                                                                                                        \
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];                                                      \
+    const mobocmf_tiny_model& md = *(const mobocmf_tiny_model*)lds_all;                                                   \
+    const CGeom& g = *(const CGeom*)(lds_all + MDW);                                                                      \
+    Ctx* cx = (Ctx*)(lds_all + MDW + GEW);                                                                                \
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;                       \
+    const int k = uni(cx->k), wj = uni(cx->wj), do_update = uni(cx->do_update);                                           \
+    const mobocmf_tiny_model* models = uni(cx->models);                                                                   \
+    const int L = uni(g.L), M = uni(g.M), Mp = uni(g.Mp), nt = uni(g.nt), d = uni(g.d), S = uni(g.S);                     \
+    const int64_t mm = (int64_t)Mp * Mp;                                                                                  \
+    double* W = uni(md.work);                                                                                             \
+    double* gflat = W;                                                                                                    \
+    double* hy = lds_all + MDW + GEW + CXW;        /* [TLM][HS] constrained hyper-parameters (derived from the __shared__ symbol: a pointer read back from memory would be a generic one and every LDS access a flat one) */                           \
+    double* il = hy + TLM * HS;                    /* [TLM][2 DBT] inverse lengthscales */                                \
+    double* sc = il + TLM * 2 * DBT;               /* [32]: tau[l] 0..2, log tau 8..10, Adam's bias terms 12, 13, bsum scratch 16..23, barrier flag 30 */ \
+    double** seg_ptr = (double**)(sc + 32);        /* [NSEG] parameter tensors in flat-vector order (trainable ones; else null) */ \
+    int* seg_end = (int*)(seg_ptr + NSEG);         /* [NSEG] */                                                           \
+    int* tmap = seg_end + NSEG;                    /* [40] packed lower-triangle index -> (ti << 4) | tj */               \
+    double* big = sc + 32 + NSEG + NSEG / 2 + 20;                                                                         \
+    double* ztc = big;                             /* chain view: [Mp][ZW] Z~ of the layer; later m and diag(L) */        \
+    double* Lp = ztc + Mp * ZW;                    /* packed swizzled tiles of L (later: of tril(L_S)) */                 \
+    double* Lip = Lp + g.ntri * 256;               /* ... of L^-1 */                                                      \
+    double* zta = big;                             /* column view: [L][Mp][ZW] Z~ of every layer */                       \
+    double* X0 = zta + L * Mp * ZW;                /* three [Mp][XLD] column blocks */                                    \
+    double* X1 = X0 + Mp * XLD;                                                                                           \
+    double* X2 = X1 + Mp * XLD;                                                                                           \
+    double* ava = X2 + Mp * XLD;                   /* [L][Mp] a = L^-1 m of every layer */                                \
+    double* xf = ava + L * Mp;                     /* [16][XFW] the block's data rows */                                  \
+    double* gcol = xf + 16 * XFW;                  /* [4][16] per-column scalars of the block */                          \
+    double* red = gcol + 64;                       /* [CT / 16][16][3] partial column sums */                             \
+    double* redh = red + (CT / 16) * 16 * 3;       /* [CNW][HS + 1] wavefront partials */                                 \
+    const double gkl = uni(md.kl_scale), ge = -1.0;                                                                       \
+    const double lr = uni(cx->lr), b1 = uni(cx->b1), b2 = uni(cx->b2), aeps = uni(cx->aeps);                              \
+    auto MAT = [&](int l, int m) -> double* { return W + uni((int)g.mat[l]) + (int64_t)m * mm; };                         \
+    auto VEC = [&](int l, int v) -> double* { return W + uni((int)g.vec[l]) + (int64_t)v * uni(g.ncp[l]); };              \
+    auto SML = [&](int l, int v) -> double* { return W + uni((int)g.sml[l]) + (int64_t)v * Mp; };                         \
+    auto PART = [&](int l, int cb) -> double* { return W + uni((int)g.part[l]) + (int64_t)cb * uni(g.pstr); };            \
+    (void)lane; (void)wave; (void)li; (void)lk; (void)k; (void)wj; (void)do_update; (void)models; (void)L; (void)M;      \
+    (void)nt; (void)d; (void)S; (void)mm; (void)gflat; (void)hy; (void)il; (void)sc; (void)seg_ptr; (void)seg_end;        \
+    (void)tmap; (void)ztc; (void)Lp; (void)Lip; (void)zta; (void)X0; (void)X1; (void)X2; (void)ava; (void)xf; (void)gcol; \
+    (void)red; (void)redh; (void)gkl; (void)ge; (void)lr; (void)b1; (void)b2; (void)aeps; (void)MAT; (void)VEC;          \
+    (void)SML; (void)PART
 
+#define FRAG(dst, P, k0, x0) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dst[q_] = GC(P)[(int64_t)((k0) + 4 * q_ + lk) * Mp + (x0) + li]
+#define COPY4(dst, src) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dst[q_] = src[q_]
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+#define DEF_STAGE_ROWS \
+    auto stage_rows = [&](int l, int c0, bool forward) { \
+        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l]; \
+        if (tid < 16) { \
+            const int c = c0 + tid; \
+            const bool valid = c < nc; \
+            double f = 0.0; \
+            if (kind && valid) { \
+                if (forward) { \
+                    const int fdiv = l == 1 ? S : 1, cp = c / fdiv; \
+                    const int64_t* rng = md.rng[l]; \
+                    const double ev = md.eps[l] ? md.eps[l][c] : philox_normal((uint64_t)rng[0], (uint64_t)rng[1], (uint64_t)c); \
+                    f = VEC(l - 1, V_MEAN)[cp] + sqrt(VEC(l - 1, V_VAR)[cp]) * ev; \
+                    VEC(l, V_F)[c] = f; \
+                    VEC(l, V_EPS)[c] = ev; \
+                } else { \
+                    f = VEC(l, V_F)[c]; \
+                } \
+            } \
+            const int b = valid ? c / div : 0; \
+            xf[tid * XFW + DBT] = f; \
+            xf[tid * XFW + DBT + 1] = valid ? 1.0 : 0.0; \
+            xf[tid * XFW + DBT + 2] = md.y[b]; \
+            xf[tid * XFW + DBT + 3] = md.fid[b]; \
+            xf[tid * XFW + DBT + 4] = md.row_weight ? md.row_weight[b] : 1.0; \
+        } \
+        if (tid >= 64 && tid < 64 + 16 * DBT) { \
+            const int j = (tid - 64) / DBT, kk = (tid - 64) % DBT, c = c0 + j; \
+            xf[j * XFW + kk] = (c < nc && kk < d) ? md.x[(int64_t)(c / div) * d + kk] : 0.0; \
+        } \
+    };
+
+
+PHASE_FN void ph_setup() {
+    CTX_LOCALS;
     // ---- P0 (every workgroup for itself): constrained hyper-parameters, inverse lengthscales, noise, parameter table
     for (int e = tid; e < TLM * HS; e += CT) {
         const int l = e / HS, t = e % HS;
@@ -299,6 +425,11 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
         seg_ptr[kk] = ptr;
         seg_end[kk] = end;
     }
+    if (tid >= 128 && tid < 128 + 40) {
+        int ti = 0, tj = 0;
+        if (tid - 128 < g.ntri) tile_of_slow(tid - 128, ti, tj);
+        tmap[tid - 128] = (ti << 4) | tj;
+    }
     if (tid == CT - 1 && (do_update == 1 || do_update == 4)) {
         const double step = (double)(md.steps_done[0] + 1);
         sc[12] = 1.0 - pow(b1, step);
@@ -307,6 +438,7 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     if (tid < L) {
         const double lo = md.noise_lo[tid], hi = md.noise_hi[tid], r = md.raw_noise[tid][0];
         sc[tid] = hi > lo ? lo + (hi - lo) / (1.0 + exp(-r)) : r;
+        sc[8 + tid] = log(sc[tid]);
     }
     if ((do_update == 2 || do_update == 4) && md.xrng && md.rand_rows > 0 && wj == 0) {
         // the x~ of this iteration (blackbox_mfdgp_fitter.py:276): every model of the launch draws the SAME points
@@ -325,20 +457,26 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
         il[e] = v;
     }
     __syncthreads();
+    CSTAMP(1);
+}
 
+
+PHASE_FN void ph_chain() {
+    CTX_LOCALS;
     // ---- P1: the M x M chain forward of layer l by ONE workgroup, L and L^-1 in LDS
     for (int l = wj; l < L; l += k) {
         const int kind = l > 0;
         const double* hyl = hy + l * HS;
         const double* ill = il + l * 2 * DBT;
-        for (int e = tid; e < Mp * ZW; e += CT) {
-            const int m = e / ZW, kk = e % ZW;
-            double v = 0.0;
-            if (m < M) {
-                if (kk < d) v = md.Zx[m * d + kk];
-                else if (kk == DBT && l > 0) v = md.m[l - 1][m];
+        for (int e = tid; e < Mp * ZW; e += CT) ztc[e] = 0.0;
+        __syncthreads();
+        {
+            gcd zx = GC(md.Zx);
+            batched<4>(M * d, tid, [&](int e) { return zx[e]; }, [&](int e, double v) { ztc[(e / d) * ZW + e % d] = v; });
+            if (l > 0) {
+                gcd mp = GC(md.m[l - 1]);
+                batched<1>(M, tid, [&](int e) { return mp[e]; }, [&](int e, double v) { ztc[e * ZW + DBT] = v; });
             }
-            ztc[e] = v;
         }
         __syncthreads();
         for (int e = tid; e < g.ntri * 256; e += CT) {      // K_mm + jitter I, lower tiles (identity beyond M)
@@ -357,6 +495,7 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
             Lp[t * 256 + tel(r, c)] = v;
         }
         __syncthreads();
+        CSTAMP(2);
         // blocked right-looking Cholesky, 16-wide: diagonal tile in registers (one wavefront), panel and trailing update on the MFMA
         int fail = 0;
         for (int s = 0; s < nt; ++s) {
@@ -393,11 +532,10 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
             __syncthreads();
         }
         if (tid == 0) md.info[l] = fail;
+        CSTAMP(3);
         // off-diagonal tiles of L^-1, one block column per wavefront: X_is = -L_ii^-1 sum_{t = s .. i-1} L_it X_ts
-        for (int p = wave; p < (nt + 1) / 2; p += CNW) {
-            for (int h = 0; h < 2; ++h) {
-                const int s = h ? nt - 1 - p : p;
-                if (h && s == p) break;
+        for (int s = wave; s < nt; s += CNW) {
+            {
                 for (int i = s + 1; i < nt; ++i) {
                     v4d acc = {0.0, 0.0, 0.0, 0.0};
                     for (int t = s; t < i; ++t) {
@@ -417,11 +555,12 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
             }
         }
         __syncthreads();
+        CSTAMP(4);
         // L, L^-1, L^-T to global (the other workgroups read them k-major); diag(L) and m kept; L's tiles then hold tril(L_S)
         {
-            double* Lg = MAT(l, M_L);
-            double* Lig = MAT(l, M_LI);
-            double* LiTg = MAT(l, M_LIT);
+            gwd Lg = GW(MAT(l, M_L));
+            gwd Lig = GW(MAT(l, M_LI));
+            gwd LiTg = GW(MAT(l, M_LIT));
             for (int e = tid; e < g.ntri * 256; e += CT) {
                 const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
                 int ti, tj;
@@ -431,27 +570,38 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                 LiTg[(int64_t)(tj * 16 + r) * Mp + ti * 16 + c] = Lip[t * 256 + tel(c, r)];
             }
             for (int i = tid; i < Mp; i += CT) {
-                ztc[i] = i < M ? md.m[l][i] : 0.0;
+                ztc[i] = 0.0;
                 ztc[Mp + i] = Lp[tix(i >> 4, i >> 4) + tel(i & 15, i & 15)];
             }
         }
         __syncthreads();
         {
-            const double* ls = md.L_S[l];
-            for (int e = tid; e < g.ntri * 256; e += CT) {
-                const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
-                int ti, tj;
-                tile_of(t, ti, tj);
-                const int i = ti * 16 + r, j = tj * 16 + c;
-                Lp[t * 256 + tel(r, c)] = (i < M && j <= i) ? ls[(int64_t)i * M + j] : 0.0;
-            }
+            gcd mp = GC(md.m[l]);
+            batched<1>(M, tid, [&](int e) { return mp[e]; }, [&](int e, double v) { ztc[e] = v; });
+            gcd ls = GC(md.L_S[l]);
+            batched<8>(g.ntri * 256, tid,
+                       [&](int e) {
+                           const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
+                           int ti, tj;
+                           tile_of(t, ti, tj);
+                           const int i = ti * 16 + r, j = tj * 16 + c;
+                           return ls[(int64_t)(i < M ? i : M - 1) * M + (j < M ? j : M - 1)];
+                       },
+                       [&](int e, double v) {
+                           const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
+                           int ti, tj;
+                           tile_of(t, ti, tj);
+                           const int i = ti * 16 + r, j = tj * 16 + c;
+                           Lp[t * 256 + tel(r, c)] = (i < M && j <= i) ? v : 0.0;
+                       });
         }
         __syncthreads();
+        CSTAMP(5);
         // U = L^-1 L_S (lower tiles), both orientations to global; a = L^-1 m; KL = 1/2 [2 sum log L_ii - sum log L_S,ii^2 + |U|^2 + |a|^2 - M]
         double klacc = 0.0;
         {
-            double* Ug = MAT(l, M_U);
-            double* UTg = MAT(l, M_UT);
+            gwd Ug = GW(MAT(l, M_U));
+            gwd UTg = GW(MAT(l, M_UT));
             for (int u = wave; u < g.ntri; u += CNW) {
                 int ti, tj;
                 tile_of(u, ti, tj);
@@ -471,80 +621,77 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                 }
             }
             double* avg = SML(l, S_AV);
-            for (int i = tid; i < Mp; i += CT) {
+            {
+                const int i = tid >> 2, part = tid & 3;      // four threads per row (CT / 4 >= Mp)
                 double a = 0.0;
-                const int ti = i >> 4, r = i & 15;
-                for (int kk = 0; kk <= i; ++kk) a += Lip[tix(ti, kk >> 4) + tel(r, kk & 15)] * ztc[kk];
-                avg[i] = a;
-                if (i < M) klacc += 0.5 * a * a + log(ztc[Mp + i] / fabs(Lp[tix(ti, ti) + tel(r, r)])) - 0.5;
+                if (i < Mp) {
+                    const int ti = i >> 4, r = i & 15;
+                    for (int kk = part; kk <= i; kk += 4) a += Lip[tix(ti, kk >> 4) + tel(r, kk & 15)] * ztc[kk];
+                }
+                a = xor_add(xor_add(a, 1), 2);
+                if (i < Mp && part == 0) {
+                    const int ti = i >> 4, r = i & 15;
+                    avg[i] = a;
+                    if (i < M) klacc += 0.5 * a * a + log(ztc[Mp + i] / fabs(Lp[tix(ti, ti) + tel(r, r)])) - 0.5;
+                }
             }
         }
         const double kl = bsum<CNW>(klacc, sc + 16);
-        if (tid == 0) W[g.sml[l] + 5 * Mp] = kl;
+        if (tid == 0) W[g.sml[l] + 6 * Mp] = kl;
         __syncthreads();
     }
-    CSTAMP();
-    MODEL_BARRIER();
+}
 
+
+PHASE_FN void ph_stage() {
+    CTX_LOCALS;
     // ---- forward, layer by layer: a workgroup per block of 16 columns
-    int zt_layer = -1;
-    auto stage_layer = [&](int l) {      // Z~_l and a_l into LDS (all threads; ends with a barrier)
-        if (zt_layer == l) return;
-        __syncthreads();
-        for (int e = tid; e < Mp * ZW; e += CT) {
-            const int m = e / ZW, kk = e % ZW;
-            double v = 0.0;
-            if (m < M) {
-                if (kk < d) v = md.Zx[m * d + kk];
-                else if (kk == DBT && l > 0) v = md.m[l - 1][m];
+    // Z~_l = [Z_x, m_{l-1}] and a_l of EVERY layer into LDS, once (parameters and chain results: fixed for the rest of the step)
+    for (int e = tid; e < L * Mp * ZW; e += CT) zta[e] = 0.0;
+    __syncthreads();
+    {
+        gcd zx = GC(md.Zx);
+        for (int l = 0; l < L; ++l) {
+            double* ztl = zta + l * Mp * ZW;
+            batched<4>(M * d, tid, [&](int e) { return zx[e]; }, [&](int e, double v) { ztl[(e / d) * ZW + e % d] = v; });
+            if (l > 0) {
+                gcd mp = GC(md.m[l - 1]);
+                batched<1>(M, tid, [&](int e) { return mp[e]; }, [&](int e, double v) { ztl[e * ZW + DBT] = v; });
             }
-            zt[e] = v;
+            gcd avg = GC(SML(l, S_AV));
+            double* avl_ = ava + l * Mp;
+            batched<1>(Mp, tid, [&](int e) { return avg[e]; }, [&](int e, double v) { avl_[e] = v; });
         }
-        const double* avg = SML(l, S_AV);
-        for (int i = tid; i < Mp; i += CT) avl[i] = avg[i];
-        zt_layer = l;
-        __syncthreads();
-    };
+    }
+    __syncthreads();
+    CSTAMP(7);
     // the block's data rows: x (zero padded to DBT), f, valid flag; layer >= 1 draws / reads f = mean + sqrt(var) eps
-    auto stage_rows = [&](int l, int c0, bool forward) {
-        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
-        if (tid < 16) {
-            const int c = c0 + tid;
-            const bool valid = c < nc;
-            double f = 0.0;
-            if (kind && valid) {
-                if (forward) {
-                    const int fdiv = l == 1 ? S : 1, cp = c / fdiv;
-                    const int64_t* rng = md.rng[l];
-                    const double ev = md.eps[l] ? md.eps[l][c] : philox_normal((uint64_t)rng[0], (uint64_t)rng[1], (uint64_t)c);
-                    f = VEC(l - 1, V_MEAN)[cp] + sqrt(VEC(l - 1, V_VAR)[cp]) * ev;
-                    VEC(l, V_F)[c] = f;
-                    VEC(l, V_EPS)[c] = ev;
-                } else {
-                    f = VEC(l, V_F)[c];
-                }
-            }
-            xf[tid * XFW + DBT] = f;
-            xf[tid * XFW + DBT + 1] = valid ? 1.0 : 0.0;
-        }
-        if (tid >= 64 && tid < 64 + 16 * DBT) {
-            const int j = (tid - 64) / DBT, kk = (tid - 64) % DBT, c = c0 + j;
-            xf[j * XFW + kk] = (c < nc && kk < d) ? md.x[(int64_t)(c / div) * d + kk] : 0.0;
-        }
-    };
-    for (int l = 0; l < L; ++l) {
-        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
-        const double* hyl = hy + l * HS;
-        const double* ill = il + l * 2 * DBT;
-        const double* LiTg = MAT(l, M_LIT);
-        const double* Ug = MAT(l, M_U);
-        double* ATg = W + g.pan[l];
-        double* CTg = ATg + (int64_t)g.ncp[l] * Mp;
-        for (int cb = wj; cb < g.ncb[l]; cb += k) {
-            stage_layer(l);
+}
+
+
+PHASE_FN void ph_forward(int l_in) {
+    CTX_LOCALS;
+    DEF_STAGE_ROWS
+        const bool has_tile = wave < nt;
+        for (int cb = wj; cb < g.ncb[l_in]; cb += k) {
+            // (the layer number goes through an opaque move in every iteration: what depends on it -- a dozen workspace addresses --
+            // is then formed where it is used instead of being hoisted in front of the loop and spilled across it)
+            int l = l_in;
+            asm volatile("" : "+s"(l));
+            const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
+            const double* hyl = hy + l * HS;
+            const double* ill = il + l * 2 * DBT;
+            const double* zt = zta + l * Mp * ZW;
+            const double* avl = ava + l * Mp;
+            const double* LiTg = MAT(l, M_LIT);
+            const double* Ug = MAT(l, M_U);
+            double* ATg = W + g.pan[l];
+            double* CTg = ATg + (int64_t)g.ncp[l] * Mp;
+            CSTAMP(50);
             const int c0 = cb * 16;
             stage_rows(l, c0, true);
             __syncthreads();
+            CSTAMP(51);
             // F1: K block
             for (int e = tid; e < Mp * 16; e += CT) {
                 const int m = e >> 4, j = e & 15;
@@ -557,40 +704,48 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                 X0[m * XLD + j] = v;
             }
             __syncthreads();
-            int tl[2];
-            const int ntl = wave_tiles(wave, nt, tl);
+            CSTAMP(52);
             // F2: A = L^-1 K
-            for (int h = 0; h < ntl; ++h) store_x(X1, tl[h], lane, tile_tx(LiTg, Mp, X0, tl[h], 0, tl[h] + 1, lane));
+            if (has_tile) store_x(X1, wave, lane, tile_tx(LiTg, Mp, X0, wave, 0, wave + 1, lane));
             __syncthreads();
+            CSTAMP(53);
             // F3: C = U^T A
-            for (int h = 0; h < ntl; ++h) store_x(X2, tl[h], lane, tile_tx(Ug, Mp, X1, tl[h], tl[h], nt, lane));
+            if (has_tile) store_x(X2, wave, lane, tile_tx(Ug, Mp, X1, wave, wave, nt, lane));
             __syncthreads();
+            CSTAMP(54);
             // F4: moments, the block's share of the data term; A, C to global (column-major: the backward's operand layout)
             {
                 const int j = tid & 15, part = tid >> 4;
                 double q = 0.0, mu = 0.0, r = 0.0;
-                for (int m = part; m < Mp; m += 16) {
+                for (int m = part; m < Mp; m += CT / 16) {
                     const double a = X1[m * XLD + j], c = X2[m * XLD + j];
                     q += a * a;
                     mu += avl[m] * a;
                     r += c * c;
                 }
-                red[(part * 16 + j) * 3 + 0] = q;
-                red[(part * 16 + j) * 3 + 1] = mu;
-                red[(part * 16 + j) * 3 + 2] = r;
+                q = xor_add(xor_add(q, 16), 32);
+                mu = xor_add(xor_add(mu, 16), 32);
+                r = xor_add(xor_add(r, 16), 32);
+                if (lane < 16) {
+                    red[(wave * 16 + lane) * 3 + 0] = q;
+                    red[(wave * 16 + lane) * 3 + 1] = mu;
+                    red[(wave * 16 + lane) * 3 + 2] = r;
+                }
             }
             for (int e = tid; e < 16 * Mp; e += CT) {
                 const int j = e / Mp, m = e % Mp;
-                ATg[(int64_t)(c0 + j) * Mp + m] = X1[m * XLD + j];
-                CTg[(int64_t)(c0 + j) * Mp + m] = X2[m * XLD + j];
+                GW(ATg)[(int64_t)(c0 + j) * Mp + m] = X1[m * XLD + j];
+                GW(CTg)[(int64_t)(c0 + j) * Mp + m] = X2[m * XLD + j];
             }
             __syncthreads();
+            CSTAMP(55);
             if (wave == 0) {
                 double dterm = 0.0;
                 if (lane < 16 && c0 + lane < nc) {
                     const int c = c0 + lane;
                     double q = 0.0, mu = 0.0, r = 0.0;
-                    for (int p = 0; p < 16; ++p) {
+#pragma unroll
+                    for (int p = 0; p < CNW; ++p) {
                         q += red[(p * 16 + lane) * 3 + 0];
                         mu += red[(p * 16 + lane) * 3 + 1];
                         r += red[(p * 16 + lane) * 3 + 2];
@@ -600,27 +755,30 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                     double sres = knn - q;
                     if (!md.branch && sres < 0.0) sres = 0.0;
                     const double vr = sres + r, var = vr < MINV ? MINV : vr;
-                    VEC(l, V_MEAN)[c] = mu; VEC(l, V_VAR)[c] = var; VEC(l, V_KNN)[c] = knn; VEC(l, V_Q)[c] = q; VEC(l, V_RAW)[c] = vr;
-                    const int b = c / div;
-                    if (md.fid[b] == (double)l) {
-                        const double tau = sc[l], dlt = md.y[b] - mu, w = md.row_weight ? md.row_weight[b] : 1.0;
-                        dterm = w * (-0.5 * ((dlt * dlt + var) / tau + log(tau) + LOG2PI)) / div;
+                    GW(VEC(l, V_MEAN))[c] = mu; GW(VEC(l, V_VAR))[c] = var; GW(VEC(l, V_KNN))[c] = knn; GW(VEC(l, V_Q))[c] = q;
+                    GW(VEC(l, V_RAW))[c] = vr;
+                    if (xf[lane * XFW + DBT + 3] == (double)l) {
+                        const double tau = sc[l], dlt = xf[lane * XFW + DBT + 2] - mu, w = xf[lane * XFW + DBT + 4];
+                        dterm = w * (-0.5 * ((dlt * dlt + var) / tau + sc[8 + l] + LOG2PI)) / div;
                     }
-                    if (l == L - 1 && md.top_mean) { md.top_mean[c] = mu; md.top_var[c] = var; }
+                    if (l == L - 1 && md.top_mean) { GW(md.top_mean)[c] = mu; GW(md.top_var)[c] = var; }
                 }
                 dterm = wsum63(dterm);
                 if (lane == 63) PART(l, cb)[0] = dterm;
             }
             __syncthreads();
         }
-        MODEL_BARRIER();
-    }
+}
+
+
+PHASE_FN void ph_elbo() {
+    CTX_LOCALS;
     // ---- the ELBO (one wavefront of the surrogate's first workgroup; nobody waits for it)
     if (wj == 0 && wave == 0) {
         double data = 0.0, kl = 0.0;
         for (int l = 0; l < L; ++l) {
             for (int cb = lane; cb < g.ncb[l]; cb += 64) data += PART(l, cb)[0];
-            if (lane == 0) kl += W[g.sml[l] + 5 * Mp];
+            if (lane == 0) kl += W[g.sml[l] + 6 * Mp];
         }
         data = wsum63(data);
         kl = wsum63(kl);
@@ -630,26 +788,31 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
             md.out[2] = -(data - gkl * kl);
         }
     }
-    if (do_update == 2) return;
-    if (do_update == 4) {
+}
+
+
+PHASE_FN bool ph_couple() {
+    CTX_LOCALS;
         // the conditioned iteration in one launch: all models' top-layer moments are in memory; the whole grid meets, the first
         // workgroup of every model forms the theta / omega factor gradients of its model (tiny_step.hip coupling_seeds), the
         // model's workgroups meet again
         const mobocmf_tiny_coupling& cpl = *md.coupling;
         if (cpl.n_models * k != (int)gridDim.x || cpl.T < 1 || cpl.T > 256 || cpl.P < 1) {
             if (tid == 0 && wj == 0) { atomicOr(cpl.status, 2); md.info[0] = -2; md.out[2] = __builtin_nan(""); }
-            return;
+            return false;
         }
-        if (!group_barrier(gcnt, gridDim.x, flag)) {
+        if (!group_barrier(cx->gcnt, gridDim.x, (int*)(sc + 30))) {
             if (tid == 0 && wj == 0) { atomicOr(cpl.status, 1); md.info[0] = -1; md.out[2] = __builtin_nan(""); }
-            return;
+            return false;
         }
         if (wj == 0) coupling_seeds<CT>(models, md, g.ncol[L - 1], W + g.cpl_off, sc + 16);
-        MODEL_BARRIER();
-    }
+    return true;
+}
 
     // ---- the weighted syrk H = A diag(gv) A^T, Hc = A diag(cgv) A^T of layer lh, k-sliced: one (tile, slice) per wavefront
-    auto h_tasks = [&](int lh) {
+
+PHASE_FN void ph_syrk(int lh) {
+    CTX_LOCALS;
         const double* ATg = W + g.pan[lh];
         const double* vgv = VEC(lh, V_GV);
         const double* vcg = VEC(lh, V_CGV);
@@ -712,25 +875,33 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                 dat[i] = s + gkl * avg[i];
             }
         }
-    };
+}
 
-    // ---- backward, top layer first: a workgroup per block of 16 columns; the syrk of the layer above rides along
-    for (int l = L - 1; l >= 0; --l) {
-        const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
-        const double* hyl = hy + l * HS;
-        const double* ill = il + l * 2 * DBT;
-        const double* Lig = MAT(l, M_LI);
-        const double* UTg = MAT(l, M_UT);
-        const double* ATg = W + g.pan[l];
-        const double* CTg = ATg + (int64_t)g.ncp[l] * Mp;
-        for (int cb = wj; cb < g.ncb[l]; cb += k) {
-            stage_layer(l);
+
+PHASE_FN void ph_backward(int l_in) {
+    CTX_LOCALS;
+    DEF_STAGE_ROWS
+        const bool has_tile = wave < nt;
+        for (int cb = wj; cb < g.ncb[l_in]; cb += k) {
+            int l = l_in;
+            asm volatile("" : "+s"(l));
+            const int kind = l > 0, div = l ? S : 1, nc = g.ncol[l];
+            const double* hyl = hy + l * HS;
+            const double* ill = il + l * 2 * DBT;
+            const double* zt = zta + l * Mp * ZW;
+            const double* avl = ava + l * Mp;
+            const double* Lig = MAT(l, M_LI);
+            const double* UTg = MAT(l, M_UT);
+            const double* ATg = W + g.pan[l];
+            const double* CTg = ATg + (int64_t)g.ncp[l] * Mp;
+            CSTAMP(60);
             const int c0 = cb * 16;
             stage_rows(l, c0, false);
-            for (int e = tid; e < 16 * Mp; e += CT) {
-                const int j = e / Mp, m = e % Mp;
-                X1[m * XLD + j] = ATg[(int64_t)(c0 + j) * Mp + m];
-                X2[m * XLD + j] = CTg[(int64_t)(c0 + j) * Mp + m];
+            {
+                gcd ap = GC(ATg) + (int64_t)c0 * Mp;
+                gcd cp = GC(CTg) + (int64_t)c0 * Mp;
+                batched<4>(16 * Mp, tid, [&](int e) { return ap[e]; }, [&](int e, double v) { X1[(e % Mp) * XLD + e / Mp] = v; });
+                batched<4>(16 * Mp, tid, [&](int e) { return cp[e]; }, [&](int e, double v) { X2[(e % Mp) * XLD + e / Mp] = v; });
             }
             // B1: upstream gradients of the block's moments: its own data term + what the next layer sent back through f
             if (wave == 1) {
@@ -777,14 +948,13 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                 if (lane == 63) PART(l, cb)[1] = st;
             }
             __syncthreads();
-            int tl[2];
-            const int ntl = wave_tiles(wave, nt, tl);
+            CSTAMP(61);
             // B2: dA = 2 U (C diag gv) + a g_mean^T - 2 A diag(cgv)   (the column scale commutes with the product)
-            for (int h = 0; h < ntl; ++h) {
-                const v4d acc = tile_tx(UTg, Mp, X2, tl[h], 0, tl[h] + 1, lane);
+            if (has_tile) {
+                const v4d acc = tile_tx(UTg, Mp, X2, wave, 0, wave + 1, lane);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = tl[h] * 16 + 4 * r + lk;
+                    const int i = wave * 16 + 4 * r + lk;
                     X0[i * XLD + li] = 2.0 * gcol[16 + li] * acc[r] + avl[i] * gcol[li] - 2.0 * X1[i * XLD + li] * gcol[32 + li];
                 }
             }
@@ -795,9 +965,11 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                 PART(l, cb)[PHEAD + HS + Mp + i] = s;
             }
             __syncthreads();
+            CSTAMP(62);
             // B3: dK = L^-T dA
-            for (int h = 0; h < ntl; ++h) store_x(X2, tl[h], lane, tile_tx(Lig, Mp, X0, tl[h], tl[h], nt, lane));
+            if (has_tile) store_x(X2, wave, lane, tile_tx(Lig, Mp, X0, wave, wave, nt, lane));
             __syncthreads();
+            CSTAMP(63);
             // B4: Gram backward of (dK, dk_nn = cgv), element by element
             double hacc[HS];
 #pragma unroll
@@ -830,14 +1002,16 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                 }
             }
             __syncthreads();
+            CSTAMP(64);
             // B5: the block's partial sums: hyper-parameters (fixed slot layout), d/df of its columns, d/dzf rows
             if (tid < HS) PART(l, cb)[PHEAD + tid] = slot_used(kind, d, tid) ? red_sum<CNW>(redh, HS + 1, tid) : 0.0;
             if (kind) {
                 {
                     const int j = tid & 15, part = tid >> 4;
                     double s = 0.0;
-                    for (int m = part; m < Mp; m += 16) s += X0[m * XLD + j];
-                    red[part * 16 + j] = s;
+                    for (int m = part; m < Mp; m += CT / 16) s += X0[m * XLD + j];
+                    s = xor_add(xor_add(s, 16), 32);
+                    if (lane < 16) red[wave * 16 + lane] = s;
                 }
                 for (int m = tid; m < Mp; m += CT) {
                     double s = 0.0;
@@ -849,94 +1023,161 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                 if (tid < 16) {
                     const int c = c0 + tid;
                     double s = 0.0;
-                    for (int p = 0; p < 16; ++p) s += red[p * 16 + tid];
+#pragma unroll
+                    for (int p = 0; p < CNW; ++p) s += red[p * 16 + tid];
                     VEC(l, V_GF)[c] = c < nc ? s + gcol[32 + tid] * hyl[0] * 2.0 * hyl[2] * xf[tid * XFW + DBT] : 0.0;
                 }
             }
             __syncthreads();
         }
-        if (l + 1 < L) h_tasks(l + 1);
-        MODEL_BARRIER();
-    }
-    h_tasks(0);
-    MODEL_BARRIER();
+        CSTAMP(20 + l_in);
+}
 
-    // ---- the M x M chain backward, every layer at once, tile-parallel: one 16 x 16 output tile per wavefront
+    // ---- the M x M chain backward, every layer at once, tile-parallel: one 16 x 16 output tile per wavefront.
+    // Operand fragments are k-major (rows k0 + 4 q + lk, q = 0..3; 16 contiguous columns from x0): 4 rows x 128 contiguous bytes
+    // per load instruction; the fragments of k tile kt + 1 are requested before the MFMAs of k tile kt are issued.
+
+PHASE_FN void ph_cb1() {
+    CTX_LOCALS;
     const int gw = wj * CNW + wave, nwv = k * CNW, nt2 = nt * nt;
-    // k-major fragment of a matrix: rows k0 + 4 q + lk (q = 0..3), 16 contiguous columns from column x0
-#define FRAG(dst, P, k0, x0) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dst[q_] = (P)[(int64_t)((k0) + 4 * q_ + lk) * Mp + (x0) + li]
-    // CB1: G1 = U^T H, GT = H U (= G1^T: H is symmetric -- both orientations, so that every later read is k-major)
-    for (int u = gw; u < L * nt2; u += nwv) {
-        const int l = u / nt2, ti = (u % nt2) / nt, tj = u % nt;
+    // CB1: G1 = U^T H, GT = H U (= G1^T: H is symmetric -- both orientations, so that every later read is k-major); two tile
+    // products per task, H read as the sum of its k-slices.  Beside them: the column blocks' partial sums of a layer added up
+    // (hyper-parameters, noise, d/dzf rows), one wavefront per 64 of them.
+    for (int u = gw; u < 2 * L * nt2; u += nwv) {
+        const int which = u / (L * nt2), l = (u % (L * nt2)) / nt2, ti = (u % nt2) / nt, tj = u % nt;
         const double* Ug = MAT(l, M_U);
         const int ks = g.ks[l];
-        v4d a1 = {0.0, 0.0, 0.0, 0.0}, a2 = {0.0, 0.0, 0.0, 0.0};
-        for (int kt = ti < tj ? ti : tj; kt < nt; ++kt) {
-            double ui[4], uj[4], hi[4], hj[4], tmp[4];
-            FRAG(ui, Ug, kt * 16, ti * 16);
-            FRAG(uj, Ug, kt * 16, tj * 16);
-            FRAG(hi, MAT(l, M_HS), kt * 16, ti * 16);
-            FRAG(hj, MAT(l, M_HS), kt * 16, tj * 16);
-            for (int s2 = 1; s2 < ks; ++s2) {
-                FRAG(tmp, MAT(l, M_HS + s2), kt * 16, ti * 16);
+        // which 0: G1[i][j] = sum_{k >= i-block} U[k][i] H[k][j];  1: GT[i][j] = sum_{k >= j-block} H[k][i] U[k][j]
+        const int ucol = which ? tj * 16 : ti * 16, hcol = which ? ti * 16 : tj * 16, kt0 = which ? tj : ti;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        double uf[4], hf[KSMAX][4], un[4], hn[KSMAX][4];
+        const double* Hb = MAT(l, M_HS);
+        FRAG(uf, Ug, kt0 * 16, ucol);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hi[q] += tmp[q];
-                FRAG(tmp, MAT(l, M_HS + s2), kt * 16, tj * 16);
+        for (int s2 = 0; s2 < KSMAX; ++s2)
+            if (s2 < ks) { FRAG(hf[s2], Hb + s2 * mm, kt0 * 16, hcol); }
+        for (int kt = kt0; kt < nt; ++kt) {
+            const int kn = kt + 1 < nt ? kt + 1 : kt;
+            FRAG(un, Ug, kn * 16, ucol);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hj[q] += tmp[q];
+            for (int s2 = 0; s2 < KSMAX; ++s2)
+                if (s2 < ks) { FRAG(hn[s2], Hb + s2 * mm, kn * 16, hcol); }
+            PIN();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double h = hf[0][q];
+#pragma unroll
+                for (int s2 = 1; s2 < KSMAX; ++s2)
+                    if (s2 < ks) h += hf[s2][q];
+                acc = which ? mfma(h, uf[q], acc) : mfma(uf[q], h, acc);
             }
-            if (kt >= ti) {
+            PIN();
+            COPY4(uf, un);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a1 = mfma(ui[q], hj[q], a1);
-            }
-            if (kt >= tj) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a2 = mfma(hi[q], uj[q], a2);
-            }
+            for (int s2 = 0; s2 < KSMAX; ++s2)
+                if (s2 < ks) { COPY4(hf[s2], hn[s2]); }
         }
-        double* G1 = MAT(l, M_G1);
-        double* GT = MAT(l, M_GT);
+        gwd G = GW(MAT(l, which ? M_GT : M_G1));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            G1[(int64_t)(ti * 16 + 4 * r + lk) * Mp + tj * 16 + li] = a1[r];
-            GT[(int64_t)(ti * 16 + 4 * r + lk) * Mp + tj * 16 + li] = a2[r];
+        for (int r = 0; r < 4; ++r) G[(int64_t)(ti * 16 + 4 * r + lk) * Mp + tj * 16 + li] = acc[r];
+    }
+    {
+        const int nel = PHEAD + HS + Mp, nch = (nel + 63) / 64, first = (2 * L * nt2) % nwv;
+        for (int u = (gw - first + nwv) % nwv; u < L * nch; u += nwv) {
+            const int l = u / nch, e = (u % nch) * 64 + lane, ncb = g.ncb[l];
+            if (e < nel) {
+                gcd pp = GC(W + g.part[l]) + e;
+                double s = 0.0;
+                for (int cb = 0; cb < ncb; cb += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) v[b] = pp[(int64_t)(cb + b < ncb ? cb + b : ncb - 1) * g.pstr];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) s += cb + b < ncb ? v[b] : 0.0;
+                }
+                // (layout of the sums: [PHEAD scalars | HS hyper-parameter slots] behind the KL, the d/dzf rows in S_GZ)
+                if (e < PHEAD + HS) W[g.sml[l] + 6 * Mp + 1 + e] = s;
+                else SML(l, S_GZ)[e - PHEAD - HS] = s;
+            }
         }
     }
-    MODEL_BARRIER();
-    // CB2+3: Y = 2 (U G1 - Hc) + a da^T + da_tot a^T + dU_tot U^T with dU_tot = 2 tril(G1^T) + gkl U;
-    //        g_LS = tril(L^-T dU_tot) - gkl diag(1 / L_S,ii);  g_m += L^-T da_tot (one more wavefront task per layer)
-    for (int u = gw; u < L * nt2 + L; u += nwv) {
+}
+
+
+PHASE_FN void ph_cb23() {
+    CTX_LOCALS;
+    const int gw = wj * CNW + wave, nwv = k * CNW, nt2 = nt * nt;
+    // CB2+3: Y = 2 (U G1 - Hc) + a da^T + da_tot a^T + dU_tot U^T with dU_tot = 2 tril(G1^T) + gkl U (one task per tile);
+    //        g_LS = tril(L^-T dU_tot) - gkl diag(1 / L_S,ii) (one task per lower tile)
+    for (int u = gw; u < L * nt2 + L * g.ntri; u += nwv) {
         if (u >= L * nt2) {
-            const int l = u - L * nt2;
+            const int l = (u - L * nt2) / g.ntri;
+            int ti, tj;
+            tile_of((u - L * nt2) % g.ntri, ti, tj);
+            const double* Ug = MAT(l, M_U);
+            const double* GT = MAT(l, M_GT);
             const double* Lig = MAT(l, M_LI);
-            const double* dat = SML(l, S_DAT);
-            double* gma = SML(l, S_GMA);
-            for (int i = lane; i < Mp; i += 64) {
-                double s = 0.0;
-                for (int kk = i; kk < Mp; ++kk) s += Lig[(int64_t)kk * Mp + i] * dat[kk];
-                gma[i] = s;
+            v4d s3 = {0.0, 0.0, 0.0, 0.0};
+            double la[4], gt[4], ub[4], lan[4], gtn[4], ubn[4];
+            FRAG(la, Lig, ti * 16, ti * 16);      // L^-1[k][i]
+            FRAG(gt, GT, ti * 16, tj * 16);       // G1[j][k]
+            FRAG(ub, Ug, ti * 16, tj * 16);       // U[k][j]
+            for (int kt = ti; kt < nt; ++kt) {
+                const int kn = kt + 1 < nt ? kt + 1 : kt;
+                FRAG(lan, Lig, kn * 16, ti * 16);
+                FRAG(gtn, GT, kn * 16, tj * 16);
+                FRAG(ubn, Ug, kn * 16, tj * 16);
+                PIN();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = kt * 16 + 4 * q + lk, j = tj * 16 + li;
+                    const double du = j <= kk ? 2.0 * gt[q] + gkl * ub[q] : 0.0;      // dU_tot[k][j]
+                    s3 = mfma(la[q], du, s3);
+                }
+                PIN();
+                COPY4(la, lan); COPY4(gt, gtn); COPY4(ub, ubn);
+            }
+            gwd gls = GW(gflat + g.flat_off[l] + g.H[l] + M);
+            gcd ls = GC(md.L_S[l]);
+            const int j = tj * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + 4 * r + lk;
+                if (i < M && j < M) {
+                    double t = 0.0;
+                    if (j <= i) {
+                        t = s3[r];
+                        if (i == j) t -= gkl / ls[(int64_t)i * M + i];
+                    }
+                    gls[(int64_t)i * M + j] = t;
+                    if (ti != tj) gls[(int64_t)j * M + i] = 0.0;      // the upper triangle of g_LS: zeros
+                }
             }
             continue;
         }
         const int l = u / nt2, ti = (u % nt2) / nt, tj = u % nt;
-        const double* Ug = MAT(l, M_U);
         const double* UTg = MAT(l, M_UT);
         const double* G1 = MAT(l, M_G1);
-        const double* GT = MAT(l, M_GT);
-        const double* Lig = MAT(l, M_LI);
         const int ks = g.ks[l];
-        v4d s1 = {0.0, 0.0, 0.0, 0.0}, s2 = {0.0, 0.0, 0.0, 0.0}, s3 = {0.0, 0.0, 0.0, 0.0};
+        v4d s1 = {0.0, 0.0, 0.0, 0.0}, s2 = {0.0, 0.0, 0.0, 0.0};
         const int kmin = ti < tj ? ti : tj;
+        double ua[4], gb[4], gi[4], ub[4], uan[4], gbn[4], gin[4], ubn[4];
+        FRAG(ua, UTg, 0, ti * 16);      // U[i][k]
+        FRAG(gb, G1, 0, tj * 16);       // G1[k][j]
+        FRAG(gi, G1, 0, ti * 16);       // G1[k][i]
+        FRAG(ub, UTg, 0, tj * 16);      // U[j][k]
         for (int kt = 0; kt <= ti; ++kt) {
-            double ua[4], gb[4];
-            FRAG(ua, UTg, kt * 16, ti * 16);      // U[i][k]
-            FRAG(gb, G1, kt * 16, tj * 16);       // G1[k][j]
+            const int kn = kt + 1 <= ti ? kt + 1 : kt;
+            FRAG(uan, UTg, kn * 16, ti * 16);
+            FRAG(gbn, G1, kn * 16, tj * 16);
+            if (kn <= kmin) {
+                FRAG(gin, G1, kn * 16, ti * 16);
+                FRAG(ubn, UTg, kn * 16, tj * 16);
+            }
+            PIN();
 #pragma unroll
             for (int q = 0; q < 4; ++q) s1 = mfma(ua[q], gb[q], s1);
             if (kt <= kmin) {
-                double gi[4], ub[4];
-                FRAG(gi, G1, kt * 16, ti * 16);   // G1[k][i]
-                FRAG(ub, UTg, kt * 16, tj * 16);  // U[j][k]
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int kk = kt * 16 + 4 * q + lk, i = ti * 16 + li;
@@ -944,112 +1185,135 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
                     s2 = mfma(du, ub[q], s2);
                 }
             }
+            PIN();
+            COPY4(ua, uan); COPY4(gb, gbn); COPY4(gi, gin); COPY4(ub, ubn);
         }
-        if (tj <= ti) {
-            for (int kt = ti; kt < nt; ++kt) {
-                double la[4], gt[4], ub[4];
-                FRAG(la, Lig, kt * 16, ti * 16);  // L^-1[k][i]
-                FRAG(gt, GT, kt * 16, tj * 16);   // G1[j][k]
-                FRAG(ub, Ug, kt * 16, tj * 16);   // U[k][j]
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int kk = kt * 16 + 4 * q + lk, j = tj * 16 + li;
-                    const double du = j <= kk ? 2.0 * gt[q] + gkl * ub[q] : 0.0;      // dU_tot[k][j]
-                    s3 = mfma(la[q], du, s3);
-                }
-            }
-        }
-        const double* avg = SML(l, S_AV);
-        const double* dav = SML(l, S_DAV);
-        const double* dat = SML(l, S_DAT);
-        double* Y = MAT(l, M_Y);
-        double* gls = gflat + g.flat_off[l] + g.H[l] + M;
-        const double* ls = md.L_S[l];
+        gcd avg = GC(SML(l, S_AV));
+        gcd dav = GC(SML(l, S_DAV));
+        gcd dat = GC(SML(l, S_DAT));
+        gwd Y = GW(MAT(l, M_Y));
         const int j = tj * 16 + li;
         const double aj = avg[j], dj = dav[j];
+        double hc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sl = 0; sl < KSMAX; ++sl) {
+            if (sl < ks) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hc[r] += GC(MAT(l, M_HCS) + sl * mm)[(int64_t)(ti * 16 + 4 * r + lk) * Mp + j];
+            }
+        }
+        // (Y overwrites slice 0 of H, which CB1 was the last to read; Hc is a different matrix)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + 4 * r + lk;
-            double hc = 0.0;
-            for (int sl = 0; sl < ks; ++sl) hc += MAT(l, M_HCS + sl)[(int64_t)i * Mp + j];
-            // (Y overwrites slice 0 of H, which CB1 was the last to read; Hc is a different matrix)
-            Y[(int64_t)i * Mp + j] = 2.0 * (s1[r] - hc) + avg[i] * dj + dat[i] * aj + s2[r];
-            if (i < M && j < M) {
-                double t = 0.0;
-                if (j <= i) {
-                    t = s3[r];
-                    if (i == j) t -= gkl / ls[(int64_t)i * M + i];
-                }
-                gls[(int64_t)i * M + j] = t;
-            }
+            Y[(int64_t)i * Mp + j] = 2.0 * (s1[r] - hc[r]) + avg[i] * dj + dat[i] * aj + s2[r];
         }
     }
-    MODEL_BARRIER();
-    // CB4-6, one workgroup per block of 16 columns of Y: dL = -tril(L^-T Y) + gkl diag(1 / L_ii), P = Phi(L^T dL), T4 = L^-T P
+}
+
+
+PHASE_FN void ph_cb456() {
+    CTX_LOCALS;
+    // CB4-6, one workgroup per block of 16 columns of Y: dL = -tril(L^-T Y) + gkl diag(1 / L_ii), P = Phi(L^T dL), T4 = L^-T P;
     for (int u = wj; u < L * nt; u += k) {
         const int l = u / nt, cb = u % nt;
         const double* Lg = MAT(l, M_L);
         const double* Lig = MAT(l, M_LI);
         const double* Y = MAT(l, M_Y);
         __syncthreads();
-        for (int e = tid; e < Mp * 16; e += CT) X0[(e >> 4) * XLD + (e & 15)] = Y[(int64_t)(e >> 4) * Mp + cb * 16 + (e & 15)];
+        const int ntl = wave < nt ? 1 : 0, t = wave;
+        {
+            gcd yp = GC(Y) + cb * 16;
+            batched<4>(Mp * 16, tid, [&](int e) { return yp[(int64_t)(e >> 4) * Mp + (e & 15)]; },
+                       [&](int e, double v) { X0[(e >> 4) * XLD + (e & 15)] = v; });
+        }
         __syncthreads();
-        int tl[2];
-        const int ntl = wave_tiles(wave, nt, tl);
-        for (int h = 0; h < ntl; ++h) {
-            const v4d acc = tile_tx(Lig, Mp, X0, tl[h], tl[h], nt, lane);
+        if (ntl) {
+            const v4d acc = tile_tx(Lig, Mp, X0, t, t, nt, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = tl[h] * 16 + 4 * r + lk, j = cb * 16 + li;
+                const int i = t * 16 + 4 * r + lk, j = cb * 16 + li;
                 double v = j <= i ? -acc[r] : 0.0;
-                if (i == j && i < M) v += gkl / Lg[(int64_t)i * Mp + i];
+                if (i == j && i < M) v += gkl / GC(Lg)[(int64_t)i * Mp + i];
                 X1[i * XLD + li] = v;
             }
         }
         __syncthreads();
-        for (int h = 0; h < ntl; ++h) {
-            const v4d acc = tile_tx(Lg, Mp, X1, tl[h], tl[h], nt, lane);
+        if (ntl) {
+            const v4d acc = tile_tx(Lg, Mp, X1, t, t, nt, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = tl[h] * 16 + 4 * r + lk, j = cb * 16 + li;
+                const int i = t * 16 + 4 * r + lk, j = cb * 16 + li;
                 X2[i * XLD + li] = j < i ? acc[r] : (j == i ? 0.5 * acc[r] : 0.0);
             }
         }
         __syncthreads();
-        for (int h = 0; h < ntl; ++h) {
-            const int t = tl[h];
-            store_x(X0, t, lane, tile_tx(Lig, Mp, X2, t, t > cb ? t : cb, nt, lane));
-        }
+        if (ntl) store_x(X0, t, lane, tile_tx(Lig, Mp, X2, t, t > cb ? t : cb, nt, lane));
         __syncthreads();
-        double* T4T = MAT(l, M_T4T);
+        gwd T4T = GW(MAT(l, M_T4T));
         for (int e = tid; e < 16 * Mp; e += CT) {
             const int j = e / Mp, m = e % Mp;
             T4T[(int64_t)(cb * 16 + j) * Mp + m] = X0[m * XLD + j];
         }
     }
-    MODEL_BARRIER();
-    // CB7: T5 = T4 L^-1
-    for (int u = gw; u < L * nt2; u += nwv) {
+}
+
+
+PHASE_FN void ph_cb7() {
+    CTX_LOCALS;
+    const int gw = wj * CNW + wave, nwv = k * CNW, nt2 = nt * nt;
+    // CB7: T5 = T4 L^-1 (a task per tile); g_m += L^-T da_tot (a task per 16 rows: da_tot rides as column 0 of a B operand)
+    for (int u = gw; u < L * nt2 + L * nt; u += nwv) {
+        if (u >= L * nt2) {
+            const int l = (u - L * nt2) / nt, t = (u - L * nt2) % nt;
+            const double* Lig = MAT(l, M_LI);
+            gcd dat = GC(SML(l, S_DAT));
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kt = t; kt < nt; ++kt) {
+                double a[4], b[4];
+                FRAG(a, Lig, kt * 16, t * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = dat[kt * 16 + 4 * q + lk];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = mfma(a[q], li == 0 ? b[q] : 0.0, acc);
+            }
+            if (li == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) SML(l, S_GMA)[t * 16 + 4 * r + lk] = acc[r];
+            }
+            continue;
+        }
         const int l = u / nt2, ti = (u % nt2) / nt, tj = u % nt;
         const double* T4T = MAT(l, M_T4T);
         const double* Lig = MAT(l, M_LI);
         v4d acc = {0.0, 0.0, 0.0, 0.0};
+        double a[4], b[4], an[4], bn[4];
+        FRAG(a, T4T, tj * 16, ti * 16);
+        FRAG(b, Lig, tj * 16, tj * 16);
         for (int kt = tj; kt < nt; ++kt) {
-            double a[4], b[4];
-            FRAG(a, T4T, kt * 16, ti * 16);
-            FRAG(b, Lig, kt * 16, tj * 16);
+            const int kn = kt + 1 < nt ? kt + 1 : kt;
+            FRAG(an, T4T, kn * 16, ti * 16);
+            FRAG(bn, Lig, kn * 16, tj * 16);
+            PIN();
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = mfma(a[q], b[q], acc);
+            PIN();
+            COPY4(a, an); COPY4(b, bn);
         }
-        double* T5 = MAT(l, M_T5);
+        gwd T5 = GW(MAT(l, M_T5));
 #pragma unroll
         for (int r = 0; r < 4; ++r) T5[(int64_t)(ti * 16 + 4 * r + lk) * Mp + tj * 16 + li] = acc[r];
     }
-    MODEL_BARRIER();
+}
+
+
+PHASE_FN void ph_cb8() {
+    CTX_LOCALS;
     // CB8: Gram backward of dK_mm = sym(T5), a workgroup per 16 rows (both arguments are Z~: a pair's f gradient counts twice)
     for (int u = wj; u < L * nt; u += k) {
         const int l = u / nt, ti = u % nt, kind = l > 0;
-        stage_layer(l);
+        const double* zt = zta + l * Mp * ZW;
+        __syncthreads();
         const double* T5 = MAT(l, M_T5);
         const double* hyl = hy + l * HS;
         const double* ill = il + l * 2 * DBT;
@@ -1059,8 +1323,8 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
         const int i = ti * 16 + (tid & 15);
         double rs = 0.0;
         if (i < M) {
-            for (int j = tid >> 4; j < M; j += 16) {
-                const double G = 0.5 * (T5[(int64_t)i * Mp + j] + T5[(int64_t)j * Mp + i]);
+            for (int j = tid >> 4; j < M; j += CT / 16) {
+                const double G = 0.5 * (GC(T5)[(int64_t)i * Mp + j] + GC(T5)[(int64_t)j * Mp + i]);
                 double dfa, dzf;
                 kern_back(kind, d, zt + i * ZW, zt[i * ZW + DBT], zt + j * ZW, hyl, ill, G, hacc, dfa, dzf);
                 rs += dfa;
@@ -1078,71 +1342,86 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
         if (tid < HS) W[g.hpart[l] + (int64_t)ti * HS + tid] = slot_used(kind, d, tid) ? red_sum<CNW>(redh, HS + 1, tid) : 0.0;
         if (tid >= 64 && tid < 80) {
             double s = 0.0;
-            for (int p = 0; p < 16; ++p) s += red[p * 16 + (tid - 64)];
+            for (int p = 0; p < CT / 16; ++p) s += red[p * 16 + (tid - 64)];
             SML(l, S_GMB)[ti * 16 + (tid - 64)] = 2.0 * s;
         }
         __syncthreads();
     }
-    MODEL_BARRIER();
+}
 
-    // ---- raw-parameter gradients assembled from the partial sums, element by element of the flat vector, and Adam
-    // (torch.optim.Adam: p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)); g_LS is in the flat vector already
+
+PHASE_FN void ph_adam() {
+    CTX_LOCALS;
+    // ---- raw-parameter gradients assembled from the (pre-reduced) partial sums, element by element of the flat vector, and Adam
+    // (torch.optim.Adam: p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)); g_LS is in the flat vector already.  Four elements
+    // per thread at a time: their loads are in flight together.
     {
         const double bc1 = sc[12], bc2s = sc[13];
         const bool upd = do_update == 1 || do_update == 4;
-        for (int e = wj * CT + tid; e < (int)g.flat_len; e += k * CT) {
-            int kk = 0;
-#pragma unroll
-            for (int sft = NSEG / 2; sft > 0; sft >>= 1)
-                if (seg_end[kk + sft - 1] <= e) kk += sft;
-            double gi;
+        const int flat = (int)g.flat_len;
+        auto grad_of = [&](int e) -> double {
             if (e >= (int)g.flat_noise) {
                 const int l = e - (int)g.flat_noise, div = l ? S : 1;
-                double s = 0.0;
-                for (int cb = 0; cb < g.ncb[l]; ++cb) s += PART(l, cb)[1];
+                const double s = GC(W)[g.sml[l] + 6 * Mp + 1 + 1];
                 double chain = 1.0;
                 if (md.noise_hi[l] > md.noise_lo[l]) {
                     const double sg = 1.0 / (1.0 + exp(-md.raw_noise[l][0]));
                     chain = (md.noise_hi[l] - md.noise_lo[l]) * sg * (1.0 - sg);
                 }
-                gi = s / div * ge * chain;
-            } else {
-                int l = 0;
-                while (l + 1 < L && e >= (int)g.flat_off[l + 1]) ++l;
-                const int t = e - (int)g.flat_off[l], Hl = g.H[l];
-                if (t < Hl) {
-                    const int slot = slot_of(l > 0, d, t);
-                    double s = 0.0;
-                    for (int cb = 0; cb < g.ncb[l]; ++cb) s += PART(l, cb)[PHEAD + slot];
-                    for (int ti = 0; ti < nt; ++ti) s += W[g.hpart[l] + (int64_t)ti * HS + slot];
-                    int sgm = 0, off = 0;
-                    while (t >= off + seg_len(l, sgm, d)) { off += seg_len(l, sgm, d); ++sgm; }
-                    const double x = md.raw[l][sgm][t - off];
-                    gi = x > 20.0 ? s : s / (1.0 + exp(-x));
-                } else if (t < Hl + M) {
-                    const int i = t - Hl;
-                    double s = SML(l, S_GMA)[i];
-                    if (l + 1 < L) {
-                        s += SML(l + 1, S_GMB)[i];
-                        for (int cb = 0; cb < g.ncb[l + 1]; ++cb) s += PART(l + 1, cb)[PHEAD + HS + i];
-                    }
-                    gi = s;
-                } else {
-                    gi = gflat[e];
-                }
+                return s / div * ge * chain;
             }
-            gflat[e] = gi;
-            if (md.grad) md.grad[e] = gi;
-            double* p = seg_ptr[kk];
-            if (!upd || !p) continue;
-            const int start = kk ? seg_end[kk - 1] : 0;
-            const double mi2 = b1 * md.adam_m[e] + (1.0 - b1) * gi;
-            const double vi = b2 * md.adam_v[e] + (1.0 - b2) * gi * gi;
-            md.adam_m[e] = mi2;
-            md.adam_v[e] = vi;
-            p[e - start] -= (lr / bc1) * mi2 / (sqrt(vi) / bc2s + aeps);
+            int l = 0;
+            while (l + 1 < L && e >= (int)g.flat_off[l + 1]) ++l;
+            const int t = e - (int)g.flat_off[l], Hl = g.H[l];
+            if (t < Hl) {
+                const int slot = slot_of(l > 0, d, t);
+                double s = GC(W)[g.sml[l] + 6 * Mp + 1 + PHEAD + slot];
+                for (int ti = 0; ti < nt; ++ti) s += GC(W)[g.hpart[l] + (int64_t)ti * HS + slot];
+                int sgm = 0, off = 0;
+                while (t >= off + seg_len(l, sgm, d)) { off += seg_len(l, sgm, d); ++sgm; }
+                const double x = md.raw[l][sgm][t - off];
+                return x > 20.0 ? s : s / (1.0 + exp(-x));
+            }
+            if (t < Hl + M) {
+                const int i = t - Hl;
+                double s = GC(SML(l, S_GMA))[i];
+                if (l + 1 < L) s += GC(SML(l + 1, S_GMB))[i] + GC(SML(l + 1, S_GZ))[i];
+                return s;
+            }
+            return GC(gflat)[e];
+        };
+        for (int base = wj * CT + tid; base < flat; base += 4 * k * CT) {
+            double gi[4], am[4], av[4], pv[4];
+            double* pp[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int e0 = base + b * k * CT, e = e0 < flat ? e0 : flat - 1;
+                int kk = 0;
+#pragma unroll
+                for (int sft = NSEG / 2; sft > 0; sft >>= 1)
+                    if (seg_end[kk + sft - 1] <= e) kk += sft;
+                double* p = seg_ptr[kk];
+                pp[b] = (upd && p && e0 < flat) ? p + (e - (kk ? seg_end[kk - 1] : 0)) : nullptr;
+                gi[b] = grad_of(e);
+                am[b] = GC(md.adam_m)[e];
+                av[b] = GC(md.adam_v)[e];
+                pv[b] = pp[b] ? GC(pp[b])[0] : 0.0;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int e = base + b * k * CT;
+                if (e >= flat) continue;
+                GW(gflat)[e] = gi[b];
+                if (md.grad) GW(md.grad)[e] = gi[b];
+                if (!pp[b]) continue;
+                const double mi2 = b1 * am[b] + (1.0 - b1) * gi[b];
+                const double vi = b2 * av[b] + (1.0 - b2) * gi[b] * gi[b];
+                GW(md.adam_m)[e] = mi2;
+                GW(md.adam_v)[e] = vi;
+                GW(pp[b])[0] = pv[b] - (lr / bc1) * mi2 / (sqrt(vi) / bc2s + aeps);
+            }
         }
-        CSTAMP();
+        CSTAMP(40);
         if (upd && wj == 0 && tid == 0) {
             md.steps_done[0] += 1;
             for (int l = 1; l < L; ++l)
@@ -1151,15 +1430,80 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
         }
     }
 }
+
+
+#define MODEL_BARRIER(id) do { CSTAMP(id); if (!group_barrier(cx->mcnt, (unsigned)k, (int*)(sc + 30))) { if (tid == 0) { md.info[0] = -1; md.out[2] = __builtin_nan(""); } return; } CSTAMP(99); } while (0)
+
+__global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model* models_, int k_, unsigned long long* sync_words,
+                                                       double lr_, double b1_, double b2_, double aeps_, int do_update_) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    {
+        // the surrogate's descriptor, its geometry and the phases' context: into LDS once (a descriptor field read through the
+        // global pointer is an L2 round trip whenever the compiler cannot prove that no store in between changed it; the
+        // geometry's per-layer arrays, indexed by the run-time layer, would live in scratch memory as a private struct)
+        const int mi = blockIdx.x / k_;
+        if (threadIdx.x < (int)(sizeof(mobocmf_tiny_model) / 8))
+            ((uint64_t*)lds_all)[threadIdx.x] = ((const uint64_t*)(models_ + mi))[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            cgeom_of(*(const mobocmf_tiny_model*)lds_all, *(CGeom*)(lds_all + MDW));
+            Ctx* c0 = (Ctx*)(lds_all + MDW + GEW);
+            c0->models = models_;
+            c0->lds = lds_all + MDW + GEW + CXW;
+            c0->mcnt = sync_words + 16 * (int64_t)mi;
+            c0->gcnt = sync_words + 16 * (int64_t)(gridDim.x / k_);
+            c0->lr = lr_; c0->b1 = b1_; c0->b2 = b2_; c0->aeps = aeps_;
+            c0->k = k_; c0->wj = blockIdx.x % k_; c0->do_update = do_update_; c0->n_stamp = 0;
+        }
+        __syncthreads();
+    }
+    CTX_LOCALS;
+    CSTAMP(0);
+    ph_setup();
+    ph_chain();
+    MODEL_BARRIER(6);
+    ph_stage();
+    for (int l = 0; l < L; ++l) {
+        ph_forward(l);
+        MODEL_BARRIER(10 + l);
+    }
+    ph_elbo();
+    if (do_update == 2) return;
+    if (do_update == 4) {
+        if (!ph_couple()) return;
+        MODEL_BARRIER(15);
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        ph_backward(l);
+        if (l + 1 < L) ph_syrk(l + 1);
+        MODEL_BARRIER(25 + l);
+    }
+    ph_syrk(0);
+    MODEL_BARRIER(30);
+    ph_cb1();
+    MODEL_BARRIER(31);
+    ph_cb23();
+    MODEL_BARRIER(32);
+    ph_cb456();
+    MODEL_BARRIER(33);
+    ph_cb7();
+    MODEL_BARRIER(34);
+    ph_cb8();
+    MODEL_BARRIER(35);
+    ph_adam();
+}
 #undef FRAG
+#undef COPY4
+#undef PIN
 #undef MODEL_BARRIER
+
 #undef CSTAMP
 
 size_t coop_lds_bytes(int Mp) {
     const int ntri = (Mp / 16) * (Mp / 16 + 1) / 2;
-    const size_t common = (size_t)TLM * HS + (size_t)TLM * 2 * DBT + 32 + NSEG + NSEG / 2;
+    const size_t common = (sizeof(mobocmf_tiny_model) + 15) / 16 * 2 + (sizeof(CGeom) + 15) / 16 * 2 + (size_t)TLM * HS + (size_t)TLM * 2 * DBT + 32 + NSEG + NSEG / 2 + 20;
     const size_t chain = (size_t)Mp * ZW + 2 * (size_t)ntri * 256;
-    const size_t col = (size_t)Mp * ZW + 3 * (size_t)Mp * XLD + Mp + 16 * XFW + 64 + 768 + CNW * (HS + 1);
+    const size_t col = (size_t)TLM * Mp * ZW + 3 * (size_t)Mp * XLD + (size_t)TLM * Mp + 16 * XFW + 64 + (CT / 16) * 16 * 3 + CNW * (HS + 1);
     return (common + (chain > col ? chain : col)) * sizeof(double);
 }
 
@@ -1194,7 +1538,7 @@ int mobocmf_coop_work_bytes(const mobocmf_tiny_model* model, size_t* bytes) {
     cgeom_of(*model, g);
     size_t n = (size_t)g.work_len;
 #ifdef COOP_STAMPS
-    n += 64;
+    n += 256;
 #endif
     *bytes = n * sizeof(double);
     return MOBOCMF_OK;

@@ -35,9 +35,12 @@ def _coop(models, xs, ys, fids, epss, lr=1e-2, want_grad=False, wgs=0):
 @pytest.mark.parametrize("cfg", CASES, ids=IDS)
 def test_coop_step_gradients_match_oracle(cfg):
     """ELBO, scaled KL and every raw-parameter gradient of one launch (no update) vs the oracle's autograd through its dense
-    evaluation of every layer at every row, on a shuffled batch.  Gates as for the one-workgroup kernel and the layer path."""
+    evaluation of every layer at every row, on a shuffled batch.  Gates as for the one-workgroup kernel and the layer path:
+    1e-5 on the gradients, the north star's 1e-4 where dozens of inducing points crowd [0,1]^2 (cond(K_mm + 1e-6 I) ~ 1e9:
+    either implementation carries ~cond * eps, test_hip_fullsize.py at C2)."""
     prob, x, y, fid, eps = _problem(cfg)
     L, S = cfg["L"], cfg["S"]
+    gate = 1e-4 if (cfg["d"] <= 2 and cfg["M"] >= 48) else 1e-5
     model = synthetic.model_from_problem(prob, num_samples_for_training=S, device=DEV)
     raw = _raw_from_model(model, L)
     e_o, skl_o = O.elbo(O.state_from_raw(raw), x, y, fid, eps=eps, S=S)
@@ -51,9 +54,9 @@ def test_coop_step_gradients_match_oracle(cfg):
         for key, tt in raw["layers"][l].items():
             p = _model_param_for(model, l, key)
             gref = tt.grad if key != "L_S" else torch.tril(tt.grad)
-            assert rel(grads[p].reshape(gref.shape), gref) < 1e-5, (l, key, rel(grads[p].reshape(gref.shape), gref))
+            assert rel(grads[p].reshape(gref.shape), gref) < gate, (l, key, rel(grads[p].reshape(gref.shape), gref))
         lk = getattr(model, f"hidden_layer_likelihood_{l}")
-        assert rel(grads[lk.raw_noise].reshape(()), raw["raw_noise"][l].grad) < 1e-5
+        assert rel(grads[lk.raw_noise].reshape(()), raw["raw_noise"][l].grad) < gate
 
 
 @pytest.mark.parametrize("wgs", [1, 2, 3, 7, 16, 40])
