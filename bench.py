@@ -460,6 +460,7 @@ def main():
                     help="skip the second timing of the step in the reference's layout (every layer at every row, dense backward)")
     ap.add_argument("--launch", action="store_true", help="go through the rank launcher even for --gpus 1")
     ap.add_argument("--no-rccl", action="store_true", help="one GPU: do not create the one-rank process group")
+    ap.add_argument("--coop-wgs", type=int, default=0, help="A/B knob: workgroups per surrogate of the cooperative one-launch step (0: automatic)")
     ap.add_argument("--layer-path", action="store_true",
                     help="small configurations: the layer entry points (HIP-graph replay) instead of the one-launch step")
     args = ap.parse_args()
@@ -562,12 +563,22 @@ def main():
 
         # the reference's own sizes (C1): the package trains such surrogates through ONE launch per step for all of them
         # (mobocmf_tiny_elbo_step, util/tiny_step.py) -- so does the bench, unless --layer-path asks for the launch sequence
+        # -- and mid-size surrogates (M <= 128, e.g. C2) through the cooperative one-launch step (mobocmf_coop_elbo_step,
+        # util/coop_step.py), as BlackBoxMFDGPFitter.train_mfdgps does
         tiny = None
         if not rows and not args.layer_path:
+            from mobocmf_amd.util import coop_step as CS
             from mobocmf_amd.util import tiny_step as TS
+            cls = None
             if all(TS.eligible(g.model, g.x, g.fid) for g in gsteps):
-                tiny = TS.TinyELBOStep([g.model for g in gsteps], [cfg["N"]] * len(gsteps), [g.x for g in gsteps],
-                                       [g.y for g in gsteps], [g.fid for g in gsteps], lr=1e-3)
+                cls = TS.TinyELBOStep
+            elif all(CS.worthwhile(g.model, g.x, g.fid) for g in gsteps):
+                cls = CS.CoopELBOStep
+            if cls is not None:
+                tiny = cls([g.model for g in gsteps], [cfg["N"]] * len(gsteps), [g.x for g in gsteps],
+                           [g.y for g in gsteps], [g.fid for g in gsteps], lr=1e-3)
+                if args.coop_wgs and cls is CS.CoopELBOStep:
+                    tiny.wgs_per_model = args.coop_wgs
 
                 def one_step(*_a):
                     return [tiny.step()]
@@ -733,8 +744,10 @@ def main():
             "exchange_payload_bytes": int(local.numel() * 8),
             "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
             "backend": (args.backend if dist is not None else None), "librccl_mapped": rccl_loaded, "rccl_error": rccl_error,
-            "finite": finite, "step_issue": "eager" if args.eager else ("one launch per step for all surrogates "
-                                                                        "(mobocmf_tiny_elbo_step)" if tiny is not None else "hip-graph replay"),
+            "finite": finite, "step_issue": "eager" if args.eager else (
+                ("one launch per step for all surrogates (%s)" % ("mobocmf_coop_elbo_step, %d workgroups per surrogate" % tiny.wgs_used
+                                                                   if hasattr(tiny, "wgs_used") else "mobocmf_tiny_elbo_step"))
+                if tiny is not None else "hip-graph replay"),
         }
         if not args.no_roofline:
             line["roofline"] = measure_dominant_kernel(cfg, device, n_cols=cols[dom], layer=dom)

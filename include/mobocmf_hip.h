@@ -476,7 +476,7 @@ int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
  * `work` is sized by mobocmf_coop_work_bytes.  do_update: 0 gradients only | 1 the step | 2 forward only | 4 the conditioned
  * iteration in one launch (mobocmf_tiny_coupling with n_models = the models of the launch; the barrier of its record is not
  * used: the whole grid meets on the launch's own sync words).
- * wgs_per_model: workgroups sharing one surrogate, 1..64, or 0 = chosen from the widest phase (at most 16); *wgs_used (may be
+ * wgs_per_model: workgroups sharing one surrogate, 1..64, or 0 = chosen from the widest phase (at most 32); *wgs_used (may be
  * NULL) receives the choice.  Every workgroup of the launch must be resident at once (n_models * wgs_per_model <= what the
  * device holds of this kernel: checked, MOBOCMF_BAD_ARG otherwise -- an ordinary launch, not a cooperative one, so that it can
  * be captured into a graph).  sync_words: 16 * (n_models + 1) device int64, zero-initialised ONCE by the caller and then left to

@@ -57,7 +57,7 @@ __host__ __device__ inline void cgeom_of(const mobocmf_tiny_model& md, CGeom& g)
         g.ncp[l] = (g.ncol[l] + 15) & ~15;
         g.ncb[l] = g.ncp[l] / 16;
         g.H[l] = l == 0 ? 1 + md.d : 5 + 2 * md.d;
-        int ks = (g.ncp[l] + 255) / 256;      // ~256 columns (64 MFMAs) per k-slice
+        int ks = (g.ncp[l] + 255) / 256;      // ~256 columns (64 MFMAs of each product) per k-slice
         g.ks[l] = ks < 1 ? 1 : (ks > KSMAX ? KSMAX : ks);
         g.flat_off[l] = fo;
         if (l < md.L) fo += g.H[l] + md.M + (int64_t)md.M * md.M;
@@ -461,73 +461,124 @@ PHASE_FN void ph_setup() {
 }
 
 
-PHASE_FN void ph_chain() {
+// K_mm + jitter I of layer l (lower tiles; identity beyond M): elements first, first + step, ... of the packed tiles, into the
+// swizzled LDS tiles (to_lds) or into the row-major matrix L of the workspace
+PHASE_FN void kmm_tiles(int l, int first, int step, bool to_lds) {
+    CTX_LOCALS;
+    const int kind = l > 0;
+    const double* hyl = hy + l * HS;
+    const double* ill = il + l * 2 * DBT;
+    for (int e = tid; e < Mp * ZW; e += CT) ztc[e] = 0.0;
+    __syncthreads();
+    {
+        gcd zx = GC(md.Zx);
+        batched<4>(M * d, tid, [&](int e) { return zx[e]; }, [&](int e, double v) { ztc[(e / d) * ZW + e % d] = v; });
+        if (l > 0) {
+            gcd mp = GC(md.m[l - 1]);
+            batched<1>(M, tid, [&](int e) { return mp[e]; }, [&](int e, double v) { ztc[e * ZW + DBT] = v; });
+        }
+    }
+    __syncthreads();
+    gwd Kg = GW(MAT(l, M_L));
+    for (int e = first + tid; e < g.ntri * 256; e += step) {
+        const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        int ti, tj;
+        tile_of(t, ti, tj);
+        const int i = ti * 16 + r, j = tj * 16 + c;
+        double v = 0.0;
+        if (i < M && j <= i) {
+            KV o;
+            kern_eval(kind, d, ztc + i * ZW, ztc[i * ZW + DBT], ztc + j * ZW, hyl, ill, o);
+            v = o.k + (i == j ? md.jitter : 0.0);
+        } else if (i == j) {
+            v = 1.0;
+        }
+        if (to_lds) Lp[t * 256 + tel(r, c)] = v;
+        else Kg[(int64_t)i * Mp + j] = v;
+    }
+}
+// beyond 64 inducing points the K_mm of every layer is formed by ALL workgroups of the surrogate (thousands of covariance
+// evaluations, three exponentials each: 14 us on one CU at M = 128) and handed to the chain's workgroup through the workspace
+PHASE_FN void ph_kmm() {
+    CTX_LOCALS;
+    const int l = wj % L, r = wj / L, kl = (k - l + L - 1) / L;      // the kl workgroups wj = l, l + L, ... share layer l
+    kmm_tiles(l, r * CT, kl * CT, false);
+}
+
+PHASE_FN void ph_chain(bool kmm_done) {
     CTX_LOCALS;
     // ---- P1: the M x M chain forward of layer l by ONE workgroup, L and L^-1 in LDS
     for (int l = wj; l < L; l += k) {
-        const int kind = l > 0;
-        const double* hyl = hy + l * HS;
-        const double* ill = il + l * 2 * DBT;
-        for (int e = tid; e < Mp * ZW; e += CT) ztc[e] = 0.0;
-        __syncthreads();
-        {
-            gcd zx = GC(md.Zx);
-            batched<4>(M * d, tid, [&](int e) { return zx[e]; }, [&](int e, double v) { ztc[(e / d) * ZW + e % d] = v; });
-            if (l > 0) {
-                gcd mp = GC(md.m[l - 1]);
-                batched<1>(M, tid, [&](int e) { return mp[e]; }, [&](int e, double v) { ztc[e * ZW + DBT] = v; });
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < g.ntri * 256; e += CT) {      // K_mm + jitter I, lower tiles (identity beyond M)
-            const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
-            int ti, tj;
-            tile_of(t, ti, tj);
-            const int i = ti * 16 + r, j = tj * 16 + c;
-            double v = 0.0;
-            if (i < M && j <= i) {
-                KV o;
-                kern_eval(kind, d, ztc + i * ZW, ztc[i * ZW + DBT], ztc + j * ZW, hyl, ill, o);
-                v = o.k + (i == j ? md.jitter : 0.0);
-            } else if (i == j) {
-                v = 1.0;
-            }
-            Lp[t * 256 + tel(r, c)] = v;
+        if (kmm_done) {
+            gcd Kg = GC(MAT(l, M_L));
+            batched<8>(g.ntri * 256, tid,
+                       [&](int e) {
+                           int ti, tj;
+                           tile_of(e >> 8, ti, tj);
+                           return Kg[(int64_t)(ti * 16 + ((e >> 4) & 15)) * Mp + tj * 16 + (e & 15)];
+                       },
+                       [&](int e, double v) { Lp[(e >> 8) * 256 + tel((e >> 4) & 15, e & 15)] = v; });
+        } else {
+            kmm_tiles(l, 0, CT, true);
         }
         __syncthreads();
         CSTAMP(2);
-        // blocked right-looking Cholesky, 16-wide: diagonal tile in registers (one wavefront), panel and trailing update on the MFMA
+        // blocked right-looking Cholesky, 16-wide, with look-ahead: the diagonal tile is factorised (and inverted) row-per-lane in
+        // registers by wavefront 0 -- ~3 us of dependent instructions, the critical path -- so in step s wavefront 0 forms ONLY the
+        // next pivot block (panel tile (s+1, s), its update of the diagonal tile (s+1, s+1), factorisation) while the other
+        // wavefronts run the rest of the panel and of the trailing update on the MFMA
         int fail = 0;
-        for (int s = 0; s < nt; ++s) {
+        if (wave == 0) fail = chol_inv_tile16(Lp + tix(0, 0), Lip + tix(0, 0), lane);
+        __syncthreads();
+        for (int s = 0; s + 1 < nt; ++s) {
+            const double* Bi = Lip + tix(s, s);      // L_ss^-1
             if (wave == 0) {
-                const int f = chol_inv_tile16(Lp + tix(s, s), Lip + tix(s, s), lane);
-                if (f && !fail) fail = s * 16 + f;
-            }
-            __syncthreads();
-            for (int i = s + 1 + wave; i < nt; i += CNW) {      // L_is = A_is L_ss^-T
-                double* A = Lp + tix(i, s);
-                const double* B = Lip + tix(s, s);
+                double* A = Lp + tix(s + 1, s);      // L_{s+1,s} = A_{s+1,s} L_ss^-T
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = mfma(A[tel(li, 4 * q + lk)], B[tel(li, 4 * q + lk)], acc);
+                for (int q = 0; q < 4; ++q) acc = mfma(A[tel(li, 4 * q + lk)], Bi[tel(li, 4 * q + lk)], acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) A[tel(4 * r + lk, li)] = acc[r];
+            } else {
+                for (int i = s + 1 + wave; i < nt; i += CNW - 1) {      // the other panel tiles
+                    double* A = Lp + tix(i, s);
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = mfma(A[tel(li, 4 * q + lk)], Bi[tel(li, 4 * q + lk)], acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A[tel(4 * r + lk, li)] = acc[r];
+                }
             }
             __syncthreads();
-            const int nrem = nt - s - 1, ntr = nrem * (nrem + 1) / 2;
-            for (int u = wave; u < ntr; u += CNW) {      // A_ij -= L_is L_js^T
-                int a, b;
-                tile_of(u, a, b);
-                const double* P = Lp + tix(s + 1 + a, s);
-                const double* Q = Lp + tix(s + 1 + b, s);
-                double* D = Lp + tix(s + 1 + a, s + 1 + b);
+            if (wave == 0) {
+                // the next pivot block: A_{s+1,s+1} -= L_{s+1,s} L_{s+1,s}^T, then its factorisation
+                const double* P = Lp + tix(s + 1, s);
+                double* D = Lp + tix(s + 1, s + 1);
                 v4d acc;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] = D[tel(4 * r + lk, li)];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = mfma(-P[tel(li, 4 * q + lk)], Q[tel(li, 4 * q + lk)], acc);
+                for (int q = 0; q < 4; ++q) acc = mfma(-P[tel(li, 4 * q + lk)], P[tel(li, 4 * q + lk)], acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) D[tel(4 * r + lk, li)] = acc[r];
+                const int f = chol_inv_tile16(D, Lip + tix(s + 1, s + 1), lane);
+                if (f && !fail) fail = (s + 1) * 16 + f;
+            } else {
+                const int nrem = nt - s - 1, ntr = nrem * (nrem + 1) / 2;
+                for (int u = wave; u < ntr; u += CNW - 1) {      // A_ij -= L_is L_js^T, all tiles but (s+1, s+1) (u = 0)
+                    int a, b;
+                    tile_of(u, a, b);
+                    const double* P = Lp + tix(s + 1 + a, s);
+                    const double* Q = Lp + tix(s + 1 + b, s);
+                    double* D = Lp + tix(s + 1 + a, s + 1 + b);
+                    v4d acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = D[tel(4 * r + lk, li)];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = mfma(-P[tel(li, 4 * q + lk)], Q[tel(li, 4 * q + lk)], acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) D[tel(4 * r + lk, li)] = acc[r];
+                }
             }
             __syncthreads();
         }
@@ -824,32 +875,38 @@ PHASE_FN void ph_syrk(int lh) {
             tile_of(u % g.ntri, ti, tj);
             const int cbeg = ch * len, cend = cbeg + len < ncp ? cbeg + len : ncp;
             v4d ah = {0.0, 0.0, 0.0, 0.0}, ac = {0.0, 0.0, 0.0, 0.0};
-            const double* pa = ATg + (int64_t)lk * Mp + ti * 16 + li;
-            const double* pb = ATg + (int64_t)lk * Mp + tj * 16 + li;
-            double a[4], b[4], w1[4], w2[4];
+            gcd pa = GC(ATg) + (int64_t)lk * Mp + ti * 16 + li;
+            gcd pb = GC(ATg) + (int64_t)lk * Mp + tj * 16 + li;
+            gcd pw1 = GC(vgv) + lk;
+            gcd pw2 = GC(vcg) + lk;
+            // 16 columns (4 MFMA steps of each product) per stage, two stages requested ahead of the one being multiplied
+            double a[3][4], b[3][4], w1[3][4], w2[3][4];
+#define SYRK_LOAD(st, c_)                                                                                           \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                 \
+        a[st][q] = pa[(int64_t)((c_) + 4 * q) * Mp]; b[st][q] = pb[(int64_t)((c_) + 4 * q) * Mp];                   \
+        w1[st][q] = pw1[(c_) + 4 * q]; w2[st][q] = pw2[(c_) + 4 * q];                                               \
+    }
             if (cbeg < cend) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    a[q] = pa[(int64_t)(cbeg + 4 * q) * Mp]; b[q] = pb[(int64_t)(cbeg + 4 * q) * Mp];
-                    w1[q] = vgv[cbeg + 4 * q + lk]; w2[q] = vcg[cbeg + 4 * q + lk];
-                }
+                SYRK_LOAD(0, cbeg);
+                SYRK_LOAD(1, (cbeg + 16 < cend ? cbeg + 16 : cbeg));
             }
             for (int c = cbeg; c < cend; c += 16) {
-                double an[4], bn[4], w1n[4], w2n[4];
-                const int cn = c + 16 < cend ? c + 16 : c;
+                const int cn = c + 32 < cend ? c + 32 : c;
+                SYRK_LOAD(2, cn);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    an[q] = pa[(int64_t)(cn + 4 * q) * Mp]; bn[q] = pb[(int64_t)(cn + 4 * q) * Mp];
-                    w1n[q] = vgv[cn + 4 * q + lk]; w2n[q] = vcg[cn + 4 * q + lk];
+                    ah = mfma(a[0][q], b[0][q] * w1[0][q], ah);
+                    ac = mfma(a[0][q], b[0][q] * w2[0][q], ac);
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    ah = mfma(a[q], b[q] * w1[q], ah);
-                    ac = mfma(a[q], b[q] * w2[q], ac);
+                    a[0][q] = a[1][q]; b[0][q] = b[1][q]; w1[0][q] = w1[1][q]; w2[0][q] = w2[1][q];
+                    a[1][q] = a[2][q]; b[1][q] = b[2][q]; w1[1][q] = w1[2][q]; w2[1][q] = w2[2][q];
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { a[q] = an[q]; b[q] = bn[q]; w1[q] = w1n[q]; w2[q] = w2n[q]; }
             }
+#undef SYRK_LOAD
             double* Hs = MAT(lh, M_HS + ch);
             double* Hcs = MAT(lh, M_HCS + ch);
 #pragma unroll
@@ -868,9 +925,17 @@ PHASE_FN void ph_syrk(int lh) {
             double* dav = SML(lh, S_DAV);
             double* dat = SML(lh, S_DAT);
             const double* avg = SML(lh, S_AV);
+            const int ncb = g.ncb[lh], pstr = g.pstr;
             for (int i = lane; i < Mp; i += 64) {
+                gcd pp = GC(PART(lh, 0)) + PHEAD + HS + Mp + i;
                 double s = 0.0;
-                for (int cb = 0; cb < g.ncb[lh]; ++cb) s += PART(lh, cb)[PHEAD + HS + Mp + i];
+                for (int cb = 0; cb < ncb; cb += 8) {      // (eight partial rows requested together: one L2 round trip, not eight)
+                    double v[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) v[b] = pp[(int64_t)(cb + b < ncb ? cb + b : ncb - 1) * pstr];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) s += cb + b < ncb ? v[b] : 0.0;
+                }
                 dav[i] = s;
                 dat[i] = s + gkl * avg[i];
             }
@@ -1460,7 +1525,12 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     CTX_LOCALS;
     CSTAMP(0);
     ph_setup();
-    ph_chain();
+    const bool spread_kmm = nt > 4 && k >= 4;      // (the same in every workgroup of the surrogate: one barrier more)
+    if (spread_kmm) {
+        ph_kmm();
+        MODEL_BARRIER(8);
+    }
+    ph_chain(spread_kmm);
     MODEL_BARRIER(6);
     ph_stage();
     for (int l = 0; l < L; ++l) {
@@ -1562,11 +1632,13 @@ int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
         CGeom g;
         cgeom_of(m, g);
         if (g.Mp > mpmax) mpmax = g.Mp;
-        // the widest phase of this model: column blocks of a layer, the chain backward's column blocks of all layers
+        // what this model's widest phase can use: the chain backward's column blocks of all layers, half the column blocks of a
+        // layer's panel (two rounds of column blocks cost less than the barrier among twice the workgroups)
         int w = m.L * g.nt;
         for (int l = 0; l < m.L; ++l)
-            if (g.ncb[l] > w) w = g.ncb[l];
+            if ((g.ncb[l] + 1) / 2 > w) w = (g.ncb[l] + 1) / 2;
         if (w > want) want = w;
+        if (g.work_len >= ((int64_t)1 << 31)) return MOBOCMF_BAD_ARG;      // (workspace offsets are formed in 32 bits)
     }
     const size_t shm = coop_lds_bytes(mpmax);
     static std::atomic<uint64_t> granted{0};      // one write-once bit per device: the dynamic-LDS attribute was set there
@@ -1584,8 +1656,9 @@ int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
     const int64_t resident = (int64_t)per_cu * cus;
     int k = wgs_per_model;
     if (k == 0) {
-        k = want < 16 ? want : 16;
-        while (k > 1 && (int64_t)k * n_models > resident) --k;
+        k = want < 32 ? want : 32;
+        const int64_t cap = resident < 160 ? resident : 160;      // (the barrier's fences cost with the workgroups of the whole launch)
+        while (k > 1 && (int64_t)k * n_models > cap) --k;
     }
     if ((int64_t)k * n_models > resident || k < 1) return MOBOCMF_BAD_ARG;
     if (wgs_used) *wgs_used = k;

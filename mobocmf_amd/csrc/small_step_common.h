@@ -165,7 +165,7 @@ __device__ __forceinline__ double peer(const double* p) {
 // Pareto columns, the omega factors (all models' moments at x~) on the x~ columns.  part: >= 256 * (1 + 2 n_obj) doubles of
 // workgroup scratch.  NT threads; all of them call it.
 template <int NT>
-__device__ void coupling_seeds(const mobocmf_tiny_model* models, const mobocmf_tiny_model& md, int ncol_top, double* part,
+__device__ __forceinline__ void coupling_seeds(const mobocmf_tiny_model* models, const mobocmf_tiny_model& md, int ncol_top, double* part,
                                double* sh) {
     const mobocmf_tiny_coupling& cp = *md.coupling;
     const int tid = threadIdx.x, P = cp.P, T = cp.T, no = cp.n_obj, nc = cp.n_con;
@@ -179,33 +179,49 @@ __device__ void coupling_seeds(const mobocmf_tiny_model* models, const mobocmf_t
     const int tl = tid % T, grp = tid / T;
     const bool on = grp < NG;
     if (on) {
+        // (loops over the <= 8 objectives with compile-time bounds and a predicate: the per-objective arrays then stay in
+        // registers; indexed by a run-time bound they were 448 bytes of scratch memory per lane)
         double isd[8], fmv[8], fvv[8], gm[8], gv[8], osum = 0.0;
-        for (int j = 0; j < no; ++j) {
-            const mobocmf_tiny_model& mj = models[cp.obj_model[j]];
-            fmv[j] = peer(mj.top_mean + P + tl);
-            fvv[j] = peer(mj.top_var + P + tl);
-            isd[j] = 1.0 / sqrt(fvv[j]);
-            gm[j] = gv[j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            fmv[j] = fvv[j] = isd[j] = gm[j] = gv[j] = 0.0;
+            if (j < no) {
+                const mobocmf_tiny_model& mj = models[cp.obj_model[j]];
+                fmv[j] = peer(mj.top_mean + P + tl);
+                fvv[j] = peer(mj.top_var + P + tl);
+                isd[j] = 1.0 / sqrt(fvv[j]);
+            }
         }
         for (int p = grp; p < P; p += NG) {
             double ph[8], u[8], O = 1.0;
-            for (int j = 0; j < no; ++j) {
-                u[j] = (cp.front[(int64_t)p * no + j] - fmv[j]) * isd[j];
-                ph[j] = ncdf_t(u[j]);
-                O *= ph[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                u[j] = 0.0;
+                ph[j] = 1.0;
+                if (j < no) {
+                    u[j] = (cp.front[(int64_t)p * no + j] - fmv[j]) * isd[j];
+                    ph[j] = ncdf_t(u[j]);
+                    O *= ph[j];
+                }
             }
             osum += O;
-            for (int j = 0; j < no; ++j) {
-                double rest = 1.0;
-                for (int q = 0; q < no; ++q) rest *= q == j ? 1.0 : ph[q];
-                const double pd = npdf_t(u[j]);
-                gm[j] += rest * pd * (-isd[j]);
-                gv[j] += rest * pd * (-0.5 * u[j] / fvv[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < no) {
+                    double rest = 1.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rest *= (q == j || q >= no) ? 1.0 : ph[q];
+                    const double pd = npdf_t(u[j]);
+                    gm[j] += rest * pd * (-isd[j]);
+                    gv[j] += rest * pd * (-0.5 * u[j] / fvv[j]);
+                }
             }
         }
         double* pp = part + (int64_t)(grp * T + tl) * stride;
         pp[0] = osum;
-        for (int j = 0; j < no; ++j) { pp[1 + j] = gm[j]; pp[1 + no + j] = gv[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < no) { pp[1 + j] = gm[j]; pp[1 + no + j] = gv[j]; }
     }
     __syncthreads();
     const double dldc = cp.log_eps - cp.log_1m_eps;      // omega: coef_c = log eps, coef_1mc = log(1 - eps)
@@ -217,27 +233,36 @@ __device__ void coupling_seeds(const mobocmf_tiny_model* models, const mobocmf_t
         for (int g2 = 0; g2 < NG; ++g2) {
             const double* pp = part + (int64_t)(g2 * T + t) * stride;
             osum += pp[0];
-            if (no) { gm += pp[1 + j0]; gv += pp[1 + no + j0]; }
+            if (no) { gm += pp[1 + j0]; gv += pp[1 + no + j0]; }      // (LDS / global reads with a run-time index: no private array)
         }
         double phic[8], dzm[8], dzv[8], C = 1.0;
-        for (int k = 0; k < nc; ++k) {
-            const mobocmf_tiny_model& mk = models[cp.con_model[k]];
-            const double cm = peer(mk.top_mean + P + t), cv = peer(mk.top_var + P + t);
-            const double sd = sqrt(cv), z = (cm - cp.thresholds[k]) / sd, pd = npdf_t(z);
-            phic[k] = ncdf_t(z);
-            dzm[k] = pd / sd;
-            dzv[k] = -0.5 * pd * z / cv;
-            C *= phic[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            phic[k] = 1.0;
+            dzm[k] = dzv[k] = 0.0;
+            if (k < nc) {
+                const mobocmf_tiny_model& mk = models[cp.con_model[k]];
+                const double cm = peer(mk.top_mean + P + t), cv = peer(mk.top_var + P + t);
+                const double sd = sqrt(cv), z = (cm - cp.thresholds[k]) / sd, pd = npdf_t(z);
+                phic[k] = ncdf_t(z);
+                dzm[k] = pd / sd;
+                dzv[k] = -0.5 * pd * z / cv;
+                C *= phic[k];
+            }
         }
         acc = dldc * C * osum + cp.log_1m_eps * (double)P;
         if (md.role == 0) {
             sgm[P + t] = dldc * C * gm;
             sgv[P + t] = dldc * C * gv;
         } else {
-            double rest = osum;
-            for (int q = 0; q < nc; ++q) rest *= q == md.role_index ? 1.0 : phic[q];
-            sgm[P + t] = dldc * rest * dzm[md.role_index];
-            sgv[P + t] = dldc * rest * dzv[md.role_index];
+            double rest = osum, zm = 0.0, zv = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                rest *= (q == md.role_index || q >= nc) ? 1.0 : phic[q];
+                if (q == md.role_index) { zm = dzm[q]; zv = dzv[q]; }
+            }
+            sgm[P + t] = dldc * rest * zm;
+            sgv[P + t] = dldc * rest * zv;
         }
     }
     if (blockIdx.x == 0) {      // (uniform) the omega term itself, once per launch

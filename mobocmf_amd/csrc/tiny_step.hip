@@ -64,13 +64,14 @@ __host__ __device__ inline void geom_of(const mobocmf_tiny_model& md, Geom& g) {
 // inverse is a forward substitution with lane c owning column c of L^-1 (L_ik broadcast the same way).  No LDS traffic
 // inside, no barrier; Lm / Li receive L and L^-1 (zeros above the diagonal) at the end.
 template <int MM>
-__device__ void chol_inv_wave(double* Lm, double* Li, int LD, int lane, int32_t* info) {
+__device__ __forceinline__ void chol_inv_wave(double* Lm, double* Li, int LD, int lane, int32_t* info) {
     double row[MM];
     const int ln = lane < MM ? lane : 0;
 #pragma unroll
     for (int k = 0; k < MM; ++k) row[k] = Lm[ln * LD + k];
     int fail = 0;
-    double rr[MM];      // 1 / L_jj (wave-uniform)
+    // 1 / L_jj (wave-uniform) is parked in row 0 of Li until the inverse needs it (Li is written at the very end): MM values in
+    // registers per lane next to row[] and x[] pushed the 32-wide instantiation over its register budget and into scratch
 #pragma unroll
     for (int j = 0; j < MM; ++j) {
         const double djj = rdlane(row[j], j);
@@ -79,26 +80,29 @@ __device__ void chol_inv_wave(double* Lm, double* Li, int LD, int lane, int32_t*
         double r = __builtin_amdgcn_rsq(djj);
         r = r * (1.5 - (0.5 * djj) * r * r);
         r = __builtin_fma(0.5 * r, __builtin_fma(-(djj * r), r, 1.0), r);      // residual form: ~1 ulp (chol.hip rsqrt_nr)
-        rr[j] = r;
+        if (lane == 0) Li[j] = r;
         const double lij = row[j] * r;      // lane j: d / sqrt(d) = L_jj
         row[j] = lij;
 #pragma unroll
         for (int k = j + 1; k < MM; ++k) row[k] -= lij * rdlane(lij, k);
+    }
+    // L goes to LDS now: the inverse reads L_ik back as wave-uniform broadcasts, so row[] is dead while x[] is alive (both in
+    // registers were 2 x 2 MM VGPRs: at MM = 32 all 256 of them)
+    if (lane < MM) {
+#pragma unroll
+        for (int k = 0; k < MM; ++k) Lm[lane * LD + k] = k <= lane ? row[k] : 0.0;
     }
     double x[MM];
 #pragma unroll
     for (int i = 0; i < MM; ++i) {
         double s = i == lane ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; ++k) s -= rdlane(row[k], i) * x[k];
-        x[i] = s * rr[i];
+        for (int k = 0; k < i; ++k) s -= Lm[i * LD + k] * x[k];
+        x[i] = s * Li[i];
     }
     if (lane < MM) {
 #pragma unroll
-        for (int k = 0; k < MM; ++k) {
-            Lm[lane * LD + k] = k <= lane ? row[k] : 0.0;
-            Li[k * LD + lane] = x[k];
-        }
+        for (int k = 0; k < MM; ++k) Li[k * LD + lane] = x[k];
     }
     if (lane == 0) info[0] = fail;
 }
@@ -111,8 +115,13 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     constexpr int LD = MR + 1, MS = MR * LD;
     constexpr int NW = TT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    Geom g;
-    geom_of(md, g);
+    // the geometry -- per-layer sizes and workspace offsets, indexed by the run-time layer -- lives in LDS, formed by one thread: as
+    // a private struct its arrays sat in scratch memory (624 B per lane) and every g.ncol[l] / g.work_off[l] at the head of a
+    // phase was a scratch round trip
+    __shared__ Geom g_lds;
+    if (tid == 0) geom_of(md, g_lds);
+    __syncthreads();
+    const Geom& g = g_lds;
     const int L = g.L, M = g.M, d = g.d, S = g.S;
     double* Lm = lds;                       // [TLM][MS]  L
     double* Li = Lm + TLM * MS;             // [TLM][MS]  L^-1
@@ -790,7 +799,7 @@ __global__ __launch_bounds__(TT) void tiny_step_kernel(const mobocmf_tiny_model*
     }
 }
 
-constexpr size_t LDS_BUDGET = 160 * 1024;      // LDS of a gfx950 CU; one workgroup per CU may hold all of it
+constexpr size_t LDS_BUDGET = 160 * 1024 - 512;      // LDS of a gfx950 CU (one workgroup per CU may hold all of it), less the kernel's static part (the geometry)
 size_t lds_bytes(int MR) {
     const int LD = MR + 1, MS = MR * LD;
     const size_t n = (size_t)(3 * TLM + 3) * MS + (size_t)TLM * MR * ZW + 2 * (size_t)TLM * HS + (size_t)TLM * 2 * DBT +

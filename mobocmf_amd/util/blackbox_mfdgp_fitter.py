@@ -258,6 +258,7 @@ class BlackBoxMFDGPFitter:
         per epoch for all of them.  Returns (epochs completed, step object or None): fewer than ``num_epochs`` when the
         surrogates do not fit (0, None) or when a Cholesky failed -- the state is then rolled back to the last verified epoch
         and the layer path, which can retry with more jitter as the reference does at every step, continues from there."""
+        from . import coop_step
         from .tiny_step import TinyELBOStep, eligible
         from ..layers.mfdgp_hidden_layer import NotPSDError
         hs = self._handlers()
@@ -266,11 +267,17 @@ class BlackBoxMFDGPFitter:
         for _, _, h in hs:
             h.mfdgp.fix_variational_hypers(fix_variational_hypers)
         data = [h.train_dataset.tensors for _, _, h in hs]
-        if not all(x.is_cuda and eligible(h.mfdgp, x, fid) for (_, _, h), (x, _, fid) in zip(hs, data)):
+        # M <= 32 and narrow panels: one workgroup per surrogate (csrc/tiny_step.hip); up to M = 128: several workgroups per
+        # surrogate, MFMA products (csrc/coop_step.hip); beyond that, or for wide panels, the layer path
+        if all(x.is_cuda and eligible(h.mfdgp, x, fid) for (_, _, h), (x, _, fid) in zip(hs, data)):
+            cls = TinyELBOStep
+        elif all(x.is_cuda and coop_step.worthwhile(h.mfdgp, x, fid) for (_, _, h), (x, _, fid) in zip(hs, data)):
+            cls = coop_step.CoopELBOStep
+        else:
             return 0, None
         dev = data[0][0].device
-        step = TinyELBOStep([h.mfdgp for _, _, h in hs], [h.num_data for _, _, h in hs], [t[0] for t in data],
-                            [t[1] for t in data], [t[2] for t in data], lr=lr, stream=self._stream_for(0, dev))
+        step = cls([h.mfdgp for _, _, h in hs], [h.num_data for _, _, h in hs], [t[0] for t in data],
+                   [t[1] for t in data], [t[2] for t in data], lr=lr, stream=self._stream_for(0, dev))
         step.stream.wait_stream(torch.cuda.current_stream(dev))
         step.snapshot()
         last_good = -1
@@ -553,11 +560,17 @@ class BlackBoxMFDGPFitter:
         back to the last verified iteration; the layer path continues)."""
         from .. import _lib
         from ..layers.mfdgp_hidden_layer import NotPSDError
+        from .coop_step import CoopConditionedStep
         from .tiny_step import TinyConditionedStep
         dev = self.pareto_set.device
-        try:
-            step = TinyConditionedStep(self, lr=self.lr_2, stream=self._stream_for(0, dev))
-        except _lib.MobocmfError:
+        step = None
+        for cls in (TinyConditionedStep, CoopConditionedStep):      # M <= 32 in one workgroup per surrogate, M <= 128 in several
+            try:
+                step = cls(self, lr=self.lr_2, stream=self._stream_for(0, dev))
+                break
+            except _lib.MobocmfError:
+                continue
+        if step is None:
             return 0, None
         step.stream.wait_stream(torch.cuda.current_stream(dev))
         step.snapshot()

@@ -23,6 +23,22 @@ def eligible(model, x, fidelities):
     return TS.eligible(model, x, fidelities, speed_rule=False, max_m=_lib.COOP_MAX_M, max_columns=MAX_COLUMNS)
 
 
+MAX_WORTHWHILE_COLUMNS = 2048      # summed over the layers: beyond, the layer path's grid-filling launches win (tools/coop_sweep.py)
+
+
+def worthwhile(model, x, fidelities):
+    """``eligible`` and small enough for the launch to beat the layer path (profiles/r05_coop_step.txt: BASELINE config 2 --
+    M = 128, 512 + 1024 columns -- 1.3x; the reference's loop sizes 2-2.5x; a single workgroup round per phase is what wins, so
+    the gate is the number of columns)."""
+    if not eligible(model, x, fidelities):
+        return False
+    L = len(model._layers())
+    S = model.num_samples_for_training
+    fidv = fidelities.reshape(-1)
+    cols = sum(int((fidv >= l).sum()) * (S if l else 1) for l in range(L))
+    return cols <= MAX_WORTHWHILE_COLUMNS
+
+
 class _CoopLaunch:
     """The launch of mobocmf_coop_elbo_step for the descriptor table a Tiny* step object built."""
     _work_bytes_fn = "mobocmf_coop_work_bytes"
@@ -30,6 +46,10 @@ class _CoopLaunch:
 
     @staticmethod
     def _eligible(model, x, fid, force):
+        return eligible(model, x, fid)
+
+    @staticmethod
+    def _eligible_conditioned(model, x, fid):
         return eligible(model, x, fid)
 
     def _sync_words(self):

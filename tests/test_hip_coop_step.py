@@ -206,3 +206,111 @@ def test_C2_seeds_match_oracle():
                 p = _model_param_for(model, l, key)
                 gref = tt.grad if key != "L_S" else torch.tril(tt.grad)
                 assert rel(grads[p].reshape(gref.shape), gref) < 1e-4, (seed, l, key, rel(grads[p].reshape(gref.shape), gref))
+
+
+# ------------------------------------------------------------------ conditioned training at the loop's later sizes
+def _cond_setup(M, N, P=7, T=10, d=2, seed=0):
+    from tests.helpers import oracle_state, to_t
+    from tests.test_hip_conditioned import _fitter
+    n_obj, n_con = 2, 2
+    fitter, probs = _fitter(n_obj, n_con, N, M=M, d=d)
+    fitter.thresholds_cons = torch.tensor([0.1, -0.05], dtype=torch.float64)
+    g = torch.Generator().manual_seed(seed)
+    pareto_set = torch.rand(P, d, dtype=torch.float64, generator=g)
+    pareto_front = torch.randn(P, n_obj, dtype=torch.float64, generator=g) * 0.5
+    x_tilde = torch.rand(T, d, dtype=torch.float64, generator=g)
+    fitter.set_pareto_solution(pareto_set, pareto_front)
+    eps_all, objs, cons = {}, [], []
+    for idx, (tag, i, h) in enumerate(fitter._handlers()):
+        e = torch.randn(N + P + T, dtype=torch.float64, generator=g)
+        eps_all[(tag, i)] = [None, e.to(DEV)]
+        st = oracle_state(probs[idx], requires_grad=True)
+        rec = {"state": st, "x": to_t(probs[idx]["x"]), "y": to_t(probs[idx]["y"]), "fid": to_t(probs[idx]["fid"]),
+               "eps_batch": [None, e[:N]], "eps_pareto": [None, e[N:N + P]], "eps_tilde": [None, e[N + P:]]}
+        (objs if tag == "OBJ" else cons).append(rec)
+        h.mfdgp.fix_variational_hypers_cond(True)
+    return fitter, objs, cons, pareto_set, pareto_front, x_tilde, eps_all
+
+
+@pytest.mark.parametrize("M,N,d", [(48, 56, 4), (64, 80, 5), (24, 40, 2)])
+def test_coop_conditioned_iteration_matches_oracle(M, N, d):
+    """CoopConditionedStep on 2 objectives + 2 constraints vs the oracle's joint loss (blackbox_mfdgp_fitter.py:270-343 restated):
+    the loss and d loss / d (m, L_S) of every layer of every surrogate, explicit x~ and eps; then one iteration moves only m and
+    L_S, by Adam's first step.  (d >= 4 for the larger M: the factor terms are Phi((threshold - mean) / sd) at points whose
+    predictive variance k_nn - q sits at the jitter's scale when 48+ inducing points crowd [0,1]^2 -- there the float64 oracle
+    and the kernel differ by cond(K_mm) * eps in sd.  N > M: with N = M the unshuffled batch IS the inducing set and the oracle,
+    like GPyTorch, takes the equal-inputs shortcut for it, which the reordered rows of the step never do.)"""
+    from mobocmf_amd.util.coop_step import CoopConditionedStep
+    fitter, objs, cons, pareto_set, pareto_front, x_tilde, eps_all = _cond_setup(M, N, d=d)
+    loss_o = O.conditioned_loss(objs, cons, pareto_set, pareto_front, x_tilde, fitter.thresholds_cons, fitter.eps)
+    loss_o.backward()
+    step = CoopConditionedStep(fitter, lr=1e-3, fixed_x_tilde=x_tilde.to(DEV), fixed_eps=eps_all, want_grad=True)
+    grads = step.gradients()
+    step.check()
+    assert rel(step.loss, loss_o) < 1e-8, rel(step.loss, loss_o)
+    for k, (rec, (tag, i, h)) in enumerate(zip(objs + cons, fitter._handlers())):
+        for l in range(2):
+            vd = getattr(h.mfdgp, f"hidden_layer_{l}").variational_strategy._variational_distribution
+            assert rel(grads[k][vd.variational_mean], rec["state"]["layers"][l]["m"].grad) < 1e-5, (tag, i, l)
+            assert rel(grads[k][vd.chol_variational_covar], torch.tril(rec["state"]["layers"][l]["L_S"].grad)) < 1e-5, (tag, i, l)
+    before = [[p.detach().clone() for p in h.mfdgp.parameters()] for _, _, h in fitter._handlers()]
+    step.step()
+    step.check()
+    for k, (_, _, h) in enumerate(fitter._handlers()):
+        for p, p0 in zip(h.mfdgp.parameters(), before[k]):
+            if p.requires_grad:
+                gk = grads[k][p]
+                moved = (p.detach() - p0)
+                big = gk.abs() > 1e-9 * gk.abs().max()
+                assert torch.allclose(moved[big], -1e-3 * torch.sign(gk[big]), rtol=1e-4, atol=0)
+            else:
+                assert torch.equal(p.detach(), p0)
+
+
+def test_coop_one_launch_conditioned_iteration_equals_the_three_launch_form():
+    """Mode 4 (the whole grid meets once after the forward, every surrogate's first workgroup forms its factor gradients) == the
+    forward-only launch + mobocmf_cond_factors_forward launches + step launch: losses, factor terms, parameters after 3 iterations."""
+    from mobocmf_amd.util.coop_step import CoopConditionedStep
+    runs = {}
+    for one in (True, False):
+        fitter, *_rest = _cond_setup(48, 48, d=4, seed=3)
+        step = CoopConditionedStep(fitter, lr=1e-3)
+        step.xrng.copy_(torch.tensor([1234567, 0], dtype=torch.int64))
+        for layer_owner in step.models:
+            for j, layer in enumerate(layer_owner._layers()):
+                layer._rng(torch.device(DEV, torch.cuda.current_device())).copy_(torch.tensor([99 + j, 0, 0], dtype=torch.int64))
+        step.one_launch = one
+        hist = []
+        for _ in range(3):
+            step.step()
+            step.check()
+            hist.append((step.losses.clone(), step.factor_losses.clone()))
+        assert step.one_launch is one
+        runs[one] = (hist, [p.detach().clone() for _, _, h in fitter._handlers() for p in h.mfdgp.parameters()])
+    for (la, fa), (lb, fb) in zip(runs[True][0], runs[False][0]):
+        assert rel(la, lb) < 1e-10 and rel(fa, fb) < 1e-10, (rel(la, lb), rel(fa, fb))
+    for pa, pb in zip(runs[True][1], runs[False][1]):
+        assert rel(pa, pb) < 1e-9
+
+
+def test_fitter_trains_mid_size_surrogates_through_the_cooperative_launch():
+    """BlackBoxMFDGPFitter.train_mfdgps / train_conditioned_mfdgps at M = N = 48 (iteration ~33 of the reference's own loop,
+    toy_synthetic_2D_JESMOCMF.py:305-331): the one-workgroup kernel does not take the size, the cooperative launch does -- the
+    loss decreases, nothing falls back to the layer path."""
+    from mobocmf_amd.util import coop_step, tiny_step
+    from tests.test_hip_conditioned import _fitter
+    fitter, _ = _fitter(2, 1, 48, M=48)
+    hs = fitter._handlers()
+    x, _, fid = hs[0][2].train_dataset.tensors
+    assert not tiny_step.eligible(hs[0][2].mfdgp, x, fid) and coop_step.eligible(hs[0][2].mfdgp, x, fid)
+    done, step = fitter._train_mfdgp_tiny(False, 30, 1e-3)
+    assert done == 30 and isinstance(step, coop_step.CoopELBOStep)
+    l0 = step.losses[:, 2].clone()
+    done, step = fitter._train_mfdgp_tiny(False, 200, 3e-3)
+    assert done == 200 and bool((step.losses[:, 2] < l0).all())
+    g = torch.Generator().manual_seed(1)
+    fitter.set_pareto_solution(torch.rand(5, 2, dtype=torch.float64, generator=g), torch.randn(5, 2, dtype=torch.float64, generator=g) * 0.3)
+    for _, _, h in hs:
+        h.mfdgp.fix_variational_hypers_cond(True)
+    done, cstep = fitter._train_conditioned_tiny(50)
+    assert done == 50 and isinstance(cstep, coop_step.CoopConditionedStep) and bool(torch.isfinite(cstep.loss))

@@ -178,3 +178,84 @@ def test_C4_three_layers_million_rows_properties():
         assert abs(float(kl)) < 1e-6
     del out, model
     torch.cuda.empty_cache()
+
+
+def test_C4_three_layers_pruned_as_the_timed_step_runs_it():
+    """C4 as `bench.py --config C4` and the fitter actually run it: rows ordered by descending fidelity, layer l
+    on the prefix of rows with fidelity >= l -- panels of [65 536, 524 288, 262 144] columns instead of 1 048 576, prefix
+    propagation through two hidden layers, per-layer row counts in the fused ELBO (variational_elbo_mf.py:33-38 masks AFTER
+    evaluating every layer at every row; the prefix is what survives the mask).  Checks at the launches' own shapes: finite
+    ELBO; the scaled KL vs the oracle; a 4096-row slice of every layer's moments INSIDE its prefix vs the oracle evaluated on
+    exactly those rows; the data term of each layer vs the oracle's on a slice; D1 prior recovery through the prefix entry
+    points (layer 1 on 524 288 columns with q(u) = p(u): mean 0, variance k_nn, KL 0)."""
+    from mobocmf_amd import functional as F
+    cfg = {k: v for k, v in synthetic.CONFIGS["C4"].items() if k != "outputs"}
+    prob = synthetic.make_problem(**cfg, seed=0)
+    S, L, N = cfg["S"], cfg["L"], cfg["N"]
+    model = build_model(prob, S_train=S)
+    model.set_check_pd(False)
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device=DEV)
+    fid = np.asarray(prob["fid"])
+    rows = [int((fid >= l).sum()) for l in range(L)]
+    assert rows == [65536, 32768, 16384]          # columns: 65 536, 32 768 * 16, 16 384 * 16
+    with torch.no_grad():
+        (e, skl), out = _pruned_elbo(model, prob, S)
+        assert bool(torch.isfinite(e)) and bool(torch.isfinite(skl))
+        st = O.state_from_raw(_to_dev(_raw_from_model(model, L)))
+        kl_o = sum(O.kl_layer(st["layers"][l]["hyp"], O.inducing_inputs(st, l), st["layers"][l]["m"],
+                              st["layers"][l]["L_S"]) for l in range(L))
+        assert rel(skl, kl_o) < 1e-8
+        # a slice of base rows inside the TOP layer's prefix (so that every layer covers it): rows 9000..9255
+        b0, nb = 9000, 256
+        assert b0 + nb <= rows[-1]
+        x = t(prob["x"])[b0:b0 + nb]
+        eps = [None] + [t(e_).reshape(N, S)[b0:b0 + nb].reshape(-1) for e_ in prob["eps"][1:]]
+        outs_o = O.model_forward(st, x, eps=eps, S=S)
+        assert rel(out[0].mean.reshape(-1)[b0:b0 + nb], outs_o[0][0]) < 1e-7
+        assert rel(out[0].variance.reshape(-1)[b0:b0 + nb], outs_o[0][1]) < 1e-6
+        for l in range(1, L):
+            sl = slice(b0 * S, (b0 + nb) * S)
+            assert out[l].mean.numel() == rows[l] * S
+            assert rel(out[l].mean.reshape(-1)[sl], outs_o[l][0]) < 1e-6, l
+            assert rel(out[l].variance.reshape(-1)[sl], outs_o[l][1]) < 1e-5, l
+        # ... and one INSIDE layer 1's prefix but beyond layer 2's (rows the top layer never sees): 20000..20255
+        b1 = 20000
+        assert rows[2] <= b1 and b1 + nb <= rows[1]
+        x1 = t(prob["x"])[b1:b1 + nb]
+        eps1 = [None] + [t(e_).reshape(N, S)[b1:b1 + nb].reshape(-1) for e_ in prob["eps"][1:]]
+        o1 = O.model_forward(st, x1, eps=eps1, S=S)
+        sl = slice(b1 * S, (b1 + nb) * S)
+        assert rel(out[1].mean.reshape(-1)[sl], o1[1][0]) < 1e-6 and rel(out[1].variance.reshape(-1)[sl], o1[1][1]) < 1e-5
+        # the ELBO itself: data terms of the full batch from the pruned moments == ELBO + scaled KL; the oracle's data term on the
+        # two slices agrees with the same rows of the pruned evaluation (row-separable sum)
+        y, fd = t(prob["y"]), t(prob["fid"])
+        for (bb, oo) in ((b0, outs_o), (b1, o1)):
+            for l in range(L):
+                if bb >= rows[l]:
+                    continue
+                tau = st["noise"][l]
+                mu = out[l].mean.reshape(-1)
+                var = out[l].variance.reshape(-1)
+                div = 1 if l == 0 else S
+                idx = slice(bb * div, (bb + nb) * div)
+                yy = y[bb:bb + nb].repeat_interleave(div)
+                mask = (fd[bb:bb + nb].repeat_interleave(div) == float(l))
+                mine = (-0.5 * (((yy - mu[idx]) ** 2 + var[idx]) / tau + torch.log(tau) + np.log(2 * np.pi)))[mask].sum() / div
+                ref = (-0.5 * (((yy - oo[l][0].reshape(-1)) ** 2 + oo[l][1].reshape(-1)) / tau + torch.log(tau) +
+                               np.log(2 * np.pi)))[mask].sum() / div
+                if bool(mask.any()):
+                    assert rel(mine, ref) < 1e-7, (bb, l)
+        # D1 through the prefix shapes: layer 1 on its 524 288 columns with q(u) = p(u)
+        lay = st["layers"][1]
+        Zt = O.inducing_inputs(st, 1)
+        Lp = torch.linalg.cholesky(O.gram(lay["hyp"], Zt, Zt) + 1e-6 * torch.eye(Zt.shape[0], dtype=torch.float64, device=DEV))
+        hyp = torch.cat([lay["hyp"][k_].reshape(-1) for k_ in ("a1", "af", "nu", "a2", "lsf", "ls1", "ls2")])
+        f1 = torch.randn(rows[1] * S, dtype=torch.float64, device=DEV)
+        mean, var, kl = F.layer_forward(t(prob["x"])[:rows[1]], f1, Zt[:, :-1].contiguous(), Zt[:, -1].contiguous(), hyp,
+                                        torch.zeros(Zt.shape[0], dtype=torch.float64, device=DEV), Lp, 1, xdiv=S)
+        knn = lay["hyp"]["a1"] * (lay["hyp"]["nu"] * f1 * f1 + lay["hyp"]["af"]) + lay["hyp"]["a2"]
+        assert float(mean.abs().max()) < 1e-8
+        assert float(((var - knn).abs() / knn).max()) < 1e-8
+        assert abs(float(kl)) < 1e-6
+    del out, model
+    torch.cuda.empty_cache()

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mobocmf_amd.util import synthetic  # noqa: E402
 from mobocmf_amd.util.coop_step import CoopELBOStep  # noqa: E402
 
-NAMES = {0: "start", 1: "P0 hyper-parameters", 2: "K_mm", 3: "Cholesky", 4: "inverse", 5: "L, L^-1 out; L_S in", 6: "U, a, KL",
+NAMES = {0: "start", 1: "P0 hyper-parameters", 2: "K_mm", 3: "Cholesky", 4: "inverse", 5: "L, L^-1 out; L_S in", 6: "U, a, KL", 7: "Z~, a of every layer staged", 8: "K_mm by all workgroups",
          10: "forward layer 0", 11: "forward layer 1", 12: "forward layer 2", 15: "coupling", 20: "backward columns layer 0",
          21: "backward columns layer 1", 22: "backward columns layer 2", 25: "+ syrk of the layer above (0)", 26: "+ syrk (1)",
          27: "+ syrk (2)", 30: "syrk layer 0", 31: "CB1 G1 = U^T H", 32: "CB2+3 Y, g_LS", 33: "CB4-6 dL, P, T4", 34: "CB7 T5",
