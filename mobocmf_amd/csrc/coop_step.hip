@@ -121,9 +121,11 @@ __device__ __forceinline__ v4d mfma(double a, double b, v4d c) { return __builti
 __device__ __forceinline__ int tix(int ti, int tj) { return (ti * (ti + 1) / 2 + tj) * 256; }
 __device__ __forceinline__ int tel(int r, int c) { return r * 16 + (c ^ r); }
 
-// Cholesky + inverse of the 16 x 16 tile T (swizzled; lower part used) by the lanes 0..15 of one wavefront: lane i holds row i,
-// right-looking, multipliers broadcast by v_readlane (tiny_step.hip chol_inv_wave).  T receives L (zeros above the diagonal),
-// Ti its inverse.  Returns the 1-based failed pivot or 0 (wave-uniform).
+// Cholesky + inverse of the 16 x 16 tile T (swizzled; lower part used) by one wavefront: lane i of every 16-lane row holds row i
+// (the four rows of the wavefront do the same work), right-looking, multipliers broadcast by v_readlane (tiny_step.hip
+// chol_inv_wave).  T receives L (zeros above the diagonal), Ti its inverse.  Returns the 1-based failed pivot or 0 (wave-uniform).
+// (Tried: the broadcasts as DPP row_newbcast moves -- no trip through an SGPR -- are SLOWER: 17.6 -> 21 us for the four tiles of
+// M = 64, profiles/r05_coop_step.txt; the DPP move waits for its source's write-back where v_readlane's result is forwarded.)
 __device__ int chol_inv_tile16(double* T, double* Ti, int lane) {
     double row[16];
     const int ln = lane & 15;
@@ -1183,24 +1185,28 @@ PHASE_FN void ph_cb23() {
             const double* GT = MAT(l, M_GT);
             const double* Lig = MAT(l, M_LI);
             v4d s3 = {0.0, 0.0, 0.0, 0.0};
-            double la[4], gt[4], ub[4], lan[4], gtn[4], ubn[4];
-            FRAG(la, Lig, ti * 16, ti * 16);      // L^-1[k][i]
-            FRAG(gt, GT, ti * 16, tj * 16);       // G1[j][k]
-            FRAG(ub, Ug, ti * 16, tj * 16);       // U[k][j]
-            for (int kt = ti; kt < nt; ++kt) {
-                const int kn = kt + 1 < nt ? kt + 1 : kt;
-                FRAG(lan, Lig, kn * 16, ti * 16);
-                FRAG(gtn, GT, kn * 16, tj * 16);
-                FRAG(ubn, Ug, kn * 16, tj * 16);
-                PIN();
+            // (the fragments of up to four k tiles are requested together: one L2 round trip per four tiles, not one per tile)
+            for (int kb = ti; kb < nt; kb += 4) {
+                double la[4][4], gt[4][4], ub[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int kk = kt * 16 + 4 * q + lk, j = tj * 16 + li;
-                    const double du = j <= kk ? 2.0 * gt[q] + gkl * ub[q] : 0.0;      // dU_tot[k][j]
-                    s3 = mfma(la[q], du, s3);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int kt = kb + s4 < nt ? kb + s4 : nt - 1;
+                    FRAG(la[s4], Lig, kt * 16, ti * 16);      // L^-1[k][i]
+                    FRAG(gt[s4], GT, kt * 16, tj * 16);       // G1[j][k]
+                    FRAG(ub[s4], Ug, kt * 16, tj * 16);       // U[k][j]
                 }
                 PIN();
-                COPY4(la, lan); COPY4(gt, gtn); COPY4(ub, ubn);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (kb + s4 < nt) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int kk = (kb + s4) * 16 + 4 * q + lk, j = tj * 16 + li;
+                            const double du = j <= kk ? 2.0 * gt[s4][q] + gkl * ub[s4][q] : 0.0;      // dU_tot[k][j]
+                            s3 = mfma(la[s4][q], du, s3);
+                        }
+                    }
+                }
             }
             gwd gls = GW(gflat + g.flat_off[l] + g.H[l] + M);
             gcd ls = GC(md.L_S[l]);
@@ -1226,32 +1232,33 @@ PHASE_FN void ph_cb23() {
         const int ks = g.ks[l];
         v4d s1 = {0.0, 0.0, 0.0, 0.0}, s2 = {0.0, 0.0, 0.0, 0.0};
         const int kmin = ti < tj ? ti : tj;
-        double ua[4], gb[4], gi[4], ub[4], uan[4], gbn[4], gin[4], ubn[4];
-        FRAG(ua, UTg, 0, ti * 16);      // U[i][k]
-        FRAG(gb, G1, 0, tj * 16);       // G1[k][j]
-        FRAG(gi, G1, 0, ti * 16);       // G1[k][i]
-        FRAG(ub, UTg, 0, tj * 16);      // U[j][k]
-        for (int kt = 0; kt <= ti; ++kt) {
-            const int kn = kt + 1 <= ti ? kt + 1 : kt;
-            FRAG(uan, UTg, kn * 16, ti * 16);
-            FRAG(gbn, G1, kn * 16, tj * 16);
-            if (kn <= kmin) {
-                FRAG(gin, G1, kn * 16, ti * 16);
-                FRAG(ubn, UTg, kn * 16, tj * 16);
+        for (int kb = 0; kb <= ti; kb += 4) {
+            double ua[4][4], gb[4][4], gi[4][4], ub[4][4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kt = kb + s4 <= ti ? kb + s4 : ti, k2 = kt <= kmin ? kt : kmin;
+                FRAG(ua[s4], UTg, kt * 16, ti * 16);      // U[i][k]
+                FRAG(gb[s4], G1, kt * 16, tj * 16);       // G1[k][j]
+                FRAG(gi[s4], G1, k2 * 16, ti * 16);       // G1[k][i]   (k <= min(i, j) only)
+                FRAG(ub[s4], UTg, k2 * 16, tj * 16);      // U[j][k]
             }
             PIN();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s1 = mfma(ua[q], gb[q], s1);
-            if (kt <= kmin) {
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kt = kb + s4;
+                if (kt <= ti) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int kk = kt * 16 + 4 * q + lk, i = ti * 16 + li;
-                    const double du = kk <= i ? 2.0 * gi[q] + gkl * ua[q] : 0.0;      // dU_tot[i][k]
-                    s2 = mfma(du, ub[q], s2);
+                    for (int q = 0; q < 4; ++q) s1 = mfma(ua[s4][q], gb[s4][q], s1);
+                    if (kt <= kmin) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int kk = kt * 16 + 4 * q + lk, i = ti * 16 + li;
+                            const double du = kk <= i ? 2.0 * gi[s4][q] + gkl * ua[s4][q] : 0.0;      // dU_tot[i][k]
+                            s2 = mfma(du, ub[s4][q], s2);
+                        }
+                    }
                 }
             }
-            PIN();
-            COPY4(ua, uan); COPY4(gb, gbn); COPY4(gi, gin); COPY4(ub, ubn);
         }
         gcd avg = GC(SML(l, S_AV));
         gcd dav = GC(SML(l, S_DAV));
@@ -1352,18 +1359,22 @@ PHASE_FN void ph_cb7() {
         const double* T4T = MAT(l, M_T4T);
         const double* Lig = MAT(l, M_LI);
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        double a[4], b[4], an[4], bn[4];
-        FRAG(a, T4T, tj * 16, ti * 16);
-        FRAG(b, Lig, tj * 16, tj * 16);
-        for (int kt = tj; kt < nt; ++kt) {
-            const int kn = kt + 1 < nt ? kt + 1 : kt;
-            FRAG(an, T4T, kn * 16, ti * 16);
-            FRAG(bn, Lig, kn * 16, tj * 16);
+        for (int kb = tj; kb < nt; kb += 4) {
+            double a[4][4], b[4][4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kt = kb + s4 < nt ? kb + s4 : nt - 1;
+                FRAG(a[s4], T4T, kt * 16, ti * 16);
+                FRAG(b[s4], Lig, kt * 16, tj * 16);
+            }
             PIN();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = mfma(a[q], b[q], acc);
-            PIN();
-            COPY4(a, an); COPY4(b, bn);
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (kb + s4 < nt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = mfma(a[s4][q], b[s4][q], acc);
+                }
+            }
         }
         gwd T5 = GW(MAT(l, M_T5));
 #pragma unroll
