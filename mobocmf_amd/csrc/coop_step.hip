@@ -36,7 +36,9 @@ constexpr int KSMAX = 4;                         // k-slices of the weighted syr
 constexpr int XLD = 17;                          // leading dimension of an [Mp][16] column block in LDS
 constexpr int NMAT = 7 + 2 * KSMAX;              // M x M matrices of a layer in `work`
 constexpr int PHEAD = 4;                         // leading scalars of a column block's partial record
-constexpr int SPIN_LIMIT = 1 << 18;
+constexpr int SPIN_LIMIT = 1 << 22;      // polls of an in-launch barrier before it is abandoned: several seconds.  The wait is for peers of the SAME
+                                         // launch; it is long only while other work keeps them off the CUs (measured: a test whose predecessors left
+                                         // grid-filling kernels running on other streams needed > 0.4 s), and it is finite because that work ends
 
 struct CGeom {
     int L, M, Mp, nt, ntri, d, S;
@@ -126,7 +128,7 @@ __device__ __forceinline__ int tel(int r, int c) { return r * 16 + (c ^ r); }
 // chol_inv_wave).  T receives L (zeros above the diagonal), Ti its inverse.  Returns the 1-based failed pivot or 0 (wave-uniform).
 // (Tried: the broadcasts as DPP row_newbcast moves -- no trip through an SGPR -- are SLOWER: 17.6 -> 21 us for the four tiles of
 // M = 64, profiles/r05_coop_step.txt; the DPP move waits for its source's write-back where v_readlane's result is forwarded.)
-__device__ int chol_inv_tile16(double* T, double* Ti, int lane) {
+__device__ __forceinline__ int chol_inv_tile16(double* T, double* Ti, int lane) {
     double row[16];
     const int ln = lane & 15;
 #pragma unroll
@@ -188,54 +190,29 @@ __device__ __forceinline__ bool group_barrier(unsigned long long* cnt, unsigned 
 }
 
 // One 16 x 16 tile of T X for a column block X [k][XLD] in LDS and a matrix T given k-major in global memory (Tk[k * ld + row]
-// = T[row][k]): k tiles kt0 .. kt1-1 (at most 8).  ALL 4 x 16 fragments of T are requested before the first MFMA: one L2 round
-// trip per tile instead of one per k tile.
+// = T[row][k]): k tiles kt0 .. kt1-1.  The 4 x 16 fragments of FOUR k tiles are requested together, before their MFMAs: one L2
+// round trip per four k tiles (all eight at once -- 64 VGPRs of fragments -- was the register-pressure peak of the column phases
+// and put 150 values into scratch memory; a kernel that needs scratch also competes for the queue's scratch wave slots, see
+// SPIN_LIMIT).
 __device__ __forceinline__ v4d tile_tx(const double* Tk_, int ld, const double* X, int t, int kt0, int kt1, int lane) {
     v4d acc = {0.0, 0.0, 0.0, 0.0};
-    if (kt0 >= kt1) return acc;
-    const int li = lane & 15, lk = lane >> 4, nk = kt1 - kt0;
+    const int li = lane & 15, lk = lane >> 4;
     gcd tp = GC(Tk_) + (int64_t)lk * ld + t * 16 + li;
     const double* xp = X + lk * XLD + li;
-    double a[8][4];
+    for (int kb = kt0; kb < kt1; kb += 4) {
+        double a[4][4];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        if (kk < 4 || nk > 4) {      // (uniform)
-            const int kt = kk < nk ? kt0 + kk : kt1 - 1;
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kt = kb + kk < kt1 ? kb + kk : kt1 - 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[kk][q] = tp[(int64_t)(kt * 16 + 4 * q) * ld];
         }
-    }
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        if (kk < nk) {
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kb + kk < kt1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = mfma(a[kk][q], xp[((kt0 + kk) * 16 + 4 * q) * XLD], acc);
-        }
-    }
-    return acc;
-}
-// The same in two halves: the fragments of T's tile column t requested into registers (they depend on the layer only: a
-// workgroup that runs several column blocks of a layer keeps them), and the product with a column block.
-__device__ __forceinline__ void tile_load(const double* Tk_, int ld, int t, int kt0, int kt1, int lane, double (&a)[8][4]) {
-    const int li = lane & 15, lk = lane >> 4, nk = kt1 - kt0;
-    gcd tp = GC(Tk_) + (int64_t)lk * ld + t * 16 + li;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        if (kk < nk) {      // (uniform)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[kk][q] = tp[(int64_t)((kt0 + kk) * 16 + 4 * q) * ld];
-        }
-    }
-}
-__device__ __forceinline__ v4d tile_mma(const double (&a)[8][4], const double* X, int kt0, int kt1, int lane) {
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    const int li = lane & 15, lk = lane >> 4, nk = kt1 - kt0;
-    const double* xp = X + lk * XLD + li;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        if (kk < nk) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = mfma(a[kk][q], xp[((kt0 + kk) * 16 + 4 * q) * XLD], acc);
+                for (int q = 0; q < 4; ++q) acc = mfma(a[kk][q], xp[((kb + kk) * 16 + 4 * q) * XLD], acc);
+            }
         }
     }
     return acc;
@@ -482,6 +459,7 @@ PHASE_FN void kmm_tiles(int l, int first, int step, bool to_lds) {
     }
     __syncthreads();
     gwd Kg = GW(MAT(l, M_L));
+#pragma unroll 1
     for (int e = first + tid; e < g.ntri * 256; e += step) {
         const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
         int ti, tj;
@@ -510,7 +488,9 @@ PHASE_FN void ph_kmm() {
 PHASE_FN void ph_chain(bool kmm_done) {
     CTX_LOCALS;
     // ---- P1: the M x M chain forward of layer l by ONE workgroup, L and L^-1 in LDS
-    for (int l = wj; l < L; l += k) {
+    for (int l_it = wj; l_it < L; l_it += k) {
+        int l = l_it;
+        asm volatile("" : "+s"(l));      // (as in the column phases: the layer's addresses are formed where they are used)
         if (kmm_done) {
             gcd Kg = GC(MAT(l, M_L));
             batched<8>(g.ntri * 256, tid,
@@ -746,6 +726,7 @@ PHASE_FN void ph_forward(int l_in) {
             __syncthreads();
             CSTAMP(51);
             // F1: K block
+#pragma unroll 1
             for (int e = tid; e < Mp * 16; e += CT) {
                 const int m = e >> 4, j = e & 15;
                 double v = 0.0;
@@ -1041,6 +1022,7 @@ PHASE_FN void ph_backward(int l_in) {
             double hacc[HS];
 #pragma unroll
             for (int t = 0; t < HS; ++t) hacc[t] = 0.0;
+#pragma unroll 1
             for (int e = tid; e < Mp * 16; e += CT) {
                 const int m = e >> 4, j = e & 15;
                 double dfa = 0.0, dzf = 0.0;
@@ -1399,6 +1381,7 @@ PHASE_FN void ph_cb8() {
         const int i = ti * 16 + (tid & 15);
         double rs = 0.0;
         if (i < M) {
+#pragma unroll 1
             for (int j = tid >> 4; j < M; j += CT / 16) {
                 const double G = 0.5 * (GC(T5)[(int64_t)i * Mp + j] + GC(T5)[(int64_t)j * Mp + i]);
                 double dfa, dzf;
@@ -1508,7 +1491,7 @@ PHASE_FN void ph_adam() {
 }
 
 
-#define MODEL_BARRIER(id) do { CSTAMP(id); if (!group_barrier(cx->mcnt, (unsigned)k, (int*)(sc + 30))) { if (tid == 0) { md.info[0] = -1; md.out[2] = __builtin_nan(""); } return; } CSTAMP(99); } while (0)
+#define MODEL_BARRIER(id) do { CSTAMP(id); if (!group_barrier(cx->mcnt, (unsigned)k, (int*)(sc + 30))) { if (tid == 0) { md.info[0] = -1; md.info[1] = (id); md.info[2] = (int)(*(volatile unsigned long long*)cx->mcnt) * 1000 + wj; md.out[2] = __builtin_nan(""); } return; } CSTAMP(99); } while (0)
 
 __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model* models_, int k_, unsigned long long* sync_words,
                                                        double lr_, double b1_, double b2_, double aeps_, int do_update_) {
@@ -1533,7 +1516,13 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
         }
         __syncthreads();
     }
-    CTX_LOCALS;
+    // (only what the barriers and the phase sequence need: everything else is re-derived inside the phases)
+    const mobocmf_tiny_model& md = *(const mobocmf_tiny_model*)lds_all;
+    const CGeom& g = *(const CGeom*)(lds_all + MDW);
+    Ctx* cx = (Ctx*)(lds_all + MDW + GEW);
+    const int tid = threadIdx.x, k = uni(cx->k), wj = uni(cx->wj), do_update = uni(cx->do_update), L = uni(g.L), nt = uni(g.nt);
+    double* sc = lds_all + MDW + GEW + CXW + TLM * HS + TLM * 2 * DBT;
+    (void)wj;
     CSTAMP(0);
     ph_setup();
     const bool spread_kmm = nt > 4 && k >= 4;      // (the same in every workgroup of the surrogate: one barrier more)

@@ -301,7 +301,10 @@ class TinyELBOStep:
         self.stream.synchronize()
         if bool((self.infos != 0).any()):
             i, l = [int(v) for v in torch.nonzero(self.infos)[0]]
-            raise NotPSDError("K_mm not positive definite in model %d layer %d" % (i, l))
+            code = int(self.infos[i, l])
+            if code < 0:      # (-1: a workgroup gave up waiting at an in-launch barrier; -2: the launch did not match its coupling record)
+                raise FloatingPointError("one-launch step: in-launch barrier abandoned in model %d (info %d)" % (i, code))
+            raise NotPSDError("K_mm not positive definite in model %d layer %d (pivot %d)" % (i, l, code))
         if not bool(torch.isfinite(self.losses).all()):
             raise FloatingPointError("non-finite ELBO")
 
