@@ -32,17 +32,16 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int CT = 512;                          // threads per workgroup: two wavefronts per SIMD (the phases are latency-bound)
 constexpr int CNW = CT / 64;
 constexpr int CMAXM = MOBOCMF_COOP_MAX_M;
-constexpr int KSMAX = 4;                         // k-slices of the weighted syrk, at most
+constexpr int KSMAX = 8;                         // slabs of the weighted syrk H (k-slices, or one per column block), at most
 constexpr int XLD = 17;                          // leading dimension of an [Mp][16] column block in LDS
 constexpr int NMAT = 7 + 2 * KSMAX;              // M x M matrices of a layer in `work`
 constexpr int PHEAD = 4;                         // leading scalars of a column block's partial record
-constexpr int SPIN_LIMIT = 1 << 22;      // polls of an in-launch barrier before it is abandoned: several seconds.  The wait is for peers of the SAME
-                                         // launch; it is long only while other work keeps them off the CUs (measured: a test whose predecessors left
-                                         // grid-filling kernels running on other streams needed > 0.4 s), and it is finite because that work ends
+constexpr int SPIN_LIMIT = 1 << 21;      // polls of an in-launch barrier before it is abandoned (~1.5 s): the wait is for peers of the SAME launch,
+                                         // which are resident (checked on the host) -- it ends unless the counters were tampered with
 
 struct CGeom {
     int L, M, Mp, nt, ntri, d, S;
-    int ncol[TLM], ncp[TLM], ncb[TLM], H[TLM], ks[TLM];
+    int ncol[TLM], ncp[TLM], ncb[TLM], H[TLM], ks[TLM], hblk[TLM];
     int64_t flat_off[TLM], flat_noise, flat_len;
     int64_t mat[TLM], pan[TLM], vec[TLM], sml[TLM], part[TLM], hpart[TLM], cpl_off, work_len;
     int pstr;
@@ -59,8 +58,12 @@ __host__ __device__ inline void cgeom_of(const mobocmf_tiny_model& md, CGeom& g)
         g.ncp[l] = (g.ncol[l] + 15) & ~15;
         g.ncb[l] = g.ncp[l] / 16;
         g.H[l] = l == 0 ? 1 + md.d : 5 + 2 * md.d;
-        int ks = (g.ncp[l] + 255) / 256;      // ~256 columns (64 MFMAs of each product) per k-slice
-        g.ks[l] = ks < 1 ? 1 : (ks > KSMAX ? KSMAX : ks);
+        // H = A diag(gv) A^T: a layer of few column blocks (the reference's own sizes: N' = N <= 75 + Pareto points) forms it
+        // block by block inside the backward column phase, one slab per block -- no syrk phase, no barrier for it; a wider
+        // one k-slices it over the whole surrogate in a phase of its own, ~256 columns (64 MFMAs of each product) per slice
+        g.hblk[l] = g.ncb[l] <= KSMAX ? 1 : 0;
+        int ks = (g.ncp[l] + 255) / 256;
+        g.ks[l] = g.hblk[l] ? (g.ncb[l] < 1 ? 1 : g.ncb[l]) : (ks < 1 ? 1 : (ks > 4 ? 4 : ks));
         g.flat_off[l] = fo;
         if (l < md.L) fo += g.H[l] + md.M + (int64_t)md.M * md.M;
     }
@@ -192,8 +195,7 @@ __device__ __forceinline__ bool group_barrier(unsigned long long* cnt, unsigned 
 // One 16 x 16 tile of T X for a column block X [k][XLD] in LDS and a matrix T given k-major in global memory (Tk[k * ld + row]
 // = T[row][k]): k tiles kt0 .. kt1-1.  The 4 x 16 fragments of FOUR k tiles are requested together, before their MFMAs: one L2
 // round trip per four k tiles (all eight at once -- 64 VGPRs of fragments -- was the register-pressure peak of the column phases
-// and put 150 values into scratch memory; a kernel that needs scratch also competes for the queue's scratch wave slots, see
-// SPIN_LIMIT).
+// and put 150 values into scratch memory: with four the kernel needs no scratch at all, M = N = 64: 150 -> 132 us per step).
 __device__ __forceinline__ v4d tile_tx(const double* Tk_, int ld, const double* X, int t, int kt0, int kt1, int lane) {
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     const int li = lane & 15, lk = lane >> 4;
@@ -903,28 +905,7 @@ PHASE_FN void ph_syrk(int lh) {
                 }
             }
         }
-        // da = A g_mean of the layer: the column blocks' partial rows added up (one wavefront)
-        if (wj * CNW + wave == (g.ntri * ks) % (k * CNW)) {
-            double* dav = SML(lh, S_DAV);
-            double* dat = SML(lh, S_DAT);
-            const double* avg = SML(lh, S_AV);
-            const int ncb = g.ncb[lh], pstr = g.pstr;
-            for (int i = lane; i < Mp; i += 64) {
-                gcd pp = GC(PART(lh, 0)) + PHEAD + HS + Mp + i;
-                double s = 0.0;
-                for (int cb = 0; cb < ncb; cb += 8) {      // (eight partial rows requested together: one L2 round trip, not eight)
-                    double v[8];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) v[b] = pp[(int64_t)(cb + b < ncb ? cb + b : ncb - 1) * pstr];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) s += cb + b < ncb ? v[b] : 0.0;
-                }
-                dav[i] = s;
-                dat[i] = s + gkl * avg[i];
-            }
-        }
 }
-
 
 PHASE_FN void ph_backward(int l_in) {
     CTX_LOCALS;
@@ -997,6 +978,32 @@ PHASE_FN void ph_backward(int l_in) {
             }
             __syncthreads();
             CSTAMP(61);
+            if (g.hblk[l]) {
+                // the block's share of H = A diag(gv) A^T and Hc = A diag(cgv) A^T: slab `cb` (lower tiles and their mirrors)
+                gwd Hs = GW(MAT(l, M_HS + cb));
+                gwd Hcs = GW(MAT(l, M_HCS + cb));
+                for (int u = wave; u < g.ntri; u += CNW) {
+                    int ti, tj;
+                    tile_of(u, ti, tj);
+                    v4d ah = {0.0, 0.0, 0.0, 0.0}, ac = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double a = X1[(ti * 16 + li) * XLD + 4 * q + lk], b = X1[(tj * 16 + li) * XLD + 4 * q + lk];
+                        ah = mfma(a, b * gcol[16 + 4 * q + lk], ah);
+                        ac = mfma(a, b * gcol[32 + 4 * q + lk], ac);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = ti * 16 + 4 * r + lk, j = tj * 16 + li;
+                        Hs[(int64_t)i * Mp + j] = ah[r];
+                        Hcs[(int64_t)i * Mp + j] = ac[r];
+                        if (ti != tj) {
+                            Hs[(int64_t)j * Mp + i] = ah[r];
+                            Hcs[(int64_t)j * Mp + i] = ac[r];
+                        }
+                    }
+                }
+            }
             // B2: dA = 2 U (C diag gv) + a g_mean^T - 2 A diag(cgv)   (the column scale commutes with the product)
             if (has_tile) {
                 const v4d acc = tile_tx(UTg, Mp, X2, wave, 0, wave + 1, lane);
@@ -1099,32 +1106,37 @@ PHASE_FN void ph_cb1() {
         // which 0: G1[i][j] = sum_{k >= i-block} U[k][i] H[k][j];  1: GT[i][j] = sum_{k >= j-block} H[k][i] U[k][j]
         const int ucol = which ? tj * 16 : ti * 16, hcol = which ? ti * 16 : tj * 16, kt0 = which ? tj : ti;
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        double uf[4], hf[KSMAX][4], un[4], hn[KSMAX][4];
+        // (the fragments of U and of every slab of H for TWO k tiles -- one when there are more than four slabs -- are requested
+        // together; the slabs are added in order 0, 1, ... on the way into the MFMA)
         const double* Hb = MAT(l, M_HS);
-        FRAG(uf, Ug, kt0 * 16, ucol);
+        const int kb = ks <= 4 ? 2 : 1;
+        for (int kt = kt0; kt < nt; kt += kb) {
+            double uf[2][4], hf[8][4];
 #pragma unroll
-        for (int s2 = 0; s2 < KSMAX; ++s2)
-            if (s2 < ks) { FRAG(hf[s2], Hb + s2 * mm, kt0 * 16, hcol); }
-        for (int kt = kt0; kt < nt; ++kt) {
-            const int kn = kt + 1 < nt ? kt + 1 : kt;
-            FRAG(un, Ug, kn * 16, ucol);
+            for (int c2 = 0; c2 < 2; ++c2) {
+                if (c2 < kb) {
+                    const int kc = kt + c2 < nt ? kt + c2 : nt - 1;
+                    FRAG(uf[c2], Ug, kc * 16, ucol);
 #pragma unroll
-            for (int s2 = 0; s2 < KSMAX; ++s2)
-                if (s2 < ks) { FRAG(hn[s2], Hb + s2 * mm, kn * 16, hcol); }
-            PIN();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double h = hf[0][q];
-#pragma unroll
-                for (int s2 = 1; s2 < KSMAX; ++s2)
-                    if (s2 < ks) h += hf[s2][q];
-                acc = which ? mfma(h, uf[q], acc) : mfma(uf[q], h, acc);
+                    for (int s2 = 0; s2 < 8; ++s2)
+                        if (s2 < ks && (c2 == 0 || s2 < 4)) { FRAG(hf[c2 * 4 + s2], Hb + s2 * mm, kc * 16, hcol); }
+                }
             }
             PIN();
-            COPY4(uf, un);
 #pragma unroll
-            for (int s2 = 0; s2 < KSMAX; ++s2)
-                if (s2 < ks) { COPY4(hf[s2], hn[s2]); }
+            for (int c2 = 0; c2 < 2; ++c2) {
+                if (c2 < kb && kt + c2 < nt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        double h = hf[c2 * 4][q];
+#pragma unroll
+                        for (int s2 = 1; s2 < 8; ++s2)
+                            if (s2 < ks && (c2 == 0 || s2 < 4)) h += hf[c2 * 4 + s2][q];
+                        acc = which ? mfma(h, uf[c2][q], acc) : mfma(uf[c2][q], h, acc);
+                    }
+                }
+            }
+            PIN();
         }
         gwd G = GW(MAT(l, which ? M_GT : M_G1));
 #pragma unroll
@@ -1147,6 +1159,24 @@ PHASE_FN void ph_cb1() {
                 // (layout of the sums: [PHEAD scalars | HS hyper-parameter slots] behind the KL, the d/dzf rows in S_GZ)
                 if (e < PHEAD + HS) W[g.sml[l] + 6 * Mp + 1 + e] = s;
                 else SML(l, S_GZ)[e - PHEAD - HS] = s;
+            }
+        }
+        // da = A g_mean of every layer (the column blocks' partial rows), da_tot = da + gkl a: the same way, for CB2+3
+        const int nch2 = (Mp + 63) / 64, first2 = (first + L * nch) % nwv;
+        for (int u = (gw - first2 + nwv) % nwv; u < L * nch2; u += nwv) {
+            const int l = u / nch2, i = (u % nch2) * 64 + lane, ncb = g.ncb[l];
+            if (i < Mp) {
+                gcd pp = GC(W + g.part[l]) + PHEAD + HS + Mp + i;
+                double s = 0.0;
+                for (int cb = 0; cb < ncb; cb += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) v[b] = pp[(int64_t)(cb + b < ncb ? cb + b : ncb - 1) * g.pstr];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) s += cb + b < ncb ? v[b] : 0.0;
+                }
+                SML(l, S_DAV)[i] = s;
+                SML(l, S_DAT)[i] = s + gkl * GC(SML(l, S_AV))[i];
             }
         }
     }
@@ -1491,7 +1521,7 @@ PHASE_FN void ph_adam() {
 }
 
 
-#define MODEL_BARRIER(id) do { CSTAMP(id); if (!group_barrier(cx->mcnt, (unsigned)k, (int*)(sc + 30))) { if (tid == 0) { md.info[0] = -1; md.info[1] = (id); md.info[2] = (int)(*(volatile unsigned long long*)cx->mcnt) * 1000 + wj; md.out[2] = __builtin_nan(""); } return; } CSTAMP(99); } while (0)
+#define MODEL_BARRIER(id) do { CSTAMP(id); if (!group_barrier(cx->mcnt, (unsigned)k, (int*)(sc + 30))) { if (tid == 0) { md.info[0] = -1; md.out[2] = __builtin_nan(""); } return; } CSTAMP(99); } while (0)
 
 __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model* models_, int k_, unsigned long long* sync_words,
                                                        double lr_, double b1_, double b2_, double aeps_, int do_update_) {
@@ -1545,11 +1575,13 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     }
     for (int l = L - 1; l >= 0; --l) {
         ph_backward(l);
-        if (l + 1 < L) ph_syrk(l + 1);
+        if (l + 1 < L && !g.hblk[l + 1]) ph_syrk(l + 1);
         MODEL_BARRIER(25 + l);
     }
-    ph_syrk(0);
-    MODEL_BARRIER(30);
+    if (!g.hblk[0]) {      // (a layer of few column blocks left its H in the backward column phase: no phase, no barrier here)
+        ph_syrk(0);
+        MODEL_BARRIER(30);
+    }
     ph_cb1();
     MODEL_BARRIER(31);
     ph_cb23();

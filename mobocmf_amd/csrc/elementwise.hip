@@ -368,6 +368,22 @@ int launch_moments_bwd_prep(const double* g_mean, const double* g_var, const dou
     return CHECK_LAUNCH();
 }
 
+// sum of one element over ns slabs, eight loads in flight at a time, ALWAYS added in the order 0, 1, 2, ... (the result does not
+// depend on the batching: graph replay == eager, bit for bit).  The plain loop issued one load per trip and waited for it.
+__device__ __forceinline__ double slab_sum(const double* p, int64_t slab_stride, int ns) {
+    double v = 0.0;
+    int z = 0;
+    for (; z + 8 <= ns; z += 8) {
+        double t[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) t[b] = p[(z + b) * slab_stride];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v += t[b];
+    }
+    for (; z < ns; ++z) v += p[z * slab_stride];
+    return v;
+}
+
 // H (full symmetric) from the slabs of a lower_out syrk: out[i][j] = sum_z slab[z][max-tile order].  If `flag` is
 // given and *flag == 0 the slabs were never written (kernel skipped): out = fallback instead.
 __global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride, int nslab, int nslab_diag, double* out,
@@ -384,9 +400,8 @@ __global__ void reduce_slabs_sym_kernel(const double* slabs, int64_t slab_stride
     // diagonal tiles: the 16 x 16 blocks strictly above the diagonal are not computed by the syrk (GemmArgs.sym_out) -- every
     // element above the diagonal takes its mirror image, which also makes the result exactly symmetric
     const double* p = j > i ? slabs + (int64_t)j * Mp + i : slabs + (int64_t)i * Mp + j;
-    double v = 0.0;
     const int ns = (i / TILE == j / TILE) ? nslab_diag : nslab;      // diagonal tiles may have their own slice count
-    for (int z = 0; z < ns; ++z) v += p[z * slab_stride];
+    const double v = slab_sum(p, slab_stride, ns);
     out[idx] = v;
     if (j / TILE < i / TILE) out[(int64_t)j * Mp + i] = v;     // strictly-upper tiles mirror the lower ones
 }
@@ -399,13 +414,9 @@ __global__ void reduce_slabs_sym2_kernel(const double* slabs, const double* slab
     if (j / TILE > i / TILE) return;
     const int64_t off = j > i ? (int64_t)j * Mp + i : (int64_t)i * Mp + j;
     const int ns = (i / TILE == j / TILE) ? nslab_diag : nslab;
-    double v = 0.0;
-    for (int z = 0; z < ns; ++z) v += slabs[off + z * slab_stride];
+    const double v = slab_sum(slabs + off, slab_stride, ns);
     double v2 = v;
-    if (*flag != 0) {
-        v2 = 0.0;
-        for (int z = 0; z < ns; ++z) v2 += slabs2[off + z * slab_stride];
-    }
+    if (*flag != 0) v2 = slab_sum(slabs2 + off, slab_stride, ns);
     out[idx] = v;
     out2[idx] = v2;
     if (j / TILE < i / TILE) { out[(int64_t)j * Mp + i] = v; out2[(int64_t)j * Mp + i] = v2; }

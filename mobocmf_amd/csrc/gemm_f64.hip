@@ -3,12 +3,14 @@
 //   C[Mr x Nc] (+)= alpha * A[Mr x Kd] * B        B_T=0: B is [Kd x Nc] (n contiguous)
 //                                                 B_T=1: B is [Nc x Kd] (k contiguous)  -> A * B^T
 //
-// Matrix instruction: v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X (tools/mfma_peak.hip): it sustains
-// 73 TFLOP/s = the FP64 vector rate, whereas v_mfma_f64_16x16x4_f64 sustains only 36 TFLOP/s.  Its four
-// independent 4x4x4 blocks are used as four column groups of one 4 x 16 output strip: lane
-// (kk = l>>4, b = (l>>2)&3, i = l&3) holds A[row i][k] -- the same 4 rows in every block, an LDS broadcast
-// read -- and B[k][col 4b+j]; result lane (i = l>>4, col = l&15) (layout verified with one-hot operands,
-// tools/probe_mfma444.hip; cbsz/abid broadcast is a no-op for this instruction).
+// Matrix instruction: v_mfma_f64_16x16x4_f64 (GEMM_MI == 16, the default since round 4).  Measured on MI355X with the
+// instruction issued on VGPR tuples (tools/mfma_peak.hip, profiles/r04_mfma_peak.txt): 77.1 TFLOP/s, against 73.3 for
+// v_mfma_f64_4x4x4_4b_f64 and 67-71 for v_fma_f64.  (Rounds 1-3 ran the 4x4x4 form -- -DGEMM_MI=4 still builds it -- because the
+// builtin's accumulator copies made the 16x16x4 microbenchmark read 36 TFLOP/s: an artefact)  Lane map of
+// the 16x16x4 form: lane (li = l & 15, lk = l >> 4) feeds A[row li][k = 4 lk + kq] to MFMA kq of a K step and holds the result
+// rows 4 r + lk, column li.  The 4x4x4 form uses its four independent blocks as four column groups of one 4 x 16 output strip:
+// lane (kk = l>>4, b = (l>>2)&3, i = l&3) holds A[row i][k] -- the same 4 rows in every block, an LDS broadcast read -- and
+// B[k][col 4b+j]; result lane (i = l>>4, col = l&15) (layout verified with one-hot operands, tools/probe_mfma444.hip).
 //
 // Workgroup = 256 threads = 4 wavefronts (2 x 2), tile 128 x 128, K step 16.  Each wavefront owns 64 x 64 =
 // 64 accumulator registers (128 VGPRs).  Tiles are staged global -> LDS by global_load_lds_dwordx4 (LDS-DMA,

@@ -57,6 +57,7 @@ class _CoopLaunch:
         if sw is None:
             sw = torch.zeros(16 * (len(self.models) + 1), dtype=torch.int64, device=self.device)
             self._sync = sw
+            self._order_after_setup()      # (the zero fill runs on the current stream, the launches on self.stream)
         return sw
 
     def _launch(self, mode):

@@ -256,6 +256,13 @@ class TinyELBOStep:
         raw = bytes(self.host)
         self._dev_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._snap = None
+        self._order_after_setup()
+
+    def _order_after_setup(self):
+        """Everything above was allocated, zero-filled and uploaded on the CURRENT stream; the launches run on ``self.stream``.
+        Without this edge a fill kernel could still be pending when the first launch starts (found with a cooperative launch
+        whose arrival counters were zeroed under it: tools/coop_concurrency_probe.py)."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
 
     # ------------------------------------------------------------------ the kernel this class drives
     _work_bytes_fn = "mobocmf_tiny_work_bytes"
@@ -452,6 +459,7 @@ class TinyConditionedStep(TinyELBOStep):
         for k in range(len(self.models)):
             self.host[k].coupling = self._coupling.data_ptr()
         self._dev_table = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(self.device)
+        self._order_after_setup()
 
     def _factors(self):
         lib = _lib.require_device()

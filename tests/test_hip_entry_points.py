@@ -22,7 +22,7 @@ def rel(a, b):
 def test_gemm_epilogue_variants_match_torch(Mp, Np, rows):
     """The four launches of a layer's panel work through mobocmf_gemm_f64_epilogue vs float64 torch ops: small-panel
     kernel (Mp <= 512, few workgroups), tiled kernel without and with row-block pairing, on 128 x 128 tiles and on 64 x 128
-    tiles (three workgroups per CU, triangular operand resolved in 64-row blocks; mobocmf_set_tile_rows)."""
+    tiles (three workgroups per CU, triangular operand resolved in 64-row blocks; mobocmf_tuning.tile_rows)."""
     from mobocmf_amd import functional as F
     F.set_tile_rows(rows)
     try:
@@ -81,7 +81,7 @@ def test_layer_forward_is_the_dense_prior():
 
 
 def test_set_tuning_switches_kernels_not_results():
-    """mobocmf_set_tuning moves the hand-over between the small-operand kernels and the tiled MFMA pipeline: results agree
+    """mobocmf_tuning.small_gemm_max / small_panel_max move the hand-over between the small-operand kernels and the tiled MFMA pipeline: results agree
     to rounding on either side; bad values are refused."""
     from mobocmf_amd import _lib
     from mobocmf_amd import functional as F
@@ -255,7 +255,7 @@ def test_propagate_rng_draws_standard_normals_and_advances():
                                       (768, 512, 1024)])
 def test_mid_gemm_matches_torch_and_the_tiled_kernel(Mr, Nc, Kd, waves):
     """Plain products with every dimension in (384, 1024] -- the M x M chain of C3 / C5 -- run on the mid-size kernel (64 x 64
-    tiles, whole contraction per workgroup, one launch; mobocmf_set_mid_gemm_max): all triangular-operand flags the chain uses,
+    tiles, whole contraction per workgroup, one launch; mobocmf_tuning.mid_gemm_max): all triangular-operand flags the chain uses,
     A B and A B^T, alpha / accumulate, vs float64 torch and vs the 128 x 128 pipeline (knob off)."""
     from mobocmf_amd import functional as F
     F.set_mid_gemm_max(1024)

@@ -1,9 +1,9 @@
-"""Zero-gradient column blocks of the layer backward (mobocmf_set_sparse_backward, include/mobocmf_hip.h).
+"""Zero-gradient column blocks of the layer backward (mobocmf_tuning.sparse_backward, include/mobocmf_hip.h).
 
 The reference's ELBO scores every row at its own fidelity only (variational_elbo_mf.py:33-38), so autograd hands the top
 layer exact zeros for the rows of every other fidelity; the HIP backward finds the 128-column blocks whose upstream
 gradients are all zero on the device and leaves them out of dA, the weighted syrk, da, dK and the Gram backward.  Checked
-here: the building blocks directly (mobocmf_set_block_activity), a layer with several zero patterns against its own dense
+here: the building blocks directly (the col_activity / k_activity arguments of mobocmf_gemm_f64_epilogue / mobocmf_syrk_weighted_f64), a layer with several zero patterns against its own dense
 backward and against the oracle, and a whole model step."""
 import numpy as np
 import pytest

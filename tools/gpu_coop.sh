@@ -1,10 +1,15 @@
 #!/bin/bash
-# the cooperative step: its tests, then the timing sweep.  Output: gpurun_out/coop/
+# cooperative step: all its tests, the fitter / conditioned / BO-iteration tests that may now train through it, bench C2 both ways
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/coop
-rm -rf $O && mkdir -p $O
-timeout -k 10 ${1:-600} python -m pytest tests/test_hip_coop_step.py -x -q > $O/pytest.log 2>&1
+mkdir -p $O
+timeout -k 10 900 python -m pytest tests/test_hip_coop_step.py tests/test_hip_tiny_step.py tests/test_hip_conditioned.py tests/test_hip_bo_iteration.py -x -q > $O/pytest3.log 2>&1
 rc=$?
-tail -15 $O/pytest.log
+tail -12 $O/pytest3.log
 [ $rc = 0 ] || exit $rc
-timeout -k 10 400 python tools/coop_sweep.py ${2:-} > $O/coop_sweep.txt 2>&1; cat $O/coop_sweep.txt
+for a in "--config C2" "--config C2 --layer-path" "--config C2 --surrogates 4" "--config C2 --surrogates 1"; do
+  timeout -k 10 200 python bench.py $a --steps 300 --no-cpu-baseline --no-roofline --no-dense-leg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a |', round(d['value'],1), 'steps/s |', round(d['ms_per_step']*1e3,1), 'us per bench step |', d['step_issue'], '| repeats', [round(v) for v in d['repeat_values']])"
+done | tee $O/bench_C2.txt
+for a in "--config C1" "--config C1 --surrogates 1"; do
+  timeout -k 10 200 python bench.py $a --steps 500 --no-cpu-baseline --no-roofline --no-dense-leg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a |', round(d['value'],1), 'steps/s |', round(d['ms_per_step']*1e3,1), 'us per bench step |', d['step_issue'], '| repeats', [round(v) for v in d['repeat_values']])"
+done | tee $O/bench_C1.txt
