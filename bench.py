@@ -764,9 +764,11 @@ def main():
                 iso = {v["kernel"]: v["kernel_ms"] for v in line["roofline"]["variants"]}
                 line["per_kernel_instep_ms"] = {
                     "kernels": ins, "instep_over_isolated": {k: ins[k] / iso[k] for k in ins if k in iso},
-                    "how": "widest layer of ONE surrogate, step issued eagerly on its own stream (the launch sequence the graph "
-                           "replays), HIP events recorded by the library around each launch (mobocmf_layer_desc.probe_events), mean "
-                           "of 4 steps; `instep_over_isolated` divides by the same launch timed alone (roofline.variants)"}
+                    "how": "an EAGER SINGLE-STREAM PROBE, not the timed configuration: the widest layer of ONE surrogate, its step "
+                           "issued eagerly on its own stream (the launch sequence the graph replays), HIP events recorded by the "
+                           "library around each launch (mobocmf_layer_desc.probe_events), mean of 4 steps; `instep_over_isolated` "
+                           "divides by the same launch timed alone (roofline.variants).  Per-kernel durations of the timed "
+                           "configuration (3 streams, graph replay): profiles/r05_bench_C3_timed_only_kernel_summary.md"}
         if world == 1 and not args.no_cpu_baseline:
             cb, parity = cpu_baseline(cfg, device=device)
             line["cpu_baseline"] = cb
