@@ -129,6 +129,9 @@ __device__ __forceinline__ int tel(int r, int c) { return r * 16 + (c ^ r); }
 // Cholesky + inverse of the 16 x 16 tile T (swizzled; lower part used) by one wavefront: lane i of every 16-lane row holds row i
 // (the four rows of the wavefront do the same work), right-looking, multipliers broadcast by v_readlane (tiny_step.hip
 // chol_inv_wave).  T receives L (zeros above the diagonal), Ti its inverse.  Returns the 1-based failed pivot or 0 (wave-uniform).
+// (Tried: taking the pivot block's inverse off the critical path -- the panel below it solved by substitution in registers, 136
+// in-lane operations against wave-uniform LDS reads of L_ss, the inverses of all pivot blocks formed afterwards side by side --
+// is SLOWER: the substitution costs what the inverse cost, 16.5 -> 21.8 us at M = 64, 36 -> 46.5 at M = 128.)
 // (Tried: the broadcasts as DPP row_newbcast moves -- no trip through an SGPR -- are SLOWER: 17.6 -> 21 us for the four tiles of
 // M = 64, profiles/r05_coop_step.txt; the DPP move waits for its source's write-back where v_readlane's result is forwarded.)
 __device__ __forceinline__ int chol_inv_tile16(double* T, double* Ti, int lane) {
@@ -1188,7 +1191,26 @@ PHASE_FN void ph_cb23() {
     const int gw = wj * CNW + wave, nwv = k * CNW, nt2 = nt * nt;
     // CB2+3: Y = 2 (U G1 - Hc) + a da^T + da_tot a^T + dU_tot U^T with dU_tot = 2 tril(G1^T) + gkl U (one task per tile);
     //        g_LS = tril(L^-T dU_tot) - gkl diag(1 / L_S,ii) (one task per lower tile)
-    for (int u = gw; u < L * nt2 + L * g.ntri; u += nwv) {
+    for (int u = gw; u < L * nt2 + L * g.ntri + L * nt; u += nwv) {
+        if (u >= L * nt2 + L * g.ntri) {      // g_m += L^-T da_tot: a task per 16 rows (da_tot rides as column 0 of a B operand)
+            const int u2 = u - L * nt2 - L * g.ntri, l = u2 / nt, t = u2 % nt;
+            const double* Lig = MAT(l, M_LI);
+            gcd dat = GC(SML(l, S_DAT));
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kt = t; kt < nt; ++kt) {
+                double a[4], b[4];
+                FRAG(a, Lig, kt * 16, t * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = dat[kt * 16 + 4 * q + lk];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = mfma(a[q], li == 0 ? b[q] : 0.0, acc);
+            }
+            if (li == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) SML(l, S_GMA)[t * 16 + 4 * r + lk] = acc[r];
+            }
+            continue;
+        }
         if (u >= L * nt2) {
             const int l = (u - L * nt2) / g.ntri;
             int ti, tj;
@@ -1343,66 +1365,52 @@ PHASE_FN void ph_cb456() {
 }
 
 
-PHASE_FN void ph_cb7() {
-    CTX_LOCALS;
-    const int gw = wj * CNW + wave, nwv = k * CNW, nt2 = nt * nt;
-    // CB7: T5 = T4 L^-1 (a task per tile); g_m += L^-T da_tot (a task per 16 rows: da_tot rides as column 0 of a B operand)
-    for (int u = gw; u < L * nt2 + L * nt; u += nwv) {
-        if (u >= L * nt2) {
-            const int l = (u - L * nt2) / nt, t = (u - L * nt2) % nt;
-            const double* Lig = MAT(l, M_LI);
-            gcd dat = GC(SML(l, S_DAT));
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            for (int kt = t; kt < nt; ++kt) {
-                double a[4], b[4];
-                FRAG(a, Lig, kt * 16, t * 16);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) b[q] = dat[kt * 16 + 4 * q + lk];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = mfma(a[q], li == 0 ? b[q] : 0.0, acc);
-            }
-            if (li == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) SML(l, S_GMA)[t * 16 + 4 * r + lk] = acc[r];
-            }
-            continue;
-        }
-        const int l = u / nt2, ti = (u % nt2) / nt, tj = u % nt;
-        const double* T4T = MAT(l, M_T4T);
-        const double* Lig = MAT(l, M_LI);
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kb = tj; kb < nt; kb += 4) {
-            double a[4][4], b[4][4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int kt = kb + s4 < nt ? kb + s4 : nt - 1;
-                FRAG(a[s4], T4T, kt * 16, ti * 16);
-                FRAG(b[s4], Lig, kt * 16, tj * 16);
-            }
-            PIN();
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                if (kb + s4 < nt) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = mfma(a[s4][q], b[s4][q], acc);
-                }
-            }
-        }
-        gwd T5 = GW(MAT(l, M_T5));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T5[(int64_t)(ti * 16 + 4 * r + lk) * Mp + tj * 16 + li] = acc[r];
-    }
-}
-
-
 PHASE_FN void ph_cb8() {
     CTX_LOCALS;
-    // CB8: Gram backward of dK_mm = sym(T5), a workgroup per 16 rows (both arguments are Z~: a pair's f gradient counts twice)
+    // CB7+8: T5 = T4 L^-1 and the Gram backward of dK_mm = sym(T5), a workgroup per 16 rows (both arguments are Z~: a pair's f
+    // gradient counts twice).  The workgroup forms the tile row AND the tile column of T5 that its 16 rows of sym(T5) are made of
+    // (2 nt - 1 tile products, a wavefront each, into LDS) instead of reading them back after one more barrier.
+    double* Gs = X0;      // [16][Mp + 1]: T5[i][j] + T5[j][i] of the workgroup's rows i (fits: 16 (Mp + 1) <= 3 Mp XLD)
+    const int GLD = Mp + 1;
     for (int u = wj; u < L * nt; u += k) {
         const int l = u / nt, ti = u % nt, kind = l > 0;
         const double* zt = zta + l * Mp * ZW;
+        const double* T4T = MAT(l, M_T4T);
+        const double* Lig = MAT(l, M_LI);
         __syncthreads();
-        const double* T5 = MAT(l, M_T5);
+        for (int e = tid; e < 16 * GLD; e += CT) Gs[e] = 0.0;
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: tiles (ti, tj), added as they are; pass 1: tiles (tj, ti), added transposed (the diagonal tile takes both)
+            for (int tj = wave; tj < nt; tj += CNW) {
+                const int ta = pass ? tj : ti, tb = pass ? ti : tj;      // T5 tile (ta, tb) = sum_k T4[ta-rows][k] L^-1[k][tb-cols]
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                for (int kb = tb; kb < nt; kb += 4) {
+                    double a[4][4], b[4][4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int kt = kb + s4 < nt ? kb + s4 : nt - 1;
+                        FRAG(a[s4], T4T, kt * 16, ta * 16);
+                        FRAG(b[s4], Lig, kt * 16, tb * 16);
+                    }
+                    PIN();
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        if (kb + s4 < nt) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc = mfma(a[s4][q], b[s4][q], acc);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ra = 4 * r + lk, cb2 = li;      // element (ra, cb2) of tile (ta, tb)
+                    if (!pass) Gs[ra * GLD + tj * 16 + cb2] += acc[r];
+                    else Gs[cb2 * GLD + tj * 16 + ra] += acc[r];
+                }
+            }
+            __syncthreads();      // (a wavefront's two passes touch the same 16 x 16 patch of Gs: in order)
+        }
         const double* hyl = hy + l * HS;
         const double* ill = il + l * 2 * DBT;
         double hacc[HS];
@@ -1413,7 +1421,7 @@ PHASE_FN void ph_cb8() {
         if (i < M) {
 #pragma unroll 1
             for (int j = tid >> 4; j < M; j += CT / 16) {
-                const double G = 0.5 * (GC(T5)[(int64_t)i * Mp + j] + GC(T5)[(int64_t)j * Mp + i]);
+                const double G = 0.5 * Gs[(tid & 15) * GLD + j];
                 double dfa, dzf;
                 kern_back(kind, d, zt + i * ZW, zt[i * ZW + DBT], zt + j * ZW, hyl, ill, G, hacc, dfa, dzf);
                 rs += dfa;
@@ -1588,8 +1596,6 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     MODEL_BARRIER(32);
     ph_cb456();
     MODEL_BARRIER(33);
-    ph_cb7();
-    MODEL_BARRIER(34);
     ph_cb8();
     MODEL_BARRIER(35);
     ph_adam();

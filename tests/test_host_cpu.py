@@ -300,3 +300,39 @@ def test_tiny_step_descriptor_layout_and_argument_checks():
     assert step(0, 1) == _lib.BAD_ARG and step(1, 3) == _lib.BAD_ARG and step(1, 1, None) == _lib.BAD_ARG
     arr[0].M = 33                                  # beyond MOBOCMF_TINY_MAX_M
     assert step(1, 1) == _lib.BAD_ARG
+
+
+def test_coop_step_argument_checks_are_made_on_the_host():
+    """mobocmf_coop_elbo_step / mobocmf_coop_work_bytes refuse malformed calls on the HOST, before any HIP call (no GPU needed):
+    no models, no sync words, more workgroups per surrogate than the interface allows, a mode the kernel does not have, a
+    descriptor without its pointers, M beyond MOBOCMF_COOP_MAX_M.  The workspace grows with M^2 (the layer's matrices) and with
+    the panel columns; the flat layout is the one-workgroup kernel's."""
+    import ctypes
+    from mobocmf_amd import _lib
+    lib = _lib.load()
+    T = _lib.TinyModel()
+    T.L, T.M, T.d, T.S, T.N = 2, 100, 2, 4, 300
+    T.rows[0], T.rows[1] = 300, 75
+    wb, wb2 = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.mobocmf_coop_work_bytes(ctypes.byref(T), ctypes.byref(wb)) == _lib.OK
+    Mp = 112
+    assert wb.value > 8 * 2 * 15 * Mp * Mp        # 7 + 2 * 8 matrices per layer ... at least the 15 that always exist
+    B = _lib.TinyModel.from_buffer_copy(T)
+    B.rows[1] = 150
+    assert lib.mobocmf_coop_work_bytes(ctypes.byref(B), ctypes.byref(wb2)) == _lib.OK and wb2.value > wb.value
+    for field, bad in (("L", 0), ("L", 4), ("M", 0), ("M", _lib.COOP_MAX_M + 1), ("d", 0), ("S", 0)):
+        B = _lib.TinyModel.from_buffer_copy(T)
+        setattr(B, field, bad)
+        assert lib.mobocmf_coop_work_bytes(ctypes.byref(B), ctypes.byref(wb2)) == _lib.BAD_ARG, field
+    arr = (_lib.TinyModel * 1)(T)
+    host = ctypes.cast(arr, ctypes.c_void_p)
+    sync = (ctypes.c_int64 * 32)()
+    used = ctypes.c_int32(-7)
+    step = lambda n=1, wgs=0, mode=1, h=host, sw=sync: lib.mobocmf_coop_elbo_step(
+        h, host, n, wgs, ctypes.cast(sw, ctypes.c_void_p) if sw is not None else None, 1e-3, 0.9, 0.999, 1e-8, mode,
+        ctypes.byref(used), None)
+    assert step() == _lib.BAD_ARG                  # a descriptor without pointers
+    assert step(n=0) == _lib.BAD_ARG and step(wgs=65) == _lib.BAD_ARG and step(wgs=-1) == _lib.BAD_ARG
+    assert step(mode=3) == _lib.BAD_ARG and step(mode=5) == _lib.BAD_ARG      # input gradients: the one-workgroup kernel only
+    assert step(h=None) == _lib.BAD_ARG and step(sw=None) == _lib.BAD_ARG
+    assert used.value == -7                        # nothing was chosen, nothing launched

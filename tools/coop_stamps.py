@@ -17,7 +17,7 @@ NAMES = {0: "start", 1: "P0 hyper-parameters", 2: "K_mm", 3: "Cholesky", 4: "inv
          10: "forward layer 0", 11: "forward layer 1", 12: "forward layer 2", 15: "coupling", 20: "backward columns layer 0",
          21: "backward columns layer 1", 22: "backward columns layer 2", 25: "+ syrk of the layer above (0)", 26: "+ syrk (1)",
          27: "+ syrk (2)", 30: "syrk layer 0", 31: "CB1 G1 = U^T H", 32: "CB2+3 Y, g_LS", 33: "CB4-6 dL, P, T4", 34: "CB7 T5",
-         35: "CB8 Gram backward of K_mm", 40: "gradients + Adam", 50: "    . layer staged", 51: "    . rows staged",
+         35: "CB7+8 T5 = T4 L^-1, Gram backward of K_mm", 40: "gradients + Adam", 50: "    . layer staged", 51: "    . rows staged",
          52: "    . K block", 53: "    . A = L^-1 K", 54: "    . C = U^T A", 55: "    . sums + A, C out", 60: "    . layer staged",
          61: "    . A, C in + upstream gradients", 62: "    . dA", 63: "    . dK", 64: "    . Gram backward", 99: "  (barrier wait)"}
 d, L, M, N, S = [int(v) for v in sys.argv[1:6]]
