@@ -445,7 +445,7 @@ def main():
                     help="serialise each surrogate's layers on one stream (no chain/panel split across streams)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = median")
     ap.add_argument("--tile-rows", type=int, default=0, help="A/B knob: tile height of the panel products (0 automatic, 64, 128)")
-    ap.add_argument("--potrf-cols", type=int, default=0, help="A/B knob: columns per hand-over of the Cholesky panel kernel (4 | 1)")
+    ap.add_argument("--potrf-cols", type=int, default=None, help="A/B knob: the blocked Cholesky as one launch (0, default) or a launch pair per 64 columns (4 | 1 columns per hand-over)")
     ap.add_argument("--dense-backward", action="store_true",
                     help="A/B knob: do not skip the column blocks of a layer backward whose upstream gradients are all zero")
     ap.add_argument("--small-gemm-max", type=int, default=0, help="A/B knob: largest M x M product the small-operand kernel takes (mobocmf_tuning.small_gemm_max)")
@@ -510,7 +510,7 @@ def main():
     if args.syrk_wgs:
         from mobocmf_amd import functional as F_
         F_.set_syrk_workgroups(args.syrk_wgs)
-    if args.potrf_cols:
+    if args.potrf_cols is not None:
         from mobocmf_amd import functional as F_
         F_.set_potrf_cols(args.potrf_cols)
     dist = None

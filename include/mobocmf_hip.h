@@ -69,7 +69,9 @@ typedef struct mobocmf_tuning {
     int32_t sparse_backward; /* 1 (default): a layer backward skips 128-column blocks whose upstream gradients are all
                               * exactly zero (the rows of other fidelities, variational_elbo_mf.py:33-38) -- found on the
                               * device, same numbers; 0: the dense backward (A/B timing, parity tests) */
-    int32_t potrf_cols;      /* columns per hand-over of the 64-wide Cholesky panel kernel: 4 (default) | 1 */
+    int32_t potrf_cols;      /* the blocked Cholesky: 0 (default) = all 64-column steps in ONE launch where it applies (128 < M <= 1024;
+                              * panel and trailing-update workgroups resident together), the four-column panel kernel elsewhere |
+                              * 4 | 1 = one launch pair per 64 columns, 4 / 1 columns per hand-over of its panel kernel */
 } mobocmf_tuning;
 int mobocmf_tuning_init(mobocmf_tuning* t);
 

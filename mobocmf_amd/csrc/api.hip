@@ -48,7 +48,7 @@ int launch_mirror_lower(const double* src, int64_t lds, double* dst, int64_t ldd
                         int64_t n_real, hipStream_t s);
 // layer-batched forms (blockIdx.z = layer, workspace pointers + z*zs doubles, user tensors as tables)
 int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
-                   double* zero0, double* zero1, hipStream_t s);
+                   double* zero0, double* zero1, void* sync, int* inverse_done, hipStream_t s);
 int launch_chain_outputs_z(const double* X, const double* LSp, const double* LinvT, const double* da_tot, int M, int Mp,
                            const double* const* gkl, double* const* gLS, double* const* gm, int nz, int64_t zs, hipStream_t s);
 int launch_pad_params_z(const double* const* LS, const double* const* m, int M, double* LSp, double* mp, int Mp, int nz,
@@ -74,7 +74,7 @@ int launch_symmetrize_z(const double* S, int Mp, double* G, int nz, int64_t zs, 
 
 // ---- the tuning / probe events of the C-ABI call this thread is inside (common.h: TuneScope).  Call-scoped, thread-local:
 // the library keeps no state between calls (include/mobocmf_hip.h preamble).
-static const mobocmf_tuning kDefaultTuning = {(uint32_t)sizeof(mobocmf_tuning), 384, 512, 0, 0, 1024, 32, 0, 1, 4};
+static const mobocmf_tuning kDefaultTuning = {(uint32_t)sizeof(mobocmf_tuning), 384, 512, 0, 0, 1024, 32, 0, 1, 0};
 static thread_local const mobocmf_tuning* t_tuning = nullptr;
 static thread_local void* const* t_probe = nullptr;
 const mobocmf_tuning& tune() { return t_tuning ? *t_tuning : kDefaultTuning; }
@@ -85,7 +85,7 @@ bool tuning_ok(const mobocmf_tuning* t) {
            t->pair_mode >= 0 && t->pair_mode <= 2 && t->mid_gemm_max >= 0 && t->mid_gemm_max <= 4096 &&
            (t->mid_gemm_waves == 4 || t->mid_gemm_waves == 8 || t->mid_gemm_waves == 32) &&
            (t->syrk_workgroups == 0 || (t->syrk_workgroups >= 16 && t->syrk_workgroups <= 4096)) &&
-           (t->sparse_backward == 0 || t->sparse_backward == 1) && (t->potrf_cols == 1 || t->potrf_cols == 4);
+           (t->sparse_backward == 0 || t->sparse_backward == 1) && (t->potrf_cols == 0 || t->potrf_cols == 1 || t->potrf_cols == 4);
 }
 TuneScope::TuneScope(const mobocmf_tuning* t, void* const* probe) : prev_t(t_tuning), prev_p(t_probe) {
     t_tuning = t;
@@ -417,8 +417,11 @@ int chain_forward(int n, const ChainWs& c, int64_t zs, const ChainIO& io, const 
         TRY(launch_gram_fwd(g, s));
     }
     // (the last launch of the factorisation also clears L^-1 and U, which are filled on and below the block diagonal only)
-    TRY(launch_potrf_z(c.L, Mp, Mp, D.M, c.Dinv, c.Ld, io.info, n, zs, c.Linv, c.U, s));
-    TRY(launch_trtri_z(c.L, Mp, Mp, c.Dinv, c.Linv, c.T, c.ws, c.ws_elems, n, zs, s));
+    // (the product scratch `ws` is not in use before the triangular inverse: its first bytes are the one-launch factorisation's
+    // hand-over words)
+    int inv_done = 0;
+    TRY(launch_potrf_z(c.L, Mp, Mp, D.M, c.Dinv, c.Ld, io.info, n, zs, c.Linv, c.U, c.ws, &inv_done, s));
+    if (!inv_done) TRY(launch_trtri_z(c.L, Mp, Mp, c.Dinv, c.Linv, c.T, c.ws, c.ws_elems, n, zs, s));
     // L^-T, and the user tensors L_S, m -> padded copies (all layers): two independent jobs, one launch
     TRY(launch_transpose_pad_z(c.Linv, c.LinvT, Mp, io.L_S, io.m, D.M, c.LSp, c.mp, n, zs, s));
     // U = L^-1 L_S (lower x lower), a = L^-1 m
@@ -1031,8 +1034,9 @@ int mobocmf_exact_gp_factor(int32_t n, const double* K, int64_t ldk, const doubl
     // padded copy of K (identity on the padded diagonal), padded y
     TRY(launch_copy_pad_identity(K, ldk, n, S.L, np, s));
     TRY(launch_pad_vec(y, n, S.yp, np, s));
-    TRY(launch_potrf_z(S.L, np, np, n, F.Dinv, F.Ld, &info, 1, 0, S.Linv, nullptr, s));
-    TRY(launch_trtri(S.L, np, np, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
+    int inv_done = 0;
+    TRY(launch_potrf_z(S.L, np, np, n, F.Dinv, F.Ld, &info, 1, 0, S.Linv, nullptr, F.ws, &inv_done, s));
+    if (!inv_done) TRY(launch_trtri(S.L, np, np, F.Dinv, S.Linv, F.T, F.ws, F.ws_elems, s));
     TRY(launch_gemv_rows(S.Linv, np, S.yp, S.a, np, np, 1.0, 0, s));
     return launch_exact_gp_mll(S.L, np, S.a, n, mll, s);
 }

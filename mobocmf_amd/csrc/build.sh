@@ -13,7 +13,7 @@ ccver=$($HIPCC --version 2>/dev/null | sha256sum | cut -c1-16)
 objs=""
 pids=""
 for f in gemm_f64 chol gram elementwise rff tiny_step coop_step api; do
-  want=$( (echo "$ccver $FLAGS"; cat $f.hip common.h small_step_common.h ../../include/mobocmf_hip.h) | sha256sum | cut -c1-32)
+  want=$( (echo "$ccver $FLAGS"; cat $f.hip common.h small_step_common.h tile16.h ../../include/mobocmf_hip.h) | sha256sum | cut -c1-32)
   have=$(cat $f.o.stamp 2>/dev/null || true)
   if [ $force = 1 ] || [ ! -f $f.o ] || [ "$want" != "$have" ]; then
     rm -f $f.o $f.o.stamp           # a failed compile must not leave a stale object for the link step

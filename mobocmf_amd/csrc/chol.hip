@@ -7,7 +7,9 @@
 // blocked triangular inverse).  The trailing update A22 -= L21 L21^T runs on the f64 MFMA.
 // Reference behaviour replaced: gpytorch psd_safe_cholesky(K_mm) -> torch.linalg.cholesky_ex.
 #include "common.h"
+#include "tile16.h"
 #include <atomic>
+#include <cstdlib>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -439,6 +441,603 @@ __global__ __launch_bounds__(256) void syrk64_update_kernel(double* A, int64_t l
             }
 }
 
+// ---------------------------------------------------------------------------------- the factorisation as ONE launch
+// potrf_coop_kernel: all 64-column steps of the right-looking factorisation inside one launch, G workgroups per layer, resident
+// together.  Workgroup 0 (the PANEL workgroup) owns the critical path: it factorises the 64 x 64 diagonal block of step jb in
+// LDS -- four 16-wide pivot tiles row-per-lane in registers by wavefront 0 (chol_inv_tile16), the updates between them on the
+// matrix cores by wavefronts 1-3, the block's inverse row by row by wavefronts 4-7 as the pivots complete -- then (look-ahead)
+// the next panel block L[jb+1, jb] = A[jb+1, jb] L_jj^-T and with it the next diagonal block, and goes straight on to step
+// jb + 1; the two blocks of the next block row are fetched by wavefronts 4-7 WHILE the pivots run.  The TRAILING workgroups do
+// the rest of step jb meanwhile (X: the panel blocks below and the update of column jb + 1, Y: the update of the columns beyond),
+// and the INVERSE workgroups form L^-1 block row by block row behind them.  Hand-over is by monotonic words per layer (zeroed
+// before the launch): `f` (steps published by the panel workgroup), `pri` (look-ahead blocks of the next step updated), `xd`
+// (panel column complete), and an arrival counter per group.  Every wait is bounded: a workgroup that gives up writes info = -1
+// and leaves, and so do its peers.
+// Replaces the launch pair potrf_panel4_kernel + syrk64_update_kernel per 64 columns (launch_potrf_z below).
+#define PC_T 512
+#define PC_SPIN (1 << 22)
+#define PC_S (NB * LD64)
+#define PC_LDS_DOUBLES (4 * PC_S)      // the others' four dense blocks; the panel workgroup's 62 tiles (15 872 doubles) fit in it
+#define PC_WORDS 8                     // sync words per layer
+
+__device__ __forceinline__ bool pc_wait_ge(unsigned long long* w, unsigned long long target, int* flag_lds) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int spins = 0, ok = 1;
+        while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > PC_SPIN) { ok = 0; break; }
+        }
+        __threadfence();
+        *flag_lds = ok;
+    }
+    __syncthreads();
+    return *flag_lds != 0;
+}
+// publish what the workgroup wrote so far: all its stores are issued (barrier), then one agent-scope release by thread 0
+__device__ __forceinline__ void pc_signal_store(unsigned long long* w, unsigned long long v) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void pc_signal_add(unsigned long long* w) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(w, 1ull);
+    }
+}
+__device__ __forceinline__ bool pc_barrier(unsigned long long* cnt, unsigned n, int* flag_lds) {
+    __syncthreads();
+    if (n > 1) {
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned long long old = atomicAdd(cnt, 1ull), target = (old / n + 1ull) * n;
+            int spins = 0, ok = 1;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > PC_SPIN) { ok = 0; break; }
+            }
+            __threadfence();
+            *flag_lds = ok;
+        }
+        __syncthreads();
+        return *flag_lds != 0;
+    }
+    return true;
+}
+#ifdef PC_STAMPS
+// diagnostic build (tools/build_variant.sh pcstamps -DPC_STAMPS; tools/chol_stamps.py): wall-clock stamps of the panel workgroup
+__device__ double pc_stamp_buf[1024];
+extern "C" int mobocmf_debug_potrf_stamps(double* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_stamp_buf), sizeof(double) * 1024) == hipSuccess ? 0 : 3;
+}
+#define PCSTAMP(id) do { if (tid == 0 && z == 0 && nst < 510) { pc_stamp_buf[2 * nst + 2] = (double)(id); pc_stamp_buf[2 * nst + 3] = (double)wall_clock64(); ++nst; pc_stamp_buf[0] = (double)nst; } } while (0)
+#else
+#define PCSTAMP(id) do { } while (0)
+#endif
+typedef const double __attribute__((address_space(1)))* pc_gc;
+typedef double __attribute__((address_space(1)))* pc_gw;
+// a 64 x 64 block (row-major, ld) -> LDS [64][LD64], 512 threads; a wavefront reads one 512-byte row per instruction, all 8
+// requests of a thread in flight before the first LDS store
+__device__ __forceinline__ void pc_load64(double* dst, const double* src, int64_t ld, int tid) {
+    pc_gc g = (pc_gc)src;
+    double v[8];
+    const int c = tid & 63, r0 = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = g[(int64_t)(r0 + 8 * q) * ld + c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[(r0 + 8 * q) * LD64 + c] = v[q];
+}
+// 64 x 64 x 64 on eight wavefronts: wavefront (wr = wave / 4, wc = wave % 4) forms rows 32 wr .. +32, columns 16 wc .. +16 of
+// As[i][k] * (BT ? Bs[j][k] : Bs[k][j])
+template <bool BT>
+__device__ __forceinline__ void pc_mm64(const double* As, const double* Bs, v4f64 (&acc)[2], int wr, int wc, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    acc[0] = acc[1] = (v4f64){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const double a0 = As[(wr * 32 + li) * LD64 + ks * 4 + lk], a1 = As[(wr * 32 + 16 + li) * LD64 + ks * 4 + lk];
+        const double bf = BT ? Bs[(wc * 16 + li) * LD64 + ks * 4 + lk] : Bs[(ks * 4 + lk) * LD64 + wc * 16 + li];
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bf, acc[1], 0, 0, 0);
+    }
+}
+// dst (global 64 x 64 block) += sgn * acc: all loads first, then the stores
+__device__ __forceinline__ void pc_add_global(double* blk, int64_t ld, const v4f64 (&acc)[2], double sgn, int wr, int wc, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    pc_gw g = (pc_gw)blk;
+    double v[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[t][r] = g[(int64_t)(wr * 32 + t * 16 + lk + 4 * r) * ld + wc * 16 + li];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[(int64_t)(wr * 32 + t * 16 + lk + 4 * r) * ld + wc * 16 + li] = __builtin_fma(sgn, acc[t][r], v[t][r]);
+}
+// tile (a, b <= a) number u of a packed lower triangle, u < 10
+__device__ __forceinline__ void pc_tile_of(int u, int& a, int& b) {
+    a = (u >= 1) + (u >= 3) + (u >= 6);
+    b = u - a * (a + 1) / 2;
+}
+// the 10 lower 16 x 16 tiles of a 64 x 64 block -> swizzled tiles (256 threads, p = r * 16 + c)
+__device__ __forceinline__ void pc_fetch_lower(double* dst, const double* blk, int64_t ld, int p) {
+    pc_gc g = (pc_gc)blk;
+    double v[10];
+    const int r = p >> 4, c = p & 15;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        int ti, tj;
+        pc_tile_of(t, ti, tj);
+        v[t] = g[(int64_t)(ti * 16 + r) * ld + tj * 16 + c];
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) dst[t * 256 + tel(r, c)] = v[t];
+}
+// all 16 tiles (tile (a, k) at (4 a + k) * 256)
+__device__ __forceinline__ void pc_fetch_full(double* dst, const double* blk, int64_t ld, int p) {
+    pc_gc g = (pc_gc)blk;
+    double v[16];
+    const int r = p >> 4, c = p & 15;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = g[(int64_t)((t >> 2) * 16 + r) * ld + (t & 3) * 16 + c];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dst[t * 256 + tel(r, c)] = v[t];
+}
+
+// C += sgn * A B over a list of 64-block tasks.  The destination values are requested together with the operands, so the
+// read-modify-write of C costs no round trip of its own after the matrix instructions.  (Tried: requesting task u + step's
+// operands and destination before the matrix instructions of task u -- 24 more live registers per thread put 65 values into
+// scratch and the launch got slower, 225 -> 250 us at n = 512.)
+struct PcTask { const double* a; int64_t lda; const double* b; int64_t ldb; double* c; int64_t ldc; };
+template <bool BT, class GetTask>
+__device__ __forceinline__ void pc_tasks(int first, int ntask, int step, GetTask get, double sgn, double* Sa, double* Sb, int tid,
+                                         int wr, int wc, int lane) {
+    const int li = lane & 15, lk = lane >> 4, c = tid & 63, r0 = tid >> 6;
+    for (int u = first; u < ntask; u += step) {
+        const PcTask t = get(u);
+        pc_gc ga = (pc_gc)t.a;
+        pc_gc gb = (pc_gc)t.b;
+        pc_gw gd = (pc_gw)t.c;
+        double va[8], vb[8], vc[2][4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) va[q] = ga[(int64_t)(r0 + 8 * q) * t.lda + c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vb[q] = gb[(int64_t)(r0 + 8 * q) * t.ldb + c];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vc[h][r] = gd[(int64_t)(wr * 32 + h * 16 + lk + 4 * r) * t.ldc + wc * 16 + li];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            Sa[(r0 + 8 * q) * LD64 + c] = va[q];
+            Sb[(r0 + 8 * q) * LD64 + c] = vb[q];
+        }
+        __syncthreads();
+        v4f64 acc[2];
+        pc_mm64<BT>(Sa, Sb, acc, wr, wc, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gd[(int64_t)(wr * 32 + h * 16 + lk + 4 * r) * t.ldc + wc * 16 + li] = __builtin_fma(sgn, acc[h][r], vc[h][r]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(PC_T) void potrf_coop_kernel(double* A, int64_t ld, int nreal, double* Dinv, double* Ld, InfoZ infoz,
+                                                           int64_t zs, unsigned long long* sync, double* Linv, int nblk, int NT) {
+    extern __shared__ __attribute__((aligned(16))) double pc_lds[];
+    __shared__ int flag, giveup;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int z = blockIdx.y, w = blockIdx.x, NI = (int)gridDim.x - 1 - NT;      // 1 panel + NT trailing + NI inverse workgroups
+    A += z * zs; Dinv += z * zs; Ld += z * zs;
+    if (Linv) Linv += z * zs;
+    int32_t* info = infoz.p[z];
+    unsigned long long* const F = sync + z * PC_WORDS;
+    unsigned long long* const PRI = F + 1;       // steps whose look-ahead blocks the first trailing workgroup has updated
+    unsigned long long* const BART = F + 2;      // barrier of the trailing workgroups
+    unsigned long long* const XD = F + 3;        // steps whose panel L[:, jb] is complete
+    unsigned long long* const BARI = F + 4;      // barrier of the inverse workgroups
+    if (tid == 0) giveup = 0;
+#ifdef PC_STAMPS
+    int nst = 0;
+#endif
+    if (w == 0) {
+        // ------------------------------------------------------------------ the panel workgroup
+        double* const T0 = pc_lds;               // the diagonal block of this step / of the next one, 10 swizzled lower tiles each
+        double* const T1 = T0 + 10 * 256;
+        double* const Lip = T1 + 10 * 256;       // the block's inverse, same layout
+        double* const An = Lip + 10 * 256;       // A[jb+1, jb], 16 tiles
+        double* const Ln = An + 16 * 256;        // L[jb+1, jb], 16 tiles
+        int fail = 0, cur = 0;
+        if (tid < 256) pc_fetch_lower(T0, A, ld, tid);
+        __syncthreads();
+        for (int jb = 0; jb < nreal; ++jb) {
+            double* const Lp = cur ? T1 : T0;
+            double* const Dn = cur ? T0 : T1;
+            const bool need = jb + 1 < nreal;
+            bool fetched = !need || wave < 4;
+            const unsigned long long target = (unsigned long long)jb;
+            // wavefronts 4-7: the next block row's two blocks, as soon as the other workgroups are through with them
+            auto try_fetch = [&](bool block) {
+                if (fetched) return;
+                bool ready = jb == 0;
+                if (!ready) {
+                    int spins = 0;
+                    for (;;) {
+                        ready = __hip_atomic_load(PRI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+                        if (ready || !block) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > PC_SPIN) { giveup = 1; break; }
+                    }
+                }
+                if (ready) {
+                    __threadfence();
+                    const double* row = A + (int64_t)(jb + 1) * NB * ld;
+                    pc_fetch_full(An, row + (int64_t)jb * NB, ld, tid - 256);
+                    pc_fetch_lower(Dn, row + (int64_t)(jb + 1) * NB, ld, tid - 256);
+                    fetched = true;
+                }
+            };
+            // (A) the 64 x 64 diagonal block: 16-wide right-looking with look-ahead (coop_step.hip ph_chain, four tiles)
+            PCSTAMP(1);
+            if (wave == 0) {
+                const int f = chol_inv_tile16(Lp + tix(0, 0), Lip + tix(0, 0), lane);
+                if (f && !fail) fail = jb * NB + f;
+            }
+            try_fetch(false);
+            __syncthreads();
+#pragma unroll 1
+            for (int s = 0; s < 3; ++s) {
+                const double* Bi = Lip + tix(s, s);
+                {
+                    const int i = s + 1 + wave;      // panel tile (i, s): L_is = A_is L_ss^-T
+                    if (i < 4) {
+                        double* T = Lp + tix(i, s);
+                        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = mfma(T[tel(li, 4 * q + lk)], Bi[tel(li, 4 * q + lk)], acc);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T[tel(4 * r + lk, li)] = acc[r];
+                    }
+                }
+                __syncthreads();
+                if (wave < 4) {
+                    const int nrem = 3 - s, ntr = nrem * (nrem + 1) / 2;
+                    for (int u = wave; u < ntr; u += 3 + (wave == 0 ? ntr : 0)) {      // A_ab -= L_as L_bs^T; u = 0: the next pivot tile, wavefront 0 alone
+                        int a, b;
+                        pc_tile_of(u, a, b);
+                        const double* P = Lp + tix(s + 1 + a, s);
+                        const double* Q = Lp + tix(s + 1 + b, s);
+                        double* D = Lp + tix(s + 1 + a, s + 1 + b);
+                        v4d acc;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = D[tel(4 * r + lk, li)];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = mfma(-P[tel(li, 4 * q + lk)], Q[tel(li, 4 * q + lk)], acc);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) D[tel(4 * r + lk, li)] = acc[r];
+                        if (u == 0) {
+                            const int f = chol_inv_tile16(D, Lip + tix(s + 1, s + 1), lane);
+                            if (f && !fail) fail = jb * NB + (s + 1) * 16 + f;
+                        }
+                    }
+                } else {
+                    // row s of the block's inverse (its pivots are complete): X_sc = -L_ss^-1 sum_{t = c .. s-1} L_st X_tc, column c
+                    // by wavefront 4 + c
+                    const int c = wave - 4;
+                    if (c < s) {
+                        v4d acc = {0.0, 0.0, 0.0, 0.0};
+                        for (int t = c; t < s; ++t) {
+                            const double* P = Lp + tix(s, t);
+                            const double* Q = Lip + tix(t, c);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc = mfma(P[tel(li, 4 * q + lk)], Q[tel(4 * q + lk, li)], acc);
+                        }
+                        const double* Aii = Lip + tix(s, s);
+                        v4d d2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d2 = mfma(Aii[tel(li, 4 * q + lk)], acc[q], d2);      // the accumulator IS the B fragment
+                        double* X = Lip + tix(s, c);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[tel(4 * r + lk, li)] = -d2[r];
+                    }
+                    try_fetch(false);
+                }
+                __syncthreads();
+            }
+            PCSTAMP(2);
+            if (wave >= 4) {      // the last row of the inverse
+                const int c = wave - 4;
+                if (c < 3) {
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int t = c; t < 3; ++t) {
+                        const double* P = Lp + tix(3, t);
+                        const double* Q = Lip + tix(t, c);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = mfma(P[tel(li, 4 * q + lk)], Q[tel(4 * q + lk, li)], acc);
+                    }
+                    const double* Aii = Lip + tix(3, 3);
+                    v4d d2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d2 = mfma(Aii[tel(li, 4 * q + lk)], acc[q], d2);
+                    double* X = Lip + tix(3, c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[tel(4 * r + lk, li)] = -d2[r];
+                }
+                try_fetch(true);
+            }
+            __syncthreads();
+            if (giveup) {
+                if (tid == 0) *info = -1;
+                return;
+            }
+            PCSTAMP(3);
+            // (C) L_jj and its inverse out (dense, zeros above the diagonal)
+            {
+                pc_gw Ldb = (pc_gw)(Ld + (int64_t)jb * NB * NB);
+                pc_gw Dib = (pc_gw)(Dinv + (int64_t)jb * NB * NB);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = tid + PC_T * q, r = e >> 6, c = e & 63, ti = r >> 4, tj = c >> 4;
+                    double vl = 0.0, vi = 0.0;
+                    if (tj <= ti) {
+                        vl = Lp[tix(ti, tj) + tel(r & 15, c & 15)];
+                        vi = Lip[tix(ti, tj) + tel(r & 15, c & 15)];
+                    }
+                    Ldb[e] = vl;
+                    Dib[e] = vi;
+                }
+            }
+            PCSTAMP(4);
+            if (!need) {
+                if (Linv) pc_signal_store(F, (unsigned long long)(jb + 1));      // (the others invert the last block row)
+                break;
+            }
+            // (D) look-ahead: L[jb+1, jb] = A[jb+1, jb] L_jj^-T, tile (a, tj) from the k tiles <= tj (the inverse is lower triangular);
+            // wavefront w: a = w / 2 and the tile pair {0, 3} or {1, 2} -- five k tiles each
+            {
+                const int a = wave >> 1;
+                pc_gw Pn = (pc_gw)(A + (int64_t)(jb + 1) * NB * ld + (int64_t)jb * NB);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tj = (wave & 1) ? 1 + h : 3 * h;
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int tk = 0; tk <= tj; ++tk) {
+                        const double* P = An + (4 * a + tk) * 256;
+                        const double* Q = Lip + tix(tj, tk);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = mfma(P[tel(li, 4 * q + lk)], Q[tel(li, 4 * q + lk)], acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Ln[(4 * a + tj) * 256 + tel(4 * r + lk, li)] = acc[r];
+                        Pn[(int64_t)(a * 16 + 4 * r + lk) * ld + tj * 16 + li] = acc[r];
+                    }
+                }
+            }
+            PCSTAMP(5);
+            __syncthreads();      // Ln is complete for everybody, and the stores of L[jb+1, jb], L_jj^-1 are issued
+            PCSTAMP(6);
+            // the next diagonal block: D_ab -= sum_k Ln_ak Ln_bk^T.  Wavefront 0 takes the next pivot tile alone and goes on with it;
+            // wavefront 4 -- on wavefront 0's SIMD -- only publishes the step (a release fence costs ~1 us), the other six share
+            // the remaining nine tiles
+            if (wave == 4) {
+                if (lane == 0) {
+                    __threadfence();
+                    __hip_atomic_store(F, (unsigned long long)(jb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const int slot = wave == 0 ? 0 : wave < 4 ? wave : wave - 1;      // 0 | 1 2 3 | (4: none) 4 5 6
+            for (int u = wave == 4 ? 10 : slot; u < 10; u += wave == 0 ? 10 : 6) {
+                int a, b;
+                pc_tile_of(u, a, b);
+                double* D = Dn + tix(a, b);
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = D[tel(4 * r + lk, li)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double* P = Ln + (4 * a + k) * 256;
+                    const double* Q = Ln + (4 * b + k) * 256;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = mfma(-P[tel(li, 4 * q + lk)], Q[tel(li, 4 * q + lk)], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) D[tel(4 * r + lk, li)] = acc[r];
+            }
+            cur ^= 1;
+            PCSTAMP(7);
+        }
+        if (tid == 0) *info = fail;
+        return;
+    }
+    double* S0 = pc_lds;
+    double* S1 = S0 + PC_S;      // L_jj^-1
+    double* S2 = S1 + PC_S;      // L[jb+1, jb]
+    double* S3 = S2 + PC_S;
+    const int wr = wave >> 2, wc = wave & 3;
+    if (w <= NT) {
+        // ------------------------------------------------------------------ the trailing workgroups
+        // Step jb: X: L[i, jb] = A[i, jb] L_jj^-T and A[i, jb+1] -= L[i, jb] L[jb+1, jb]^T (i >= jb+2); barrier; Y: A[i, c] -=
+        // L[i, jb] L[c, jb]^T for the columns beyond (c >= jb+2); barrier.  The FIRST of them takes row jb+2 and, straight after
+        // it, the diagonal block (jb+2, jb+2) -- it needs L[jb+2, jb] only, which is in its LDS -- and publishes `pri`: those are
+        // the two blocks the panel workgroup fetches next, so its wait ends ~12 us after it published the step, not after the
+        // whole update (~23 us: five hand-overs across XCDs at 2-3 us each).
+        // The first trailing workgroup does nothing else but what the look-ahead of the NEXT steps hangs on -- after the barrier
+        // the two blocks of row jb+3 that its own next priority row reads, (jb+3, jb+2) and (jb+3, jb+3) -- and does not join the
+        // others' second barrier: it never waits for the slowest block of Y.
+        const int tw = w - 1, NR = NT - 1;      // NR: the trailing workgroups but the first
+        auto do_row = [&](int jb, int i, bool pri) {
+            double* Pi = A + (int64_t)i * NB * ld + (int64_t)jb * NB;
+            pc_load64(S0, Pi, ld, tid);
+            double cc[2][4], cd[2][4];      // A[i, jb+1] (and A[i, i] on the priority row): requested now, used after the products
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t ro = (int64_t)(wr * 32 + t * 16 + lk + 4 * r) * ld + wc * 16 + li;
+                    cc[t][r] = ((pc_gc)Pi)[ro + NB];
+                    cd[t][r] = pri ? ((pc_gc)Pi)[ro + 2 * NB] : 0.0;
+                }
+            __syncthreads();
+            v4f64 acc[2];
+            pc_mm64<true>(S0, S1, acc, wr, wc, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wr * 32 + t * 16 + lk + 4 * r, col = wc * 16 + li;
+                    ((pc_gw)Pi)[(int64_t)row * ld + col] = acc[t][r];
+                    S3[row * LD64 + col] = acc[t][r];
+                }
+            __syncthreads();
+            pc_mm64<true>(S3, S2, acc, wr, wc, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ((pc_gw)Pi)[(int64_t)(wr * 32 + t * 16 + lk + 4 * r) * ld + NB + wc * 16 + li] = cc[t][r] - acc[t][r];
+            if (pri) {
+                pc_mm64<true>(S3, S3, acc, wr, wc, lane);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ((pc_gw)Pi)[(int64_t)(wr * 32 + t * 16 + lk + 4 * r) * ld + 2 * NB + wc * 16 + li] = cd[t][r] - acc[t][r];
+                pc_signal_store(PRI, (unsigned long long)(jb + 1));
+            }
+            __syncthreads();
+        };
+        for (int jb = 0; jb + 2 < nreal; ++jb) {
+            if (!pc_wait_ge(F, (unsigned long long)(jb + 1), &flag)) {
+                if (tid == 0) *info = -1;
+                return;
+            }
+            const int64_t j0 = (int64_t)jb * NB;
+            pc_load64(S1, Dinv + (int64_t)jb * NB * NB, NB, tid);
+            pc_load64(S2, A + (int64_t)(jb + 1) * NB * ld + j0, ld, tid);
+            if (tw == 0) {
+                do_row(jb, jb + 2, true);
+                if (NR == 0)
+                    for (int i = jb + 3; i < nreal; ++i) do_row(jb, i, false);
+            } else {
+                for (int i = jb + 3 + tw - 1; i < nreal; i += NR) do_row(jb, i, false);
+            }
+            if (!pc_barrier(BART, (unsigned)NT, &flag)) {
+                if (tid == 0) *info = -1;
+                return;
+            }
+            if (tw == 0 && NI > 0) pc_signal_store(XD, (unsigned long long)(jb + 1));      // (every L[i, jb] is written: the barrier)
+            // Y, column by column: task u of the packed lower triangle of order nrem.  Task 0 -- block (jb+2, jb+2) -- is done;
+            // tasks 1 and nrem -- (jb+3, jb+2), (jb+3, jb+3) -- are the first workgroup's, the rest the others'
+            const int nrem = nreal - jb - 2, ntr = nrem * (nrem + 1) / 2;
+            auto task = [&](int u) {
+                int b = 0, rest = u;
+                while (rest >= nrem - b) { rest -= nrem - b; ++b; }
+                const int ci = jb + 2 + b, ri = ci + rest;
+                return PcTask{A + (int64_t)ri * NB * ld + j0, ld, A + (int64_t)ci * NB * ld + j0, ld,
+                              A + (int64_t)ri * NB * ld + (int64_t)ci * NB, ld};
+            };
+            const int nspecial = nrem >= 2 ? 3 : 1;
+            auto rest_task = [&](int v) {
+                int u = v + (nrem >= 2 ? 2 : 1);
+                if (nrem >= 2 && u >= nrem) ++u;
+                return task(u);
+            };
+            if (tw == 0) {
+                if (nrem >= 2) pc_tasks<true>(0, 2, 1, [&](int v) { return task(v ? nrem : 1); }, -1.0, S0, S3, tid, wr, wc, lane);
+                if (NR == 0) pc_tasks<true>(0, ntr - nspecial, 1, rest_task, -1.0, S0, S3, tid, wr, wc, lane);
+            } else {
+                pc_tasks<true>(tw - 1, ntr - nspecial, NR, rest_task, -1.0, S0, S3, tid, wr, wc, lane);
+                if (jb + 3 < nreal && !pc_barrier(BART + 3, (unsigned)NR, &flag)) {      // this step's Y before the next step's X
+                    if (tid == 0) *info = -1;
+                    return;
+                }
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- the inverse workgroups
+    // X = L^-1 (nblk 64-blocks square, ld = 64 nblk), right-looking in 64-blocks: S_ic = sum_{t < i} L_it X_tc is accumulated in
+    // X's own storage as the block rows of X complete -- Zf(jb): X_jb,c = -L_jj^-1 S_jb,c (c < jb), X_jb,jb = L_jj^-1; Zu(jb):
+    // S_ic += L_i,jb X_jb,c for i > jb, c <= jb -- so the inverse is complete one product after the last step's pivots (it
+    // replaces trtri_level0_kernel and the merge products of launch_trtri_z).
+    const int iw = w - NT - 1;
+    const int64_t ldi = (int64_t)nblk * NB;
+    // X <- 0, identity on the diagonal blocks of the padding rows
+    for (int u = iw; u < nblk * nblk; u += NI) {
+        const int bi = u / nblk, bj = u - bi * nblk;
+        pc_gw g = (pc_gw)(Linv + (int64_t)bi * NB * ldi + (int64_t)bj * NB);
+        const bool eye = bi == bj && bi >= nreal;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = (tid >> 6) + 8 * q, c = tid & 63;
+            g[(int64_t)r * ldi + c] = eye && r == c ? 1.0 : 0.0;
+        }
+    }
+    if (!pc_barrier(BARI, (unsigned)NI, &flag)) {
+        if (tid == 0) *info = -1;
+        return;
+    }
+    for (int jb = 0; jb < nreal; ++jb) {
+        if (!pc_wait_ge(F, (unsigned long long)(jb + 1), &flag) ||
+            (jb + 2 < nreal && !pc_wait_ge(XD, (unsigned long long)(jb + 1), &flag))) {
+            if (tid == 0) *info = -1;
+            return;
+        }
+        const int64_t j0 = (int64_t)jb * NB;
+        pc_load64(S1, Dinv + (int64_t)jb * NB * NB, NB, tid);
+        __syncthreads();
+        // Zf: block row jb of the inverse
+        for (int c = iw; c <= jb; c += NI) {
+            double* Xc = Linv + (int64_t)jb * NB * ldi + (int64_t)c * NB;
+            if (c == jb) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = (tid >> 6) + 8 * q, cc = tid & 63;
+                    ((pc_gw)Xc)[(int64_t)r * ldi + cc] = S1[r * LD64 + cc];
+                }
+            } else {
+                pc_load64(S0, Xc, ldi, tid);
+                __syncthreads();
+                v4f64 acc[2];
+                pc_mm64<false>(S1, S0, acc, wr, wc, lane);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ((pc_gw)Xc)[(int64_t)(wr * 32 + t * 16 + lk + 4 * r) * ldi + wc * 16 + li] = -acc[t][r];
+                __syncthreads();
+            }
+        }
+        if (jb + 1 == nreal) break;
+        if (!pc_barrier(BARI, (unsigned)NI, &flag)) {
+            if (tid == 0) *info = -1;
+            return;
+        }
+        // Zu: S_ic += L[i, jb] X[jb, c], i > jb, c <= jb
+        const int nc = jb + 1, ntask = (nreal - jb - 1) * nc;
+        pc_tasks<false>(iw, ntask, NI,
+                        [&](int u) {
+                            const int i = jb + 1 + u / nc, c = u % nc;
+                            return PcTask{A + (int64_t)i * NB * ld + j0, ld, Linv + (int64_t)jb * NB * ldi + (int64_t)c * NB, ldi,
+                                          Linv + (int64_t)i * NB * ldi + (int64_t)c * NB, ldi};
+                        },
+                        1.0, S0, S3, tid, wr, wc, lane);
+        if (!pc_barrier(BARI, (unsigned)NI, &flag)) {
+            if (tid == 0) *info = -1;
+            return;
+        }
+    }
+}
+
 // zero the strict upper triangle
 __global__ void tril_inplace_kernel(double* A, int64_t ld, int n) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,19 +1083,73 @@ __global__ void finish_l_kernel(double* A, int64_t ld, int n, double* Ld, double
 // columns per hand-over of the 64-wide panel kernel: tune().potrf_cols = 4 (potrf_panel4_kernel, default) or 1 (potrf_panel2_kernel)
 // Dinv and Ld: (Mp/64) x 64 x 64 doubles each.  M = real order: rows/columns >= M of A are identity padding, which the
 // factorisation leaves alone -- a 16-point problem padded to 128 costs 16 elimination steps, not 128.
+// workgroups per layer of the one-launch form: the panel workgroup + nt trailing (one per block of the first step's update beyond
+// the look-ahead column) + ni inverse (one per product of the largest accumulation step), capped so that three such launches --
+// the surrogates of a step, one stream each -- fit the 256 CUs side by side
+static void potrf_coop_workgroups(int nreal, int nz, bool inverse, int& nt, int& ni) {
+    int cap = 84 / nz - 1;
+    cap = cap < 15 ? 15 : cap > 83 ? 83 : cap;
+    const int y0 = (nreal - 2) * (nreal - 1) / 2, z0 = inverse ? ((nreal + 1) / 2) * (nreal / 2) : 0;
+    nt = y0 < 1 ? 1 : y0;
+    ni = z0;
+    if (nt + ni > cap) {
+        const int tot = nt + ni;
+        nt = nt * cap / tot;
+        nt = nt < 1 ? 1 : nt;
+        ni = inverse ? (cap - nt < 1 ? 1 : cap - nt) : 0;
+    }
+#ifdef PC_STAMPS
+    if (const char* e = getenv("MOBOCMF_DEBUG_POTRF_NT")) nt = atoi(e);
+    if (const char* e = getenv("MOBOCMF_DEBUG_POTRF_NI")) ni = inverse ? atoi(e) : 0;
+#endif
+}
+// bytes of `sync` the one-launch form needs for nz layers
+int64_t potrf_sync_bytes(int nz) { return (int64_t)nz * PC_WORDS * 8; }
+
 int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* const* info, int nz, int64_t zs,
-                   double* zero0, double* zero1, hipStream_t s) {
+                   double* zero0, double* zero1, void* sync, int* inverse_done, hipStream_t s) {
     // nz layers (same M): layer z works on A + z*zs, Dinv + z*zs, Ld + z*zs (doubles) and reports through info[z]
+    // sync: potrf_sync_bytes(nz) of device memory for the one-launch form (tune().potrf_cols == 0), or null: one launch pair per step
+    // inverse_done (may be null): the caller wants L^-1 in zero0 (Mp x Mp, ld Mp) next and would call launch_trtri_z for it;
+    // set to 1 when the one-launch form has formed it already (then no launch_trtri_z), else to 0
+    if (inverse_done) *inverse_done = 0;
     const int nblk = Mp / NB;
     const int nreal = (M + NB - 1) / NB;          // 64-blocks that hold real rows
     InfoZ iz = {};
     for (int z = 0; z < nz; ++z) iz.p[z] = info[z];      // (re)set by the first panel
-    for (int jb = 0; jb < nreal; ++jb) {
+    bool one_launch = false;
+    if (sync && tune().potrf_cols == 0 && nreal >= 3 && nreal <= 16) {
+        double* Linv = inverse_done && zero0 ? zero0 : nullptr;
+        int NT = 1, NI = 0;
+        potrf_coop_workgroups(nreal, nz, Linv != nullptr, NT, NI);
+        const int G = 1 + NT + NI;
+        const size_t shm = (size_t)PC_LDS_DOUBLES * sizeof(double);
+        static std::atomic<uint64_t> granted{0};      // one write-once bit per device: the dynamic-LDS attribute was set there
+        int devid = 0, cus = 0;
+        HIP_TRY(hipGetDevice(&devid));
+        const uint64_t bit = devid >= 0 && devid < 64 ? 1ull << devid : 0ull;
+        if (!(granted.load() & bit)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)potrf_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            granted.fetch_or(bit);
+        }
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
+        if (G * nz <= cus) {      // (one workgroup per CU at this LDS size: all of them resident together)
+            HIP_TRY(hipMemsetAsync(sync, 0, (size_t)potrf_sync_bytes(nz), s));
+            hipLaunchKernelGGL(potrf_coop_kernel, dim3(G, nz), dim3(PC_T), shm, s, A, ld, nreal, Dinv, Ld, iz, zs,
+                               (unsigned long long*)sync, Linv, Mp / NB, NT);
+            one_launch = true;
+            if (Linv) {
+                *inverse_done = 1;
+                zero0 = nullptr;      // (written in full by the launch: not cleared below)
+            }
+        }
+    }
+    for (int jb = 0; jb < nreal && !one_launch; ++jb) {
         int nact = M - jb * NB;
         nact = nact >= NB ? NB : (nact + 15) & ~15;
         const dim3 grid(nreal - jb, nz);          // blocks below the real rows are zero in these columns and stay zero
         if (nact == 16) hipLaunchKernelGGL(potrf_panel_pad_kernel<16>, grid, dim3(64), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
-        else if (tune().potrf_cols == 1)
+        else if (tune().potrf_cols == 1)  // (0: the one-launch form where it applies, the four-column panel elsewhere)
             hipLaunchKernelGGL(potrf_panel2_kernel, grid, dim3(128), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
         else hipLaunchKernelGGL(potrf_panel4_kernel, grid, dim3(128), 0, s, A, ld, jb, Dinv, Ld, iz, zs);
         int nt = nreal - jb - 1;
@@ -511,7 +1164,7 @@ int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* L
 
 int launch_potrf(double* A, int64_t ld, int Mp, int M, double* Dinv, double* Ld, int32_t* info, hipStream_t s) {
     int32_t* one[1] = {info};
-    return launch_potrf_z(A, ld, Mp, M, Dinv, Ld, one, 1, 0, nullptr, nullptr, s);
+    return launch_potrf_z(A, ld, Mp, M, Dinv, Ld, one, 1, 0, nullptr, nullptr, nullptr, nullptr, s);
 }
 
 // ---------------------------------------------------------------------------------- triangular inverse

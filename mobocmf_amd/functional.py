@@ -1320,10 +1320,11 @@ def set_tile_rows(rows=0, pair_mode=0):
     _set_default(tile_rows=rows, pair_mode=pair_mode)
 
 
-def set_potrf_cols(cols=4):
-    """Columns per hand-over of the Cholesky panel kernel: 4 (default) or 1."""
-    if int(cols) not in (1, 4):
-        raise _lib.MobocmfError("set_potrf_cols: 1 | 4")
+def set_potrf_cols(cols=0):
+    """The blocked Cholesky: 0 (default) all 64-column steps in one launch where it applies; 4 or 1: a launch pair per 64
+    columns with that many columns per hand-over of the panel kernel."""
+    if int(cols) not in (0, 1, 4):
+        raise _lib.MobocmfError("set_potrf_cols: 0 | 1 | 4")
     _set_default(potrf_cols=cols)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Backward error of the blocked Cholesky + triangular inverse (through mobocmf_exact_gp_factor) for the two panel kernels
-(4 columns / 1 column per hand-over) and torch.linalg.cholesky (rocSOLVER), on Gram matrices of growing condition number."""
+"""Backward error of the blocked Cholesky + triangular inverse (through mobocmf_exact_gp_factor) for its three forms
+(0 = all steps in one launch; 4 / 1 = a launch pair per 64 columns, 4 columns / 1 column per hand-over) and torch.linalg.cholesky (rocSOLVER), on Gram matrices of growing condition number."""
 import os
 import sys
 
@@ -20,7 +20,7 @@ for n, d, ls in ((80, 3, 0.6), (512, 8, 1.4), (1000, 8, 1.4), (700, 2, 0.5), (10
     cond = float(torch.linalg.cond(K))
     npad = (n + 127) // 128 * 128
     out = []
-    for cols in (4, 1):
+    for cols in (0, 4, 1):
         F.set_potrf_cols(cols)
         st = F.exact_gp_factor(K, y)
         assert F.check_info(st.info) == 0
@@ -31,7 +31,7 @@ for n, d, ls in ((80, 3, 0.6), (512, 8, 1.4), (1000, 8, 1.4), (700, 2, 0.5), (10
         r1 = float(torch.linalg.norm(L @ L.T - K) / torch.linalg.norm(K))
         r2 = float(torch.linalg.norm(Li @ L - torch.eye(n, dtype=torch.float64, device=dev)))
         out.append("cols=%d: |LL^T-K|/|K| %.2e  |L^-1 L - I| %.2e  mll %.12e" % (cols, r1, r2, float(st.mll)))
-    F.set_potrf_cols(4)
+    F.set_potrf_cols(0)
     Lt = torch.linalg.cholesky(K)
     r1 = float(torch.linalg.norm(Lt @ Lt.T - K) / torch.linalg.norm(K))
-    print("n=%d d=%d cond %.1e | %s | %s | torch: %.2e" % (n, d, cond, out[0], out[1], r1), flush=True)
+    print("n=%d d=%d cond %.1e | %s | %s | %s | torch: %.2e" % (n, d, cond, out[0], out[1], out[2], r1), flush=True)
