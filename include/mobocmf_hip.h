@@ -556,7 +556,10 @@ int mobocmf_syrk_weighted_f64(int32_t Mr, int64_t Kd, const double* A, int64_t l
                               void* workspace, int64_t workspace_bytes, const int32_t* k_activity,
                               const mobocmf_tuning* tuning, mobocmf_stream_t stream);
 
-/* Host-side, synchronising: copies the device word and returns MOBOCMF_OK or MOBOCMF_NOT_PD (pivot in *pivot). */
+/* Host-side, synchronising: copies the device word and returns MOBOCMF_OK or MOBOCMF_NOT_PD (pivot in *pivot: the 1-based
+ * column of the first non-positive pivot; -1 = a one-launch form -- the cooperative step, the one-launch Cholesky
+ * (mobocmf_tuning.potrf_cols = 0) -- abandoned a bounded in-launch wait because its workgroups were not resident together:
+ * the results of that call are invalid, repeat it with less concurrent work or with the launch-per-step form). */
 int mobocmf_check_info(const int32_t* info, int32_t* pivot, mobocmf_stream_t stream);
 
 #ifdef __cplusplus

@@ -60,7 +60,7 @@ def test_tuning_travels_with_the_call_and_the_library_keeps_no_knobs():
     t = _lib.Tuning()
     assert lib.mobocmf_tuning_init(ctypes.byref(t)) == _lib.OK and lib.mobocmf_tuning_init(None) == _lib.BAD_ARG
     assert t.struct_size == ctypes.sizeof(_lib.Tuning)
-    assert [getattr(t, k) for k in _lib.Tuning.KNOBS] == [384, 512, 0, 0, 1024, 32, 0, 1, 4]
+    assert [getattr(t, k) for k in _lib.Tuning.KNOBS] == [384, 512, 0, 0, 1024, 32, 0, 1, 0]
     nb_def, nb_64, nb_4096 = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
     assert lib.mobocmf_syrk_workspace_bytes(512, 65536, None, ctypes.byref(nb_def)) == _lib.OK
     t64, t4096 = t.copy(), t.copy()
