@@ -1083,21 +1083,19 @@ __global__ void finish_l_kernel(double* A, int64_t ld, int n, double* Ld, double
 // columns per hand-over of the 64-wide panel kernel: tune().potrf_cols = 4 (potrf_panel4_kernel, default) or 1 (potrf_panel2_kernel)
 // Dinv and Ld: (Mp/64) x 64 x 64 doubles each.  M = real order: rows/columns >= M of A are identity padding, which the
 // factorisation leaves alone -- a 16-point problem padded to 128 costs 16 elimination steps, not 128.
-// workgroups per layer of the one-launch form: the panel workgroup + nt trailing (one per block of the first step's update beyond
-// the look-ahead column) + ni inverse (one per product of the largest accumulation step), capped so that three such launches --
-// the surrogates of a step, one stream each -- fit the 256 CUs side by side
+// workgroups per layer of the one-launch form: the panel workgroup + nt trailing + ni inverse.  What the others' steps cost is
+// hand-overs, and a barrier grows with its participants: beyond 32 trailing and 16 inverse workgroups the launch gets SLOWER
+// (n = 1024: 32 + 16 -> 446 us, 51 + 32 -> 491, 77 + 48 -> 576; 25 + 8 -> 558: the inverse group then trails the pivots;
+// profiles/r05_chol_one_launch.txt).  Capped so that three such launches -- the surrogates of a step, one stream each -- fit the
+// 256 CUs side by side: all workgroups of a launch must be resident together.
 static void potrf_coop_workgroups(int nreal, int nz, bool inverse, int& nt, int& ni) {
     int cap = 84 / nz - 1;
-    cap = cap < 15 ? 15 : cap > 83 ? 83 : cap;
+    cap = cap < 15 ? 15 : cap;
     const int y0 = (nreal - 2) * (nreal - 1) / 2, z0 = inverse ? ((nreal + 1) / 2) * (nreal / 2) : 0;
-    nt = y0 < 1 ? 1 : y0;
-    ni = z0;
-    if (nt + ni > cap) {
-        const int tot = nt + ni;
-        nt = nt * cap / tot;
-        nt = nt < 1 ? 1 : nt;
-        ni = inverse ? (cap - nt < 1 ? 1 : cap - nt) : 0;
-    }
+    ni = z0 > 16 ? 16 : z0;
+    if (ni > cap / 3 + 2) ni = cap / 3 + 2;
+    nt = y0 < 1 ? 1 : y0 > 32 ? 32 : y0;
+    if (nt > cap - ni) nt = cap - ni;
 #ifdef PC_STAMPS
     if (const char* e = getenv("MOBOCMF_DEBUG_POTRF_NT")) nt = atoi(e);
     if (const char* e = getenv("MOBOCMF_DEBUG_POTRF_NI")) ni = inverse ? atoi(e) : 0;
