@@ -1130,8 +1130,12 @@ int launch_potrf_z(double* A, int64_t ld, int Mp, int M, double* Dinv, double* L
             HIP_TRY(hipFuncSetAttribute((const void*)potrf_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
             granted.fetch_or(bit);
         }
+        // every workgroup of the launch waits for its peers inside the launch: all of them must be resident at once (an
+        // ordinary launch, not a cooperative one: the bound is checked here, the waits inside are bounded)
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)potrf_coop_kernel, PC_T, shm));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
-        if (G * nz <= cus) {      // (one workgroup per CU at this LDS size: all of them resident together)
+        if (per_cu >= 1 && (int64_t)G * nz <= (int64_t)per_cu * cus) {
             HIP_TRY(hipMemsetAsync(sync, 0, (size_t)potrf_sync_bytes(nz), s));
             hipLaunchKernelGGL(potrf_coop_kernel, dim3(G, nz), dim3(PC_T), shm, s, A, ld, nreal, Dinv, Ld, iz, zs,
                                (unsigned long long*)sync, Linv, Mp / NB, NT);

@@ -26,6 +26,12 @@ __device__ __forceinline__ int tel(int r, int c) { return r * 16 + (c ^ r); }
 // (Tried: taking the pivot block's inverse off the critical path -- the panel below it solved by substitution in registers, 136
 // in-lane operations against wave-uniform LDS reads of L_ss, the inverses of all pivot blocks formed afterwards side by side --
 // is SLOWER: the substitution costs what the inverse cost, 16.5 -> 21.8 us at M = 64, 36 -> 46.5 at M = 128.)
+// (Tried: the panel tiles below the pivot tile riding in the factorisation's own column loop -- lane groups 1-3 of the wavefront
+// hold their rows, scaling and elimination are the same instructions for them, the multipliers come out of the diagonal lanes by
+// v_readlane either way -- so that nothing inside the factorisation waits for L_ss^-1 (inverted by an idle wavefront one pivot
+// later): parity-green, and NO faster -- Cholesky phase 16.8 -> 16.0 us at M = 64, 35.7 -> 35.3 at M = 128, the step unchanged.
+// The 3.3 us of this routine are its 16 dependent column steps (~0.2 us each: two v_readlane, v_rsq_f64, six dependent f64
+// operations, then the eliminations that feed the next pivot), not the inverse behind them.)
 // (Tried: the broadcasts as DPP row_newbcast moves -- no trip through an SGPR -- are SLOWER: 17.6 -> 21 us for the four tiles of
 // M = 64, profiles/r05_coop_step.txt; the DPP move waits for its source's write-back where v_readlane's result is forwarded.)
 __device__ __forceinline__ int chol_inv_tile16(double* T, double* Ti, int lane) {
@@ -65,3 +71,4 @@ __device__ __forceinline__ int chol_inv_tile16(double* T, double* Ti, int lane) 
     }
     return fail;
 }
+
