@@ -1263,6 +1263,19 @@ def check_info(info):
     return 0
 
 
+class InLaunchWaitAbandoned(FloatingPointError):
+    """A one-launch form (cooperative step, one-launch Cholesky) gave up a bounded in-launch wait: its workgroups were not resident
+    together (too many such launches in flight on the device, or a partition with few CUs).  The call's results are invalid."""
+
+
+def raise_if_abandoned(pivot, what="Cholesky"):
+    """``pivot`` as returned by check_info: -1 is not a failed pivot but an abandoned in-launch wait (include/mobocmf_hip.h,
+    mobocmf_check_info)."""
+    if pivot < 0:
+        raise InLaunchWaitAbandoned("%s: the one-launch form abandoned a bounded in-launch wait (its workgroups were not resident "
+                                    "together); repeat the call with F.tuning(potrf_cols=4) or less concurrent work" % what)
+
+
 def gemm_colstat_rows(Mr, Nc, Kd, tri=0, tune=None):
     """Partial rows the column-statistics epilogue writes for a product of that shape (two per row block of the tile
     height the tuning gives: mobocmf_gemm_colstat_rows)."""

@@ -274,6 +274,7 @@ class MFDGPHiddenLayer(nn.Module):
             pivot = F.check_info(self._info)
             if pivot == 0:
                 break
+            F.raise_if_abandoned(pivot, "layer forward")      # (-1: not a pivot, no jitter helps)
             if attempt == 3:
                 raise NotPSDError(f"K_mm not positive definite (pivot {pivot}) after adding jitter {jit:.1e}")
             jit = vs.jitter_val + 1e-8 * (10 ** attempt)      # psd_safe_cholesky retry ladder
@@ -313,6 +314,7 @@ class MFDGPHiddenLayer(nn.Module):
             pivot = F.check_info(fc.info)
             if pivot == 0:
                 return fc
+            F.raise_if_abandoned(pivot, "chain forward")
             if attempt == 3:
                 raise NotPSDError(f"K_mm not positive definite (pivot {pivot}) after adding jitter {jit:.1e}")
             jit = vs.jitter_val + 1e-8 * (10 ** attempt)

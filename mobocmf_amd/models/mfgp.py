@@ -170,7 +170,9 @@ class _ExactMFGP(nn.Module):
         with torch.no_grad():
             K = self._hip_cov(self.x_train, self.x_train, diag=float(self.likelihood.noise))
             st = F.exact_gp_factor(K, self.y_train)
-        if F.check_info(st.info) != 0:
+        pivot = F.check_info(st.info)
+        F.raise_if_abandoned(pivot, "exact-GP factorisation")
+        if pivot != 0:
             raise gp_NotPSD("exact-GP training covariance not positive definite")
         return st
 

@@ -196,8 +196,11 @@ class GraphedELBOStep:
         from ..layers.mfdgp_hidden_layer import NotPSDError
         self.stream.synchronize()
         for layer in self.model._layers():
-            if layer._info is not None and F.check_info(layer._info) != 0:
-                raise NotPSDError("K_mm not positive definite in layer %d" % layer.num_layer)
+            if layer._info is not None:
+                pivot = F.check_info(layer._info)
+                F.raise_if_abandoned(pivot, "layer %d" % layer.num_layer)
+                if pivot != 0:
+                    raise NotPSDError("K_mm not positive definite in layer %d" % layer.num_layer)
         if not bool(torch.isfinite(self.loss)):
             raise FloatingPointError("non-finite ELBO")
 

@@ -336,3 +336,14 @@ def test_coop_step_argument_checks_are_made_on_the_host():
     assert step(mode=3) == _lib.BAD_ARG and step(mode=5) == _lib.BAD_ARG      # input gradients: the one-workgroup kernel only
     assert step(h=None) == _lib.BAD_ARG and step(sw=None) == _lib.BAD_ARG
     assert used.value == -7                        # nothing was chosen, nothing launched
+
+
+def test_an_abandoned_in_launch_wait_is_not_a_failed_pivot():
+    """mobocmf_check_info's pivot -1 (include/mobocmf_hip.h): a one-launch form gave up a bounded wait.  The host mirror raises
+    InLaunchWaitAbandoned (a FloatingPointError) for it and keeps NotPSDError / the jitter ladder for real pivots."""
+    from mobocmf_amd import functional as F
+    with pytest.raises(F.InLaunchWaitAbandoned, match="potrf_cols=4"):
+        F.raise_if_abandoned(-1, "layer 0")
+    assert issubclass(F.InLaunchWaitAbandoned, FloatingPointError)
+    F.raise_if_abandoned(0)
+    F.raise_if_abandoned(17)
