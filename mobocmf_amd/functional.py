@@ -1459,6 +1459,52 @@ def exact_gp_factor(K, y):
     return st
 
 
+def _exact_state_views(st):
+    """(L, L^-1, a = L^-1 y) of an ExactGPState as padded views (npad x npad, npad)."""
+    npad = (st.n + 127) // 128 * 128
+    buf = st.state.view(torch.float64)
+    step = (npad * npad * 8 + 255) // 256 * 256 // 8
+    vstep = (npad * 8 + 255) // 256 * 256 // 8
+    L = buf[:npad * npad].view(npad, npad)
+    Li = buf[step:step + npad * npad].view(npad, npad)
+    a = buf[2 * step:2 * step + npad]
+    del vstep
+    return L, Li, a, npad
+
+
+class _ExactGPMLL(torch.autograd.Function):
+    """log N(y | 0, K) with its gradient, both on the library's kernels: forward = mobocmf_exact_gp_factor (blocked Cholesky,
+    triangular inverse, a = L^-1 y, the likelihood), backward = d/dK = (alpha alpha^T - K^-1) / 2 with alpha = L^-T a and
+    K^-1 = L^-T L^-1 as ONE triangular product on the f64 MFMA kernel, d/dy = -alpha.  What gpytorch's
+    ExactMarginalLogLikelihood (x n) differentiates through torch.linalg (mfgp.py:63-64 of the reference fits through it)."""
+
+    @staticmethod
+    def forward(ctx, K, y):
+        st = exact_gp_factor(K, y)
+        ctx.st = st
+        ctx.y_shape = y.shape
+        return st.mll.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.st
+        n = st.n
+        with torch.no_grad():
+            _, Li, a, npad = _exact_state_views(st)
+            LiT = Li.t().contiguous()
+            Kinv = gemm_f64(LiT, LiT, trans_b=True, tri=2)          # L^-T (L^-T)^T, A upper triangular
+            alpha = LiT @ a
+            gK = (0.5 * g) * (torch.outer(alpha[:n], alpha[:n]) - Kinv[:n, :n])
+            gy = (-g) * alpha[:n]
+        return gK, gy.reshape(ctx.y_shape)
+
+
+def exact_gp_mll(K, y):
+    """Differentiable log N(y | 0, K) on the library's kernels (K: n x n incl. the noise on its diagonal).  The caller checks
+    ``exact_gp_mll.last_info`` style failures through the returned value: a failed pivot makes the value NaN."""
+    return _ExactGPMLL.apply(K, y)
+
+
 def exact_gp_predict(st, Kts, kss):
     """Posterior mean and variance at the nt columns of Kts [n x nt] (prior variances kss)."""
     lib = _lib.require_device()

@@ -200,8 +200,18 @@ class _ExactMFGP(nn.Module):
 
     def marginal_log_likelihood(self, hip=None):
         """log p(y | X) of the exact GP (what gpytorch's ExactMarginalLogLikelihood x n evaluates).  ``hip``: None = the
-        package's kernels when the model is on the GPU and no gradient is recorded, else plain torch; True / False force."""
+        package's kernels when the model is on the GPU (with a gradient recorded: the differentiable torch statement of the
+        kernel matrix, its factorisation, inverse, likelihood AND their backward on the library -- functional.exact_gp_mll),
+        else plain torch; True / False force."""
+        if hip is None and self.x_train.is_cuda and torch.is_grad_enabled():
+            hip = True
         if self._hip_wanted(hip):
+            if torch.is_grad_enabled():
+                from .. import functional as F
+                n = self.x_train.shape[0]
+                K = self.covar_module(self.x_train, self.x_train)
+                K = K + self.likelihood.noise.reshape(()) * torch.eye(n, dtype=K.dtype, device=K.device)
+                return F.exact_gp_mll(K, self.y_train.reshape(-1))
             return self._hip_factor().mll
         L = self._train_factor()
         alpha = torch.cholesky_solve(self.y_train, L)

@@ -73,7 +73,8 @@ def test_exact_gp_baselines_on_the_hip_kernels_match_torch(cls_name, n, d, nf):
             p_hip = gpu.predict(Xt.to(DEV), f)
             assert _rel(p_hip.mean, p_ref.mean) < 1e-8, f
             assert float((p_hip.variance.cpu() - p_ref.variance).abs().max()) < 1e-8 * float(p_ref.variance.abs().max() + 1.0), f
-    # with gradients recorded the differentiable torch statement is used (fit(), acquisition optimisation) -- same value
+    # with gradients recorded: the torch statement of the kernel matrix, then factorisation, likelihood and their backward on the
+    # library (functional.exact_gp_mll) -- same value
     mll_t = gpu.marginal_log_likelihood()
     assert mll_t.requires_grad and abs(float(mll_t) - float(mll_ref)) < 1e-8 * max(1.0, abs(float(mll_ref)))
 
@@ -88,3 +89,43 @@ def test_exact_gp_not_positive_definite_is_reported():
     st = F.exact_gp_factor(K, torch.ones(40, dtype=torch.float64, device=DEV))
     assert F.check_info(st.info) == 0
     assert abs(float(st.mll) - (-0.5 * 39.5 - 0.5 * math.log(2.0) - 20 * math.log(2 * math.pi))) < 1e-12
+
+
+@pytest.mark.parametrize("cls_name,n,d,nf", [("MFGP", 60, 2, 2), ("MFGP", 300, 4, 3), ("MFGP_lin", 150, 3, 3), ("MFGP", 520, 6, 2)])
+def test_marginal_likelihood_gradient_and_fit_run_on_the_library(cls_name, n, d, nf):
+    """The baselines' fit() (mfgp.py:63-64 / mfgp_lin.py: fit_gpytorch_mll on ExactMarginalLogLikelihood): value AND gradient of
+    log p(y | X) through mobocmf_exact_gp_factor + one triangular MFMA product (functional.exact_gp_mll) equal the plain torch
+    statement's (torch.linalg Cholesky + solves, autograd) for every raw parameter; a short fit follows the same trajectory."""
+    from mobocmf_amd.models.mfgp import MFGP, MFGP_lin
+    cls = MFGP if cls_name == "MFGP" else MFGP_lin
+    X, Y = _data(n, d, nf, seed=3 * n + d)
+    base = cls(X, Y, nf)
+    with torch.no_grad():
+        base.covar_module.cov_funct_signal.outputscale = 0.9
+        base.covar_module.cov_funct_noise.outputscale = 0.3
+        base.likelihood.noise = 0.03
+    grads = {}
+    for hip in (True, False):
+        m = copy.deepcopy(base).to(DEV)
+        v = m.marginal_log_likelihood(hip=hip)
+        assert v.requires_grad
+        v.backward()
+        grads[hip] = (float(v), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert abs(grads[True][0] - grads[False][0]) < 1e-9 * max(1.0, abs(grads[False][0]))
+    assert grads[True][1].keys() == grads[False][1].keys() and len(grads[True][1]) >= 4
+    for k in grads[False][1]:
+        a, b = grads[True][1][k], grads[False][1][k]
+        assert float((a - b).abs().max()) <= 1e-7 * max(1e-6, float(b.abs().max())), k
+    # fit(): the default on the GPU is the library path; the torch statement is forced by patching the dispatcher
+    fitted = {}
+    for hip in (True, False):
+        m = copy.deepcopy(base).to(DEV)
+        if not hip:
+            orig = m.marginal_log_likelihood
+            m.marginal_log_likelihood = lambda hip=None, _o=orig: _o(hip=False)
+        m.fit(num_iters=15, lr=0.05)
+        with torch.no_grad():
+            fitted[hip] = (float(m._hip_factor().mll), torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
+    assert abs(fitted[True][0] - fitted[False][0]) < 1e-6 * max(1.0, abs(fitted[False][0]))
+    assert float((fitted[True][1] - fitted[False][1]).abs().max()) < 1e-6
+    assert fitted[True][0] > grads[True][0]      # the fit improved the likelihood
