@@ -475,8 +475,9 @@ int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
  * phases separated by an in-launch barrier of the surrogate's workgroups (arrival counter + agent-scope fences); every product
  * runs on v_mfma_f64_16x16x4_f64.  Same descriptor (mobocmf_tiny_model; M <= MOBOCMF_COOP_MAX_M, d <= 8, L <= 3), same flat
  * layout of grad / adam_m / adam_v (mobocmf_tiny_flat_len), same draws, same results as the layer path up to summation order;
- * `work` is sized by mobocmf_coop_work_bytes.  do_update: 0 gradients only | 1 the step | 2 forward only | 4 the conditioned
- * iteration in one launch (mobocmf_tiny_coupling with n_models = the models of the launch; the barrier of its record is not
+ * `work` is sized by mobocmf_coop_work_bytes.  do_update: 0 gradients only | 1 the step | 2 forward only | 3 input gradients
+ * (as mobocmf_tiny_elbo_step's mode 3: `grad` <- N x d, d/dx of <seed_gmean, top mean> + <seed_gvar, top var>; needs `grad`
+ * and the seeds; nothing else is written) | 4 the conditioned iteration in one launch (mobocmf_tiny_coupling with n_models = the models of the launch; the barrier of its record is not
  * used: the whole grid meets on the launch's own sync words).
  * wgs_per_model: workgroups sharing one surrogate, 1..64, or 0 = chosen from the widest phase (at most 32); *wgs_used (may be
  * NULL) receives the choice.  Every workgroup of the launch must be resident at once (n_models * wgs_per_model <= what the

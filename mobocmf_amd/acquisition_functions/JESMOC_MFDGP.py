@@ -125,16 +125,21 @@ class JESMOC_MFDGP:
         return state
 
     def _tiny_group(self, jess, fidelity, T, d):
-        """TinyPredictGroup over (uncond, cond) of every black-box of ``fidelity`` for T test points -- when all of them are
-        small enough for the one-launch kernel (util/tiny_step.py) -- else None.  Built once per (fidelity, T)."""
+        """TinyPredictGroup (M <= 32) or CoopPredictGroup (M <= 128) over (uncond, cond) of every black-box of ``fidelity`` for T
+        test points -- when all of them fit a one-launch kernel (util/tiny_step.py, util/coop_step.py) -- else None.  Built once
+        per (fidelity, T)."""
         cache = self.__dict__.setdefault("_tiny_groups", {})
         key = (fidelity, T, d)
         if key not in cache:
             from ..util import tiny_step as TS
             models = [m for jes in jess for m in (jes.mfdgp_uncond, jes.mfdgp_cond)]
-            ok = bool(models) and all(p.is_cuda for p in models[0].parameters()) and \
-                all(TS.fits_predict(m, fidelity, T, d) for m in models)
-            cache[key] = TS.TinyPredictGroup(models, fidelity, T, d) if ok else None
+            on_gpu = bool(models) and all(p.is_cuda for p in models[0].parameters())
+            if on_gpu and all(TS.fits_predict(m, fidelity, T, d) for m in models):
+                cache[key] = TS.TinyPredictGroup(models, fidelity, T, d)
+            else:      # mid-size surrogates (M <= 128): the cooperative launch, several workgroups per model
+                from ..util import coop_step as CS
+                ok = on_gpu and all(CS.fits_predict(m, fidelity, T, d) for m in models)
+                cache[key] = CS.CoopPredictGroup(models, fidelity, T, d) if ok else None
         return cache[key]
 
     def coupled_acq(self, X, fidelity):

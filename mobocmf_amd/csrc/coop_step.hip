@@ -18,7 +18,8 @@
 //     backward's products), operands read from L2 in k-major form (4 rows x 128 contiguous bytes per load instruction), which
 //     is why L^-1, U are kept in both orientations.
 // Rows ordered by descending fidelity, layer l on the first rows[l] of them, as the one-workgroup kernel.
-// Modes (do_update): 0 gradients only, 1 the step, 2 forward only, 4 the conditioned iteration in one launch (all models'
+// Modes (do_update): 0 gradients only, 1 the step, 2 forward only, 3 input gradients (acquisition search: `grad` <- d/dx of the
+// seeded top-layer moments, nothing else written), 4 the conditioned iteration in one launch (all models'
 // workgroups meet once more after the forward and form the theta / omega factor gradients, as tiny_step.hip's mode 4).
 #include <atomic>
 
@@ -928,7 +929,7 @@ PHASE_FN void ph_backward(int l_in) {
             }
             __syncthreads();
             CSTAMP(61);
-            if (g.hblk[l]) {
+            if (g.hblk[l] && do_update != 3) {
                 // the block's share of H = A diag(gv) A^T and Hc = A diag(cgv) A^T: slab `cb` (lower tiles and their mirrors)
                 gwd Hs = GW(MAT(l, M_HS + cb));
                 gwd Hcs = GW(MAT(l, M_HCS + cb));
@@ -975,6 +976,37 @@ PHASE_FN void ph_backward(int l_in) {
             if (has_tile) store_x(X2, wave, lane, tile_tx(Lig, Mp, X0, wave, wave, nt, lane));
             __syncthreads();
             CSTAMP(63);
+            if (do_update == 3) {
+                // B4' (input gradients, the parameters are constants): d/dx and d/df of the block's columns from dK.  A thread
+                // keeps one column (CT is a multiple of 16) and sums over its inducing rows; the 32 threads of a column are
+                // reduced through the wavefront (lanes j, j+16, j+32, j+48) and LDS.  The column's d/dx goes where its column
+                // of A was (the block has it in LDS and nothing reads it again in this mode).
+                double dxa[DBT], dfs = 0.0;
+#pragma unroll
+                for (int t = 0; t < DBT; ++t) dxa[t] = 0.0;
+#pragma unroll 1
+                for (int e = tid; e < Mp * 16; e += CT) {
+                    const int m = e >> 4, j = e & 15;
+                    if (m < M && xf[j * XFW + DBT + 1] != 0.0)
+                        kern_back_in(kind, d, xf + j * XFW, xf[j * XFW + DBT], zt + m * ZW, hyl, ill, X2[m * XLD + j], dxa, dfs);
+                }
+#pragma unroll
+                for (int t = 0; t <= DBT; ++t) {
+                    const double v = xor_add(xor_add(t < DBT ? dxa[t < DBT ? t : 0] : dfs, 16), 32);
+                    if (lane < 16) red[(wave * 16 + lane) * (DBT + 1) + t] = v;
+                }
+                __syncthreads();
+                if (tid < 16 * (DBT + 1)) {
+                    const int j = tid / (DBT + 1), t = tid % (DBT + 1), c = c0 + j;
+                    double sum = 0.0;
+#pragma unroll
+                    for (int p = 0; p < CNW; ++p) sum += red[(p * 16 + j) * (DBT + 1) + t];
+                    if (t < DBT) W[g.pan[l] + (int64_t)c * Mp + t] = c < nc ? sum : 0.0;
+                    else if (kind) VEC(l, V_GF)[c] = c < nc ? sum + gcol[32 + j] * hyl[0] * 2.0 * hyl[2] * xf[j * XFW + DBT] : 0.0;
+                }
+                __syncthreads();
+                continue;
+            }
             // B4: Gram backward of (dK, dk_nn = cgv), element by element
             double hacc[HS];
 #pragma unroll
@@ -1037,6 +1069,23 @@ PHASE_FN void ph_backward(int l_in) {
             __syncthreads();
         }
         CSTAMP(20 + l_in);
+}
+
+// mode 3, last phase: d/dx of a base row = the sum over the layers that hold the row and over its sample columns
+PHASE_FN void ph_dx() {
+    CTX_LOCALS;
+    gwd out = GW(md.grad);
+    for (int e = wj * CT + tid; e < md.N * d; e += k * CT) {
+        const int n = e / d, t = e - n * d;
+        double sum = 0.0;
+        for (int l = 0; l < L; ++l) {
+            if (n < md.rows[l]) {
+                const int div = l ? S : 1;
+                for (int s2 = 0; s2 < div; ++s2) sum += W[g.pan[l] + (int64_t)(n * div + s2) * Mp + t];
+            }
+        }
+        out[e] = sum;
+    }
 }
 
     // ---- the M x M chain backward, every layer at once, tile-parallel: one 16 x 16 output tile per wavefront.
@@ -1524,6 +1573,14 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     }
     ph_elbo();
     if (do_update == 2) return;
+    if (do_update == 3) {      // input gradients: the backward column phases only, then the rows' sums
+        for (int l = L - 1; l >= 0; --l) {
+            ph_backward(l);
+            MODEL_BARRIER(25 + l);
+        }
+        ph_dx();
+        return;
+    }
     if (do_update == 4) {
         if (!ph_couple()) return;
         MODEL_BARRIER(15);
@@ -1604,7 +1661,7 @@ int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
                            int32_t do_update, int32_t* wgs_used, mobocmf_stream_t stream) {
     if (!host_models || !dev_models || !sync_words || n_models < 1 || n_models > 256 || wgs_per_model < 0 || wgs_per_model > 64)
         return MOBOCMF_BAD_ARG;
-    if (do_update != 0 && do_update != 1 && do_update != 2 && do_update != 4) return MOBOCMF_BAD_ARG;
+    if (do_update < 0 || do_update > 4) return MOBOCMF_BAD_ARG;
     int mpmax = 0, want = 1;
     for (int i = 0; i < n_models; ++i) {
         const mobocmf_tiny_model& m = host_models[i];
@@ -1614,6 +1671,7 @@ int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
                 m.role_index > 7 || m.coupling != host_models[0].coupling)
                 return MOBOCMF_BAD_ARG;
         }
+        if (do_update == 3 && (!m.grad || !m.seed_gmean)) return MOBOCMF_BAD_ARG;      // (grad receives N x d input gradients)
         CGeom g;
         cgeom_of(m, g);
         if (g.Mp > mpmax) mpmax = g.Mp;

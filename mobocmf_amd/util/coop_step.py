@@ -99,3 +99,37 @@ class CoopConditionedStep(_CoopLaunch, TS.TinyConditionedStep):
         super().restore()
         with torch.cuda.stream(self.stream):
             self._sync_words().zero_()
+
+
+MAX_PREDICT_COLUMNS = 4096      # T * S per layer beyond which the layer path (frozen chains) is the better search engine
+
+
+def fits_predict(model, fidelity, T, d):
+    """``tiny_step.fits_predict`` with the cooperative kernel's limits (M <= 128) and its column bound."""
+    S = model.num_samples_for_acquisition if fidelity > 0 else 1
+    return T * S <= MAX_PREDICT_COLUMNS and TS.fits_predict(model, fidelity, T, d, speed_rule=False, max_m=_lib.COOP_MAX_M)
+
+
+class CoopPredictGroup(TS.TinyPredictGroup):
+    """``TinyPredictGroup`` for mid-size models (32 < M <= 128): predictive moments of several fitted models at the same T test
+    points in ONE cooperative launch (mode 2), their gradient w.r.t. the test points in one more (mode 3) -- the acquisition
+    search of the reference's later BO iterations (JESMOC_MFDGP.py:137-184 against M = N = 33 ... 75 surrogates)."""
+    _work_bytes_fn = "mobocmf_coop_work_bytes"
+    wgs_per_model = 0
+
+    @staticmethod
+    def _fits(model, fidelity, T, d):
+        return fits_predict(model, fidelity, T, d)
+
+    def _launch(self, mode):
+        lib = _lib.require_device()
+        sw = self.__dict__.get("_sync")
+        if sw is None:
+            sw = self._sync = torch.zeros(16 * (len(self.models) + 1), dtype=torch.int64, device=self.device)
+        used = ctypes.c_int32(0)
+        _lib.check(lib.mobocmf_coop_elbo_step(ctypes.cast(self.host, ctypes.c_void_p), ctypes.c_void_p(self._dev_table.data_ptr()),
+                                              len(self.models), int(self.wgs_per_model), ctypes.c_void_p(sw.data_ptr()),
+                                              0.0, 0.9, 0.999, 1e-8, int(mode), ctypes.byref(used),
+                                              ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                   "mobocmf_coop_elbo_step")
+        self.wgs_used = used.value

@@ -29,16 +29,17 @@ def _hyper_params(layer):
     return [getattr(m, n) for m, n in gp._hyper_sources(layer.covar_module, layer.kind)]
 
 
-def fits_predict(model, fidelity, T, d, speed_rule=True):
+def fits_predict(model, fidelity, T, d, speed_rule=True, max_m=None):
     """True when ``model``'s predictive moments at T test points up to layer ``fidelity`` fit the one-launch kernel (the
-    structural limits of ``eligible``; the training flags do not matter: prediction runs the eval branch)."""
+    structural limits of ``eligible``; the training flags do not matter: prediction runs the eval branch).  ``max_m``: the
+    inducing-point limit of the kernel asked about (default: the one-workgroup kernel's)."""
     try:
         layers = model._layers()[:fidelity + 1]
         if not (1 <= len(layers) <= _lib.TINY_MAX_LAYERS) or model.use_only_highest_fidelity or not (1 <= d <= _lib.TINY_MAX_D):
             return False
         Z0 = layers[0].variational_strategy._inducing_points
         M = Z0.shape[0]
-        if not (1 <= M <= _lib.TINY_MAX_M) or Z0.shape[1] != d or not Z0.is_cuda:
+        if not (1 <= M <= (max_m or _lib.TINY_MAX_M)) or Z0.shape[1] != d or not Z0.is_cuda:
             return False
         S = model.num_samples_for_acquisition
         cols = [T] + [T * S] * (len(layers) - 1)
@@ -572,6 +573,12 @@ class TinyPredictGroup:
     times against constant parameters (JESMOC_MFDGP.py:137-184).  ``moments_at(X)`` -> (n_models, 2, T * S) (T for
     fidelity 0): mean and variance of the top layer's columns, WITHOUT the likelihood noise; differentiable w.r.t. X."""
 
+    _work_bytes_fn = "mobocmf_tiny_work_bytes"
+
+    @staticmethod
+    def _fits(model, fidelity, T, d):
+        return fits_predict(model, fidelity, T, d, speed_rule=False)
+
     def __init__(self, models, fidelity, T, d, stream=None):
         lib = _lib.require_device()
         self.models, self.fidelity, self.T, self.d = list(models), fidelity, int(T), int(d)
@@ -591,7 +598,7 @@ class TinyPredictGroup:
         nofid = torch.full((self.T,), -1.0, dtype=torch.float64, device=dev)      # no row is scored: moments only
         self._keep += [zrow, nofid]
         for i, model in enumerate(self.models):
-            if not fits_predict(model, fidelity, self.T, d, speed_rule=False) or \
+            if not self._fits(model, fidelity, self.T, d) or \
                     (L > 1 and model.num_samples_for_acquisition != self.S):
                 raise _lib.MobocmfError("TinyPredictGroup: model %d does not fit the one-launch kernel" % i)
             layers = model._layers()[:L]
@@ -617,7 +624,7 @@ class TinyPredictGroup:
                     self._keep.append(e)
             flat, wb = ctypes.c_int64(), ctypes.c_size_t()
             _lib.check(lib.mobocmf_tiny_flat_len(ctypes.byref(Tm), ctypes.byref(flat)), "mobocmf_tiny_flat_len")
-            _lib.check(lib.mobocmf_tiny_work_bytes(ctypes.byref(Tm), ctypes.byref(wb)), "mobocmf_tiny_work_bytes")
+            _lib.check(getattr(lib, self._work_bytes_fn)(ctypes.byref(Tm), ctypes.byref(wb)), self._work_bytes_fn)
             work = torch.zeros(wb.value // 8, dtype=torch.float64, device=dev)
             dummy = torch.zeros(2, flat.value, dtype=torch.float64, device=dev)      # (never written: modes 2 / 3 only)
             misc = torch.zeros(8, dtype=torch.int64, device=dev)

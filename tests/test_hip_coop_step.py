@@ -314,3 +314,96 @@ def test_fitter_trains_mid_size_surrogates_through_the_cooperative_launch():
         h.mfdgp.fix_variational_hypers_cond(True)
     done, cstep = fitter._train_conditioned_tiny(50)
     assert done == 50 and isinstance(cstep, coop_step.CoopConditionedStep) and bool(torch.isfinite(cstep.loss))
+
+
+PRED = [dict(M=64, N=64, d=2, S=5, f=1, T=9), dict(M=48, N=60, d=3, S=4, f=0, T=20), dict(M=100, N=100, d=2, S=6, f=1, T=33),
+        dict(M=128, N=128, d=2, S=8, f=1, T=40), dict(M=75, N=75, d=8, S=3, f=1, T=17), dict(M=24, N=30, d=2, S=5, f=1, T=7)]
+
+
+@pytest.mark.parametrize("c", PRED, ids=["M%d_d%d_S%d_f%d_T%d" % (c["M"], c["d"], c["S"], c["f"], c["T"]) for c in PRED])
+def test_coop_predict_group_matches_predict_for_acquisition_and_its_input_gradient(c):
+    """The acquisition search at the reference's later loop sizes (JESMOC_MFDGP.py:137-184 against M = N = 33 ... 75 surrogates):
+    CoopPredictGroup -- mode 2 of the cooperative launch for the moments of all models, mode 3 for d/dX -- against
+    MFDGP.predict_for_acquisition through the layer entry points (pinned to the oracle in test_hip_model.py), T test points,
+    S fixed samples.  Inputs of <= 3 dimensions with M >= 48 give cond(K_mm + 1e-6 I) ~ 1e9: either side carries cond * eps."""
+    from mobocmf_amd.util.coop_step import CoopPredictGroup, fits_predict
+    from tests.test_hip_model import build_model
+    M, N, d, S, fidelity, T = c["M"], c["N"], c["d"], c["S"], c["f"], c["T"]
+    models = [build_model(synthetic.make_problem(d=d, L=2, M=M, N=N, S=S, seed=s), S_train=S, S_acq=S) for s in (1, 2, 3)]
+    assert all(fits_predict(m, fidelity, T, d) for m in models)
+    g = torch.Generator().manual_seed(3)
+    X = torch.rand(T, d, dtype=torch.float64, generator=g).to(DEV)
+    wm = torch.randn(len(models), T, dtype=torch.float64, generator=g).to(DEV)
+    wv = torch.randn(len(models), T, dtype=torch.float64, generator=g).to(DEV)
+    Xa = X.clone().requires_grad_(True)
+    ref_m, ref_v = [], []
+    for m in models:
+        m.eval()
+        mu, v = m.predict_for_acquisition(Xa, fidelity)
+        m.train()
+        ref_m.append(mu), ref_v.append(v)
+    ref_m, ref_v = torch.stack(ref_m), torch.stack(ref_v)
+    ((ref_m * wm).sum() + (ref_v * wv).sum()).backward()
+    grp = CoopPredictGroup(models, fidelity, T, d)
+    Xb = X.clone().requires_grad_(True)
+    mus, v = grp.acquisition_moments(Xb)
+    ((mus * wm).sum() + (v * wv).sum()).backward()
+    hard = d <= 3 and M >= 48
+    assert rel(mus, ref_m) < (1e-6 if hard else 1e-8) and rel(v, ref_v) < (1e-5 if hard else 1e-7), (rel(mus, ref_m), rel(v, ref_v))
+    assert rel(Xb.grad, Xa.grad) < (1e-4 if hard else 1e-6), rel(Xb.grad, Xa.grad)
+    # a second evaluation at other points reuses the group (descriptors, workspace, arrival counters)
+    X2 = torch.rand(T, d, dtype=torch.float64, generator=g).to(DEV)
+    m2, v2 = grp.acquisition_moments(X2)
+    with torch.no_grad():
+        for i, m in enumerate(models):
+            m.eval()
+            mu, vv = m.predict_for_acquisition(X2, fidelity)
+            m.train()
+            assert rel(m2[i], mu) < (1e-6 if hard else 1e-8) and rel(v2[i], vv) < (1e-5 if hard else 1e-7)
+    if M <= 32:      # inside the one-workgroup kernel's window both kernels answer: same numbers
+        from mobocmf_amd.util.tiny_step import TinyPredictGroup
+        tg = TinyPredictGroup(models, fidelity, T, d)
+        Xc = X.clone().requires_grad_(True)
+        mt, vt = tg.acquisition_moments(Xc)
+        ((mt * wm).sum() + (vt * wv).sum()).backward()
+        assert rel(mus, mt) < 1e-8 and rel(v, vt) < 1e-7 and rel(Xb.grad, Xc.grad) < 1e-6
+
+
+def test_coupled_jes_at_mid_sizes_goes_through_the_cooperative_launch():
+    """JESMOC_MFDGP.coupled_acq (JESMOC_MFDGP.py:38-52,125-135) for surrogates of M = N = 40 (iteration ~25 of the reference's
+    loop): value and candidate gradient through CoopPredictGroup (two launches for all six models) equal the layer path's."""
+    from mobocmf_amd.acquisition_functions.JESMOC_MFDGP import JESMOC_MFDGP
+    from mobocmf_amd.util.coop_step import CoopPredictGroup
+    from tests.test_hip_conditioned import _fitter
+    fu, _ = _fitter(2, 1, 40, M=40)
+    fc, _ = _fitter(2, 1, 40, M=40)
+    g = torch.Generator().manual_seed(1)
+    for _, _, h in fc._handlers():
+        for layer in h.mfdgp._layers():
+            vd = layer.variational_strategy._variational_distribution
+            with torch.no_grad():
+                vd.variational_mean.add_(0.05 * torch.randn(vd.variational_mean.shape, dtype=torch.float64, generator=g).to(DEV))
+                vd.chol_variational_covar.mul_(0.7)
+    fc.pareto_set = torch.zeros(1, 2, dtype=torch.float64, device=DEV)
+    fc.pareto_front = torch.zeros(1, 2, dtype=torch.float64, device=DEV)
+    acq = JESMOC_MFDGP.__new__(JESMOC_MFDGP)
+    acq.blackbox_mfdgp_fitter_uncond, acq.blackbox_mfdgp_fitter_cond = fu, fc
+    acq.num_fidelities, acq.eval_highest_fidelity = 2, False
+    acq.standard_bounds = torch.tensor([[0.0, 0.0], [1.0, 1.0]], dtype=torch.float64, device=DEV)
+    acq.objectives, acq.constraints, acq.costs_blackboxes = {0: {}, 1: {}}, {0: {}, 1: {}}, {0: {"total": 0.0}, 1: {"total": 0.0}}
+    for f in (0, 1):
+        for name, is_con in (("bb0", False), ("bb1", False), ("bb2", True)):
+            acq.add_blackbox(f, name, is_constraint=is_con)
+    X = torch.rand(11, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(9)).to(DEV)
+    for f in (0, 1):
+        res = {}
+        for one_launch in (True, False):
+            acq.use_tiny_step = one_launch
+            Xg = X.clone().requires_grad_(True)
+            v = acq.coupled_acq(Xg, fidelity=f)
+            v.sum().backward()
+            res[one_launch] = (v.detach(), Xg.grad)
+        assert isinstance(acq._tiny_groups[(f, 11, 2)], CoopPredictGroup)
+        assert float(res[False][0].abs().max()) > 0
+        assert rel(res[True][0], res[False][0]) < 1e-6, (f, rel(res[True][0], res[False][0]))
+        assert rel(res[True][1], res[False][1]) < 1e-4, (f, rel(res[True][1], res[False][1]))
