@@ -487,6 +487,10 @@ int mobocmf_tiny_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
  * and n_models).  A wait that does not end within ~0.3 s is abandoned: info[0] = -1, out[2] = NaN, nothing is updated by that
  * workgroup. */
 #define MOBOCMF_COOP_MAX_M 128
+/* OR'd into do_update 2 or 3 of mobocmf_coop_elbo_step: the parameters are the ones of an earlier launch on the same `work`
+ * (an acquisition search against fitted models, JESMOC_MFDGP.py:137-184): K_mm, its Cholesky and inverse, U, a and the KL stay as
+ * that launch left them and are not formed again (35-65 us of a ~140 us launch).  The caller vouches for it. */
+#define MOBOCMF_STEP_CHAIN_VALID 16
 int mobocmf_coop_work_bytes(const mobocmf_tiny_model* model, size_t* bytes);
 int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_tiny_model* dev_models, int32_t n_models,
                            int32_t wgs_per_model, int64_t* sync_words, double lr, double beta1, double beta2, double eps,

@@ -40,6 +40,7 @@ class LayerDesc(ctypes.Structure):
 
 TINY_MAX_LAYERS, TINY_MAX_M, TINY_MAX_D = 3, 32, 8      # MOBOCMF_TINY_MAX_* of include/mobocmf_hip.h
 COOP_MAX_M = 128                                         # MOBOCMF_COOP_MAX_M
+STEP_CHAIN_VALID = 16                                    # MOBOCMF_STEP_CHAIN_VALID
 
 
 class TinyModel(ctypes.Structure):

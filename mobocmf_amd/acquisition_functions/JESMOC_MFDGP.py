@@ -153,6 +153,8 @@ class JESMOC_MFDGP:
             X2 = X[:, 0, :] if X.dim() > 2 else X
             grp = self._tiny_group(jess, fidelity, X2.shape[0], X2.shape[1])
             if grp is not None:
+                if self.__dict__.get("_search_running") and hasattr(grp, "freeze"):
+                    grp.freeze()      # (constant parameters for the whole search: the chains are formed by its first launch only)
                 _, v = grp.acquisition_moments(X2)
                 return (0.5 * torch.clamp(torch.log(v[0::2]) - torch.log(v[1::2]), min=0.0)).sum(0)
         local = [obj(X) for obj in self.objectives[fidelity].values()] + \
@@ -165,10 +167,23 @@ class JESMOC_MFDGP:
             acq = acq + (parallel.coupled_acquisition(acq.detach()[None]) - acq.detach())
         return acq
 
+    @contextlib.contextmanager
+    def _frozen_groups(self):
+        """The one-launch predict groups used inside keep their chains (util/coop_step.py CoopPredictGroup.freeze)."""
+        self._search_running = True
+        try:
+            yield
+        finally:
+            self._search_running = False
+            for grp in self.__dict__.get("_tiny_groups", {}).values():
+                if grp is not None and hasattr(grp, "thaw"):
+                    grp.thaw()
+
     def _optimize(self, fidelity, **kw):
         with contextlib.ExitStack() as stack:       # fitted models: freeze every surrogate's chain for the whole search
             for jes in list(self.objectives[fidelity].values()) + list(self.constraints[fidelity].values()):
                 stack.enter_context(jes.frozen())
+            stack.enter_context(self._frozen_groups())
             return optimize_acqf_multistart(lambda x: self.coupled_acq(x, fidelity=fidelity), self.standard_bounds,
                                             num_restarts=5, raw_samples=200, maxiter=kw.get("maxiter", 200))
 

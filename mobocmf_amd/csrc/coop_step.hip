@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
             c0->mcnt = sync_words + 16 * (int64_t)mi;
             c0->gcnt = sync_words + 16 * (int64_t)(gridDim.x / k_);
             c0->lr = lr_; c0->b1 = b1_; c0->b2 = b2_; c0->aeps = aeps_;
-            c0->k = k_; c0->wj = blockIdx.x % k_; c0->do_update = do_update_; c0->n_stamp = 0;
+            c0->k = k_; c0->wj = blockIdx.x % k_; c0->do_update = do_update_ & 15; c0->n_stamp = 0;
         }
         __syncthreads();
     }
@@ -1559,13 +1559,15 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     (void)wj;
     CSTAMP(0);
     ph_setup();
-    const bool spread_kmm = nt > 4 && k >= 4;      // (the same in every workgroup of the surrogate: one barrier more)
-    if (spread_kmm) {
-        ph_kmm();
-        MODEL_BARRIER(8);
+    if (!(do_update_ & MOBOCMF_STEP_CHAIN_VALID)) {      // (set: L^-1, U, a, KL of these parameters are in `work` from an earlier launch)
+        const bool spread_kmm = nt > 4 && k >= 4;      // (the same in every workgroup of the surrogate: one barrier more)
+        if (spread_kmm) {
+            ph_kmm();
+            MODEL_BARRIER(8);
+        }
+        ph_chain(spread_kmm);
+        MODEL_BARRIER(6);
     }
-    ph_chain(spread_kmm);
-    MODEL_BARRIER(6);
     ph_stage();
     for (int l = 0; l < L; ++l) {
         ph_forward(l);
@@ -1661,7 +1663,9 @@ int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
                            int32_t do_update, int32_t* wgs_used, mobocmf_stream_t stream) {
     if (!host_models || !dev_models || !sync_words || n_models < 1 || n_models > 256 || wgs_per_model < 0 || wgs_per_model > 64)
         return MOBOCMF_BAD_ARG;
-    if (do_update < 0 || do_update > 4) return MOBOCMF_BAD_ARG;
+    const int chain_valid = do_update & MOBOCMF_STEP_CHAIN_VALID;
+    do_update &= ~MOBOCMF_STEP_CHAIN_VALID;
+    if (do_update < 0 || do_update > 4 || (chain_valid && do_update != 2 && do_update != 3)) return MOBOCMF_BAD_ARG;
     int mpmax = 0, want = 1;
     for (int i = 0; i < n_models; ++i) {
         const mobocmf_tiny_model& m = host_models[i];
@@ -1706,7 +1710,7 @@ int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
     if ((int64_t)k * n_models > resident || k < 1) return MOBOCMF_BAD_ARG;
     if (wgs_used) *wgs_used = k;
     hipLaunchKernelGGL(coop_step_kernel, dim3((unsigned)(n_models * k)), dim3(CT), shm, (hipStream_t)stream, dev_models, k,
-                       (unsigned long long*)sync_words, lr, beta1, beta2, eps, do_update);
+                       (unsigned long long*)sync_words, lr, beta1, beta2, eps, do_update | chain_valid);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 

@@ -116,16 +116,30 @@ class CoopPredictGroup(TS.TinyPredictGroup):
     search of the reference's later BO iterations (JESMOC_MFDGP.py:137-184 against M = N = 33 ... 75 surrogates)."""
     _work_bytes_fn = "mobocmf_coop_work_bytes"
     wgs_per_model = 0
+    _frozen = False            # inside freeze() ... thaw(): the models' parameters do not change between launches
+    _chain_ready = False       # ... and a launch since freeze() has left their chains (L^-1, U, a) in the workspaces
 
     @staticmethod
     def _fits(model, fidelity, T, d):
         return fits_predict(model, fidelity, T, d)
+
+    def freeze(self):
+        """The parameters are constants until ``thaw()`` (an acquisition search, JESMOC_MFDGP._optimize): the first launch
+        computes the chains, the following ones reuse them (MOBOCMF_STEP_CHAIN_VALID)."""
+        if not self._frozen:
+            self._frozen, self._chain_ready = True, False
+
+    def thaw(self):
+        self._frozen = self._chain_ready = False
 
     def _launch(self, mode):
         lib = _lib.require_device()
         sw = self.__dict__.get("_sync")
         if sw is None:
             sw = self._sync = torch.zeros(16 * (len(self.models) + 1), dtype=torch.int64, device=self.device)
+        if self._frozen and self._chain_ready:
+            mode = int(mode) | _lib.STEP_CHAIN_VALID
+        self._chain_ready = self._frozen
         used = ctypes.c_int32(0)
         _lib.check(lib.mobocmf_coop_elbo_step(ctypes.cast(self.host, ctypes.c_void_p), ctypes.c_void_p(self._dev_table.data_ptr()),
                                               len(self.models), int(self.wgs_per_model), ctypes.c_void_p(sw.data_ptr()),

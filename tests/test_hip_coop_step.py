@@ -360,6 +360,19 @@ def test_coop_predict_group_matches_predict_for_acquisition_and_its_input_gradie
             mu, vv = m.predict_for_acquisition(X2, fidelity)
             m.train()
             assert rel(m2[i], mu) < (1e-6 if hard else 1e-8) and rel(v2[i], vv) < (1e-5 if hard else 1e-7)
+    # constant parameters for a whole search (JESMOC_MFDGP._optimize): the chains are formed by the first launch after freeze()
+    # only (MOBOCMF_STEP_CHAIN_VALID) -- bit for bit the same moments and gradients
+    grp.freeze()
+    for Xq in (X2, X):
+        Xf = Xq.clone().requires_grad_(True)
+        mf, vf = grp.acquisition_moments(Xf)
+        ((mf * wm).sum() + (vf * wv).sum()).backward()
+        if Xq is X:
+            assert grp._chain_ready and torch.equal(mf, mus.detach()) and torch.equal(vf, v.detach()) and torch.equal(Xf.grad, Xb.grad)
+        else:
+            assert torch.equal(mf, m2) and torch.equal(vf, v2)
+    grp.thaw()
+    assert not grp._frozen and not grp._chain_ready
     if M <= 32:      # inside the one-workgroup kernel's window both kernels answer: same numbers
         from mobocmf_amd.util.tiny_step import TinyPredictGroup
         tg = TinyPredictGroup(models, fidelity, T, d)

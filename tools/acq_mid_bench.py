@@ -42,12 +42,19 @@ for M, T, S, nmod in ((48, 50, 10, 6), (64, 50, 10, 6), (75, 200, 10, 6), (128, 
         return layer_path()
 
     out = []
-    for name, fn, reps in (("cooperative launches", one_launch, 200), ("layer path", layer_path, 20),
+    def one_launch_frozen():
+        return one_launch()
+
+    for name, fn, reps in (("cooperative launches", one_launch, 200), ("the same, chains kept (freeze())", one_launch_frozen, 200),
+                           ("layer path", layer_path, 20),
                            ("layer path, frozen chains", layer_path_frozen, 50)):
         stack = contextlib.ExitStack()
         if fn is layer_path_frozen:
             for m in models:
                 stack.enter_context(m.frozen_chains())
+        if fn is one_launch_frozen:
+            grp.freeze()
+            stack.callback(grp.thaw)
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
