@@ -333,7 +333,10 @@ def test_coop_step_argument_checks_are_made_on_the_host():
         ctypes.byref(used), None)
     assert step() == _lib.BAD_ARG                  # a descriptor without pointers
     assert step(n=0) == _lib.BAD_ARG and step(wgs=65) == _lib.BAD_ARG and step(wgs=-1) == _lib.BAD_ARG
-    assert step(mode=3) == _lib.BAD_ARG and step(mode=5) == _lib.BAD_ARG      # input gradients: the one-workgroup kernel only
+    assert step(mode=5) == _lib.BAD_ARG and step(mode=-1) == _lib.BAD_ARG
+    # MOBOCMF_STEP_CHAIN_VALID goes with the forward-only and the input-gradient mode only
+    for m in (0, 1, 4):
+        assert step(mode=m | _lib.STEP_CHAIN_VALID) == _lib.BAD_ARG, m
     assert step(h=None) == _lib.BAD_ARG and step(sw=None) == _lib.BAD_ARG
     assert used.value == -7                        # nothing was chosen, nothing launched
 
