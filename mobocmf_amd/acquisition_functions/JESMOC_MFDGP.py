@@ -63,19 +63,33 @@ def optimize_acqf_multistart(acq_function, bounds, num_restarts=5, raw_samples=2
         opt = F.FusedAdam([X], lr=lr * float((hi - lo).mean()))
     else:
         opt = torch.optim.Adam([X], lr=lr * float((hi - lo).mean()))
-    best_x, best_v = X.detach().clone(), acq_function(X.detach())
-    for _ in range(maxiter):
+    # every iterate X_0 ... X_maxiter is scored ONCE: the value of the evaluation that also yields its gradient is the score of the
+    # iterate (round 4 scored X_{t+1} after the step and evaluated it again, with gradient, at the top of the next iteration --
+    # a third of the search's launches)
+    best_x, best_v = X.detach().clone(), None
+    for it in range(maxiter + 1):
+        last = it == maxiter
         opt.zero_grad()
-        v = acq_function(X)
+        if last:
+            with torch.no_grad():
+                v = acq_function(X)
+        else:
+            v = acq_function(X)
+        with torch.no_grad():
+            vd = v.detach()
+            if best_v is None:
+                best_v = vd.clone()
+            else:
+                better = vd > best_v
+                best_v = torch.where(better, vd, best_v)
+                best_x[better] = X.detach()[better]
+        if last:
+            break
         (-v.sum()).backward()
         opt.step()
         with torch.no_grad():
             X.clamp_(min=lo, max=hi)
             parallel.broadcast_(X)    # (no-op on one rank) summation order may differ by an ulp between ranks
-            v = acq_function(X)
-            better = v > best_v
-            best_v = torch.where(better, v, best_v)
-            best_x[better] = X[better]
     k = int(torch.argmax(best_v))
     return best_x[k:k + 1].detach(), best_v[k].detach()
 

@@ -146,3 +146,27 @@ def test_mes_acquisition_values_and_search():
     torch.manual_seed(0)
     xn, fsel = acq.get_nextpoint_coupled(maxiter=10)
     assert xn.shape == (2,) and fsel in (0, 1) and bool(((xn >= 0) & (xn <= 1)).all())
+
+
+def test_multistart_search_scores_every_iterate_once_and_returns_the_best():
+    """optimize_acqf_multistart (the stand-in for BoTorch's optimize_acqf at JESMOC_MFDGP.py:137-184): on a concave test
+    function it finds the maximiser inside the box, the value it returns is the function's value at the candidate it returns, and
+    the function is called once for the raw samples and once per iterate (X_0 ... X_maxiter) -- not twice."""
+    from mobocmf_amd.acquisition_functions.JESMOC_MFDGP import optimize_acqf_multistart
+    c = torch.tensor([0.3, 0.8], dtype=torch.float64)
+    calls = []
+
+    def f(X):
+        calls.append(X.shape[0])
+        return 1.0 - ((X - c) ** 2).sum(-1)
+
+    bounds = torch.tensor([[0.0, 0.0], [1.0, 1.0]], dtype=torch.float64)
+    g = torch.Generator().manual_seed(0)
+    x, v = optimize_acqf_multistart(f, bounds, num_restarts=4, raw_samples=50, maxiter=60, lr=0.05, generator=g)
+    assert x.shape == (1, 2) and float((x[0] - c).abs().max()) < 2e-2
+    assert abs(float(v) - float(f(x)[0])) < 1e-15
+    assert calls[0] == 50 and calls[1:-1] == [4] * 61
+    # a maximiser outside the box: the search stops at the boundary
+    c = torch.tensor([1.4, -0.2], dtype=torch.float64)
+    x, v = optimize_acqf_multistart(f, bounds, num_restarts=3, raw_samples=30, maxiter=80, lr=0.05, generator=g)
+    assert bool(((x >= 0) & (x <= 1)).all()) and float((x[0] - torch.tensor([1.0, 0.0], dtype=torch.float64)).abs().max()) < 2e-2
