@@ -113,3 +113,36 @@ def test_layer_chain_is_the_same_through_both_forms_and_replays_from_a_graph():
         g.check()
         losses.append(ls)
     assert losses[0] == losses[1]
+
+
+def test_more_concurrent_one_launch_factorisations_than_the_chip_holds_are_still_right_or_say_so():
+    """Six streams, each with the one-launch factorisation of a 1024 x 1024 matrix in flight (49 workgroups each that must be
+    resident together: 294 on 256 CUs).  The launches are ordinary ones: the hardware may hold some of them only partly until
+    others finish.  Every result must be EITHER bit-identical to the factorisation done alone OR carry info = -1 (a bounded
+    in-launch wait was abandoned: functional.InLaunchWaitAbandoned) -- never a wrong factor, never a hang."""
+    from mobocmf_amd import functional as F
+    n, ns = 1024, 6
+    mats = [_gram(n, 4, 1.0, 1e-4, 10 + i) for i in range(ns)]
+    alone = []
+    for K, y in mats:
+        st = F.exact_gp_factor(K, y)
+        assert F.check_info(st.info) == 0
+        alone.append((_factors(st, n)[0].clone(), _factors(st, n)[1].clone(), float(st.mll)))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(ns)]
+    abandoned = 0
+    for rnd in range(3):
+        states = []
+        for (K, y), s in zip(mats, streams):
+            with torch.cuda.stream(s):
+                states.append(F.exact_gp_factor(K, y))      # (scratch is per (device, stream): functional.scratch_buffer)
+        torch.cuda.synchronize()
+        for i, st in enumerate(states):
+            piv = F.check_info(st.info)
+            if piv == -1:
+                abandoned += 1
+                continue
+            assert piv == 0
+            L, Li, _ = _factors(st, n)
+            assert torch.equal(L, alone[i][0]) and torch.equal(Li, alone[i][1]) and float(st.mll) == alone[i][2]
+    print("abandoned waits: %d of %d concurrent factorisations" % (abandoned, 3 * ns))
