@@ -858,6 +858,8 @@ PHASE_FN void ph_syrk(int lh) {
         }
 }
 
+// INGRAD: mode 3 (input gradients; a compile-time variant so that the training step's code is what it was without it)
+template <bool INGRAD>
 PHASE_FN void ph_backward(int l_in) {
     CTX_LOCALS;
     DEF_STAGE_ROWS
@@ -929,7 +931,7 @@ PHASE_FN void ph_backward(int l_in) {
             }
             __syncthreads();
             CSTAMP(61);
-            if (g.hblk[l] && do_update != 3) {
+            if (!INGRAD && g.hblk[l]) {
                 // the block's share of H = A diag(gv) A^T and Hc = A diag(cgv) A^T: slab `cb` (lower tiles and their mirrors)
                 gwd Hs = GW(MAT(l, M_HS + cb));
                 gwd Hcs = GW(MAT(l, M_HCS + cb));
@@ -976,7 +978,7 @@ PHASE_FN void ph_backward(int l_in) {
             if (has_tile) store_x(X2, wave, lane, tile_tx(Lig, Mp, X0, wave, wave, nt, lane));
             __syncthreads();
             CSTAMP(63);
-            if (do_update == 3) {
+            if constexpr (INGRAD) {
                 // B4' (input gradients, the parameters are constants): d/dx and d/df of the block's columns from dK.  A thread
                 // keeps one column (CT is a multiple of 16) and sums over its inducing rows; the 32 threads of a column are
                 // reduced through the wavefront (lanes j, j+16, j+32, j+48) and LDS.  The column's d/dx goes where its column
@@ -1577,7 +1579,7 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     if (do_update == 2) return;
     if (do_update == 3) {      // input gradients: the backward column phases only, then the rows' sums
         for (int l = L - 1; l >= 0; --l) {
-            ph_backward(l);
+            ph_backward<true>(l);
             MODEL_BARRIER(25 + l);
         }
         ph_dx();
@@ -1588,7 +1590,7 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
         MODEL_BARRIER(15);
     }
     for (int l = L - 1; l >= 0; --l) {
-        ph_backward(l);
+        ph_backward<false>(l);
         if (l + 1 < L && !g.hblk[l + 1]) ph_syrk(l + 1);
         MODEL_BARRIER(25 + l);
     }
