@@ -32,6 +32,10 @@ __device__ __forceinline__ int tel(int r, int c) { return r * 16 + (c ^ r); }
 // later): parity-green, and NO faster -- Cholesky phase 16.8 -> 16.0 us at M = 64, 35.7 -> 35.3 at M = 128, the step unchanged.
 // The 3.3 us of this routine are its 16 dependent column steps (~0.2 us each: two v_readlane, v_rsq_f64, six dependent f64
 // operations, then the eliminations that feed the next pivot), not the inverse behind them.)
+// (Tried: pinning the eliminations where they are written -- an empty asm on the updated values after every column step: hipcc
+// otherwise defers every update row[k] -= ... to column k's own step, a left-looking loop whose columns open with a chain of k
+// dependent FMAs and whose multipliers wait in SGPRs, some spilled through v_writelane -- gives the right-looking instruction
+// order and is NOT faster: Cholesky phase 16.0 -> 17.1 us at M = 64, the one-launch factorisation 214 -> 226 us at n = 512.)
 // (Tried: the broadcasts as DPP row_newbcast moves -- no trip through an SGPR -- are SLOWER: 17.6 -> 21 us for the four tiles of
 // M = 64, profiles/r05_coop_step.txt; the DPP move waits for its source's write-back where v_readlane's result is forwarded.)
 __device__ __forceinline__ int chol_inv_tile16(double* T, double* Ti, int lane) {
