@@ -1529,6 +1529,10 @@ PHASE_FN void ph_adam() {
 
 #define MODEL_BARRIER(id) do { CSTAMP(id); if (!group_barrier(cx->mcnt, (unsigned)k, (int*)(sc + 30))) { if (tid == 0) { md.info[0] = -1; md.out[2] = __builtin_nan(""); } return; } CSTAMP(99); } while (0)
 
+// PREDICT: the instantiation for an acquisition search (mode 3, and mode 2 with MOBOCMF_STEP_CHAIN_VALID) -- a kernel of its own, so
+// that the training step's kernel carries none of its code (with the input-gradient phases inlined into ONE kernel the training
+// step lost ~1.5 %: 316.5 -> 321.5 us at C2)
+template <bool PREDICT>
 __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model* models_, int k_, unsigned long long* sync_words,
                                                        double lr_, double b1_, double b2_, double aeps_, int do_update_) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -1561,7 +1565,7 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     (void)wj;
     CSTAMP(0);
     ph_setup();
-    if (!(do_update_ & MOBOCMF_STEP_CHAIN_VALID)) {      // (set: L^-1, U, a, KL of these parameters are in `work` from an earlier launch)
+    if (!PREDICT || !(do_update_ & MOBOCMF_STEP_CHAIN_VALID)) {      // (set: L^-1, U, a, KL of these parameters are in `work` from an earlier launch)
         const bool spread_kmm = nt > 4 && k >= 4;      // (the same in every workgroup of the surrogate: one barrier more)
         if (spread_kmm) {
             ph_kmm();
@@ -1577,14 +1581,14 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     }
     ph_elbo();
     if (do_update == 2) return;
-    if (do_update == 3) {      // input gradients: the backward column phases only, then the rows' sums
+    if constexpr (PREDICT) {      // input gradients: the backward column phases only, then the rows' sums
         for (int l = L - 1; l >= 0; --l) {
             ph_backward<true>(l);
             MODEL_BARRIER(25 + l);
         }
         ph_dx();
         return;
-    }
+    } else {
     if (do_update == 4) {
         if (!ph_couple()) return;
         MODEL_BARRIER(15);
@@ -1607,6 +1611,7 @@ __global__ __launch_bounds__(CT) void coop_step_kernel(const mobocmf_tiny_model*
     ph_cb8();
     MODEL_BARRIER(35);
     ph_adam();
+    }
 }
 #undef FRAG
 #undef COPY4
@@ -1690,17 +1695,19 @@ int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
         if (g.work_len >= ((int64_t)1 << 31)) return MOBOCMF_BAD_ARG;      // (workspace offsets are formed in 32 bits)
     }
     const size_t shm = coop_lds_bytes(mpmax);
-    static std::atomic<uint64_t> granted{0};      // one write-once bit per device: the dynamic-LDS attribute was set there
+    const bool predict = do_update == 3 || chain_valid;
+    const void* kfn = predict ? (const void*)coop_step_kernel<true> : (const void*)coop_step_kernel<false>;
+    static std::atomic<uint64_t> granted[2] = {{0}, {0}};      // one write-once bit per device and instantiation: the dynamic-LDS attribute was set there
     int devid = 0;
     HIP_TRY(hipGetDevice(&devid));
     const uint64_t bit = devid >= 0 && devid < 64 ? 1ull << devid : 0ull;
-    if (shm > 64 * 1024 && !(granted.load() & bit)) {
-        HIP_TRY(hipFuncSetAttribute((const void*)coop_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        granted.fetch_or(bit);
+    if (shm > 64 * 1024 && !(granted[predict].load() & bit)) {
+        HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        granted[predict].fetch_or(bit);
     }
     // every workgroup of the launch waits for its peers inside the launch: all of them must be resident at once
     int per_cu = 0, cus = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)coop_step_kernel, CT, shm));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, CT, shm));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
     const int64_t resident = (int64_t)per_cu * cus;
     int k = wgs_per_model;
@@ -1711,8 +1718,12 @@ int mobocmf_coop_elbo_step(const mobocmf_tiny_model* host_models, const mobocmf_
     }
     if ((int64_t)k * n_models > resident || k < 1) return MOBOCMF_BAD_ARG;
     if (wgs_used) *wgs_used = k;
-    hipLaunchKernelGGL(coop_step_kernel, dim3((unsigned)(n_models * k)), dim3(CT), shm, (hipStream_t)stream, dev_models, k,
-                       (unsigned long long*)sync_words, lr, beta1, beta2, eps, do_update | chain_valid);
+    if (predict)
+        hipLaunchKernelGGL(coop_step_kernel<true>, dim3((unsigned)(n_models * k)), dim3(CT), shm, (hipStream_t)stream, dev_models, k,
+                           (unsigned long long*)sync_words, lr, beta1, beta2, eps, do_update | chain_valid);
+    else
+        hipLaunchKernelGGL(coop_step_kernel<false>, dim3((unsigned)(n_models * k)), dim3(CT), shm, (hipStream_t)stream, dev_models, k,
+                           (unsigned long long*)sync_words, lr, beta1, beta2, eps, do_update);
     return hipGetLastError() == hipSuccess ? MOBOCMF_OK : MOBOCMF_HIP_ERROR;
 }
 
