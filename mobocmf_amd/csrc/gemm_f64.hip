@@ -27,6 +27,7 @@
 // Within a K step lane group kk handles k = 4*kk + ks (ks = 0..3), so that per-k weights are contiguous.
 // Triangular operands only visit the non-zero k range of their tile.  blockIdx -> tile mapping is XCD-aware.
 #include "common.h"
+#include <type_traits>
 #include <atomic>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -1586,22 +1587,22 @@ __device__ __forceinline__ void gemm_mid32_body(const GemmArgs& g, int nrb, int 
     if (g.tri & TRI_LOWER_B) { const int64_t b = (int64_t)cb * MD_BN; if (k0 < b) k0 = b; }
     if (g.tri & TRI_UPPER_B) { const int64_t e = (int64_t)(cb + 1) * MD_BN; if (k1 > e) k1 = e; }
     const int nst = k1 > k0 ? (int)((k1 - k0) / MS_BK) : 0;
-    // staging maps: A image 32 rows x 64 k -- thread = (row t/8, 8 k); B image 64 k x 64 columns -- (k t/8 and t/8 + 32, 8 columns);
-    // B^T image 64 columns x 64 k -- (column t/8 and t/8 + 32, 8 k)
-    const int ar = tid >> 3, ak = (tid & 7) * 8;
-    const double* Ag = A + ((int64_t)rb * MS_BM + ar) * g.lda + ak;
-    const double* Bg = B_T ? B + ((int64_t)cb * MD_BN + ar) * g.ldb + ak : B + (int64_t)ar * g.ldb + (int64_t)cb * MD_BN + ak;
-    const int64_t bstep = B_T ? 32 * g.ldb : 32 * g.ldb;      // second half: 32 columns (B^T) / 32 k rows (B) further
-    v2f64 ra[4], rb0[4], rb1[4];
+    // staging maps (round 5): every image row is 64 doubles = 512 contiguous bytes; thread t takes the 16 bytes number t % 32 of
+    // row t / 32 + 8 i -- a wavefront's load instruction reads two whole rows, 16 sectors of 64 bytes.  Until round 5 a thread
+    // took 64 contiguous bytes of a row as four 16-byte loads: every one of its load instructions touched 64 separate sectors,
+    // four times the address-unit work for the same bytes, 768 sector accesses per wavefront and stage -- ~1.3 us of each
+    // 2.3 us stage, whatever else in the kernel was changed.
+    const int fr = tid >> 5, fc = (tid & 31) * 2;
+    const double* Ag = A + ((int64_t)rb * MS_BM + fr) * g.lda + fc;
+    const double* Bg = B_T ? B + ((int64_t)cb * MD_BN + fr) * g.ldb + fc : B + (int64_t)fr * g.ldb + (int64_t)cb * MD_BN + fc;
+    v2f64 ra[4], rbv[8];
     auto fetch = [&](int st) {
         const int64_t k = k0 + (int64_t)st * MS_BK;
         const double* bp = B_T ? Bg + k : Bg + k * g.ldb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *(const v2f64*)(Ag + k + 2 * i);
-            rb0[i] = *(const v2f64*)(bp + 2 * i);
-            rb1[i] = *(const v2f64*)(bp + bstep + 2 * i);
-        }
+        for (int i = 0; i < 4; ++i) ra[i] = *(const v2f64*)(Ag + (int64_t)(8 * i) * g.lda + k);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rbv[i] = *(const v2f64*)(bp + (int64_t)(8 * i) * g.ldb);
     };
     v4f64 acc[2];      // [nt][r]: row = wr*16 + 4r + lk, column = wc*32 + 2 li + nt
     acc[0] = acc[1] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -1612,50 +1613,53 @@ __device__ __forceinline__ void gemm_mid32_body(const GemmArgs& g, int nrb, int 
     for (int st = 0; st < nst; ++st) {
         __syncthreads();      // the previous stage's fragment reads are done
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(v2f64*)(As + ar * MS_LDA + ak + 2 * i) = ra[i];
-            if (B_T) {
-                *(v2f64*)(Bs + ar * MS_LDA + ak + 2 * i) = rb0[i];
-                *(v2f64*)(Bs + (ar + 32) * MS_LDA + ak + 2 * i) = rb1[i];
-            } else {
-                *(v2f64*)(Bs + ar * MD_LDB + ak + 2 * i) = rb0[i];
-                *(v2f64*)(Bs + (ar + 32) * MD_LDB + ak + 2 * i) = rb1[i];
-            }
-        }
+        for (int i = 0; i < 4; ++i) *(v2f64*)(As + (fr + 8 * i) * MS_LDA + fc) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(v2f64*)(Bs + (fr + 8 * i) * (B_T ? MS_LDA : MD_LDB) + fc) = rbv[i];
         __syncthreads();
         fetch(st + 1 < nst ? st + 1 : st);      // unconditional: a path-dependent load count costs a full drain (see above)
+        // eight groups of 16 MFMAs, (kq, p) = (16 (g / 2), g % 2); the six 16-byte fragment reads of group g + 1 are issued BEFORE
+        // the MFMAs of group g (round 5): left to the compiler every group opened by waiting ~250 cycles for its own reads --
+        // with one wavefront per SIMD nothing hides them -- which was most of what a stage cost beside its MFMAs (2.3 us for
+        // 0.85 us of MFMA issue, whatever else was varied: DESIGN 3.2)
+        v2f64 fa[2][4];
+        v2f64 fb[2][2];      // B^T form: [nt] = (k, k+1) of column nt; A B form: [e] = columns (nt 0, nt 1) of row k + e
+        auto frag = [&](auto SET, int gi) {
+            constexpr int S = decltype(SET)::value;
+            const int kk = 16 * (gi >> 1) + 2 * (gi & 1);
+            if (B_T) {
 #pragma unroll
-        for (int kq = 0; kq < MS_BK; kq += 16) {
+                for (int nt = 0; nt < 2; ++nt) fb[S][nt] = *(const v2f64*)(Bs + bt_off + nt * MS_LDA + kk);
+            } else {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int kk = kq + 2 * p;
-                double b[2][2];      // [e][nt]
-                if (B_T) {
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const v2f64 v = *(const v2f64*)(Bs + bt_off + nt * MS_LDA + kk);
-                        b[0][nt] = v[0];
-                        b[1][nt] = v[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const v2f64 v = *(const v2f64*)(Bs + bn_off + (kk + e) * MD_LDB);
-                        b[e][0] = v[0];
-                        b[e][1] = v[1];
-                    }
-                }
-                v2f64 a[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = *(const v2f64*)(As + a_off + (4 * r) * MS_LDA + kk);
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[nt][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[r][e], b[e][nt], acc[nt][r], 0, 0, 0);
+                for (int e = 0; e < 2; ++e) fb[S][e] = *(const v2f64*)(Bs + bn_off + (kk + e) * MD_LDB);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fa[S][r] = *(const v2f64*)(As + a_off + (4 * r) * MS_LDA + kk);
+        };
+        auto mma = [&](auto SET) {
+            constexpr int S = decltype(SET)::value;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[nt][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[S][r][e], B_T ? fb[S][nt][e] : fb[S][e][nt], acc[nt][r], 0, 0, 0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        frag(I0{}, 0);
+#pragma unroll
+        for (int gp = 0; gp < 4; ++gp) {
+            frag(I1{}, 2 * gp + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (gp < 3) frag(I0{}, 2 * gp + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(I1{});
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     double* cp = C + ((int64_t)rb * MS_BM + wr * 16 + lk) * g.ldc + (int64_t)cb * MD_BN + wc * 32 + 2 * li;
