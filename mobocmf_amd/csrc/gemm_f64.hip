@@ -1619,9 +1619,8 @@ __device__ __forceinline__ void gemm_mid32_body(const GemmArgs& g, int nrb, int 
         __syncthreads();
         fetch(st + 1 < nst ? st + 1 : st);      // unconditional: a path-dependent load count costs a full drain (see above)
         // eight groups of 16 MFMAs, (kq, p) = (16 (g / 2), g % 2); the six 16-byte fragment reads of group g + 1 are issued BEFORE
-        // the MFMAs of group g (round 5): left to the compiler every group opened by waiting ~250 cycles for its own reads --
-        // with one wavefront per SIMD nothing hides them -- which was most of what a stage cost beside its MFMAs (2.3 us for
-        // 0.85 us of MFMA issue, whatever else was varied: DESIGN 3.2)
+        // the MFMAs of group g (round 5): left to the compiler every group opened by waiting for its own reads, and with one
+        // wavefront per SIMD nothing hides them (worth 4 % of the launch; the coalesced staging loads above were worth 16 %)
         v2f64 fa[2][4];
         v2f64 fb[2][2];      // B^T form: [nt] = (k, k+1) of column nt; A B form: [e] = columns (nt 0, nt 1) of row k + e
         auto frag = [&](auto SET, int gi) {
