@@ -1478,9 +1478,11 @@ PHASE_FN void ph_adam() {
                 return x > 20.0 ? s : s / (1.0 + exp(-x));
             }
             if (t < Hl + M) {
+                // (the layer is LANE-varying here -- a wavefront of this loop can hold the m entries of two layers when M^2 is
+                // small: M <= 6 -- so the layer's base is formed per lane, not through SML(), which makes it wave-uniform)
                 const int i = t - Hl;
-                double s = GC(SML(l, S_GMA))[i];
-                if (l + 1 < L) s += GC(SML(l + 1, S_GMB))[i] + GC(SML(l + 1, S_GZ))[i];
+                double s = GC(W)[g.sml[l] + (int64_t)S_GMA * Mp + i];
+                if (l + 1 < L) s += GC(W)[g.sml[l + 1] + (int64_t)S_GMB * Mp + i] + GC(W)[g.sml[l + 1] + (int64_t)S_GZ * Mp + i];
                 return s;
             }
             return GC(gflat)[e];

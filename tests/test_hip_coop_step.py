@@ -18,7 +18,10 @@ CASES = [dict(d=2, L=2, M=64, N=64, S=1, seed=0), dict(d=2, L=2, M=48, N=48, S=1
          dict(d=2, L=2, M=96, N=120, S=2, seed=2), dict(d=2, L=2, M=128, N=256, S=4, seed=3),
          dict(d=5, L=3, M=40, N=57, S=2, seed=4), dict(d=8, L=3, M=75, N=75, S=1, seed=5),
          dict(d=3, L=1, M=33, N=50, S=1, seed=6), dict(d=1, L=2, M=16, N=16, S=4, seed=7),
-         dict(d=4, L=3, M=7, N=23, S=1, seed=8), dict(d=2, L=2, M=128, N=512, S=8, seed=9)]
+         dict(d=4, L=3, M=7, N=23, S=1, seed=8), dict(d=2, L=2, M=128, N=512, S=8, seed=9),
+         # M <= 6: the variational means of TWO layers fall into one wavefront of the gradient assembly (found by
+         # tools/fuzz_tiny_step.py ... coop: the layer's workspace base was formed wave-uniformly there)
+         dict(d=1, L=2, M=4, N=64, S=1, seed=10), dict(d=1, L=3, M=4, N=100, S=4, seed=11), dict(d=4, L=2, M=2, N=40, S=2, seed=12)]
 IDS = ["d%d_L%d_M%d_N%d_S%d" % (c["d"], c["L"], c["M"], c["N"], c["S"]) for c in CASES]
 
 
