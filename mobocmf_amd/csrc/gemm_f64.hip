@@ -1567,9 +1567,13 @@ __device__ __forceinline__ void gemm_mid8_body(const GemmArgs& g, int nrb, int n
 #define MS_BM 32
 #define MS_BK 64
 #define MS_LDA (MS_BK + 2)
+#define MS_ASWZ(row) ((((row) & 1) << 1) | ((((row) >> 1) & 1) << 4))      // doubles: {0, 2, 16, 18} for row % 4 = 0 .. 3
 template <bool B_T>
 __device__ __forceinline__ void gemm_mid32_body(const GemmArgs& g, int nrb, int ncb) {
-    __shared__ __attribute__((aligned(16))) double As[MS_BM * MS_LDA];
+    // A image: rows of exactly 64 doubles, the 16-byte column groups XOR-swizzled by the row (MS_ASWZ): a wavefront's fragment read
+    // has 16 distinct addresses -- rows j = lane % 4, contraction offsets 4 lk -- and with padded rows (stride = 4 banks mod 64) the
+    // four lane groups' offsets (8 banks apart) land on each other's rows' banks; swizzled, the 16 addresses cover the 64 banks once
+    __shared__ __attribute__((aligned(16))) double As[MS_BM * MS_BK];
     __shared__ __attribute__((aligned(16))) double Bs[B_T ? MD_BN * MS_LDA : MS_BK * MD_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
@@ -1607,13 +1611,13 @@ __device__ __forceinline__ void gemm_mid32_body(const GemmArgs& g, int nrb, int 
     v4f64 acc[2];      // [nt][r]: row = wr*16 + 4r + lk, column = wc*32 + 2 li + nt
     acc[0] = acc[1] = (v4f64){0.0, 0.0, 0.0, 0.0};
     if (nst > 0) fetch(0);
-    const int a_off = (wr * 16 + (lane & 3)) * MS_LDA + 4 * lk;
+    const int a_row = (wr * 16 + (lane & 3)) * MS_BK, a_swz = MS_ASWZ(lane);
     const int bn_off = (4 * lk) * MD_LDB + wc * 32 + 2 * li;
     const int bt_off = (wc * 32 + 2 * li) * MS_LDA + 4 * lk;
     for (int st = 0; st < nst; ++st) {
         __syncthreads();      // the previous stage's fragment reads are done
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(v2f64*)(As + (fr + 8 * i) * MS_LDA + fc) = ra[i];
+        for (int i = 0; i < 4; ++i) *(v2f64*)(As + (fr + 8 * i) * MS_BK + (fc ^ MS_ASWZ(fr))) = ra[i];      // ((fr + 8 i) % 4 == fr % 4)
 #pragma unroll
         for (int i = 0; i < 8; ++i) *(v2f64*)(Bs + (fr + 8 * i) * (B_T ? MS_LDA : MD_LDB) + fc) = rbv[i];
         __syncthreads();
@@ -1634,7 +1638,7 @@ __device__ __forceinline__ void gemm_mid32_body(const GemmArgs& g, int nrb, int 
                 for (int e = 0; e < 2; ++e) fb[S][e] = *(const v2f64*)(Bs + bn_off + (kk + e) * MD_LDB);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fa[S][r] = *(const v2f64*)(As + a_off + (4 * r) * MS_LDA + kk);
+            for (int r = 0; r < 4; ++r) fa[S][r] = *(const v2f64*)(As + a_row + (4 * r) * MS_BK + ((4 * lk + kk) ^ a_swz));
         };
         auto mma = [&](auto SET) {
             constexpr int S = decltype(SET)::value;
