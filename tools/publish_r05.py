@@ -32,7 +32,8 @@ s = s[:i] + h1 + clean(R + 'chol_accuracy.txt') + s[j:]
 h2 = 'matrix-vector product, the likelihood; eager launches, 50 calls)\n'
 i, j = between(h2, '#\n# == 3.')
 s = s[:i] + h2 + clean(R + 'chol_bench.txt') + s[j:]
-i, j = s.index('potrf_cols 0  --config C3 '), s.index('#       C3 (headline')
+i = s.index('potrf_cols 0  --config C3 ')
+j = s.index('#       (', i)      # the comment block behind the six lines
 s = s[:i] + open(R + 'chol_ab.txt').read() + s[j:]
 open(P + 'chol_one_launch.txt', 'w').write(s)
 print("published")
